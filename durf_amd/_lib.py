@@ -1,0 +1,66 @@
+"""ctypes binding of libdurf_hip.so (C ABI in include/durf_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the shared
+object is missing this module raises at import of any op (run `python -c "import
+__graft_entry__ as g; g.build()"` or `make -C durf_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libdurf_hip.so')
+
+_lib = None
+
+vp, i32, u64, f32 = C.c_void_p, C.c_int, C.c_size_t, C.c_float
+
+_SIGS = {
+    'durf_last_error': (C.c_char_p, []),
+    'durf_version': (i32, []),
+    'durf_mlp_param_count': (u64, [i32, i32]),
+    'durf_mlp_layer_offset': (u64, [i32, i32, i32, i32]),
+    'durf_wpack_fwd_bytes': (u64, [i32]),
+    'durf_wpack_bwd_bytes': (u64, [i32]),
+    'durf_pack_weights': (i32, [vp, i32, i32, vp, vp, vp]),
+    'durf_ray_setup': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_compact_hits': (i32, [vp, i32, i32, vp, vp, vp, vp]),
+    'durf_sample_t': (i32, [vp, i32, i32, vp, vp, vp, vp]),
+    'durf_view_enc': (i32, [vp, i32, vp, vp, vp]),
+    'durf_encode_bkgd': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'durf_encode_obj': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
+    'durf_mlp_stash_bytes': (u64, [i32, u64]),
+    'durf_mlp_fwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_composite_fwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32,
+                                 vp, vp, vp, vp, vp, vp]),
+    'durf_resample': (i32, [vp, i32, i32, vp, vp, f32, vp, vp]),
+}
+
+
+def symbols():
+    """Every symbol include/durf_hip.h declares (checked by the CPU test-suite)."""
+    return sorted(_SIGS)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                'libdurf_hip.so not built (%s): the HIP extension is required, there is no '
+                'fallback path.  Run __graft_entry__.build().' % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+class DurfError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DurfError('%s failed (%d): %s' % (what, rc, lib().durf_last_error().decode()))

@@ -1,0 +1,92 @@
+// Shared helpers for the gfx950 kernels of libdurf_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/durf_hip.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#define DURF_WAVE 64
+
+void durf_set_error(const char* fmt, ...);
+
+#define DURF_CHECK_LAUNCH(name)                                              \
+    do {                                                                     \
+        hipError_t e__ = hipGetLastError();                                  \
+        if (e__ != hipSuccess) {                                             \
+            durf_set_error("%s: %s", name, hipGetErrorString(e__));          \
+            return (int)e__;                                                 \
+        }                                                                    \
+    } while (0)
+
+#define DURF_REQUIRE(cond, msg)                                              \
+    do {                                                                     \
+        if (!(cond)) {                                                       \
+            durf_set_error("%s: requirement failed: %s", __func__, msg);     \
+            return -1;                                                       \
+        }                                                                    \
+    } while (0)
+
+static inline unsigned durf_cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
+
+// ---- device helpers -------------------------------------------------------
+__device__ __forceinline__ float nan_min(float a, float b) {   // jnp.minimum propagates NaN
+    return (a != a || b != b) ? __builtin_nanf("") : fminf(a, b);
+}
+__device__ __forceinline__ float nan_max(float a, float b) {
+    return (a != a || b != b) ? __builtin_nanf("") : fmaxf(a, b);
+}
+// jnp.nan_to_num(x): nan -> 0, +-inf -> +-FLT_MAX
+__device__ __forceinline__ float nan_to_num(float x) {
+    if (x != x) return 0.0f;
+    if (x == __builtin_inff()) return 3.4028234663852886e+38f;
+    if (x == -__builtin_inff()) return -3.4028234663852886e+38f;
+    return x;
+}
+// math.safe_sin (internal/math.py:35-46): sin(|x| < 100*pi ? x : x mod 100*pi), the mod
+// being jnp.remainder (exact fmod, then shifted to the sign of the divisor).
+__device__ __forceinline__ float safe_sin(float x) {
+    const float t = 314.15927124023438f;   // float32(100*pi)
+    if (!(fabsf(x) < t)) {
+        float m = fmodf(x, t);
+        if (m != 0.0f && m < 0.0f) m += t;
+        x = m;
+    }
+    return sinf(x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive prefix sum across the 64 lanes of a wave
+__device__ __forceinline__ float wave_incl_scan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_up(v, o, 64);
+        if (lane >= o) v += t;
+    }
+    return v;
+}
+// inclusive suffix sum across the 64 lanes of a wave
+__device__ __forceinline__ float wave_incl_rscan(float v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        float t = __shfl_down(v, o, 64);
+        if (lane + o < 64) v += t;
+    }
+    return v;
+}
+
+// byte offset of the 16-byte vector holding features [8q, 8q+8) of `row` in the bf16 tile
+// layout of a [rows, 16*nks] matrix (include/durf_hip.h): q = feature/8 in [0, 2*nks)
+__device__ __forceinline__ size_t tile_vec_offset(size_t row, int q, int nks) {
+    return ((((row >> 5) * nks + (q >> 1)) * 64) + (size_t)((q & 1) * 32) + (row & 31)) * 16;
+}

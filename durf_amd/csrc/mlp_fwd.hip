@@ -1,0 +1,292 @@
+// Fused MLP forward (K6 bkgd 8x256, K7 per-object 8x128): obbpose_model.py:305-354 / :369-418.
+//
+// One workgroup = 8 waves = 256 samples; each wave owns 32 samples (one MFMA N tile) and
+// carries their activations in registers through all 11 stages (see mlp_spec.h for the
+// orientation trick).  Weights are pre-packed bf16 A-fragments streamed L2 -> LDS with
+// global_load_lds (one 1 KB chunk per wave-instruction, lane-linear = fragment order, so
+// ds_read_b128 is conflict-free), double buffered per output M-tile, one barrier per tile.
+// MFMA-bound: 2*606 208 padded MAC per sample (591 872 algorithmic) for W=256.
+#include "mlp_spec.h"
+
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// weight packer: fp32 flax params -> bf16 fragment stream (one thread per 16-byte vector)
+// ---------------------------------------------------------------------------
+template <int W>
+__global__ void __launch_bounds__(256)
+k_pack_fwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
+    using S = MlpSpec<W>;
+    const int vec = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec >= S::TOTAL_CHUNKS * 64) return;
+    const int chunk = vec >> 6, lane = vec & 63;
+    int s = 0, base = 0;
+    for (; s < S::NSTAGE; s++) {
+        const int cnt = S::n_mt(s) * S::tile_chunks(s);
+        if (chunk < base + cnt) break;
+        base += cnt;
+    }
+    const int rel = chunk - base;
+    const int mo = rel / S::tile_chunks(s), ck = rel % S::tile_chunks(s);
+    bf16x8 v;
+    if (ck < S::n_ks(s)) {
+        const int i = lane & 31, hi = lane >> 5;
+        int L, col;
+        durf_fwd_out_col<W>(s, mo, i, &L, &col);
+        int fi = 0, fo = 0;
+        if (L >= 0) durf_layer_shape(W, in_dim, L, &fi, &fo);
+        const size_t koff = (L >= 0) ? durf_layer_offset(W, in_dim, L, 0) : 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int row = durf_fwd_in_row<W>(s, ck, hi, e, in_dim);
+            float val = 0.0f;
+            if (L >= 0 && col < fo && row >= 0 && row < fi) val = P[koff + (size_t)row * fo + col];
+            v[e] = (__bf16)val;
+        }
+        out[vec] = v;
+    } else {
+        // bias chunk: floats [hi][r] = bias[out feature 32*mo + (r&3) + 8*(r>>2) + 4*hi]
+        float f[4] = {0.f, 0.f, 0.f, 0.f};
+        if (lane < 8) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int idx = lane * 4 + j, hi = idx >> 4, r = idx & 15;
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
+                int L, col;
+                durf_fwd_out_col<W>(s, mo, i, &L, &col);
+                if (L >= 0) {
+                    int fi, fo;
+                    durf_layer_shape(W, in_dim, L, &fi, &fo);
+                    if (col < fo) f[j] = P[durf_layer_offset(W, in_dim, L, 1) + col];
+                }
+            }
+        }
+        f32x4 fv = {f[0], f[1], f[2], f[3]};
+        *(f32x4*)&out[vec] = fv;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// fused forward
+// ---------------------------------------------------------------------------
+struct WPipe {
+    const char* gnext;   // next tile to prefetch (global)
+    char* lds;           // base of the two slots
+    int slot_bytes;
+    int par;             // slot that holds the tile about to be consumed
+    int wave, lane;
+    // Make the prefetched tile visible, start the prefetch of the following one (next_chunks
+    // KB, 0 = none) into the other slot, and return the slot to consume.
+    __device__ __forceinline__ const char* begin(int next_chunks) {
+        __syncthreads();   // drains this wave's glds (vmcnt) + all waves done with the other slot
+        char* dst = lds + (par ^ 1) * slot_bytes;
+        for (int c = wave; c < next_chunks; c += 8)
+            glds16(gnext + (size_t)c * 1024 + lane * 16, dst + c * 1024);
+        gnext += (size_t)next_chunks * 1024;
+        const char* cur = lds + par * slot_bytes;
+        par ^= 1;
+        return cur;
+    }
+};
+
+template <int NA, int NB>
+__device__ __forceinline__ f32x16 mma_tile(const char* slot, int lane, const bf16x8* inA,
+                                           const bf16x8* inB) {
+    const f32x4* bp = (const f32x4*)(slot + (NA + NB) * 1024 + (lane >> 5) * 64);
+    f32x16 acc;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        const f32x4 b4 = bp[g];
+        acc[4 * g + 0] = b4[0]; acc[4 * g + 1] = b4[1]; acc[4 * g + 2] = b4[2]; acc[4 * g + 3] = b4[3];
+    }
+    const char* ap = slot + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < NA; ks++) {
+        const bf16x8 a = *(const bf16x8*)(ap + ks * 1024);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, inA[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NB; ks++) {
+        const bf16x8 a = *(const bf16x8*)(ap + (NA + ks) * 1024);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, inB[ks], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+template <bool RELU>
+__device__ __forceinline__ void pack_tile(const f32x16& acc, bf16x8& o0, bf16x8& o1) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float v0 = acc[e], v1 = acc[8 + e];
+        if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+        o0[e] = (__bf16)v0;
+        o1[e] = (__bf16)v1;
+    }
+}
+
+// One dense stage: NMT output tiles, inputs inA[NA] (C-perm) ++ inB[NB] (natural).
+template <int NA, int NB, int NMT, bool RELU, bool TRAIN>
+__device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf16x8* inB,
+                                          bf16x8* out, int next_stage_chunks, bf16x8* stash_dst,
+                                          bool valid) {
+    constexpr int CH = NA + NB + 1;
+#pragma unroll
+    for (int mo = 0; mo < NMT; mo++) {
+        const char* slot = p.begin(mo == NMT - 1 ? next_stage_chunks : CH);
+        if (TRAIN && mo > 0 && valid) {     // delayed store of the previous tile's output
+            stash_dst[(2 * mo - 2) * 64] = out[2 * mo - 2];
+            stash_dst[(2 * mo - 1) * 64] = out[2 * mo - 1];
+        }
+        const f32x16 acc = mma_tile<NA, NB>(slot, p.lane, inA, inB);
+        pack_tile<RELU>(acc, out[2 * mo], out[2 * mo + 1]);
+    }
+    if (TRAIN && valid) {
+        stash_dst[(2 * NMT - 2) * 64] = out[2 * NMT - 2];
+        stash_dst[(2 * NMT - 1) * 64] = out[2 * NMT - 1];
+    }
+}
+
+template <int W, bool TRAIN>
+__global__ void __launch_bounds__(512, 2)
+k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
+          const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
+          const char* __restrict__ wpack, float* __restrict__ raw, bf16x8* __restrict__ stash) {
+    using S = MlpSpec<W>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    size_t nrows = rows;
+    if (count) {
+        const size_t c = (size_t)(*count) * (size_t)N;
+        nrows = c < rows ? c : rows;
+    }
+    if ((size_t)blockIdx.x * 256 >= nrows) return;           // whole workgroup idle
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t tile32 = (size_t)blockIdx.x * 8 + wave;
+    const size_t row = tile32 * 32 + (lane & 31);
+    const bool valid = row < nrows;
+    const bool tile_valid = tile32 * 32 < nrows;
+    const size_t ntile32 = rows >> 5;
+
+    WPipe p;
+    p.gnext = wpack; p.lds = smem; p.slot_bytes = S::MAX_TILE_CHUNKS * 1024; p.par = 0;
+    p.wave = wave; p.lane = lane;
+    // prologue: tile 0 -> slot 0
+    for (int c = wave; c < S::tile_chunks(0); c += 8)
+        glds16(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
+    p.gnext += (size_t)S::tile_chunks(0) * 1024;
+
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    bf16x8 encf[S::KE];
+    const bf16x8* enc_t = enc + (tile32 * S::KE) * 64 + lane;
+#pragma unroll
+    for (int k = 0; k < S::KE; k++) encf[k] = tile_valid ? enc_t[k * 64] : zero8;
+
+    bf16x8 a[S::KW], b[S::KW];
+    auto stash_at = [&](int j) -> bf16x8* {
+        return stash + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 64 + lane;
+    };
+    constexpr int CHW = S::KW + 1;
+    // stage 0: enc -> a
+    run_stage<0, S::KE, S::WT, true, TRAIN>(p, nullptr, encf, a, CHW, TRAIN ? stash_at(0) : nullptr, tile_valid);
+    // stages 1-4
+    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, CHW, TRAIN ? stash_at(1) : nullptr, tile_valid);
+    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, CHW, TRAIN ? stash_at(2) : nullptr, tile_valid);
+    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, CHW, TRAIN ? stash_at(3) : nullptr, tile_valid);
+    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, S::KW + S::KE + 1, TRAIN ? stash_at(4) : nullptr, tile_valid);
+    // stage 5: [a, enc] -> b
+    run_stage<S::KW, S::KE, S::WT, true, TRAIN>(p, a, encf, b, CHW, TRAIN ? stash_at(5) : nullptr, tile_valid);
+    // stages 6, 7
+    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, CHW, TRAIN ? stash_at(6) : nullptr, tile_valid);
+    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, CHW, TRAIN ? stash_at(7) : nullptr, tile_valid);
+    // stage 8: b -> bottleneck (a, linear) + density
+    run_stage<S::KW, 0, S::WT, false, TRAIN>(p, b, nullptr, a, CHW, TRAIN ? stash_at(8) : nullptr, tile_valid);
+    float dens;
+    {
+        const char* slot = p.begin(S::KW + S::KV + 1);
+        const f32x16 acc = mma_tile<S::KW, 0>(slot, lane, b, nullptr);
+        dens = acc[0];
+    }
+    // stage 9: [bottleneck, view] -> c (128, relu)
+    bf16x8 vf[S::KV];
+    {
+        size_t ray = row / (size_t)N;
+        if (ray_idx && valid) ray = (size_t)ray_idx[ray];
+#pragma unroll
+        for (int k = 0; k < S::KV; k++)
+            vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + (lane >> 5)] : zero8;
+    }
+    bf16x8 c[S::KC];
+    run_stage<S::KW, S::KV, S::CT, true, TRAIN>(p, a, vf, c, S::KC + 1, TRAIN ? stash_at(9) : nullptr, tile_valid);
+    // stage 10: c -> rgb
+    {
+        const char* slot = p.begin(0);
+        const f32x16 acc = mma_tile<S::KC, 0>(slot, lane, c, nullptr);
+        if (valid && lane < 32) {
+            const f32x4 o = {acc[0], acc[1], acc[2], dens};
+            *(f32x4*)(raw + row * 4) = o;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+size_t durf_mlp_param_count(int width, int in_dim) { return durf_layer_offset(width, in_dim, 12, 0); }
+size_t durf_mlp_layer_offset(int width, int in_dim, int layer, int want_bias) {
+    return durf_layer_offset(width, in_dim, layer, want_bias);
+}
+size_t durf_wpack_fwd_bytes(int width) {
+    return (size_t)(width == 256 ? MlpSpec<256>::TOTAL_CHUNKS : MlpSpec<128>::TOTAL_CHUNKS) * 1024;
+}
+size_t durf_mlp_stash_bytes(int width, size_t rows) {
+    const size_t kb = width == 256 ? MlpSpec<256>::STASH_KS_TOTAL : MlpSpec<128>::STASH_KS_TOTAL;
+    return ((rows + 31) / 32) * kb * 1024;
+}
+
+int durf_pack_weights_fwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_fwd) {
+    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+    DURF_REQUIRE(in_dim > 0 && in_dim <= DURF_ENC_DIM, "in_dim <= 64");
+    hipStream_t s = (hipStream_t)stream;
+    if (width == 256) {
+        hipLaunchKernelGGL(k_pack_fwd<256>, dim3(durf_cdiv(MlpSpec<256>::TOTAL_CHUNKS * 64, 256)), dim3(256),
+                           0, s, in_dim, mlp_params, (bf16x8*)wpack_fwd);
+    } else {
+        hipLaunchKernelGGL(k_pack_fwd<128>, dim3(durf_cdiv(MlpSpec<128>::TOTAL_CHUNKS * 64, 256)), dim3(256),
+                           0, s, in_dim, mlp_params, (bf16x8*)wpack_fwd);
+    }
+    DURF_CHECK_LAUNCH("durf_pack_weights_fwd");
+    return 0;
+}
+
+int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_bwd);
+
+int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_fwd,
+                      void* wpack_bwd) {
+    int rc = durf_pack_weights_fwd(stream, width, in_dim, mlp_params, wpack_fwd);
+    if (rc == 0 && wpack_bwd) rc = durf_pack_weights_bwd(stream, width, in_dim, mlp_params, wpack_bwd);
+    return rc;
+}
+
+int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
+                 const void* view_bf16, const int32_t* ray_idx, const int32_t* count,
+                 const void* wpack_fwd, float* raw, void* stash) {
+    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+    DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(durf_cdiv(rows, 256)), block(512);
+#define LAUNCH_F(WW, TR)                                                                          \
+    hipLaunchKernelGGL((k_mlp_fwd<WW, TR>), grid, block, 2 * MlpSpec<WW>::MAX_TILE_CHUNKS * 1024, s, \
+                       rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16, ray_idx, count, \
+                       (const char*)wpack_fwd, raw, (bf16x8*)stash)
+    if (width == 256) { if (stash) LAUNCH_F(256, true); else LAUNCH_F(256, false); }
+    else { if (stash) LAUNCH_F(128, true); else LAUNCH_F(128, false); }
+#undef LAUNCH_F
+    DURF_CHECK_LAUNCH("durf_mlp_fwd");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,369 @@
+// Ray-side kernels: box setup (K1), hit compaction, stratified sampling (K2),
+// view-direction encoding (K5), conical-frustum -> Gaussian -> contraction -> IPE (K3/K4).
+// All arithmetic is fp32 and follows the op order of the reference lines cited in
+// include/durf_hip.h so that results agree with an fp32 evaluation of the reference to
+// rounding.  These kernels are HBM-write-bound (31 KB written per ray-level for the
+// background encoding); lanes are arranged so every store instruction writes full lines.
+#include "durf_common.h"
+
+// ---------------------------------------------------------------------------
+// K1: ray_setup.  One thread per ray, K-loop; rotation matrices built once per block.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_ray_setup(int B, int K, const float* __restrict__ origins, const float* __restrict__ dirs,
+            const float* __restrict__ pose, const float* __restrict__ ext,
+            float* __restrict__ origins_s, float* __restrict__ dirs_s,
+            int32_t* __restrict__ hit, float* __restrict__ zo) {
+    __shared__ float sR[DURF_MAX_OBJ][9];
+    __shared__ float sT[DURF_MAX_OBJ][3];   // R * (-c)
+    __shared__ float sE[DURF_MAX_OBJ][3];
+    if (threadIdx.x < K) {
+        const int k = threadIdx.x;
+        // box_helpers.aa2matrix (:148-167)
+        const float rx = pose[k * 6 + 3], ry = pose[k * 6 + 4], rz = pose[k * 6 + 5];
+        float s = rx * rx + ry * ry + rz * rz;
+        s = (s < 1e-12f) ? 1e-12f : s;                    // math.safe_norm (:27-32)
+        const float th = sqrtf(s) + 1e-12f;
+        const float a = sinf(th) / th;
+        const float b = (1.0f - cosf(th)) / (th * th);
+        // skew = [[0,-z,y],[z,0,-x],[-y,x,0]]; skew^2 computed as a matmul
+        const float S[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+        float R[9];
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                float s2 = S[i * 3 + 0] * S[0 * 3 + j] + S[i * 3 + 1] * S[1 * 3 + j] + S[i * 3 + 2] * S[2 * 3 + j];
+                R[i * 3 + j] = ((i == j) ? 1.0f : 0.0f) + a * S[i * 3 + j] + b * s2;
+            }
+        const float cx = -pose[k * 6 + 0], cy = -pose[k * 6 + 1], cz = -pose[k * 6 + 2];
+#pragma unroll
+        for (int i = 0; i < 9; i++) sR[k][i] = R[i];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            sT[k][i] = R[i * 3 + 0] * cx + R[i * 3 + 1] * cy + R[i * 3 + 2] * cz;   // rotate_matrix(-pose)
+            sE[k][i] = ext[k * 3 + i];
+        }
+    }
+    __syncthreads();
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float ox = origins[b * 3 + 0], oy = origins[b * 3 + 1], oz = origins[b * 3 + 2];
+    const float dx = dirs[b * 3 + 0], dy = dirs[b * 3 + 1], dz = dirs[b * 3 + 2];
+    float so[3] = {0.f, 0.f, 0.f}, sd[3] = {0.f, 0.f, 0.f};
+    float zsum = 0.f;
+    int nhit = 0;
+    for (int k = 0; k < K; k++) {
+        const float* R = sR[k];
+        float po[3], pd[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            po[i] = (R[i * 3 + 0] * ox + R[i * 3 + 1] * oy + R[i * 3 + 2] * oz) + sT[k][i];
+            pd[i] = R[i * 3 + 0] * dx + R[i * 3 + 1] * dy + R[i * 3 + 2] * dz;
+        }
+        const float nrm = sqrtf(pd[0] * pd[0] + pd[1] * pd[1] + pd[2] * pd[2]);   // :340
+        float tn = -__builtin_inff(), tf = __builtin_inff();
+        bool first = true;
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            pd[i] = pd[i] / nrm;
+            const float inv = 1.0f / pd[i];                                       // :79
+            const float tmin = (-sE[k][i] - po[i]) * inv;
+            const float tmax = (sE[k][i] - po[i]) * inv;
+            const float t0 = nan_min(tmin, tmax), t1 = nan_max(tmin, tmax);
+            tn = first ? t0 : nan_max(tn, t0);
+            tf = first ? t1 : nan_min(tf, t1);
+            first = false;
+        }
+        int h = (tf > tn) ? 1 : 0;                                                // :91
+        const int pos = (tf * (float)h > 0.0f) ? 1 : 0;                           // :95
+        h *= pos;
+        const float hf = (float)h;
+        hit[b * K + k] = h;
+        zsum += hf * (tf * hf);                                                   // :102, model :131
+        nhit += h;
+#pragma unroll
+        for (int i = 0; i < 3; i++) { so[i] += po[i] * hf; sd[i] += pd[i] * hf; } // model :117-118
+    }
+    const float bk = (nhit == 0) ? 1.0f : 0.0f;                                   // model :115
+    origins_s[b * 3 + 0] = so[0] + bk * ox;
+    origins_s[b * 3 + 1] = so[1] + bk * oy;
+    origins_s[b * 3 + 2] = so[2] + bk * oz;
+    dirs_s[b * 3 + 0] = sd[0] + bk * dx;
+    dirs_s[b * 3 + 1] = sd[1] + bk * dy;
+    dirs_s[b * 3 + 2] = sd[2] + bk * dz;
+    zo[b] = zsum;
+}
+
+// ---------------------------------------------------------------------------
+// ordered stream compaction of hit[:,k]; one block per object, wave-ballot scan.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024)
+k_compact_hits(int B, int K, const int32_t* __restrict__ hit, int32_t* __restrict__ idx,
+               int32_t* __restrict__ count, int32_t* __restrict__ slot) {
+    const int k = blockIdx.x;
+    __shared__ int wave_tot[16];
+    __shared__ int base_s;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) base_s = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < B; b0 += 1024) {
+        const int b = b0 + threadIdx.x;
+        const int h = (b < B) ? (hit[b * K + k] != 0) : 0;
+        const unsigned long long m = __ballot(h);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) wave_tot[wave] = __popcll(m);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int w = 0; w < 16; w++) { const int t = wave_tot[w]; if (w < wave) woff += t; tot += t; }
+        const int base = base_s;
+        if (b < B) {
+            const int pos = base + woff + before;
+            slot[b * K + k] = h ? pos : -1;
+            if (h) idx[(size_t)k * B + pos] = b;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_s = base + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) count[k] = base_s;
+}
+
+// ---------------------------------------------------------------------------
+// K2: level-0 t_vals (mip.py:353-368).  linspace(0,1,N+1)[i] == i/N in fp32.
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sample_t(int B, int N, const float* __restrict__ near, const float* __restrict__ far,
+           const float* __restrict__ t_rand, float* __restrict__ t_vals) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t tot = (size_t)B * (N + 1);
+    if (i >= tot) return;
+    const int b = (int)(i / (N + 1)), n = (int)(i % (N + 1));
+    const float nr = near[b], fr = far[b];
+    auto tv = [&](int m) {
+        const float s = (m == N) ? 1.0f : (float)m / (float)N;
+        return nr * (1.0f - s) + fr * s;
+    };
+    float t = tv(n);
+    if (t_rand) {                                                       // :360-365
+        const float lower = (n == 0) ? t : 0.5f * (t + tv(n - 1));
+        const float upper = (n == N) ? t : 0.5f * (tv(n + 1) + t);
+        t = lower + (upper - lower) * t_rand[i];
+    }
+    t_vals[i] = t;
+}
+
+// ---------------------------------------------------------------------------
+// K5: view-direction encoding (mip.py:36-45): [v, sin(2^i v_j), sin(2^i v_j + pi/2)]
+// ---------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_view_enc(int B, const float* __restrict__ viewdirs, __bf16* __restrict__ out_bf16,
+           float* __restrict__ out_f32) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * DURF_VIEW_DIM) return;
+    const int b = i / DURF_VIEW_DIM, f = i % DURF_VIEW_DIM;
+    float val = 0.0f;
+    if (f < 3) {
+        val = viewdirs[b * 3 + f];
+    } else if (f < 27) {
+        const int g = f - 3, c = g / 12, r = g % 12, deg = r / 3, j = r % 3;
+        float y = viewdirs[b * 3 + j] * (float)(1 << deg);
+        if (c) y = y + 1.5707963705062866f;                // float32(0.5*pi)
+        val = sinf(y);                                      // plain jnp.sin here (mip.py:41)
+    }
+    if (out_bf16) out_bf16[i] = (__bf16)val;
+    if (out_f32 && f < 27) out_f32[b * 27 + f] = val;
+}
+
+// ---------------------------------------------------------------------------
+// K3/K4: per-sample Gaussian + encoding.  8 lanes per sample, each lane produces the 8
+// consecutive features of one 16-byte output vector, so a wave writes 8 samples x 128 B.
+// ---------------------------------------------------------------------------
+struct Gauss { float x[3]; float var[3]; };
+struct BarfW { float w[10]; };
+
+// mip.cast_rays / conical_frustum_to_gaussian / lift_gaussian (mip.py:155-179,99-130,76-96);
+// only diag(cov) is ever consumed downstream.
+__device__ __forceinline__ Gauss frustum_gaussian(float t0, float t1, const float* o,
+                                                  const float* d, float radius) {
+    const float mu = (t0 + t1) / 2.0f;
+    const float hw = (t1 - t0) / 2.0f;
+    const float mu2 = mu * mu, hw2 = hw * hw;
+    const float den = 3.0f * mu2 + hw2;
+    const float hw4 = hw2 * hw2;
+    const float t_mean = mu + (2.0f * mu * hw2) / den;
+    const float t_var = hw2 / 3.0f - (4.0f / 15.0f) * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
+    const float r_var = (radius * radius) * (mu2 / 4.0f + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / den);
+    const float dmag = fmaxf(1e-10f, d[0] * d[0] + d[1] * d[1] + d[2] * d[2]);
+    Gauss g;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        g.x[j] = d[j] * t_mean + o[j];
+        const float dd = d[j] * d[j];
+        const float null_d = 1.0f - d[j] * (d[j] / dmag);
+        g.var[j] = t_var * dd + r_var * null_d;
+    }
+    return g;
+}
+
+// mip360.new_space (mip360.py:47-79): x -> contract(x); var_j -> (var_j * v_j) * v_j with
+// v = JVP of contract along (1,1,1), written in the op order reverse-free JVP produces.
+__device__ __forceinline__ void contract_gaussian(Gauss& g) {
+    const float s0 = g.x[0] * g.x[0] + g.x[1] * g.x[1] + g.x[2] * g.x[2];
+    const bool tiny = s0 < 1e-12f;
+    const float n = sqrtf(tiny ? 1e-12f : s0);
+    if (n <= 0.1f) return;                                     // x_smaller branch: x' = x, v = 1
+    const float dn = tiny ? 0.0f : (2.0f * (g.x[0] + g.x[1] + g.x[2])) / (2.0f * n);
+    const float inv = 1.0f / n;
+    const float fac = 2.0f - inv;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const float xn = g.x[j] / n;
+        // d(2 - 1/n) = dn/n^2 ; d(x/n) = 1/n - x*dn/n^2
+        const float v = (dn / (n * n)) * xn + fac * (inv - g.x[j] * dn / (n * n));
+        g.x[j] = fac * xn;
+        g.var[j] = (g.var[j] * v) * v;
+    }
+}
+
+// one IPE feature f in [0,60): mip.py:273-282 with basis [2^i I3]
+__device__ __forceinline__ float ipe_feature(const Gauss& g, int f) {
+    const int c = f / 30, r = f - c * 30, deg = r / 3, j = r - deg * 3;
+    const float sc = (float)(1 << deg);
+    float y = g.x[j] * sc;
+    if (c) y = y + 1.5707963705062866f;
+    const float yv = g.var[j] * sc * sc;
+    return expf(-0.5f * yv) * safe_sin(y);
+}
+
+template <bool OBJ>
+__global__ void __launch_bounds__(256)
+k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+         const float* __restrict__ t_vals, const float* __restrict__ origins_s,
+         const float* __restrict__ dirs_s, const float* __restrict__ radii,
+         const int32_t* __restrict__ hit, int K, int contraction, BarfW barf_w,
+         bf16x8* __restrict__ out_tile, float* __restrict__ out_f32) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t row = gid >> 3;          // sample row (ray-major)
+    const int q = (int)(gid & 7);         // which 8-feature vector
+    const int j = (int)(row / N), n = (int)(row % N);
+    if (j >= rays) return;
+    int b = j;
+    if (OBJ) {
+        if (j >= *count) return;
+        b = idx[j];
+    }
+    const float t0 = t_vals[(size_t)b * (N + 1) + n], t1 = t_vals[(size_t)b * (N + 1) + n + 1];
+    float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
+    float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
+    Gauss g = frustum_gaussian(t0, t1, o, d, radii[b]);
+    float w[10];
+    if (OBJ) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) w[i] = barf_w.w[i];
+    } else {
+        int nh = 0;
+        for (int k = 0; k < K; k++) nh += hit[b * K + k];
+        if (nh != 0) {                               // bkgd_mask = 1 - sum(masks) (model :205-210)
+            const float m = 1.0f - (float)nh;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { g.x[i] *= m; g.var[i] *= m; }
+        }
+        if (contraction) contract_gaussian(g);
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int p = q * 8 + e;
+        float val;
+        if (OBJ) {
+            if (p < 3) val = g.x[p];
+            else if (p < 63) { const int f = p - 3; val = w[f / 6] * ipe_feature(g, f); }   // mip.py:217-222
+            else val = 0.0f;
+        } else {
+            val = (p < 60) ? ipe_feature(g, p) : 0.0f;
+        }
+        v[e] = val;
+    }
+    if (out_tile) {
+        bf16x8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o8[e] = (__bf16)v[e];
+        *(bf16x8*)((char*)out_tile + tile_vec_offset(row, q, 4)) = o8;
+    }
+    if (out_f32) {
+        const int dim = OBJ ? 63 : 60;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int p = q * 8 + e;
+            if (p < dim) out_f32[row * dim + p] = v[e];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int durf_ray_setup(void* stream, int B, int K, const float* origins, const float* dirs,
+                   const float* pose, const float* ext, float* origins_s, float* dirs_s,
+                   int32_t* hit, float* zo) {
+    DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_ray_setup, dim3(durf_cdiv(B, 256)), dim3(256), 0, (hipStream_t)stream, B, K,
+                       origins, dirs, pose, ext, origins_s, dirs_s, hit, zo);
+    DURF_CHECK_LAUNCH("durf_ray_setup");
+    return 0;
+}
+
+int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* idx,
+                      int32_t* count, int32_t* slot) {
+    if (K <= 0 || B <= 0) return 0;
+    hipLaunchKernelGGL(k_compact_hits, dim3(K), dim3(1024), 0, (hipStream_t)stream, B, K, hit, idx,
+                       count, slot);
+    DURF_CHECK_LAUNCH("durf_compact_hits");
+    return 0;
+}
+
+int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
+                  const float* t_rand, float* t_vals) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_sample_t, dim3(durf_cdiv((size_t)B * (N + 1), 256)), dim3(256), 0,
+                       (hipStream_t)stream, B, N, near, far, t_rand, t_vals);
+    DURF_CHECK_LAUNCH("durf_sample_t");
+    return 0;
+}
+
+int durf_view_enc(void* stream, int B, const float* viewdirs, void* out_bf16, float* out_f32) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_view_enc, dim3(durf_cdiv((size_t)B * DURF_VIEW_DIM, 256)), dim3(256), 0,
+                       (hipStream_t)stream, B, viewdirs, (__bf16*)out_bf16, out_f32);
+    DURF_CHECK_LAUNCH("durf_view_enc");
+    return 0;
+}
+
+int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const float* origins_s,
+                     const float* dirs_s, const float* radii, const int32_t* hit, int K,
+                     int contraction, void* out_tile, float* out_f32) {
+    if (B <= 0) return 0;
+    DURF_REQUIRE(((size_t)B * N) % 32 == 0 || out_tile == nullptr, "B*N must be a multiple of 32");
+    hipLaunchKernelGGL(k_encode<false>, dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
+                       (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
+                       hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
+    DURF_CHECK_LAUNCH("durf_encode_bkgd");
+    return 0;
+}
+
+int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const int32_t* count,
+                    const float* t_vals, const float* origins_s, const float* dirs_s,
+                    const float* radii, const float* barf_w, void* out_tile, float* out_f32) {
+    if (max_rays <= 0) return 0;
+    BarfW bw;
+    for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
+    hipLaunchKernelGGL(k_encode<true>, dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
+                       (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
+                       nullptr, 0, 0, bw, (bf16x8*)out_tile, out_f32);
+    DURF_CHECK_LAUNCH("durf_encode_obj");
+    return 0;
+}
+
+}  // extern "C"

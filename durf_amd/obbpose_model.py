@@ -1,0 +1,285 @@
+"""MI355X-native MipNerfModel -- host-side mirror of internal/obbpose_model.py.
+
+Same call surface as the reference (`MipNerfModel`, `construct_mipnerf`, `render_image`,
+gin knobs with the reference's names); the body of `MipNerfModel.__call__`
+(obbpose_model.py:68-261) runs as hand-written gfx950 kernels behind the C ABI of
+libdurf_hip.so.  torch tensors stand in for jnp arrays; `variables` keeps flax's tree
+names (`params/box_centers`, `params/MLP_0/Dense_i/{kernel,bias}`, `params/BoxMLP_k/...`)
+as views into ONE flat fp32 buffer, so the data-parallel gradient exchange is a single
+all-reduce (train_boxpose.py:253).
+"""
+import dataclasses
+import math
+from typing import Any
+
+import torch
+
+from . import ops
+from . import utils
+
+IN_BKGD, IN_OBJ, W_BKGD, W_OBJ = 60, 63, 256, 128
+
+
+# ----------------------------------------------------------------------------
+# parameters
+# ----------------------------------------------------------------------------
+def _layer_shapes(width, in_dim):
+    return [(in_dim, width)] + [(width, width)] * 4 + [(width + in_dim, width)] + [(width, width)] * 2 + \
+           [(width, 1), (width, width), (width + 27, 128), (128, 3)]
+
+
+class ParamLayout:
+    """Offsets of every leaf in the flat fp32 parameter buffer (include/durf_hip.h)."""
+
+    def __init__(self, T, K):
+        self.T, self.K = T, K
+        self.box = (0, T * K * 6)
+        off = T * K * 6
+        self.mlp_size = {W_BKGD: sum(a * b + b for a, b in _layer_shapes(W_BKGD, IN_BKGD)),
+                         W_OBJ: sum(a * b + b for a, b in _layer_shapes(W_OBJ, IN_OBJ))}
+        self.mlp_off = {'MLP_0': off}
+        off += self.mlp_size[W_BKGD]
+        for k in range(K):
+            self.mlp_off['BoxMLP_%d' % k] = off
+            off += self.mlp_size[W_OBJ]
+        self.total = off
+
+    def mlp_names(self):
+        return ['MLP_0'] + ['BoxMLP_%d' % k for k in range(self.K)]
+
+    @staticmethod
+    def mlp_dims(name):
+        return (W_BKGD, IN_BKGD) if name == 'MLP_0' else (W_OBJ, IN_OBJ)
+
+
+class Variables(dict):
+    """flax-style {'params': {...}} tree whose leaves are views of `flat`."""
+
+    def __init__(self, flat, layout):
+        super().__init__()
+        self.flat, self.layout = flat, layout
+        p = {'box_centers': flat[layout.box[0]:layout.box[1]].view(layout.T, layout.K, 6)}
+        for name in layout.mlp_names():
+            width, in_dim = layout.mlp_dims(name)
+            off = layout.mlp_off[name]
+            d = {}
+            for i, (fi, fo) in enumerate(_layer_shapes(width, in_dim)):
+                d['Dense_%d' % i] = {'kernel': flat[off:off + fi * fo].view(fi, fo),
+                                     'bias': flat[off + fi * fo:off + fi * fo + fo]}
+                off += fi * fo + fo
+            p[name] = d
+        self['params'] = p
+
+    def mlp_flat(self, name):
+        width, _ = self.layout.mlp_dims(name)
+        off = self.layout.mlp_off[name]
+        return self.flat[off:off + self.layout.mlp_size[width]]
+
+    def like(self, flat):
+        return Variables(flat, self.layout)
+
+
+def init_boxes(rng, box_centers):
+    """obbpose_model.py:35-39."""
+    if box_centers.dim() < 3:
+        return box_centers[:, None, :]
+    return box_centers
+
+
+# ----------------------------------------------------------------------------
+# model
+# ----------------------------------------------------------------------------
+@dataclasses.dataclass
+class MLP:
+    """obbpose_model.py:293-303 (knobs only; evaluated by the fused MFMA kernel)."""
+    net_depth: int = 8
+    net_width: int = 256
+    net_depth_condition: int = 1
+    net_width_condition: int = 128
+    net_activation: Any = 'relu'
+    skip_layer: int = 4
+    num_rgb_channels: int = 3
+    num_density_channels: int = 1
+
+
+@dataclasses.dataclass
+class BoxMLP(MLP):
+    """obbpose_model.py:357-367."""
+    net_width: int = 128
+
+
+def _check_mlp(m, width):
+    ok = (m.net_depth == 8 and m.net_width == width and m.net_depth_condition == 1 and
+          m.net_width_condition == 128 and m.skip_layer == 4 and m.num_rgb_channels == 3 and
+          m.num_density_channels == 1 and m.net_activation == 'relu')
+    if not ok:
+        raise NotImplementedError('fused MLP kernels are built for the shipped gin topology '
+                                  '(8x%d trunk, skip 4, 1x128 view layer, relu); got %r' % (width, m))
+
+
+def _make_generator(rng, device):
+    if isinstance(rng, torch.Generator):
+        return rng
+    g = torch.Generator(device=device)
+    g.manual_seed(int(rng) if rng is not None else 0)
+    return g
+
+
+@dataclasses.dataclass
+class MipNerfModel:
+    """Nerf NN Model with both coarse and fine MLPs (obbpose_model.py:42-66 knobs)."""
+    num_samples: int = 128
+    num_levels: int = 2
+    resample_padding: float = 0.01
+    stop_level_grad: bool = True
+    use_viewdirs: bool = True
+    lindisp: bool = False
+    ray_shape: str = 'cone'
+    min_deg_point: int = 0
+    max_deg_point: int = 10
+    deg_view: int = 4
+    num_objects: int = 2
+    density_activation: Any = 'softplus'
+    density_noise: float = 0.1
+    density_bias: float = -1.
+    rgb_activation: Any = 'sigmoid'
+    rgb_padding: float = 0.001
+    disable_integration: bool = False
+    contraction: bool = True
+    dynamics: bool = True
+    timesteps: int = 5
+    no_pose_opt: bool = False
+    no_yaw_opt: bool = False
+
+    def _check(self):
+        bad = []
+        if self.ray_shape != 'cone': bad.append('ray_shape')
+        if self.lindisp: bad.append('lindisp')
+        if not self.use_viewdirs: bad.append('use_viewdirs=False')
+        if (self.min_deg_point, self.max_deg_point, self.deg_view) != (0, 10, 4): bad.append('degrees')
+        if self.disable_integration: bad.append('disable_integration')
+        if not self.dynamics: bad.append('dynamics=False')
+        if not self.stop_level_grad: bad.append('stop_level_grad=False')
+        if self.num_samples % 32 or not (32 <= self.num_samples <= 256): bad.append('num_samples')
+        if bad:
+            raise NotImplementedError('knob values outside the shipped gin configs are not built: %s' % bad)
+        _check_mlp(utils.configured(MLP), W_BKGD)
+        _check_mlp(utils.configured(BoxMLP), W_OBJ)
+
+    # -- forward -------------------------------------------------------------
+    def _forward(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
+                 train=False, noise=None):
+        self._check()
+        if randomized and self.density_noise > 0:
+            raise NotImplementedError('density_noise > 0 (both shipped gin files set 0.0)')
+        lay = variables.layout
+        K, N = lay.K, self.num_samples
+        B = rays.origins.shape[0]
+        dev = rays.origins.device
+        ts = int(ts)
+        pc = variables['params']['box_centers']
+        pose = pc[ts].contiguous()
+        ext = ext.reshape(-1, 3).contiguous() if K > 0 else torch.zeros(0, 3, device=dev)
+        o_s, d_s, hit, zo = ops.ray_setup(rays.origins, rays.directions, pose, ext)
+        idx, count, slot = ops.compact_hits(hit)
+        view = ops.view_enc(rays.viewdirs)
+        radii = rays.radii.reshape(-1).contiguous()
+        near, far = rays.near.reshape(-1).contiguous(), rays.far.reshape(-1).contiguous()
+        packs = {n: ops.pack_weights(*lay.mlp_dims(n), variables.mlp_flat(n), want_bwd=train)
+                 for n in lay.mlp_names()}
+        wf = {n: (p[0] if train else p) for n, p in packs.items()}
+        bk = ops.BKGD_RAND if rand_bkgd else (ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY)
+        if randomized and noise is None:
+            g = _make_generator(rng, dev)
+            noise = dict(t_rand=torch.rand(B, N + 1, device=dev, generator=g),
+                         u_rand=torch.rand(B, N + 1, device=dev, generator=g))
+        rows = B * N
+        ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,
+                   packs=packs, levels=[], B=B, N=N, K=K, ts=ts, bkgd_mode=bk)
+        ret = []
+        t_vals = weights = None
+        box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
+        dyn_mask = hit.sum(dim=-1, keepdim=True) if K > 0 else torch.zeros(B, 1, dtype=torch.int32, device=dev)
+        for lvl in range(self.num_levels):
+            if lvl == 0:
+                t_vals = ops.sample_t(near, far, N, noise['t_rand'] if randomized else None)
+            else:
+                t_vals = ops.resample(t_vals, weights, self.resample_padding,
+                                      noise['u_rand'] if randomized else None)
+            enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction)
+            stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
+            raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, wf['MLP_0'], stash=stash_b)
+            raws, encs, stashes = [], [], []
+            for k in range(K):
+                enc_k, _ = ops.encode_obj(B, idx[k], count[k:k + 1], t_vals, o_s, d_s, radii, alpha)
+                st_k = torch.empty(ops.mlp_stash_bytes(W_OBJ, rows), dtype=torch.uint8, device=dev) if train else None
+                raws.append(ops.mlp_fwd(W_OBJ, rows, N, enc_k, view, wf['BoxMLP_%d' % k], ray_idx=idx[k],
+                                        count=count[k:k + 1], stash=st_k))
+                encs.append(enc_k)
+                stashes.append(st_k)
+            rgb, depth, acc, weights, t_mids, t_dists = ops.composite_fwd(
+                raw_b, raws, slot, t_vals, d_s, self.density_bias, bk)
+            ret.append((rgb, depth, acc, weights, t_vals, t_mids, t_dists, [pose[:, :3], box_rot0],
+                        dyn_mask, zo))
+            if train:
+                ctx['levels'].append(dict(t_vals=t_vals, enc_b=enc_b, raw_b=raw_b, stash_b=stash_b,
+                                          raws=raws, encs=encs, stashes=stashes, rgb=rgb, depth=depth,
+                                          acc=acc, weights=weights))
+        return ret, ctx
+
+    def apply(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
+              noise=None):
+        """model.apply(variables, key, rays, init, ext, ts, randomized=, rand_bkgd=, white_bkgd=,
+        alpha=) -> list[num_levels] of (rgb, depth, acc, weights, t_vals, t_mids, t_dists,
+        [box_pose, box_rot0], dyn_mask, zo)   (train_boxpose.py:82-92, obbpose_model.py:258)."""
+        return self._forward(variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd,
+                             alpha, train=False, noise=noise)[0]
+
+    __call__ = apply
+
+
+def glorot_uniform_(t, fan_in, fan_out, gen):
+    lim = math.sqrt(6.0 / (fan_in + fan_out))
+    t.copy_((torch.rand(t.shape, generator=gen, dtype=torch.float64) * 2 - 1).mul_(lim).to(t.dtype))
+
+
+def construct_mipnerf(rng, example_batch, device='cuda'):
+    """Construct a Neural Radiance Field (obbpose_model.py:264-291).
+
+    box_centers is initialised to the batch's `init` verbatim (:35-39,88); Dense kernels are
+    glorot-uniform, biases zero (flax defaults).  `rng`: int seed or CPU torch.Generator."""
+    model = utils.configured(MipNerfModel)
+    init = torch.as_tensor(example_batch['init']).squeeze()
+    if init.dim() == 2:
+        init = init[:, None, :]
+    if init.dim() == 1:    # K == 0
+        init = init.reshape(init.shape[0] if init.numel() else model.timesteps, 0, 6)
+    T, K = init.shape[0], init.shape[1]
+    layout = ParamLayout(T, K)
+    gen = rng if isinstance(rng, torch.Generator) else torch.Generator().manual_seed(int(rng))
+    flat = torch.zeros(layout.total, dtype=torch.float32)
+    v = Variables(flat, layout)
+    v['params']['box_centers'].copy_(init_boxes(None, init.float().cpu()))
+    for name in layout.mlp_names():
+        for i in range(12):
+            k = v['params'][name]['Dense_%d' % i]['kernel']
+            glorot_uniform_(k, k.shape[0], k.shape[1], gen)
+    return model, Variables(flat.to(device), layout)
+
+
+def render_image(render_fn, rays, init, ext, ts, rng, alpha, chunk=8192):
+    """Render all the pixels of an image in test mode (obbpose_model.py:421-479).
+
+    render_fn(rng, batch) -> list of per-level tuples (as the pmapped render_eval_fn,
+    train_boxpose.py:377-390); batch keys: rays, init, ext, ts, alpha."""
+    height, width = rays[0].shape[:2]
+    num_rays = height * width
+    rays = utils.namedtuple_map(lambda r: r.reshape(num_rays, -1), rays)
+    results = []
+    for i in range(0, num_rays, chunk):
+        chunk_rays = utils.namedtuple_map(lambda r: r[i:i + chunk].contiguous(), rays)
+        batch = dict(rays=chunk_rays, init=init, ext=ext, ts=ts, alpha=alpha)
+        last = render_fn(rng, batch)[-1]
+        results.append(last[:3])
+    rgb, distance, acc = [torch.cat(r, dim=0) for r in zip(*results)]
+    return (rgb.reshape(height, width, -1), distance.reshape(height, width), acc.reshape(height, width))

@@ -1,0 +1,172 @@
+"""Stage-level operators: torch tensors in, torch tensors out, every one a call through the
+C ABI of libdurf_hip.so on the current HIP stream.  PyTorch is used for device memory and
+streams only.  Reference lines each op replaces are cited in include/durf_hip.h."""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+
+ENC_DIM = 64
+VIEW_DIM = 32
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda and t.is_contiguous(), (t.dtype, t.device, t.is_contiguous())
+    return t
+
+
+def ray_setup(origins, dirs, pose, ext):
+    """-> origins_s[B,3], dirs_s[B,3], hit[B,K] int32, zo[B]"""
+    B, K = origins.shape[0], pose.shape[0]
+    dev = origins.device
+    o_s = torch.empty(B, 3, device=dev)
+    d_s = torch.empty(B, 3, device=dev)
+    hit = torch.empty(B, K, dtype=torch.int32, device=dev)
+    zo = torch.empty(B, device=dev)
+    _lib.check(_lib.lib().durf_ray_setup(_stream(), B, K, _p(_f32(origins)), _p(_f32(dirs)),
+                                         _p(_f32(pose)), _p(_f32(ext)), _p(o_s), _p(d_s), _p(hit),
+                                         _p(zo)), 'durf_ray_setup')
+    return o_s, d_s, hit, zo
+
+
+def compact_hits(hit):
+    """-> idx[K,B] int32, count[K] int32, slot[B,K] int32"""
+    B, K = hit.shape
+    dev = hit.device
+    idx = torch.zeros(max(K, 1), B, dtype=torch.int32, device=dev)
+    count = torch.zeros(max(K, 1), dtype=torch.int32, device=dev)
+    slot = torch.full((B, max(K, 1)), -1, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().durf_compact_hits(_stream(), B, K, _p(hit), _p(idx), _p(count), _p(slot)),
+               'durf_compact_hits')
+    return idx, count, slot
+
+
+def sample_t(near, far, N, t_rand=None):
+    B = near.shape[0]
+    t = torch.empty(B, N + 1, device=near.device)
+    _lib.check(_lib.lib().durf_sample_t(_stream(), B, N, _p(_f32(near)), _p(_f32(far)),
+                                        _p(None if t_rand is None else _f32(t_rand)), _p(t)),
+               'durf_sample_t')
+    return t
+
+
+def view_enc(viewdirs, want_f32=False):
+    B = viewdirs.shape[0]
+    out = torch.empty(B, VIEW_DIM, dtype=torch.bfloat16, device=viewdirs.device)
+    o32 = torch.empty(B, 27, device=viewdirs.device) if want_f32 else None
+    _lib.check(_lib.lib().durf_view_enc(_stream(), B, _p(_f32(viewdirs)), _p(out), _p(o32)),
+               'durf_view_enc')
+    return (out, o32) if want_f32 else out
+
+
+def tile_rows(rows):
+    return (rows + 31) // 32 * 32
+
+
+def encode_bkgd(t_vals, origins_s, dirs_s, radii, hit, contraction=True, tile=True, f32=False):
+    B, N = t_vals.shape[0], t_vals.shape[1] - 1
+    K = hit.shape[1]
+    dev = t_vals.device
+    ot = torch.empty(tile_rows(B * N), ENC_DIM, dtype=torch.bfloat16, device=dev) if tile else None
+    of = torch.empty(B * N, 60, device=dev) if f32 else None
+    _lib.check(_lib.lib().durf_encode_bkgd(_stream(), B, N, _p(_f32(t_vals)), _p(_f32(origins_s)),
+                                           _p(_f32(dirs_s)), _p(_f32(radii)), _p(hit), K,
+                                           int(contraction), _p(ot), _p(of)), 'durf_encode_bkgd')
+    return ot, of
+
+
+def barf_weights(alpha, max_deg=10):
+    """mip.py:217-218 evaluated on the host in float32 arithmetic."""
+    import numpy as np
+    k = np.arange(max_deg, dtype=np.float32)
+    a = np.clip(np.float32(alpha) - k, 0, 1).astype(np.float32) * np.float32(math.pi)
+    return ((np.float32(1) - np.cos(a, dtype=np.float32)) / np.float32(2)).astype(np.float32)
+
+
+def encode_obj(max_rays, idx_k, count_k, t_vals, origins_s, dirs_s, radii, alpha, tile=True, f32=False):
+    N = t_vals.shape[1] - 1
+    dev = t_vals.device
+    ot = torch.empty(tile_rows(max_rays * N), ENC_DIM, dtype=torch.bfloat16, device=dev) if tile else None
+    of = torch.zeros(max_rays * N, 63, device=dev) if f32 else None
+    w = barf_weights(alpha)
+    wa = (C.c_float * 10)(*[float(x) for x in w])
+    _lib.check(_lib.lib().durf_encode_obj(_stream(), max_rays, N, _p(idx_k), _p(count_k),
+                                          _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
+                                          _p(_f32(radii)), wa, _p(ot), _p(of)), 'durf_encode_obj')
+    return ot, of
+
+
+def mlp_param_count(width, in_dim):
+    return int(_lib.lib().durf_mlp_param_count(width, in_dim))
+
+
+def mlp_layer_offset(width, in_dim, layer, bias):
+    return int(_lib.lib().durf_mlp_layer_offset(width, in_dim, layer, int(bias)))
+
+
+def pack_weights(width, in_dim, mlp_params, want_bwd=False):
+    """fp32 flax-layout params of one MLP -> bf16 fragment streams (fwd[, bwd])."""
+    dev = mlp_params.device
+    wf = torch.empty(int(_lib.lib().durf_wpack_fwd_bytes(width)), dtype=torch.uint8, device=dev)
+    wb = None
+    if want_bwd:
+        wb = torch.empty(int(_lib.lib().durf_wpack_bwd_bytes(width)), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().durf_pack_weights(_stream(), width, in_dim, _p(_f32(mlp_params)), _p(wf),
+                                            _p(wb)), 'durf_pack_weights')
+    return (wf, wb) if want_bwd else wf
+
+
+def mlp_stash_bytes(width, rows):
+    return int(_lib.lib().durf_mlp_stash_bytes(width, rows))
+
+
+def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=None, stash=None,
+            raw=None):
+    dev = enc_tile.device
+    if raw is None:
+        raw = torch.empty(rows, 4, device=dev)
+    _lib.check(_lib.lib().durf_mlp_fwd(_stream(), width, rows, N, _p(enc_tile), _p(view_bf16),
+                                       _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash)),
+               'durf_mlp_fwd')
+    return raw
+
+
+BKGD_GREY, BKGD_WHITE, BKGD_RAND = 0, 1, 2
+
+
+def composite_fwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, density_bias=-1.0, bkgd_mode=BKGD_GREY,
+                  want_t=True):
+    B, N = t_vals.shape[0], t_vals.shape[1] - 1
+    K = len(raw_obj)
+    dev = t_vals.device
+    rgb = torch.empty(B, 3, device=dev)
+    depth = torch.empty(B, device=dev)
+    acc = torch.empty(B, device=dev)
+    weights = torch.empty(B, N, device=dev)
+    t_mids = torch.empty(B, N, device=dev) if want_t else None
+    t_dists = torch.empty(B, N, device=dev) if want_t else None
+    ptrs = (C.c_void_p * max(K, 1))(*[r.data_ptr() for r in raw_obj])
+    _lib.check(_lib.lib().durf_composite_fwd(_stream(), B, N, K, _p(_f32(raw_bkgd)), ptrs, _p(slot),
+                                             _p(_f32(t_vals)), _p(_f32(dirs_s)), density_bias,
+                                             bkgd_mode, _p(rgb), _p(depth), _p(acc), _p(weights),
+                                             _p(t_mids), _p(t_dists)), 'durf_composite_fwd')
+    return rgb, depth, acc, weights, t_mids, t_dists
+
+
+def resample(t_vals, weights, padding=0.01, u_rand=None):
+    B, N = weights.shape
+    out = torch.empty(B, N + 1, device=t_vals.device)
+    _lib.check(_lib.lib().durf_resample(_stream(), B, N, _p(_f32(t_vals)), _p(_f32(weights)), padding,
+                                        _p(None if u_rand is None else _f32(u_rand)), _p(out)),
+               'durf_resample')
+    return out

@@ -1,0 +1,119 @@
+/* durf_hip.h -- C ABI of libdurf_hip.so, the MI355X (gfx950) ray-pipeline library.
+ *
+ * The reference (FelTris/durf) has NO FFI/plugin boundary: its hot path is plain
+ * Python/JAX.  This ABI is therefore what a reference-side
+ * binding (ctypes stub) would call to replace the body of
+ *   MipNerfModel.__call__     internal/obbpose_model.py:68-261
+ *   train_step / loss_fn      train_boxpose.py:49-321
+ * Each entry point cites the reference lines it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (a torch allocation);
+ *    the library never frees or retains it past the call;
+ *  - every call is asynchronous on `stream` (a hipStream_t passed as void*);
+ *  - return value: 0 = ok, otherwise a hipError_t / negative durf error;
+ *    durf_last_error() returns a thread-local message;
+ *  - tensors are row-major fp32 with the reference's shapes unless stated;
+ *  - "tile layout" = bf16 MFMA B-fragment-major layout of a [rows, 16*nks] matrix:
+ *        elem(row, f) at  (((row/32)*nks + f/16) * 64 + ((f/8)&1)*32 + row%32) * 8 + f%8
+ *    i.e. per 32-row tile, per 16-feature k-step, lanes (hi=(f/8)&1, n=row%32) hold 8
+ *    consecutive features (one 16-byte vector per lane).
+ */
+#ifndef DURF_HIP_H
+#define DURF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DURF_MAX_OBJ 16
+#define DURF_ENC_DIM 64      /* 60 (bkgd IPE) / 63 (object IPE) features padded to 64 */
+#define DURF_VIEW_DIM 32     /* 27 view-direction features padded to 32 */
+
+const char* durf_last_error(void);
+int durf_version(void);
+
+/* ---- parameter layout -------------------------------------------------------
+ * One contiguous fp32 buffer (so the data-parallel gradient exchange is a single
+ * all-reduce, train_boxpose.py:253):
+ *   [ box_centers T*K*6 | MLP_0: Dense_0.kernel[in,out], Dense_0.bias, ... Dense_11 |
+ *     BoxMLP_0 ... | BoxMLP_{K-1} ... ]
+ * Dense order/shape as flax creates them (obbpose_model.py:329-353): 8 trunk layers,
+ * density head, bottleneck, view layer, rgb head.  kernels are [in,out] row-major. */
+size_t durf_mlp_param_count(int width, int in_dim);          /* floats in one MLP */
+size_t durf_mlp_layer_offset(int width, int in_dim, int layer, int want_bias);
+/* bf16 fragment-ordered weight streams consumed by the fused MLP kernels */
+size_t durf_wpack_fwd_bytes(int width);
+size_t durf_wpack_bwd_bytes(int width);
+int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_params,
+                      void* wpack_fwd, void* wpack_bwd /* nullable */);
+
+/* ---- stage-level entry points (each one kernel; used by parity + roofline tests) */
+
+/* K1 box setup: aa2matrix, world2object_rpy, ray_box_intersection, ray select.
+ * box_helpers.py:148-167,170-181,286-341,59-106; obbpose_model.py:99-131.
+ * pose = box_centers[ts] [K,6]; ext [K,3]; hit [B,K] int32; zo[B]; */
+int durf_ray_setup(void* stream, int B, int K, const float* origins, const float* dirs,
+                   const float* pose, const float* ext, float* origins_s, float* dirs_s,
+                   int32_t* hit, float* zo);
+
+/* deterministic stream compaction of hit[:,k]: idx[k*B + j] = j-th ray hitting k,
+ * count[k] = number of such rays, slot[b*K+k] = position of ray b in list k or -1. */
+int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* idx,
+                      int32_t* count, int32_t* slot);
+
+/* mip.sample_along_rays t_vals (mip.py:353-368). t_rand nullable (randomized=False). */
+int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
+                  const float* t_rand, float* t_vals);
+
+/* view-direction encoding mip.pos_enc(viewdirs,0,4,True) (mip.py:36-45) -> [B,32]
+ * bf16 (27 features, zero padded) and/or fp32 [B,27]. */
+int durf_view_enc(void* stream, int B, const float* viewdirs, void* out_bf16, float* out_f32);
+
+/* K2+K3 background encoding: cast_rays (mip.py:155-179,99-130,76-96), bkgd masking
+ * (obbpose_model.py:205-210), mip360.new_space (mip360.py:47-79), integrated_pos_enc
+ * (mip.py:226-282) -> 60 features/sample.  out_tile: bf16 tile layout [B*N, 64];
+ * out_f32: [B*N, 60] row-major (either may be null). */
+int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const float* origins_s,
+                     const float* dirs_s, const float* radii, const int32_t* hit, int K,
+                     int contraction, void* out_tile, float* out_f32);
+
+/* K4 object encoding for compacted hit rays of object k: weighted_ipe (mip.py:182-223),
+ * no contraction, xyz prepended -> 63 features.  idx/count from durf_compact_hits
+ * (device-side count; launch covers max_rays).  barf_w: 10 host floats (mip.py:217-218). */
+int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const int32_t* count,
+                    const float* t_vals, const float* origins_s, const float* dirs_s,
+                    const float* radii, const float* barf_w, void* out_tile, float* out_f32);
+
+/* K6/K7 fused MLP forward (obbpose_model.py:305-354 / :369-418), bf16 MFMA, fp32
+ * accumulate.  rows = number of samples (multiple of N); enc_tile: [rows,64] tile layout;
+ * view_bf16 [B,32]; ray_idx nullable (object MLPs: row r belongs to ray ray_idx[r/N]);
+ * count nullable device int (valid rays; rows beyond count*N are skipped);
+ * raw out [rows,4] = (raw_rgb[3], raw_density).  stash (nullable, training): bf16
+ * activations, durf_mlp_stash_bytes(width, rows). */
+size_t durf_mlp_stash_bytes(int width, size_t rows);
+int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
+                 const void* view_bf16, const int32_t* ray_idx, const int32_t* count,
+                 const void* wpack_fwd, float* raw, void* stash);
+
+/* K8 merge + activations + volumetric_rendering (obbpose_model.py:232-254, mip.py:285-327).
+ * raw_bkgd [B*N,4]; raw_obj[k] [count_k*N,4] compacted, slot from durf_compact_hits.
+ * bkgd_mode: 0 = grey 0.5 (rand_bkgd=False, white_bkgd=False), 1 = white, 2 = rand_bkgd
+ * (adds randint(0,1)==0, mip.py:324).  Outputs nullable except weights. */
+int durf_composite_fwd(void* stream, int B, int N, int K, const float* raw_bkgd,
+                       const float* const* raw_obj /* host array of K device ptrs */,
+                       const int32_t* slot, const float* t_vals, const float* dirs_s,
+                       float density_bias, int bkgd_mode, float* rgb, float* depth, float* acc,
+                       float* weights, float* t_mids, float* t_dists);
+
+/* K9 resample: mip.resample_along_rays + math.sorted_piecewise_constant_pdf
+ * (mip.py:373-416, math.py:222-284). u_rand nullable. */
+int durf_resample(void* stream, int B, int N, const float* t_vals, const float* weights,
+                  float resample_padding, const float* u_rand, float* t_vals_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -127,8 +127,13 @@ def sorted_piecewise_constant_pdf(u_rand, bins, weights, num_samples, randomized
         u = u + u_rand.to(dt) * (s - F32_EPS)
         u = torch.clamp(u, max=1. - F32_EPS)
     else:
-        # jnp.linspace(0., 1. - eps32, num_samples) is evaluated in float32.
-        u = torch.linspace(0., 1. - F32_EPS, num_samples, dtype=torch.float32).to(dt)
+        # jnp.linspace(0., 1. - eps32, num) in float32: start*(1-step) + stop*step with
+        # step = iota/(num-1), last element := stop (jax/_src/numpy/lax_numpy.py linspace).
+        stop = torch.tensor(1. - F32_EPS, dtype=torch.float32)
+        step = torch.arange(num_samples, dtype=torch.float32) / (num_samples - 1)
+        u = stop * step
+        u[-1] = stop
+        u = u.to(dt)
         u = u.expand(list(cdf.shape[:-1]) + [num_samples])
 
     mask = u[..., None, :] >= cdf[..., :, None]

@@ -1,0 +1,95 @@
+"""End-to-end forward parity of MipNerfModel.apply (HIP path through the C ABI) against the
+oracle's model_apply on identical ray batches and parameters.
+
+Tolerances (bf16 MFMA MLP, fp32 everywhere else):
+  * vs the oracle with bf16-rounded GEMM operands (same arithmetic): rgb/acc/weights <= 2e-3,
+    depth <= 2e-3 * far, level-1 t_vals <= 2e-3 * far;
+  * vs the plain fp32 oracle (what an fp32 JAX run computes): rgb <= 2e-2 (SURVEY.md 8c BF16 mode).
+"""
+import pytest
+import torch
+
+from durf_amd import obbpose_model, synthetic, utils
+from oracle import durf_ref as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cuda, B, K, N, randomized, seed, alpha=10.0, far=40.0):
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n' % N)
+    b = synthetic.make_batch(B, K, seed=seed, far=far)
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(seed, db, device=cuda)
+    # non-zero biases so bias packing is exercised
+    g = torch.Generator().manual_seed(seed)
+    for name in variables.layout.mlp_names():
+        for i in range(12):
+            bias = variables['params'][name]['Dense_%d' % i]['bias']
+            bias.copy_(((torch.rand(bias.shape, generator=g) - 0.5) * 0.1).to(cuda))
+    noise_c = dict(t_rand=torch.rand(B, N + 1, generator=g), u_rand=torch.rand(B, N + 1, generator=g))
+    noise_d = {k: v.to(cuda) for k, v in noise_c.items()}
+    ret = model.apply(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], randomized=randomized,
+                      rand_bkgd=False, white_bkgd=False, alpha=alpha, noise=noise_d if randomized else None)
+    torch.cuda.synchronize()
+    params = H.oracle_params_from_variables(variables)
+    mcfg = dict(num_samples=N)
+    with torch.no_grad():
+        ref_bf = R.model_apply(params, ob['rays'], b['ts'], ob['ext'], randomized, False, False, alpha,
+                               noise=noise_c if randomized else None, cfg=mcfg, mlp_hook=R.mlp_apply_bf16)
+        ref_32 = R.model_apply(params, ob['rays'], b['ts'], ob['ext'], randomized, False, False, alpha,
+                               noise=noise_c if randomized else None, cfg=mcfg)
+    return b, ret, ref_bf, ref_32
+
+
+@pytest.mark.parametrize('K,N,randomized', [(0, 64, False), (1, 32, False), (3, 64, True), (8, 32, False)])
+def test_forward_parity(cuda, K, N, randomized):
+    far = 40.0
+    b, ret, ref_bf, ref_32 = _run(cuda, 256, K, N, randomized, seed=21 + K, far=far)
+    assert len(ret) == 2
+    for lvl in range(2):
+        got, rb, r32 = ret[lvl], ref_bf[lvl], ref_32[lvl]
+        torch.testing.assert_close(got[4].cpu(), rb[4], rtol=0, atol=2e-3 * far, msg=lambda m: 't_vals l%d: %s' % (lvl, m))
+        torch.testing.assert_close(got[0].cpu(), rb[0], rtol=0, atol=2e-3, msg=lambda m: 'rgb l%d: %s' % (lvl, m))
+        torch.testing.assert_close(got[1].cpu(), rb[1], rtol=0, atol=2e-3 * far, msg=lambda m: 'depth l%d: %s' % (lvl, m))
+        torch.testing.assert_close(got[2].cpu(), rb[2], rtol=0, atol=2e-3, msg=lambda m: 'acc l%d: %s' % (lvl, m))
+        torch.testing.assert_close(got[3].cpu(), rb[3], rtol=0, atol=2e-3, msg=lambda m: 'weights l%d: %s' % (lvl, m))
+        assert (got[0].cpu() - r32[0]).abs().max() < 2e-2, 'rgb vs fp32 oracle'
+        assert torch.equal(got[8].cpu().long().reshape(-1), rb[8].reshape(-1)), 'dyn_mask'
+        torch.testing.assert_close(got[9].cpu(), rb[9], rtol=1e-6, atol=1e-5)
+        torch.testing.assert_close(got[7][0].cpu(), rb[7][0])
+    if K > 0:
+        assert 0.02 < b['hit_fraction'] < 0.3
+
+
+def test_forward_alpha_ramp(cuda):
+    """BARF coarse-to-fine mask active (alpha = 4.5): the feature//6 weight quirk is live."""
+    b, ret, ref_bf, _ = _run(cuda, 256, 2, 32, False, seed=5, alpha=4.5)
+    for lvl in range(2):
+        torch.testing.assert_close(ret[lvl][0].cpu(), ref_bf[lvl][0], rtol=0, atol=2e-3)
+
+
+def test_render_image(cuda):
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = 32\nMipNerfModel.density_noise = 0.0\n')
+    b = synthetic.make_batch(64, 1, seed=3)
+    db = H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+    img = synthetic.make_image_rays(12, 20)
+    rays = utils.BoxRays(**{k: torch.tensor(v, device=cuda) for k, v in img.items()})
+
+    def render_fn(rng, batch):
+        return model.apply(variables, rng, batch['rays'], batch['init'], batch['ext'], batch['ts'],
+                           randomized=False, rand_bkgd=False, white_bkgd=False, alpha=batch['alpha'])
+    rgb, dist, acc = obbpose_model.render_image(render_fn, rays, db['init'], db['ext'], b['ts'], 0, 10.0, chunk=100)
+    assert rgb.shape == (12, 20, 3) and dist.shape == (12, 20) and acc.shape == (12, 20)
+    rgb2, _, _ = obbpose_model.render_image(render_fn, rays, db['init'], db['ext'], b['ts'], 0, 10.0, chunk=240)
+    torch.testing.assert_close(rgb, rgb2, rtol=0, atol=1e-6)     # chunking must not change results
+    params = H.oracle_params_from_variables(variables)
+    orays = R.BoxRays(**{k: torch.tensor(v) for k, v in img.items()})
+    ref = R.render_image(params, orays, b['ts'], torch.tensor(b['ext']), 10.0, chunk=100,
+                         cfg=dict(num_samples=32), mlp_hook=R.mlp_apply_bf16)
+    torch.testing.assert_close(rgb.cpu(), ref[0], rtol=0, atol=2e-3)
+    torch.testing.assert_close(acc.cpu(), ref[2], rtol=0, atol=2e-3)
