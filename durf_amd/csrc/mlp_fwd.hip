@@ -121,7 +121,7 @@ __device__ __forceinline__ void pack_tile(const f32x16& acc, bf16x8& o0, bf16x8&
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float v0 = acc[e], v1 = acc[8 + e];
-        if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }
+        if (RELU) { v0 = v0 < 0.0f ? 0.0f : v0; v1 = v1 < 0.0f ? 0.0f : v1; }   // NaN-propagating like jnp.maximum
         o0[e] = (__bf16)v0;
         o1[e] = (__bf16)v1;
     }

@@ -41,6 +41,7 @@ def _run(cuda, B, K, N, randomized, seed, alpha=10.0, far=40.0):
                                noise=noise_c if randomized else None, cfg=mcfg, mlp_hook=R.mlp_apply_bf16)
         ref_32 = R.model_apply(params, ob['rays'], b['ts'], ob['ext'], randomized, False, False, alpha,
                                noise=noise_c if randomized else None, cfg=mcfg)
+    b['_multi'] = (ref_32[0][8].reshape(-1) > 1).numpy().astype('int64')
     return b, ret, ref_bf, ref_32
 
 
@@ -49,14 +50,22 @@ def test_forward_parity(cuda, K, N, randomized):
     far = 40.0
     b, ret, ref_bf, ref_32 = _run(cuda, 256, K, N, randomized, seed=21 + K, far=far)
     assert len(ret) == 2
+    # Rays that hit two boxes at once are garbage-in/garbage-out in the reference
+    # (obbpose_model.py:120-122 sums object-frame origins and the bkgd mask becomes -1, so
+    # variances go negative and the encoding overflows): outside the tolerance domain, only
+    # checked for "non-finite on both sides".
+    single = torch.tensor(b['_multi'] == 0)
     for lvl in range(2):
         got, rb, r32 = ret[lvl], ref_bf[lvl], ref_32[lvl]
-        torch.testing.assert_close(got[4].cpu(), rb[4], rtol=0, atol=2e-3 * far, msg=lambda m: 't_vals l%d: %s' % (lvl, m))
-        torch.testing.assert_close(got[0].cpu(), rb[0], rtol=0, atol=2e-3, msg=lambda m: 'rgb l%d: %s' % (lvl, m))
-        torch.testing.assert_close(got[1].cpu(), rb[1], rtol=0, atol=2e-3 * far, msg=lambda m: 'depth l%d: %s' % (lvl, m))
-        torch.testing.assert_close(got[2].cpu(), rb[2], rtol=0, atol=2e-3, msg=lambda m: 'acc l%d: %s' % (lvl, m))
-        torch.testing.assert_close(got[3].cpu(), rb[3], rtol=0, atol=2e-3, msg=lambda m: 'weights l%d: %s' % (lvl, m))
-        assert (got[0].cpu() - r32[0]).abs().max() < 2e-2, 'rgb vs fp32 oracle'
+        names = ['rgb', 'depth', 'acc', 'weights', 't_vals']
+        tols = [2e-3, 2e-3 * far, 2e-3, 2e-3, 2e-3 * far]
+        for i, (nm, tol) in enumerate(zip(names, tols)):
+            torch.testing.assert_close(got[i].cpu()[single], rb[i][single], rtol=0, atol=tol,
+                                       msg=lambda m: '%s l%d: %s' % (nm, lvl, m))
+        assert (got[0].cpu() - r32[0]).abs()[single].max() < 2e-2, 'rgb vs fp32 oracle'
+        assert torch.isfinite(got[0].cpu()[single]).all()
+        if (~single).any():
+            assert (~torch.isfinite(got[0].cpu()[~single]).all(-1) == ~torch.isfinite(rb[0][~single]).all(-1)).all()
         assert torch.equal(got[8].cpu().long().reshape(-1), rb[8].reshape(-1)), 'dyn_mask'
         torch.testing.assert_close(got[9].cpu(), rb[9], rtol=1e-6, atol=1e-5)
         torch.testing.assert_close(got[7][0].cpu(), rb[7][0])
@@ -67,8 +76,9 @@ def test_forward_parity(cuda, K, N, randomized):
 def test_forward_alpha_ramp(cuda):
     """BARF coarse-to-fine mask active (alpha = 4.5): the feature//6 weight quirk is live."""
     b, ret, ref_bf, _ = _run(cuda, 256, 2, 32, False, seed=5, alpha=4.5)
+    single = torch.tensor(b['_multi'] == 0)
     for lvl in range(2):
-        torch.testing.assert_close(ret[lvl][0].cpu(), ref_bf[lvl][0], rtol=0, atol=2e-3)
+        torch.testing.assert_close(ret[lvl][0].cpu()[single], ref_bf[lvl][0][single], rtol=0, atol=2e-3)
 
 
 def test_render_image(cuda):
