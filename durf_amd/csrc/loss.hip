@@ -1,0 +1,315 @@
+// Losses (K10) fused with the backward of activations + alpha compositing (part of K11).
+// train_boxpose.py:94-220 (loss_fn) and the reverse-mode of mip.volumetric_rendering
+// (mip.py:285-327) / obbpose_model.py:243-245.
+//
+// One wavefront per ray, same sample->lane split as the forward composite: the
+// transmittance prefix and the gradient's suffix sum are wave-level scans.  The reference's
+// O(N^2) distortion term  sum_ij w_i w_j |s_i - s_j|  is evaluated in O(N) with two more
+// prefix sums (s is sorted along a ray).
+//
+// Flow per level:  durf_loss_prep  -> per-ray {m, dm, sm, min dist^2, dyn}  -> durf_reduce_rows
+//                  -> norm[] (device)  -> durf_loss_bwd -> d(raw) [B*N,4] + per-ray loss terms
+#include "durf_common.h"
+
+struct ObjPtrsL { const float* p[DURF_MAX_OBJ]; };
+
+struct LossCfg {
+    float eps;              // near-loss half width (schedule value)
+    float c_rgb, c_sky, c_depth, c_near, c_empty, c_dist;   // multipliers of this level's terms
+    float box_loss_mult;
+    int level;              // depth_mask accumulates box_loss_mult*dyn*box once per level (:140)
+    float bg;               // background colour added with (1-acc): 0.5 / 1 / 0
+    float density_bias;
+    int disable_multiscale;
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
+
+// per-ray masks (train_boxpose.py:94-102,138-140)
+struct RayMasks { float m, dm, sm, box; };
+__device__ __forceinline__ RayMasks ray_masks(const LossCfg& c, float lossmult, float gt, float sky,
+                                              float dyn, float zo) {
+    RayMasks r;
+    r.m = c.disable_multiscale ? 1.0f : lossmult;
+    const float dm0 = gt > 0.0f ? 1.0f : 0.0f;
+    const float s0 = sky > 0.0f ? 1.0f : 0.0f;
+    r.sm = s0 - dm0 * s0;
+    r.box = gt < zo ? 1.0f : 0.0f;
+    r.dm = dm0 + (float)(c.level + 1) * (c.box_loss_mult * dyn * r.box);
+    return r;
+}
+
+// rows of the per-ray prep buffer
+enum { PREP_M = 0, PREP_DM = 1, PREP_SM = 2, PREP_MIND2 = 3, PREP_DYN = 4, PREP_ROWS = 5 };
+// rows of the per-ray loss-term buffer
+enum { LT_RGB = 0, LT_OBJ = 1, LT_DEPTH = 2, LT_NEAR = 3, LT_EMPTY = 4, LT_SKY = 5, LT_DIST = 6, LT_ROWS = 7 };
+
+__global__ void __launch_bounds__(256)
+k_loss_prep(int B, int N, const float* __restrict__ t_vals, const float* __restrict__ lossmult,
+            const float* __restrict__ gt_depth, const float* __restrict__ sky,
+            const int32_t* __restrict__ dyn, const float* __restrict__ zo, LossCfg c,
+            float* __restrict__ prep) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float gt = gt_depth[b];
+    const float dynf = (float)dyn[b];
+    const RayMasks r = ray_masks(c, lossmult[b], gt, sky[b], dynf, zo[b]);
+    float mind2 = __builtin_inff();
+    for (int n = lane; n < N; n += 64) {
+        const float t = t_vals[(size_t)b * (N + 1) + n];
+        const float ind = (t > gt - c.eps && t < gt + c.eps) ? 1.0f : 0.0f;
+        const float d = (ind * r.dm) * (t - gt);
+        mind2 = fminf(mind2, d * d);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mind2 = fminf(mind2, __shfl_xor(mind2, o, 64));
+    if (lane == 0) {
+        prep[(size_t)PREP_M * B + b] = r.m;
+        prep[(size_t)PREP_DM * B + b] = r.dm;
+        prep[(size_t)PREP_SM * B + b] = r.sm;
+        prep[(size_t)PREP_MIND2 * B + b] = mind2;
+        prep[(size_t)PREP_DYN * B + b] = dynf;
+    }
+}
+
+// deterministic row reduction: out[r] = sum (or min if r == min_row) of in[r*n .. r*n+n)
+__global__ void __launch_bounds__(1024)
+k_reduce_rows(int n, int min_row, const float* __restrict__ in, float* __restrict__ out) {
+    __shared__ float s[16];
+    const int r = blockIdx.x;
+    const bool is_min = (r == min_row);
+    const float* p = in + (size_t)r * n;
+    float v = is_min ? __builtin_inff() : 0.0f;
+    for (int i = threadIdx.x; i < n; i += 1024) v = is_min ? fminf(v, p[i]) : v + p[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o, 64);
+        v = is_min ? fminf(v, t) : v + t;
+    }
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = s[0];
+        for (int w = 1; w < 16; w++) a = is_min ? fminf(a, s[w]) : a + s[w];
+        out[r] = a;
+    }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw_obj,
+           const int32_t* __restrict__ slot, const float* __restrict__ t_vals,
+           const float* __restrict__ dirs_s, const float* __restrict__ pixels,
+           const float* __restrict__ lossmult, const float* __restrict__ gt_depth,
+           const float* __restrict__ sky, const int32_t* __restrict__ dyn,
+           const float* __restrict__ zo, const float* __restrict__ norm, LossCfg c,
+           float* __restrict__ draw, float* __restrict__ terms) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float dx = dirs_s[b * 3], dy = dirs_s[b * 3 + 1], dz = dirs_s[b * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float* tv = t_vals + (size_t)b * (N + 1);
+    const float gt = gt_depth[b], skyv = sky[b], dynf = (float)dyn[b];
+    const RayMasks rm = ray_masks(c, lossmult[b], gt, skyv, dynf, zo[b]);
+    const float sum_m = norm[PREP_M];
+    const float D = fmaxf(norm[PREP_DM], 1.0f);
+    const float Ssky = fmaxf(norm[PREP_SM], 1.0f);
+    const float sig = (c.eps / 3.0f) * (c.eps / 3.0f);            // :156
+    const float two_sig2 = 2.0f * sig * sig;
+    const float inv_max = 1.0f / expf(-(norm[PREP_MIND2] / two_sig2));   // distr /= distr.max() (:164)
+
+    // ---- recompute the forward composite (identical arithmetic to k_composite_fwd) ----
+    float a[P], col[P][3], rawd[P], tm[P], td[P], tl[P];
+    float run = 0.0f;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int n = lane * P + p;
+        a[p] = 0.f; col[p][0] = col[p][1] = col[p][2] = 0.f; rawd[p] = 0.f; tm[p] = 0.f; td[p] = 0.f; tl[p] = 0.f;
+        if (n < N) {
+            const f32x4 rb = *(const f32x4*)(raw_bkgd + ((size_t)b * N + n) * 4);
+            float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+            for (int k = 0; k < K; k++) {
+                const int s = slot[b * K + k];
+                if (s >= 0) {
+                    const f32x4 ro = *(const f32x4*)(raw_obj.p[k] + ((size_t)s * N + n) * 4);
+                    o0 += ro[0]; o1 += ro[1]; o2 += ro[2]; o3 += ro[3];
+                }
+            }
+            const float t0 = tv[n], t1 = tv[n + 1];
+            tl[p] = t0;
+            tm[p] = 0.5f * (t0 + t1);
+            td[p] = t1 - t0;
+            col[p][0] = sigmoidf_(rb[0] + o0);
+            col[p][1] = sigmoidf_(rb[1] + o1);
+            col[p][2] = sigmoidf_(rb[2] + o2);
+            rawd[p] = (rb[3] + o3) + c.density_bias;
+            a[p] = softplusf_(rawd[p]) * (td[p] * dnorm);
+        }
+        run += a[p];
+    }
+    float pre = wave_incl_scan(run, lane) - run;
+    float w[P], Tn[P];
+    float s_rgb[3] = {0.f, 0.f, 0.f}, s_acc = 0.f, s_dep = 0.f;
+    float wrun = 0.f, wsrun = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int n = lane * P + p;
+        Tn[p] = expf(-pre);
+        const float alpha = 1.0f - expf(-a[p]);
+        w[p] = (n < N) ? nan_to_num(alpha * Tn[p]) : 0.0f;
+        pre += a[p];
+        s_rgb[0] += w[p] * col[p][0]; s_rgb[1] += w[p] * col[p][1]; s_rgb[2] += w[p] * col[p][2];
+        s_acc += w[p];
+        s_dep += w[p] * tm[p];
+        wrun += w[p];
+        wsrun += w[p] * tm[p];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) s_rgb[i] = wave_sum(s_rgb[i]);
+    s_acc = wave_sum(s_acc);
+    s_dep = wave_sum(s_dep);
+    const float rem = 1.0f - s_acc;
+    const float rgb[3] = {s_rgb[0] + c.bg * rem, s_rgb[1] + c.bg * rem, s_rgb[2] + c.bg * rem};
+    const float depth = s_dep;
+
+    // ---- per-ray loss terms and their gradients wrt rgb / depth ----
+    const float m_eff = rm.m + c.box_loss_mult * dynf * rm.box;                     // :191
+    float g_rgb[3], sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float e = rgb[i] - pixels[b * 3 + i];
+        sq += e * e;
+        g_rgb[i] = c.c_rgb * 2.0f * m_eff * e / sum_m;
+    }
+    const float ed = depth - gt;
+    float g_depth = c.c_depth * 2.0f * rm.dm * ed / D;                                // :174-175
+    const float xs = rm.sm * depth;
+    const float mx = fmaxf(xs, 1.0f);
+    const float sd = rm.sm * (1.0f - 1.0f / mx);                                      // :186
+    const float es = sd - skyv;
+    const float dsd = (xs > 1.0f) ? rm.sm * rm.sm / (xs * xs) : 0.0f;
+    g_depth += c.c_sky * 2.0f * rm.sm * es * dsd / Ssky;
+
+    // ---- distortion: prefix sums of w and w*s over the ray ----
+    const float W_incl = wave_incl_scan(wrun, lane), WS_incl = wave_incl_scan(wsrun, lane);
+    const float W_tot = __shfl(W_incl, 63, 64), WS_tot = __shfl(WS_incl, 63, 64);
+    float Wlt = W_incl - wrun, WSlt = WS_incl - wsrun;    // sums over samples before this lane's run
+
+    float gw[P];
+    float t_near = 0.f, t_empty = 0.f, t_dist = 0.f, gwsum = 0.f;
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int n = lane * P + p;
+        gw[p] = 0.0f;
+        if (n < N) {
+            const float t = tl[p];
+            const float ind = (t > gt - c.eps && t < gt + c.eps) ? 1.0f : 0.0f;      // :158-161
+            const float near = ind * rm.dm;
+            const float empty = ((t > gt + c.eps) ? 1.0f : 0.0f) * rm.dm;
+            const float dist = near * (t - gt);
+            const float gval = (expf(-(dist * dist / two_sig2)) * inv_max) * near;    // :163-165
+            const float rn = near * w[p] - gval;
+            const float re = empty * w[p];
+            t_near += rn * rn;
+            t_empty += re * re;
+            float g = c.c_near * 2.0f * near * rn / D + c.c_empty * 2.0f * empty * re / D;
+            // distortion (:146-153): sum_ij w_i w_j |s_i - s_j| + (1/3) sum w_i^2 dt_i
+            const float s = tm[p];
+            const float left = s * Wlt - WSlt;                                  // sum_{j<i} w_j (s_i - s_j)
+            const float Wgt = W_tot - Wlt - w[p], WSgt = WS_tot - WSlt - w[p] * s;
+            const float right = WSgt - s * Wgt;                                 // sum_{j>i} w_j (s_j - s_i)
+            t_dist += 2.0f * w[p] * left + (1.0f / 3.0f) * w[p] * w[p] * td[p];
+            g += c.c_dist * (2.0f * (left + right) + (2.0f / 3.0f) * w[p] * td[p]);
+            // through rgb, depth (acc only enters through the background term of rgb)
+            g += g_rgb[0] * (col[p][0] - c.bg) + g_rgb[1] * (col[p][1] - c.bg) + g_rgb[2] * (col[p][2] - c.bg);
+            g += g_depth * tm[p];
+            gw[p] = g;
+            Wlt += w[p];
+            WSlt += w[p] * s;
+        }
+        gwsum += gw[p] * w[p];
+    }
+    // suffix sum of g_m w_m over m > n
+    float suf = wave_incl_rscan(gwsum, lane) - gwsum;     // samples after this lane's run
+    float loc[P];
+    {
+        float acc_loc = 0.f;
+#pragma unroll
+        for (int p = P - 1; p >= 0; p--) { loc[p] = acc_loc; acc_loc += gw[p] * w[p]; }
+    }
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int n = lane * P + p;
+        if (n < N) {
+            // w_n = (1 - e^{-a_n}) T_n ; T_m = exp(-sum_{k<m} a_k)
+            const float da = gw[p] * Tn[p] * expf(-a[p]) - (suf + loc[p]);
+            const float ddens = da * (td[p] * dnorm);
+            f32x4 o;
+            o[0] = g_rgb[0] * w[p] * col[p][0] * (1.0f - col[p][0]);
+            o[1] = g_rgb[1] * w[p] * col[p][1] * (1.0f - col[p][1]);
+            o[2] = g_rgb[2] * w[p] * col[p][2] * (1.0f - col[p][2]);
+            o[3] = ddens * sigmoidf_(rawd[p]);                 // softplus' = sigmoid
+            *(f32x4*)(draw + ((size_t)b * N + n) * 4) = o;
+        }
+    }
+    t_near = wave_sum(t_near);
+    t_empty = wave_sum(t_empty);
+    t_dist = wave_sum(t_dist);
+    if (lane == 0) {
+        terms[(size_t)LT_RGB * B + b] = m_eff * sq;
+        terms[(size_t)LT_OBJ * B + b] = dynf * sq;
+        terms[(size_t)LT_DEPTH * B + b] = rm.dm * ed * ed;
+        terms[(size_t)LT_NEAR * B + b] = t_near;
+        terms[(size_t)LT_EMPTY * B + b] = t_empty;
+        terms[(size_t)LT_SKY * B + b] = rm.sm * es * es;
+        terms[(size_t)LT_DIST * B + b] = t_dist;
+    }
+}
+
+extern "C" {
+
+int durf_loss_prep(void* stream, int B, int N, const float* t_vals, const float* lossmult,
+                   const float* gt_depth, const float* sky, const int32_t* dyn, const float* zo,
+                   float eps, float box_loss_mult, int level, int disable_multiscale, float* prep,
+                   float* norm) {
+    if (B <= 0) return 0;
+    LossCfg c = {};
+    c.eps = eps; c.box_loss_mult = box_loss_mult; c.level = level; c.disable_multiscale = disable_multiscale;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_loss_prep, dim3(durf_cdiv(B, 4)), dim3(256), 0, s, B, N, t_vals, lossmult, gt_depth,
+                       sky, dyn, zo, c, prep);
+    hipLaunchKernelGGL(k_reduce_rows, dim3(PREP_ROWS), dim3(1024), 0, s, B, (int)PREP_MIND2, prep, norm);
+    DURF_CHECK_LAUNCH("durf_loss_prep");
+    return 0;
+}
+
+int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, const float* const* raw_obj,
+                  const int32_t* slot, const float* t_vals, const float* dirs_s, const float* pixels,
+                  const float* lossmult, const float* gt_depth, const float* sky, const int32_t* dyn,
+                  const float* zo, const float* norm, float eps, const float* mults /*6: rgb,sky,depth,near,empty,dist*/,
+                  float box_loss_mult, int level, int disable_multiscale, float bg, float density_bias,
+                  float* draw, float* terms, float* term_sums) {
+    DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
+    if (B <= 0) return 0;
+    LossCfg c;
+    c.eps = eps; c.c_rgb = mults[0]; c.c_sky = mults[1]; c.c_depth = mults[2]; c.c_near = mults[3];
+    c.c_empty = mults[4]; c.c_dist = mults[5]; c.box_loss_mult = box_loss_mult; c.level = level;
+    c.bg = bg; c.density_bias = density_bias; c.disable_multiscale = disable_multiscale;
+    ObjPtrsL op;
+    for (int k = 0; k < DURF_MAX_OBJ; k++) op.p[k] = (k < K) ? raw_obj[k] : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(durf_cdiv(B, 4)), block(256);
+#define LAUNCH_L(P)                                                                                   \
+    hipLaunchKernelGGL(k_loss_bwd<P>, grid, block, 0, s, B, N, K, raw_bkgd, op, slot, t_vals, dirs_s,  \
+                       pixels, lossmult, gt_depth, sky, dyn, zo, norm, c, draw, terms)
+    if (N <= 64) LAUNCH_L(1); else if (N <= 128) LAUNCH_L(2); else LAUNCH_L(4);
+#undef LAUNCH_L
+    hipLaunchKernelGGL(k_reduce_rows, dim3(LT_ROWS), dim3(1024), 0, s, B, -1, terms, term_sums);
+    DURF_CHECK_LAUNCH("durf_loss_bwd");
+    return 0;
+}
+
+}  // extern "C"

@@ -1,11 +1,559 @@
-// Fused MLP backward (data path) + weight-gradient GEMM.  (under construction)
+// MLP backward (K11): reverse-mode of obbpose_model.py:305-354 / :369-418.
+//
+//  (1) k_mlp_bwd  -- fused data path.  Same orientation trick as the forward (mlp_spec.h):
+//      dX[in_feature, sample] = W[in_feature, out] * dZ[out, sample], gradients stay in
+//      registers from the heads back to layer 1; the ReLU masks come from the forward's
+//      bf16 activation stash (same fragment layout, so masking is element-wise), and every
+//      dZ is written once, in tile layout, for the weight-gradient GEMM.
+//  (2) k_dw       -- dW[out, in] = sum_samples dZ[sample, out] * X[sample, in].  Both
+//      operands are stored sample-major (what the fused kernels produce) but the MFMA needs
+//      the sample axis in the k-slots of each lane: ds_read_b64_tr_b16 does that transpose
+//      on the LDS read path (semantics verified by tools/probes/probe_tr.hip).  Split-K over
+//      workgroups with fp32 partials, summed in a fixed order by k_dw_finalize
+//      (deterministic; no atomics).  HBM-bound: 1 KB read per sample per 256x256 layer.
 #include "mlp_spec.h"
 
+__device__ __forceinline__ void glds16b(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// ---------------------------------------------------------------------------
+// backward weight stream: for fwd stage s = 10..1, tiles over INPUT features
+// ---------------------------------------------------------------------------
+template <int W>
+struct BwdSpec {
+    using S = MlpSpec<W>;
+    __host__ __device__ static constexpr int n_mt(int s) { return s == 10 ? S::CT : S::WT; }
+    __host__ __device__ static constexpr int n_ks(int s) {
+        return s == 10 ? 1 : (s == 9 ? S::KC : (s == 8 ? S::KW + 1 : S::KW));
+    }
+    // chunks before fwd-stage s in execution order 10, 9, ..., 1
+    __host__ __device__ static constexpr int chunk_base(int s) {
+        int c = 0;
+        for (int i = 10; i > s; i--) c += n_mt(i) * n_ks(i);
+        return c;
+    }
+    static constexpr int TOTAL_CHUNKS = chunk_base(0);
+    static constexpr int MAX_TILE_CHUNKS = S::KW + 1;
+};
+
+template <int W>
+__global__ void __launch_bounds__(256)
+k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
+    using S = MlpSpec<W>;
+    using Bs = BwdSpec<W>;
+    const int vec = blockIdx.x * blockDim.x + threadIdx.x;
+    if (vec >= Bs::TOTAL_CHUNKS * 64) return;
+    const int chunk = vec >> 6, lane = vec & 63;
+    int s = 10, base = 0;
+    for (; s >= 1; s--) {
+        const int cnt = Bs::n_mt(s) * Bs::n_ks(s);
+        if (chunk < base + cnt) break;
+        base += cnt;
+    }
+    const int rel = chunk - base;
+    const int mo = rel / Bs::n_ks(s), ks = rel % Bs::n_ks(s);
+    const int i = lane & 31, hi = lane >> 5;
+    const int row = 32 * mo + i;                    // input feature of fwd stage s
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int perm = 16 * ks + (e & 3) + 8 * (e >> 2) + 4 * hi;
+        const int nat = 8 * hi + e;
+        int L = -1, col = 0;
+        if (s == 10) { if (nat < 3) { L = 11; col = nat; } }
+        else if (s == 9) { L = 10; col = perm; }
+        else if (s == 8) { if (ks < S::KW) { L = 9; col = perm; } else if (nat == 0) { L = 8; col = 0; } }
+        else { L = s; col = perm; }
+        float val = 0.0f;
+        if (L >= 0) {
+            int fi, fo;
+            durf_layer_shape(W, in_dim, L, &fi, &fo);
+            const int row_lim = (s == 10) ? 128 : W;    // only trunk/bottleneck rows are propagated
+            if (row < row_lim && row < fi && col < fo)
+                val = P[durf_layer_offset(W, in_dim, L, 0) + (size_t)row * fo + col];
+        }
+        v[e] = (__bf16)val;
+    }
+    out[vec] = v;
+}
+
+// ---------------------------------------------------------------------------
+// fused backward data path
+// ---------------------------------------------------------------------------
+struct BPipe {
+    const char* gnext;
+    char* lds;
+    int slot_bytes, par, wave, lane;
+    __device__ __forceinline__ const char* begin(int next_chunks) {
+        __syncthreads();
+        char* dst = lds + (par ^ 1) * slot_bytes;
+        for (int c = wave; c < next_chunks; c += 8)
+            glds16b(gnext + (size_t)c * 1024 + lane * 16, dst + c * 1024);
+        gnext += (size_t)next_chunks * 1024;
+        const char* cur = lds + par * slot_bytes;
+        par ^= 1;
+        return cur;
+    }
+};
+
+template <int NA, int NB>
+__device__ __forceinline__ f32x16 bmma_tile(const char* slot, int lane, const bf16x8* inA,
+                                            const bf16x8* inB) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.0f;
+    const char* ap = slot + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < NA; ks++) {
+        const bf16x8 a = *(const bf16x8*)(ap + ks * 1024);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, inA[ks], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NB; ks++) {
+        const bf16x8 a = *(const bf16x8*)(ap + (NA + ks) * 1024);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, inB[ks], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// gradient wrt the pre-activation: pass where the stashed post-ReLU activation is non-zero
+template <bool MASK>
+__device__ __forceinline__ void bpack_tile(const f32x16& acc, const bf16x8& m0, const bf16x8& m1,
+                                           bf16x8& o0, bf16x8& o1) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float v0 = acc[e], v1 = acc[8 + e];
+        if (MASK) {
+            if ((float)m0[e] == 0.0f) v0 = 0.0f;
+            if ((float)m1[e] == 0.0f) v1 = 0.0f;
+        }
+        o0[e] = (__bf16)v0;
+        o1[e] = (__bf16)v1;
+    }
+}
+
+// one backward stage: NMT tiles over the fwd stage's input features
+template <int NA, int NB, int NMT, bool MASK>
+__device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf16x8* inB, bf16x8* out,
+                                           int next_stage_chunks, const bf16x8* mask_src,
+                                           bf16x8* dz_dst, bool valid) {
+    constexpr int CH = NA + NB;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int mo = 0; mo < NMT; mo++) {
+        const char* slot = p.begin(mo == NMT - 1 ? next_stage_chunks : CH);
+        bf16x8 m0 = zero8, m1 = zero8;
+        if (MASK && valid) { m0 = mask_src[(2 * mo) * 64]; m1 = mask_src[(2 * mo + 1) * 64]; }
+        if (mo > 0 && valid) {
+            dz_dst[(2 * mo - 2) * 64] = out[2 * mo - 2];
+            dz_dst[(2 * mo - 1) * 64] = out[2 * mo - 1];
+        }
+        const f32x16 acc = bmma_tile<NA, NB>(slot, p.lane, inA, inB);
+        bpack_tile<MASK>(acc, m0, m1, out[2 * mo], out[2 * mo + 1]);
+    }
+    if (valid) {
+        dz_dst[(2 * NMT - 2) * 64] = out[2 * NMT - 2];
+        dz_dst[(2 * NMT - 1) * 64] = out[2 * NMT - 1];
+    }
+}
+
+template <int W>
+__global__ void __launch_bounds__(512, 2)
+k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
+          const int32_t* __restrict__ count, const char* __restrict__ wpack,
+          const bf16x8* __restrict__ stash, bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out) {
+    using S = MlpSpec<W>;
+    using Bs = BwdSpec<W>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    size_t nrows = rows;
+    if (count) {
+        const size_t c = (size_t)(*count) * (size_t)N;
+        nrows = c < rows ? c : rows;
+    }
+    if ((size_t)blockIdx.x * 256 >= nrows) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const size_t tile32 = (size_t)blockIdx.x * 8 + wave;
+    const size_t row = tile32 * 32 + (lane & 31);
+    const bool valid = row < nrows;
+    const bool tile_valid = tile32 * 32 < nrows;
+    const size_t ntile32 = rows >> 5;
+
+    BPipe p;
+    p.gnext = wpack; p.lds = smem; p.slot_bytes = Bs::MAX_TILE_CHUNKS * 1024; p.par = 0;
+    p.wave = wave; p.lane = lane;
+    for (int c = wave; c < Bs::n_ks(10); c += 8)
+        glds16b(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
+    p.gnext += (size_t)Bs::n_ks(10) * 1024;
+
+    // head gradients (fp32 [*,4]: d raw_rgb[3], d raw_density); object MLPs gather by ray
+    f32x4 dr = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        size_t src = row;
+        if (ray_idx) src = (size_t)ray_idx[row / (size_t)N] * (size_t)N + row % (size_t)N;
+        dr = *(const f32x4*)(draw + src * 4);
+    }
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool lo = lane < 32;
+    bf16x8 g10[1], gd[1], gout = zero8;
+    g10[0] = zero8; gd[0] = zero8;
+    if (lo) {
+        g10[0][0] = (__bf16)dr[0]; g10[0][1] = (__bf16)dr[1]; g10[0][2] = (__bf16)dr[2];
+        gd[0][0] = (__bf16)dr[3];
+        gout = g10[0]; gout[3] = gd[0][0];
+    }
+    if (tile_valid) dz_out[tile32 * 64 + lane] = gout;      // [rows,16] tile: slots 0-2 rgb, 3 density
+
+    auto stash_at = [&](int j) -> const bf16x8* {
+        return stash + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 64 + lane;
+    };
+    auto dz_at = [&](int j) -> bf16x8* {
+        return dz + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 64 + lane;
+    };
+    bf16x8 a[S::KW], b[S::KW], c[S::KC];
+    // bwd of stage 10 (rgb head): d rgb -> d A9, masked by A9
+    run_bstage<1, 0, S::CT, true>(p, g10, nullptr, c, Bs::n_ks(9), stash_at(9), dz_at(9), tile_valid);
+    // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear)
+    run_bstage<S::KC, 0, S::WT, false>(p, c, nullptr, a, Bs::n_ks(8), nullptr, dz_at(8), tile_valid);
+    // bwd of stage 8 (bottleneck + density head): -> d A7
+    run_bstage<S::KW, 1, S::WT, true>(p, a, gd, b, S::KW, stash_at(7), dz_at(7), tile_valid);
+    // bwd of stages 7..1
+    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(6), dz_at(6), tile_valid);
+    run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(5), dz_at(5), tile_valid);
+    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(4), dz_at(4), tile_valid);
+    run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(3), dz_at(3), tile_valid);
+    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(2), dz_at(2), tile_valid);
+    run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(1), dz_at(1), tile_valid);
+    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, 0, stash_at(0), dz_at(0), tile_valid);
+}
+
+// view-direction features expanded per sample into tile layout [rows, 32] (dW of Dense_10)
+__global__ void __launch_bounds__(256)
+k_expand_view(size_t rows, int N, const bf16x8* __restrict__ view, const int32_t* __restrict__ ray_idx,
+              const int32_t* __restrict__ count, bf16x8* __restrict__ out) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte vector each
+    const size_t row = gid >> 2;
+    const int q = (int)(gid & 3);
+    size_t nrows = rows;
+    if (count) { const size_t c = (size_t)(*count) * N; nrows = c < rows ? c : rows; }
+    if (row >= nrows) return;
+    size_t ray = row / (size_t)N;
+    if (ray_idx) ray = (size_t)ray_idx[ray];
+    *(bf16x8*)((char*)out + tile_vec_offset(row, q, 2)) = view[ray * 4 + q];
+}
+
+// ---------------------------------------------------------------------------
+// weight-gradient GEMM
+// ---------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* base, int off0, int off1) {
+    const s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off0));
+    const s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + off1));
+    const s16x8 r = {r0[0], r0[1], r0[2], r0[3], r1[0], r1[1], r1[2], r1[3]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// NKO: k-steps (16 features) of dZ; NKA/NKB: k-steps of the two input segments.
+template <int NKO, int NKA, int NKB>
+__global__ void __launch_bounds__(512, 2)
+k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restrict__ dz,
+     const char* __restrict__ inA, const char* __restrict__ inB, int nsplit, int split_off,
+     float* __restrict__ part, float* __restrict__ bpart) {
+    constexpr int NKI = NKA + NKB;
+    constexpr int MO = (NKO + 1) / 2, NI = NKI / 2;
+    constexpr int RM = (MO + 3) / 4, RN = (NI + 1) / 2;
+    constexpr int STAGE = (NKO + NKI) * 1024;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    size_t nrows = rows;
+    if (count) { const size_t c = (size_t)(*count) * (size_t)N; nrows = c < rows ? c : rows; }
+    const size_t nt_valid = nrows >> 5;
+    const size_t tps = (nt_valid + nsplit - 1) / nsplit;     // even share of the VALID tiles
+    const size_t t0 = (size_t)blockIdx.x * tps;
+    size_t t1 = t0 + tps;
+    if (t1 > nt_valid) t1 = nt_valid;
+
+    // glds source swizzle: LDS vector position p of half hi_f holds sample n with
+    //   p = (n & 16) | ((n + 4*(2*(ks&1) + hi_f)) & 15)   -> conflict-free tr-reads
+    const int g_hif = lane >> 5, g_p = lane & 31;
+    auto stage_load = [&](size_t t, char* dst) {
+        for (int ci = wave; ci < NKO + NKI; ci += 8) {
+            const char* src;
+            int ks;
+            if (ci < NKO) { ks = ci; src = dz + (t * NKO + ks) * 1024; }
+            else if (ci < NKO + NKA) { ks = ci - NKO; src = inA + (t * NKA + ks) * 1024; }
+            else { ks = ci - NKO - NKA; src = inB + (t * NKB + ks) * 1024; ks += NKA; }
+            const int c = 2 * (ks & 1) + g_hif;
+            const int n = (g_p & 16) | ((g_p - 4 * c) & 15);
+            glds16b(src + (g_hif * 32 + n) * 16, dst + ci * 1024);
+        }
+    };
+    // per-lane tr-read geometry (see header comment): lane l -> group g, provider index L
+    const int g = lane >> 4, L = lane & 15;
+    const int ksp = g & 1, hi = g >> 1, j = L >> 2, q = L & 3, hi_f = q >> 1, half = q & 1;
+    const int cc = 2 * ksp + hi_f;
+    const int lane_off = hi_f * 512 + half * 8;
+    const int poff0 = ((8 * hi + 0 + j + 4 * cc) & 15) * 16;
+    const int poff1 = ((8 * hi + 4 + j + 4 * cc) & 15) * 16;
+
+    f32x16 acc[RM][RN];
+#pragma unroll
+    for (int rm = 0; rm < RM; rm++)
+#pragma unroll
+        for (int rn = 0; rn < RN; rn++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[rm][rn][r] = 0.0f;
+    float bsum[RM];
+#pragma unroll
+    for (int rm = 0; rm < RM; rm++) bsum[rm] = 0.0f;
+
+    int par = 0;
+    if (t0 < t1) stage_load(t0, smem);
+    for (size_t t = t0; t < t1; t++) {
+        __syncthreads();
+        if (t + 1 < t1) stage_load(t + 1, smem + (par ^ 1) * STAGE);
+        const char* st = smem + par * STAGE;
+        par ^= 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; kk++) {
+            bf16x8 af[RM], bf[RN];
+#pragma unroll
+            for (int rm = 0; rm < RM; rm++) {
+                const int mo = wm + 4 * rm;
+                if (mo < MO) {
+                    int ks = 2 * mo + ksp;
+                    if (ks > NKO - 1) ks = NKO - 1;            // odd NKO: duplicate, ignored later
+                    const char* base = st + ks * 1024 + lane_off + kk * 256;
+                    af[rm] = tr_frag(base, poff0, poff1);
+                }
+            }
+#pragma unroll
+            for (int rn = 0; rn < RN; rn++) {
+                const int ni = wn + 2 * rn;
+                if (ni < NI) {
+                    const char* base = st + (NKO + 2 * ni + ksp) * 1024 + lane_off + kk * 256;
+                    bf[rn] = tr_frag(base, poff0, poff1);
+                }
+            }
+#pragma unroll
+            for (int rm = 0; rm < RM; rm++) {
+                if (wm + 4 * rm < MO) {
+#pragma unroll
+                    for (int rn = 0; rn < RN; rn++)
+                        if (wn + 2 * rn < NI)
+                            acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm], bf[rn], acc[rm][rn], 0, 0, 0);
+                    if (wn == 0) {
+                        float s = 0.0f;
+#pragma unroll
+                        for (int e = 0; e < 8; e++) s += (float)af[rm][e];
+                        bsum[rm] += s;
+                    }
+                }
+            }
+        }
+    }
+    // partials in fragment coordinates: [split][mo][ni][lane][16]
+    const size_t sp = (size_t)split_off + blockIdx.x;
+#pragma unroll
+    for (int rm = 0; rm < RM; rm++) {
+        const int mo = wm + 4 * rm;
+        if (mo < MO) {
+#pragma unroll
+            for (int rn = 0; rn < RN; rn++) {
+                const int ni = wn + 2 * rn;
+                if (ni < NI) {
+                    float* dst = part + (((sp * MO + mo) * NI + ni) * 64 + lane) * 16;
+#pragma unroll
+                    for (int v = 0; v < 4; v++) {
+                        const f32x4 o = {acc[rm][rn][4 * v], acc[rm][rn][4 * v + 1], acc[rm][rn][4 * v + 2], acc[rm][rn][4 * v + 3]};
+                        *(f32x4*)(dst + 4 * v) = o;
+                    }
+                }
+            }
+            if (wn == 0) {
+                const float tot = bsum[rm] + __shfl_xor(bsum[rm], 32, 64);
+                if (lane < 32) bpart[(sp * MO + mo) * 32 + lane] = tot;
+            }
+        }
+    }
+}
+
+// slot index (position in tile-layout feature order) of feature f
+__host__ __device__ inline int cperm_slot(int f) {
+    const int w = f & 15;
+    return 16 * (f >> 4) + 8 * ((w >> 2) & 1) + (w & 3) + 4 * (w >> 3);
+}
+
+struct DwJob {
+    int layer;           // flax Dense index this job's gradient belongs to
+    int out_nat_off;     // >= 0: out slots are natural, out col c -> slot out_nat_off + c; < 0: C-perm
+    int in_perm_rows;    // rows [0, in_perm_rows) use C-perm slots (segment A) ...
+    int in_nat_base;     // ... rows beyond map to natural slots starting at this slot index
+    int MO, NI;
+};
+
+__global__ void __launch_bounds__(256)
+k_dw_finalize(int W, int in_dim, DwJob job, int nparts, const float* __restrict__ part,
+              const float* __restrict__ bpart, float* __restrict__ grad_mlp) {
+    int fi, fo;
+    durf_layer_shape(W, in_dim, job.layer, &fi, &fo);
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= fi * fo + fo) return;
+    const bool is_bias = idx >= fi * fo;
+    const int col = is_bias ? idx - fi * fo : idx % fo;
+    const int o_slot = job.out_nat_off >= 0 ? job.out_nat_off + col : cperm_slot(col);
+    const int mo = o_slot >> 5, i = o_slot & 31;
+    float s = 0.0f;
+    if (is_bias) {
+        for (int p = 0; p < nparts; p++) s += bpart[((size_t)p * job.MO + mo) * 32 + i];
+        grad_mlp[durf_layer_offset(W, in_dim, job.layer, 1) + col] = s;
+        return;
+    }
+    const int row = idx / fo;
+    const int i_slot = row < job.in_perm_rows ? cperm_slot(row) : job.in_nat_base + (row - job.in_perm_rows);
+    const int ni = i_slot >> 5, jn = i_slot & 31;
+    const int hi = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
+    const int lane = 32 * hi + jn;
+    const size_t stride = (size_t)job.MO * job.NI * 1024;
+    const float* p0 = part + (((size_t)mo * job.NI + ni) * 64 + lane) * 16 + r;
+    for (int p = 0; p < nparts; p++) s += p0[p * stride];
+    grad_mlp[durf_layer_offset(W, in_dim, job.layer, 0) + (size_t)row * fo + col] = s;
+}
+
+template <int NKO, int NKA, int NKB>
+static int launch_dw(hipStream_t s, size_t rows, int N, const int32_t* count, const void* dz, const void* inA,
+                     const void* inB, int nsplit, int split_off, float* part, float* bpart) {
+    hipLaunchKernelGGL((k_dw<NKO, NKA, NKB>), dim3(nsplit), dim3(512), 2 * (NKO + NKA + NKB) * 1024, s, rows, N,
+                       count, (const char*)dz, (const char*)inA, (const char*)inB, nsplit, split_off, part, bpart);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------
 extern "C" {
-size_t durf_wpack_bwd_bytes(int width) { (void)width; return 1024; }
+
+size_t durf_wpack_bwd_bytes(int width) {
+    return (size_t)(width == 256 ? BwdSpec<256>::TOTAL_CHUNKS : BwdSpec<128>::TOTAL_CHUNKS) * 1024;
+}
+
 int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_bwd) {
-    (void)stream; (void)width; (void)in_dim; (void)mlp_params; (void)wpack_bwd;
-    durf_set_error("durf_pack_weights_bwd: not built yet");
-    return -2;
+    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+    hipStream_t s = (hipStream_t)stream;
+    if (width == 256)
+        hipLaunchKernelGGL(k_pack_bwd<256>, dim3(durf_cdiv(BwdSpec<256>::TOTAL_CHUNKS * 64, 256)), dim3(256), 0, s,
+                           in_dim, mlp_params, (bf16x8*)wpack_bwd);
+    else
+        hipLaunchKernelGGL(k_pack_bwd<128>, dim3(durf_cdiv(BwdSpec<128>::TOTAL_CHUNKS * 64, 256)), dim3(256), 0, s,
+                           in_dim, mlp_params, (bf16x8*)wpack_bwd);
+    DURF_CHECK_LAUNCH("durf_pack_weights_bwd");
+    return 0;
 }
+
+int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
+                 const int32_t* count, const void* wpack_bwd, const void* stash, void* dz, void* dz_out) {
+    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+    DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(durf_cdiv(rows, 256)), block(512);
+    if (width == 256)
+        hipLaunchKernelGGL(k_mlp_bwd<256>, grid, block, 2 * BwdSpec<256>::MAX_TILE_CHUNKS * 1024, s, rows, N, draw,
+                           ray_idx, count, (const char*)wpack_bwd, (const bf16x8*)stash, (bf16x8*)dz, (bf16x8*)dz_out);
+    else
+        hipLaunchKernelGGL(k_mlp_bwd<128>, grid, block, 2 * BwdSpec<128>::MAX_TILE_CHUNKS * 1024, s, rows, N, draw,
+                           ray_idx, count, (const char*)wpack_bwd, (const bf16x8*)stash, (bf16x8*)dz, (bf16x8*)dz_out);
+    DURF_CHECK_LAUNCH("durf_mlp_bwd");
+    return 0;
 }
+
+int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
+                     const int32_t* count, void* out_tile) {
+    if (rows == 0) return 0;
+    hipLaunchKernelGGL(k_expand_view, dim3(durf_cdiv(rows * 4, 256)), dim3(256), 0, (hipStream_t)stream, rows, N,
+                       (const bf16x8*)view_bf16, ray_idx, count, (bf16x8*)out_tile);
+    DURF_CHECK_LAUNCH("durf_expand_view");
+    return 0;
+}
+
+size_t durf_dw_part_floats(int width) {     // floats per split of the largest job (256 x 320 / 128 x 192)
+    return width == 256 ? (size_t)8 * 10 * 1024 : (size_t)4 * 6 * 1024;
+}
+
+// All weight gradients of one MLP for one level.  Partials of this call go to split slots
+// [split_off, split_off + nsplit); durf_mlp_dw_finalize sums nparts slots in order.
+// Each of the 12 jobs has its own partial region: part + job * nparts_total * part_floats.
+int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, const void* enc_tile,
+                const void* view_tile, const void* stash, const void* dz, const void* dz_out, int nsplit,
+                int split_off, int nparts_total, float* part, float* bpart) {
+    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+    DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
+    if (rows == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nt = rows >> 5;
+    const size_t pf = durf_dw_part_floats(width) * (size_t)nparts_total;
+    const size_t bf = (size_t)8 * 32 * nparts_total;
+    auto P = [&](int job) { return part + (size_t)job * pf; };
+    auto BP = [&](int job) { return bpart + (size_t)job * bf; };
+#define REGION(base, j, KWv, KCv) ((const char*)(base) + ((size_t)(j) * (KWv) * nt) * 1024)
+    if (width == 256) {
+        constexpr int KW = 16, KC = 8, KE = 4, KV = 2;
+        launch_dw<KW, KE, 0>(s, rows, N, count, REGION(dz, 0, KW, KC), enc_tile, nullptr, nsplit, split_off, P(0), BP(0));
+        for (int j = 1; j <= 7; j++) {
+            if (j == 5) launch_dw<KW, KW, KE>(s, rows, N, count, REGION(dz, 5, KW, KC), REGION(stash, 4, KW, KC), enc_tile, nsplit, split_off, P(5), BP(5));
+            else launch_dw<KW, KW, 0>(s, rows, N, count, REGION(dz, j, KW, KC), REGION(stash, j - 1, KW, KC), nullptr, nsplit, split_off, P(j), BP(j));
+        }
+        launch_dw<1, KW, 0>(s, rows, N, count, dz_out, REGION(stash, 7, KW, KC), nullptr, nsplit, split_off, P(8), BP(8));
+        launch_dw<KW, KW, 0>(s, rows, N, count, REGION(dz, 8, KW, KC), REGION(stash, 7, KW, KC), nullptr, nsplit, split_off, P(9), BP(9));
+        launch_dw<KC, KW, KV>(s, rows, N, count, REGION(dz, 9, KW, KC), REGION(stash, 8, KW, KC), view_tile, nsplit, split_off, P(10), BP(10));
+        launch_dw<1, KC, 0>(s, rows, N, count, dz_out, REGION(stash, 9, KW, KC), nullptr, nsplit, split_off, P(11), BP(11));
+    } else {
+        constexpr int KW = 8, KC = 8, KE = 4, KV = 2;
+        launch_dw<KW, KE, 0>(s, rows, N, count, REGION(dz, 0, KW, KC), enc_tile, nullptr, nsplit, split_off, P(0), BP(0));
+        for (int j = 1; j <= 7; j++) {
+            if (j == 5) launch_dw<KW, KW, KE>(s, rows, N, count, REGION(dz, 5, KW, KC), REGION(stash, 4, KW, KC), enc_tile, nsplit, split_off, P(5), BP(5));
+            else launch_dw<KW, KW, 0>(s, rows, N, count, REGION(dz, j, KW, KC), REGION(stash, j - 1, KW, KC), nullptr, nsplit, split_off, P(j), BP(j));
+        }
+        launch_dw<1, KW, 0>(s, rows, N, count, dz_out, REGION(stash, 7, KW, KC), nullptr, nsplit, split_off, P(8), BP(8));
+        launch_dw<KW, KW, 0>(s, rows, N, count, REGION(dz, 8, KW, KC), REGION(stash, 7, KW, KC), nullptr, nsplit, split_off, P(9), BP(9));
+        launch_dw<KC, KW, KV>(s, rows, N, count, REGION(dz, 9, KW, KC), REGION(stash, 8, KW, KC), view_tile, nsplit, split_off, P(10), BP(10));
+        launch_dw<1, KC, 0>(s, rows, N, count, dz_out, REGION(stash, 9, KW, KC), nullptr, nsplit, split_off, P(11), BP(11));
+    }
+#undef REGION
+    DURF_CHECK_LAUNCH("durf_mlp_dw");
+    return 0;
+}
+
+int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nparts_total, const float* part,
+                         const float* bpart, float* grad_mlp) {
+    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+    hipStream_t s = (hipStream_t)stream;
+    const int W = width, KW = W / 16;
+    const size_t pf = durf_dw_part_floats(width) * (size_t)nparts_total;
+    const size_t bf = (size_t)8 * 32 * nparts_total;
+    for (int job = 0; job < 12; job++) {
+        DwJob J;
+        J.layer = job;
+        J.out_nat_off = -1;
+        J.in_perm_rows = W; J.in_nat_base = KW * 16;
+        int nko = KW, nki = KW;
+        if (job == 0) { J.in_perm_rows = 0; J.in_nat_base = 0; nki = 4; }
+        else if (job == 5) { nki = KW + 4; }
+        else if (job == 8) { J.out_nat_off = 3; nko = 1; }                 // density head: dz_out slot 3
+        else if (job == 10) { nko = 8; nki = KW + 2; }
+        else if (job == 11) { J.out_nat_off = 0; nko = 1; nki = 8; J.in_perm_rows = 128; J.in_nat_base = 128; }
+        J.MO = (nko + 1) / 2; J.NI = nki / 2;
+        int fi, fo;
+        durf_layer_shape(W, in_dim, job, &fi, &fo);
+        hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv((size_t)fi * fo + fo, 256)), dim3(256), 0, s, W, in_dim, J,
+                           nparts_total, part + (size_t)job * pf, bpart + (size_t)job * bf, grad_mlp);
+    }
+    DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
+    return 0;
+}
+
+}  // extern "C"

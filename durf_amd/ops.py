@@ -170,3 +170,92 @@ def resample(t_vals, weights, padding=0.01, u_rand=None):
                                         _p(None if u_rand is None else _f32(u_rand)), _p(out)),
                'durf_resample')
     return out
+
+
+# ---------------------------------------------------------------------------
+# training ops
+# ---------------------------------------------------------------------------
+PREP_ROWS, TERM_ROWS = 5, 7
+TERM_NAMES = ('rgb', 'obj', 'depth', 'near', 'empty', 'sky', 'dist')
+
+
+def loss_prep(t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level, disable_multiscale=False):
+    """-> norm[5] device floats: sum m, sum depth_mask, sum sky_mask, min near-dist^2, sum dyn."""
+    B, N = t_vals.shape[0], t_vals.shape[1] - 1
+    dev = t_vals.device
+    prep = torch.empty(PREP_ROWS, B, device=dev)
+    norm = torch.empty(PREP_ROWS, device=dev)
+    _lib.check(_lib.lib().durf_loss_prep(_stream(), B, N, _p(_f32(t_vals)), _p(_f32(lossmult)),
+                                         _p(_f32(gt_depth)), _p(_f32(sky)), _p(dyn), _p(_f32(zo)),
+                                         eps, box_loss_mult, level, int(disable_multiscale), _p(prep),
+                                         _p(norm)), 'durf_loss_prep')
+    return norm
+
+
+def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, eps,
+             mults, box_loss_mult, level, bg, density_bias=-1.0, disable_multiscale=False):
+    """-> draw [B*N,4], term_sums[7] (rgb, obj, depth, near, empty, sky, dist numerators)"""
+    B, N = t_vals.shape[0], t_vals.shape[1] - 1
+    K = len(raw_obj)
+    dev = t_vals.device
+    draw = torch.empty(B * N, 4, device=dev)
+    terms = torch.empty(TERM_ROWS, B, device=dev)
+    sums = torch.empty(TERM_ROWS, device=dev)
+    ptrs = (C.c_void_p * max(K, 1))(*[r.data_ptr() for r in raw_obj])
+    m = (C.c_float * 6)(*[float(x) for x in mults])
+    _lib.check(_lib.lib().durf_loss_bwd(_stream(), B, N, K, _p(_f32(raw_bkgd)), ptrs, _p(slot),
+                                        _p(_f32(t_vals)), _p(_f32(dirs_s)), _p(_f32(pixels)),
+                                        _p(_f32(lossmult)), _p(_f32(gt_depth)), _p(_f32(sky)), _p(dyn),
+                                        _p(_f32(zo)), _p(norm), eps, m, box_loss_mult, level,
+                                        int(disable_multiscale), bg, density_bias, _p(draw), _p(terms),
+                                        _p(sums)), 'durf_loss_bwd')
+    return draw, sums
+
+
+def mlp_bwd(width, rows, N, draw, wpack_bwd, stash, ray_idx=None, count=None):
+    """-> dz (same layout as stash), dz_out tile [rows,16]"""
+    dev = draw.device
+    dz = torch.empty_like(stash)
+    dz_out = torch.empty(tile_rows(rows), 16, dtype=torch.bfloat16, device=dev)
+    _lib.check(_lib.lib().durf_mlp_bwd(_stream(), width, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
+                                       _p(wpack_bwd), _p(stash), _p(dz), _p(dz_out)), 'durf_mlp_bwd')
+    return dz, dz_out
+
+
+def expand_view(rows, N, view_bf16, ray_idx=None, count=None):
+    out = torch.empty(tile_rows(rows), VIEW_DIM, dtype=torch.bfloat16, device=view_bf16.device)
+    _lib.check(_lib.lib().durf_expand_view(_stream(), rows, N, _p(view_bf16), _p(ray_idx), _p(count),
+                                           _p(out)), 'durf_expand_view')
+    return out
+
+
+def dw_buffers(width, nparts_total, device):
+    pf = int(_lib.lib().durf_dw_part_floats(width))
+    part = torch.empty(12 * nparts_total * pf, device=device)
+    bpart = torch.empty(12 * nparts_total * 256, device=device)
+    return part, bpart
+
+
+def mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, nsplit, split_off, nparts_total, part,
+           bpart, count=None):
+    _lib.check(_lib.lib().durf_mlp_dw(_stream(), width, rows, N, _p(count), _p(enc_tile), _p(view_tile),
+                                      _p(stash), _p(dz), _p(dz_out), nsplit, split_off, nparts_total,
+                                      _p(part), _p(bpart)), 'durf_mlp_dw')
+
+
+def mlp_dw_finalize(width, in_dim, nparts_total, part, bpart, grad_mlp):
+    _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, nparts_total, _p(part), _p(bpart),
+                                               _p(_f32(grad_mlp))), 'durf_mlp_dw_finalize')
+
+
+def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):
+    """In-place Adam step on the flat buffers; returns stats[4] (grad_norm, grad_abs_max,
+    clip multiplier, grad_norm_clipped) as a device tensor."""
+    n = params.numel()
+    dev = params.device
+    scratch = torch.empty(int(_lib.lib().durf_optim_scratch_floats(n)), device=dev)
+    stats = torch.empty(4, device=dev)
+    _lib.check(_lib.lib().durf_clip_adam(_stream(), n, _p(_f32(params)), _p(_f32(m)), _p(_f32(v)),
+                                         _p(_f32(grad)), inv_world, max_val, max_norm, lr, int(step),
+                                         _p(scratch), _p(stats)), 'durf_clip_adam')
+    return stats

@@ -37,9 +37,12 @@ def _hits(o, d, centers, rots, ext):
 
 
 def make_batch(B, K, T=5, far=40.0, seed=SEED, hit_range=(0.05, 0.15), noise_boxes=0.0,
-               img_hw=(320, 480), focal=515.0):
+               img_hw=(320, 480), focal=515.0, allow_multi_hit=False):
     """One training batch.  `noise_boxes` > 0 emulates Config.random_box (init = target
-    + U(-noise, noise) on the centres, configs/waymo.gin:6,8)."""
+    + U(-noise, noise) on the centres, configs/waymo.gin:6,8).  Rays that would hit two boxes
+    at once are re-drawn unless allow_multi_hit: the reference sums their object-frame origins
+    (obbpose_model.py:120-122, "assumes that objects do not occlude each other") and returns
+    NaN for them, which turns the whole step into a no-op."""
     rng = np.random.default_rng(seed)
     H, W = img_hw
     cx, cy = W / 2.0, H / 2.0
@@ -85,6 +88,19 @@ def make_batch(B, K, T=5, far=40.0, seed=SEED, hit_range=(0.05, 0.15), noise_box
                 scale *= 1.2
             else:
                 break
+    if K > 1 and not allow_multi_hit:
+        for _ in range(100):
+            bad = np.nonzero(_hits(o, d, centers, rots, ext).sum(-1) > 1)[0]
+            if bad.size == 0:
+                break
+            u[bad] = rng.uniform(0, W - 1, bad.size)
+            v[bad] = rng.uniform(0, H - 1, bad.size)
+            o[bad] = rng.uniform(-0.5, 0.5, (bad.size, 3))
+            d = cam_dirs(u)
+            dx = np.linalg.norm(cam_dirs(u + 1.0) - d, axis=-1)
+            radii = (dx * 2 / np.sqrt(12))[:, None]
+            viewdirs = d / np.linalg.norm(d, axis=-1, keepdims=True)
+        frac = float(_hits(o, d, centers, rots, ext).any(-1).mean())
     target_ts = np.concatenate([centers, rots], -1)   # [K,6]
     # T timesteps: the boxes drift a little between timesteps
     drift = rng.normal(0, 0.05, (T, K, 3))

@@ -113,6 +113,54 @@ int durf_composite_fwd(void* stream, int B, int N, int K, const float* raw_bkgd,
 int durf_resample(void* stream, int B, int N, const float* t_vals, const float* weights,
                   float resample_padding, const float* u_rand, float* t_vals_out);
 
+/* ---- training: losses, backward, optimizer ----------------------------------- */
+
+/* per-level normalisers of loss_fn (train_boxpose.py:94-102,138-140,164): writes
+ * prep[5,B] = per-ray {lossmult mask, depth_mask, sky_mask, min near-dist^2, dyn_mask} and
+ * norm[5] = their sums (row 3: min).  dyn[B] = sum_k hit; zo from durf_ray_setup. */
+int durf_loss_prep(void* stream, int B, int N, const float* t_vals, const float* lossmult,
+                   const float* gt_depth, const float* sky, const int32_t* dyn, const float* zo,
+                   float eps, float box_loss_mult, int level, int disable_multiscale, float* prep,
+                   float* norm);
+
+/* K10 + composite backward: per-level loss terms of train_boxpose.py:123-192 and
+ * d(loss)/d(raw) [B*N,4] through mip.volumetric_rendering / sigmoid / softplus.
+ * mults[6] = this level's multipliers of (rgb, sky, depth, near, empty, distortion) in the
+ * total loss (:211-220).  terms[7,B] per-ray numerators, term_sums[7] their sums:
+ * {rgb, obj_rgb, depth, near, empty, sky, distortion}. */
+int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, const float* const* raw_obj,
+                  const int32_t* slot, const float* t_vals, const float* dirs_s, const float* pixels,
+                  const float* lossmult, const float* gt_depth, const float* sky, const int32_t* dyn,
+                  const float* zo, const float* norm, float eps, const float* mults,
+                  float box_loss_mult, int level, int disable_multiscale, float bg, float density_bias,
+                  float* draw, float* terms, float* term_sums);
+
+/* K11 fused MLP backward (data path).  draw [*,4] fp32 head gradients (object MLPs gather
+ * rows through ray_idx); stash from durf_mlp_fwd; dz: same size/layout as stash, receives
+ * every pre-activation gradient; dz_out: tile layout [rows,16] (slots 0-2 d rgb, 3 d density). */
+int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
+                 const int32_t* count, const void* wpack_bwd, const void* stash, void* dz, void* dz_out);
+int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
+                     const int32_t* count, void* out_tile /* tile layout [rows,32] */);
+
+/* K11 weight gradients of one MLP over `rows` samples: 12 split-K GEMMs (one per Dense),
+ * fp32 partials in slots [split_off, split_off+nsplit) of `nparts_total`; the finalize call
+ * sums all slots in order into grad_mlp (flax layout of one MLP, overwritten).
+ * part: 12 * nparts_total * durf_dw_part_floats(width) floats; bpart: 12*nparts_total*256. */
+size_t durf_dw_part_floats(int width);
+int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, const void* enc_tile,
+                const void* view_tile, const void* stash, const void* dz, const void* dz_out, int nsplit,
+                int split_off, int nparts_total, float* part, float* bpart);
+int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nparts_total, const float* part,
+                         const float* bpart, float* grad_mlp);
+
+/* K12 gradient post-processing + Adam on the flat buffers (train_boxpose.py:257-289;
+ * flax.optim.Adam).  grad is scaled by inv_world (pmean), scrubbed and clipped in place;
+ * stats[4] = {grad_norm, grad_abs_max, clip multiplier, grad_norm_clipped}. */
+size_t durf_optim_scratch_floats(size_t n);
+int durf_clip_adam(void* stream, size_t n, float* params, float* m, float* v, float* grad, float inv_world,
+                   float max_val, float max_norm, float lr, int step, float* scratch, float* stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -581,6 +581,61 @@ def params_leaves(params):
     return leaves
 
 
+def level_terms(level_ret, batch, config, eps, mask, depth_mask, sky_mask):
+    """Body of the per-level loop of loss_fn (train_boxpose.py:123-192) for one level's
+    model outputs.  Returns ({term: scalar}, updated depth_mask) -- depth_mask accumulates
+    box_loss_mult*dyn*box across levels (:140)."""
+    (rgb, depth, _, weights, tvals, tmids, t_dists, off, dyn_mask, zo) = level_ret
+    dt = rgb.dtype
+    gt_depth = batch['depth'].reshape(-1)
+    gt_sky = batch['sky'].reshape(-1)
+    pixels = batch['pixels'][..., :3]
+    out = {}
+    box_mask = (gt_depth < zo).to(dt)                                 # :138
+    dyn_f = dyn_mask.to(dt)
+    depth_mask = depth_mask + config['box_loss_mult'] * dyn_f.reshape(-1) * box_mask  # :140
+
+    tv = tvals[:, :-1]                                                # :145
+    Sij = torch.abs(tmids[:, None, :] - tmids[:, :, None])            # :146-150
+    Wij = weights[..., :, None] * weights[..., None, :]
+    term1 = (Wij * Sij).sum()
+    term2 = (1 / 3) * (weights ** 2 * t_dists).sum()
+    out['distr_losses'] = term1 + term2
+
+    depth_t = batch['depth'].reshape(-1, 1).expand(tv.shape)          # :155
+    sigma = (eps / 3.) ** 2
+    mask_near = ((tv > (depth_t - eps)) & (tv < (depth_t + eps))).to(dt)
+    mask_near = mask_near * depth_mask.reshape(tv.shape[0], -1)
+    mask_empty = (tv > (depth_t + eps)).to(dt)
+    mask_empty = mask_empty * depth_mask.reshape(tv.shape[0], -1)
+    dist = mask_near * (tv - depth_t)
+    distr = 1.0 / (sigma * _pm.sqrt(2 * _pm.pi)) * torch.exp(-(dist ** 2 / (2 * sigma ** 2)))
+    distr = distr / distr.max()
+    distr = distr * mask_near
+    dm_sum = torch.clamp(depth_mask.sum(), min=1.0)
+    out['n_losses'] = ((mask_near * weights - distr) ** 2).sum() / dm_sum   # :166
+    out['e_losses'] = ((mask_empty * weights) ** 2).sum() / dm_sum           # :167
+    out['d_losses'] = (depth_mask * (depth - gt_depth) ** 2).sum() / dm_sum  # :174-175
+    sky_depth = sky_mask * (1.0 - (1.0 / torch.clamp(sky_mask * depth, min=1.0)))  # :186
+    out['s_losses'] = (sky_mask * (sky_depth - gt_sky) ** 2).sum() / torch.clamp(sky_mask.sum(), min=1.0)
+    out['losses'] = ((mask + config['box_loss_mult'] * dyn_f * box_mask[..., None])
+                     * (rgb - pixels) ** 2).sum() / mask.sum()   # :191
+    out['obj_losses'] = (dyn_f * (rgb - pixels) ** 2).sum() / dyn_f.sum()   # :192
+    return out, depth_mask
+
+
+def total_loss(S, c, weight_l2=0.0):
+    """train_boxpose.py:211-220 from stacked per-level terms."""
+    loss = c['coarse_loss_mult'] * S['losses'][:-1].sum() + S['losses'][-1] + weight_l2
+    loss = loss + c['sky_loss_mult'] * S['s_losses'][:-1].sum() + 10.0 * c['sky_loss_mult'] * S['s_losses'][-1]
+    loss = loss + c['depth_loss_mult'] * S['d_losses'][-1] + 0.1 * c['depth_loss_mult'] * S['d_losses'][:-1].sum()
+    loss = loss + c['near_loss_mult'] * S['n_losses'][-1] + 0.1 * c['near_loss_mult'] * S['n_losses'][:-1].sum()
+    loss = loss + c['empty_loss_mult'] * S['e_losses'][-1] + 0.1 * c['empty_loss_mult'] * S['e_losses'][:-1].sum()
+    loss = loss + c['tv_loss_mult'] * S['tv_losses'][-1] + 0.1 * c['tv_loss_mult'] * S['tv_losses'][:-1].sum()
+    loss = loss + 0.000001 * S['distr_losses'][-1] + 0.000001 * S['distr_losses'][:-1].sum()
+    return loss
+
+
 def loss_fn(params, batch, config, model_cfg, eps, alpha, prev, noise=None, mlp_hook=None):
     """train_boxpose.py:67-249.  Returns (loss, stats dict, model ret)."""
     leaves = params_leaves(params)
@@ -608,7 +663,8 @@ def loss_fn(params, batch, config, model_cfg, eps, alpha, prev, noise=None, mlp_
                           's_losses', 'e_losses', 'n_losses', 'sampling_stats', 'offsets',
                           'offset_x', 'offset_y', 'offset_z', 'offset_yaw')}
     pose = None
-    for (rgb, depth, _, weights, tvals, tmids, t_dists, off, dyn_mask, zo) in ret:
+    for level_ret in ret:
+        tvals, off = level_ret[4], level_ret[7]
         st['sampling_stats'] += [tvals[0, 0], tvals[0, -1]]
         pose, yaw = off
         st['offsets'].append(((pose - target[:, :3]) ** 2).sum())         # :130-134
@@ -617,48 +673,12 @@ def loss_fn(params, batch, config, model_cfg, eps, alpha, prev, noise=None, mlp_
         st['offset_z'].append(((pose[:, 2] - target[:, 2]) ** 2).sum())
         st['offset_yaw'].append(((yaw - target[:, 3:]) ** 2).sum())
         st['tv_losses'].append(((pose - prev[:, :, :3]) ** 2).sum())      # :136
-
-        box_mask = (gt_depth < zo).to(dt)                                 # :138
-        dyn_f = dyn_mask.to(dt)
-        depth_mask = depth_mask + config['box_loss_mult'] * dyn_f.reshape(-1) * box_mask  # :140
-
-        tv = tvals[:, :-1]                                                # :145
-        Sij = torch.abs(tmids[:, None, :] - tmids[:, :, None])            # :146-150
-        Wij = weights[..., :, None] * weights[..., None, :]
-        term1 = (Wij * Sij).sum()
-        term2 = (1 / 3) * (weights ** 2 * t_dists).sum()
-        st['distr_losses'].append(term1 + term2)
-
-        depth_t = batch['depth'].reshape(-1, 1).expand(tv.shape)          # :155
-        sigma = (eps / 3.) ** 2
-        mask_near = ((tv > (depth_t - eps)) & (tv < (depth_t + eps))).to(dt)
-        mask_near = mask_near * depth_mask.reshape(tv.shape[0], -1)
-        mask_empty = (tv > (depth_t + eps)).to(dt)
-        mask_empty = mask_empty * depth_mask.reshape(tv.shape[0], -1)
-        dist = mask_near * (tv - depth_t)
-        distr = 1.0 / (sigma * _pm.sqrt(2 * _pm.pi)) * torch.exp(-(dist ** 2 / (2 * sigma ** 2)))
-        distr = distr / distr.max()
-        distr = distr * mask_near
-        dm_sum = torch.clamp(depth_mask.sum(), min=1.0)
-        st['n_losses'].append(((mask_near * weights - distr) ** 2).sum() / dm_sum)   # :166
-        st['e_losses'].append(((mask_empty * weights) ** 2).sum() / dm_sum)           # :167
-        st['d_losses'].append((depth_mask * (depth - gt_depth) ** 2).sum() / dm_sum)  # :174-175
-        sky_depth = sky_mask * (1.0 - (1.0 / torch.clamp(sky_mask * depth, min=1.0)))  # :186
-        st['s_losses'].append((sky_mask * (sky_depth - gt_sky) ** 2).sum()
-                              / torch.clamp(sky_mask.sum(), min=1.0))
-        st['losses'].append(((mask + config['box_loss_mult'] * dyn_f * box_mask[..., None])
-                             * (rgb - pixels) ** 2).sum() / mask.sum())   # :191
-        st['obj_losses'].append((dyn_f * (rgb - pixels) ** 2).sum() / dyn_f.sum())   # :192
+        terms, depth_mask = level_terms(level_ret, batch, config, eps, mask, depth_mask, sky_mask)
+        for k, v in terms.items():
+            st[k].append(v)
 
     S = {k: torch.stack([torch.as_tensor(x, dtype=dt) for x in v]) for k, v in st.items()}
-    c = config
-    loss = c['coarse_loss_mult'] * S['losses'][:-1].sum() + S['losses'][-1] + weight_l2
-    loss = loss + c['sky_loss_mult'] * S['s_losses'][:-1].sum() + 10.0 * c['sky_loss_mult'] * S['s_losses'][-1]
-    loss = loss + c['depth_loss_mult'] * S['d_losses'][-1] + 0.1 * c['depth_loss_mult'] * S['d_losses'][:-1].sum()
-    loss = loss + c['near_loss_mult'] * S['n_losses'][-1] + 0.1 * c['near_loss_mult'] * S['n_losses'][:-1].sum()
-    loss = loss + c['empty_loss_mult'] * S['e_losses'][-1] + 0.1 * c['empty_loss_mult'] * S['e_losses'][:-1].sum()
-    loss = loss + c['tv_loss_mult'] * S['tv_losses'][-1] + 0.1 * c['tv_loss_mult'] * S['tv_losses'][:-1].sum()
-    loss = loss + 0.000001 * S['distr_losses'][-1] + 0.000001 * S['distr_losses'][:-1].sum()
+    loss = total_loss(S, config, weight_l2)
     S['loss'] = loss
     S['weight_l2'] = torch.as_tensor(weight_l2, dtype=dt)
     S['pose'] = pose

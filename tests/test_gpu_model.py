@@ -20,7 +20,7 @@ def _run(cuda, B, K, N, randomized, seed, alpha=10.0, far=40.0):
     utils.clear_gin()
     utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
                     'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n' % N)
-    b = synthetic.make_batch(B, K, seed=seed, far=far)
+    b = synthetic.make_batch(B, K, seed=seed, far=far, allow_multi_hit=True)
     ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
     model, variables = obbpose_model.construct_mipnerf(seed, db, device=cuda)
     # non-zero biases so bias packing is exercised

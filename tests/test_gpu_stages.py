@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(B, K, seed, cuda):
-    b = synthetic.make_batch(B, K, seed=seed)
+    b = synthetic.make_batch(B, K, seed=seed, allow_multi_hit=True)
     return b, H.oracle_batch(b), H.device_batch(b, cuda)
 
 

@@ -1,0 +1,198 @@
+"""Training-path parity: losses + composite backward (fp32, tight), fused MLP backward and
+weight-gradient GEMMs (bf16, norm-wise), clip+Adam, and one full train_step against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from durf_amd import obbpose_model, ops, synthetic, train_boxpose, utils
+from oracle import durf_ref as R
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize('N,level,blm,eps', [(128, 1, 0.0, 3.0), (64, 0, 0.0, 0.5), (32, 1, 2.0, 0.2)])
+def test_loss_and_composite_backward(cuda, N, level, blm, eps):
+    Bn, L = 384, 2
+    g = torch.Generator().manual_seed(11 + N)
+    raw = (torch.randn(Bn, N, 4, generator=g) * 1.5).requires_grad_(True)
+    t_vals = torch.sort(torch.rand(Bn, N + 1, generator=g) * 40, dim=-1).values
+    dirs = torch.randn(Bn, 3, generator=g)
+    pixels = torch.rand(Bn, 3, generator=g)
+    depth = torch.where(torch.rand(Bn, generator=g) < 0.4, torch.rand(Bn, generator=g) * 30 + 0.5, torch.zeros(Bn))[:, None]
+    sky = torch.where(torch.rand(Bn, generator=g) < 0.2, torch.full((Bn,), 0.975), torch.zeros(Bn))[:, None]
+    lossmult = torch.ones(Bn, 1)
+    dyn = (torch.rand(Bn, generator=g) < 0.2).long()[:, None]
+    zo = torch.rand(Bn, generator=g) * 20 * dyn.reshape(-1)
+    cfg = dict(R.CONFIG_DEFAULTS, box_loss_mult=blm)
+    conf = utils.Config(**{k: v for k, v in cfg.items() if k in utils.Config.__dataclass_fields__})
+    mults = train_boxpose.level_multipliers(conf, level, L)
+    # ---- oracle: autograd through volumetric_rendering + level_terms ----
+    rgb = torch.sigmoid(raw[..., :3])
+    dens = torch.nn.functional.softplus(raw[..., 3:] - 1.0)
+    vr = R.volumetric_rendering(rgb, dens, t_vals, dirs, False, False)
+    level_ret = vr + ([None, None], dyn, zo)
+    batch = dict(depth=depth, sky=sky, pixels=pixels)
+    dm0 = (depth.reshape(-1) > 0).float()
+    sm = (sky.reshape(-1) > 0).float()
+    sm = sm - dm0 * sm
+    box = (depth.reshape(-1) < zo).float()
+    dm_in = dm0 + level * blm * dyn.reshape(-1).float() * box
+    terms, _ = R.level_terms(level_ret, batch, cfg, eps, lossmult, dm_in, sm)
+    loss = (mults[0] * terms['losses'] + mults[1] * terms['s_losses'] + mults[2] * terms['d_losses'] +
+            mults[3] * terms['n_losses'] + mults[4] * terms['e_losses'] + mults[5] * terms['distr_losses'])
+    loss.backward()
+    # ---- HIP ----
+    d = lambda t: t.detach().to(cuda).contiguous()
+    dyn_i = d(dyn.reshape(-1).int())
+    norm = ops.loss_prep(d(t_vals), d(lossmult.reshape(-1)), d(depth.reshape(-1)), d(sky.reshape(-1)), dyn_i,
+                         d(zo), eps, blm, level)
+    slot = torch.full((Bn, 1), -1, dtype=torch.int32, device=cuda)
+    draw, sums = ops.loss_bwd(d(raw.reshape(-1, 4)), [], slot, d(t_vals), d(dirs), d(pixels), d(lossmult.reshape(-1)),
+                              d(depth.reshape(-1)), d(sky.reshape(-1)), dyn_i, d(zo), norm, eps, mults, blm, level, 0.5)
+    nrm, sm_ = norm.cpu(), sums.cpu()
+    D, S = max(float(nrm[1]), 1.0), max(float(nrm[2]), 1.0)
+    got = dict(losses=sm_[0] / nrm[0], obj_losses=sm_[1] / nrm[4], d_losses=sm_[2] / D, n_losses=sm_[3] / D,
+               e_losses=sm_[4] / D, s_losses=sm_[5] / S, distr_losses=sm_[6])
+    for k, v in got.items():
+        torch.testing.assert_close(v, terms[k].detach(), rtol=2e-5, atol=1e-7, msg=lambda m: k + ': ' + m)
+    gref = raw.grad.reshape(-1, 4)
+    scale = float(gref.abs().max())
+    torch.testing.assert_close(draw.cpu(), gref, rtol=1e-4, atol=2e-5 * scale)
+    assert _rel(draw.cpu(), gref) < 1e-5
+
+
+@pytest.mark.parametrize('width,in_dim', [(256, 60), (128, 63)])
+def test_mlp_backward_and_weight_grads(cuda, width, in_dim):
+    N, Bn = 32, 48
+    rows = N * Bn
+    g = torch.Generator().manual_seed(3)
+    cfg = R.MLP_BKGD if width == 256 else R.MLP_BOX
+    shapes = R.mlp_layer_shapes(in_dim, 27, cfg)
+    params, flat = [], []
+    for fi, fo in shapes:
+        lim = (6.0 / (fi + fo)) ** 0.5
+        k = ((torch.rand(fi, fo, generator=g) * 2 - 1) * lim).requires_grad_(True)
+        bb = ((torch.rand(fo, generator=g) - 0.5) * 0.2).requires_grad_(True)
+        params.append([k, bb])
+        flat += [k.detach().reshape(-1), bb.detach()]
+    flat = torch.cat(flat).to(cuda)
+    x = torch.randn(Bn, N, in_dim, generator=g).to(torch.bfloat16).float()
+    cond = torch.randn(Bn, 27, generator=g).to(torch.bfloat16).float()
+    draw = torch.randn(rows, 4, generator=g) * 0.1
+    xp = torch.zeros(rows, 64)
+    xp[:, :in_dim] = x.reshape(rows, in_dim)
+    enc_tile = H.tile(xp, 4).to(cuda)
+    view = torch.zeros(Bn, 32)
+    view[:, :27] = cond
+    view = view.to(torch.bfloat16).to(cuda)
+    wf, wb = ops.pack_weights(width, in_dim, flat, want_bwd=True)
+    stash = torch.zeros(ops.mlp_stash_bytes(width, rows), dtype=torch.uint8, device=cuda)
+    ops.mlp_fwd(width, rows, N, enc_tile, view, wf, stash=stash)
+    dz, dz_out = ops.mlp_bwd(width, rows, N, draw.to(cuda), wb, stash)
+    nsplit = 3
+    part, bpart = ops.dw_buffers(width, 2 * nsplit, cuda)
+    part.zero_(); bpart.zero_()
+    view_tile = ops.expand_view(rows, N, view)
+    # two calls into disjoint split slots (as the two levels of a training step do)
+    ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, nsplit, 0, 2 * nsplit, part, bpart)
+    ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, nsplit, nsplit, 2 * nsplit, part, bpart)
+    grad = torch.zeros_like(flat)
+    ops.mlp_dw_finalize(width, in_dim, 2 * nsplit, part, bpart, grad)
+    grad = grad.cpu() / 2
+    # oracle
+    rgb, dens = R.mlp_apply_bf16(params, x, cond, cfg)
+    out = torch.cat([rgb.reshape(rows, 3), dens.reshape(rows, 1)], -1)
+    (out * draw).sum().backward()
+    off = 0
+    for li, (k, bb) in enumerate(params):
+        gk = grad[off:off + k.numel()].reshape(k.shape); off += k.numel()
+        gb = grad[off:off + bb.numel()]; off += bb.numel()
+        assert _rel(gk, k.grad) < 3e-2, 'dW Dense_%d rel err %g' % (li, _rel(gk, k.grad))
+        assert _rel(gb, bb.grad) < 3e-2, 'db Dense_%d rel err %g' % (li, _rel(gb, bb.grad))
+    # dz_out tile: slots 0-3 = bf16(draw)
+    torch.testing.assert_close(H.untile(dz_out.cpu(), rows, 1)[:, :4], draw.to(torch.bfloat16).float(), rtol=0, atol=0)
+
+
+def test_clip_adam(cuda):
+    g = torch.Generator().manual_seed(9)
+    n = 70001
+    p = torch.randn(n, generator=g)
+    grad = torch.randn(n, generator=g) * 0.3
+    grad[5] = float('nan'); grad[6] = float('inf'); grad[7] = float('-inf')
+    cfg = dict(grad_max_val=0.1, grad_max_norm=1.0)
+    st = dict(step=0, m=[torch.zeros(n)], v=[torch.zeros(n)])
+    pd, md, vd = p.to(cuda), torch.zeros(n, device=cuda), torch.zeros(n, device=cuda)
+    leaves = [p.clone()]
+    for step in range(3):
+        gstep = grad * (1 + step)
+        g2, gmax, gnorm, gnc = R.grad_postprocess([gstep * 0.5], cfg)     # 0.5 = mean over a world of 2
+        leaves, st = R.adam_update(leaves, g2, st, 1e-3)
+        stats = ops.clip_adam(pd, md, vd, gstep.to(cuda), 0.5, 0.1, 1.0, 1e-3, step).cpu()
+        torch.testing.assert_close(stats[0], gnorm, rtol=1e-5, atol=0)
+        torch.testing.assert_close(stats[1], gmax, rtol=1e-6, atol=0)
+        torch.testing.assert_close(stats[3], gnc, rtol=1e-5, atol=0)
+        torch.testing.assert_close(pd.cpu(), leaves[0], rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(md.cpu(), st['m'][0], rtol=1e-5, atol=1e-9)
+        torch.testing.assert_close(vd.cpu(), st['v'][0], rtol=1e-5, atol=1e-12)
+
+
+@pytest.mark.parametrize('K,N', [(1, 32), (0, 64), (3, 32)])
+def test_train_step(cuda, K, N):
+    """One full step (forward, losses, backward, clip, Adam) vs the oracle with bf16-rounded
+    GEMM operands.  Loss terms: 1e-3 rel; gradients: 5e-2 norm-wise (bf16 backward)."""
+    B = 256
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
+                    'Config.randomized = True\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
+                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.0\n' % N)
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(B, K, seed=31 + K)
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(1, db, device=cuda)
+    g = torch.Generator().manual_seed(4)
+    for name in variables.layout.mlp_names():
+        for i in range(12):
+            bias = variables['params'][name]['Dense_%d' % i]['bias']
+            bias.copy_(((torch.rand(bias.shape, generator=g) - 0.5) * 0.1).to(cuda))
+    noise_c = dict(t_rand=torch.rand(B, N + 1, generator=g), u_rand=torch.rand(B, N + 1, generator=g))
+    noise_d = {k: v.to(cuda) for k, v in noise_c.items()}
+    params = H.oracle_params_from_variables(variables)
+    flat0 = variables.flat.clone()
+    prev_c = ob['init'][0:1]
+    prev_d = db['init'][0:1]
+    lr, eps, alpha = 5e-4, 3.0, 10.0
+    # gradient only (before Adam mutates the parameters)
+    grad, raw, pose = train_boxpose.loss_and_grad(model, config, 0, variables, db, eps, alpha, prev_d, noise=noise_d)
+    state = train_boxpose.create_train_state(variables)
+    new_state, stats, rng, pose = train_boxpose.train_step(model, config, 0, state, db, lr, eps, alpha, prev_d,
+                                                           noise=noise_d)
+    torch.cuda.synchronize()
+    ocfg = dict(R.CONFIG_DEFAULTS, randomized=True, tv_loss_mult=0.0)
+    p2, st2, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, dict(num_samples=N), lr, eps,
+                                           alpha, prev_c, noise=noise_c, mlp_hook=R.mlp_apply_bf16)
+    multi = (ostats['losses'] != ostats['losses']).any()
+    assert not multi, 'synthetic batch produced NaN losses (multi-hit ray) -- pick another seed'
+    for k in ('losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses'):
+        torch.testing.assert_close(getattr(stats, k).cpu(), ostats[k], rtol=2e-3, atol=1e-6, msg=lambda m: k + ': ' + m)
+    torch.testing.assert_close(stats.loss.cpu(), ostats['loss'], rtol=2e-3, atol=1e-6)
+    og = torch.cat([x.reshape(-1) for x in ograds])
+    assert og.numel() == grad.numel()
+    lay = variables.layout
+    for name in lay.mlp_names():
+        w, _ = lay.mlp_dims(name)
+        sl = slice(lay.mlp_off[name], lay.mlp_off[name] + lay.mlp_size[w])
+        if float(og[sl].norm()) > 0:
+            assert _rel(grad.cpu()[sl], og[sl]) < 5e-2, '%s grad rel err %g' % (name, _rel(grad.cpu()[sl], og[sl]))
+    torch.testing.assert_close(stats.grad_norm.cpu(), ostats['grad_norm'], rtol=3e-2, atol=0)
+    # post-Adam parameters: the first Adam step moves every weight by ~lr*sign(g)
+    newflat = torch.cat([x.reshape(-1) for x in R.params_leaves(p2)])
+    step_ref = newflat - flat0.cpu()
+    step_got = new_state.variables.flat.cpu() - flat0.cpu()
+    assert _rel(step_got, step_ref) < 0.15
+    assert new_state.step == 1
