@@ -398,32 +398,67 @@ struct DwJob {
     int MO, NI;
 };
 
+// feature id held at C-perm slot position s (inverse of cperm_slot)
+__host__ __device__ inline int cperm_feat(int s) {
+    const int e = s & 7;
+    return 16 * (s >> 4) + (e & 3) + 8 * (e >> 2) + 4 * ((s >> 3) & 1);
+}
+
+// Sum the split-K partials in fragment space (each wave reads 64 consecutive floats of a
+// partial: coalesced; 4 waves take interleaved partials with 8 loads in flight each, combined
+// in a fixed order -> deterministic), then scatter each sum to its flax [in,out] position.
+// One launch covers all 12 Dense layers of an MLP (blockIdx.y = job).
+struct DwJobs { DwJob j[12]; size_t part_stride, bpart_stride; };
+
 __global__ void __launch_bounds__(256)
-k_dw_finalize(int W, int in_dim, DwJob job, int nparts, const float* __restrict__ part,
-              const float* __restrict__ bpart, float* __restrict__ grad_mlp) {
+k_dw_finalize(int W, int in_dim, DwJobs jobs, int nparts, const float* __restrict__ part_all,
+              const float* __restrict__ bpart_all, float* __restrict__ grad_mlp) {
+    __shared__ float red[4][64];
+    const DwJob job = jobs.j[blockIdx.y];
+    const float* part = part_all + (size_t)blockIdx.y * jobs.part_stride;
+    const float* bpart = bpart_all + (size_t)blockIdx.y * jobs.bpart_stride;
     int fi, fo;
     durf_layer_shape(W, in_dim, job.layer, &fi, &fo);
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= fi * fo + fo) return;
-    const bool is_bias = idx >= fi * fo;
-    const int col = is_bias ? idx - fi * fo : idx % fo;
-    const int o_slot = job.out_nat_off >= 0 ? job.out_nat_off + col : cperm_slot(col);
-    const int mo = o_slot >> 5, i = o_slot & 31;
+    const int nfrag = job.MO * job.NI * 1024;
+    const int nb = job.MO * 32;
+    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
+    const int idx = blockIdx.x * 64 + el;
+    if (blockIdx.x * 64 >= nfrag + nb) return;
     float s = 0.0f;
-    if (is_bias) {
-        for (int p = 0; p < nparts; p++) s += bpart[((size_t)p * job.MO + mo) * 32 + i];
-        grad_mlp[durf_layer_offset(W, in_dim, job.layer, 1) + col] = s;
-        return;
+    if (idx < nfrag + nb) {
+        const float* p0 = idx < nfrag ? part + idx : bpart + (idx - nfrag);
+        const size_t stride = idx < nfrag ? (size_t)nfrag : (size_t)nb;
+        int p = grp;
+        for (; p + 28 < nparts; p += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = p0[(size_t)(p + 4 * u) * stride];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; p < nparts; p += 4) s += p0[(size_t)p * stride];
     }
-    const int row = idx / fo;
-    const int i_slot = row < job.in_perm_rows ? cperm_slot(row) : job.in_nat_base + (row - job.in_perm_rows);
-    const int ni = i_slot >> 5, jn = i_slot & 31;
-    const int hi = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);
-    const int lane = 32 * hi + jn;
-    const size_t stride = (size_t)job.MO * job.NI * 1024;
-    const float* p0 = part + (((size_t)mo * job.NI + ni) * 64 + lane) * 16 + r;
-    for (int p = 0; p < nparts; p++) s += p0[p * stride];
-    grad_mlp[durf_layer_offset(W, in_dim, job.layer, 0) + (size_t)row * fo + col] = s;
+    red[grp][el] = s;
+    __syncthreads();
+    if (grp != 0 || idx >= nfrag + nb) return;
+    s = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
+    if (idx < nfrag) {
+        const int r = idx & 15, lane = (idx >> 4) & 63, t = idx >> 10;
+        const int ni = t % job.NI, mo = t / job.NI;
+        const int hi = lane >> 5, jn = lane & 31;
+        const int o_slot = 32 * mo + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        const int i_slot = 32 * ni + jn;
+        const int col = job.out_nat_off >= 0 ? o_slot - job.out_nat_off : cperm_feat(o_slot);
+        int row;
+        if (i_slot < job.in_nat_base) row = cperm_feat(i_slot) < job.in_perm_rows ? cperm_feat(i_slot) : -1;
+        else row = job.in_perm_rows + (i_slot - job.in_nat_base);
+        if (col >= 0 && col < fo && row >= 0 && row < fi)
+            grad_mlp[durf_layer_offset(W, in_dim, job.layer, 0) + (size_t)row * fo + col] = s;
+    } else {
+        const int o_slot = idx - nfrag;
+        const int col = job.out_nat_off >= 0 ? o_slot - job.out_nat_off : cperm_feat(o_slot);
+        if (col >= 0 && col < fo) grad_mlp[durf_layer_offset(W, in_dim, job.layer, 1) + col] = s;
+    }
 }
 
 template <int NKO, int NKA, int NKB>
@@ -533,10 +568,12 @@ int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nparts_total, 
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     hipStream_t s = (hipStream_t)stream;
     const int W = width, KW = W / 16;
-    const size_t pf = durf_dw_part_floats(width) * (size_t)nparts_total;
-    const size_t bf = (size_t)8 * 32 * nparts_total;
+    DwJobs jobs;
+    jobs.part_stride = durf_dw_part_floats(width) * (size_t)nparts_total;
+    jobs.bpart_stride = (size_t)8 * 32 * nparts_total;
+    int max_el = 0;
     for (int job = 0; job < 12; job++) {
-        DwJob J;
+        DwJob& J = jobs.j[job];
         J.layer = job;
         J.out_nat_off = -1;
         J.in_perm_rows = W; J.in_nat_base = KW * 16;
@@ -547,11 +584,11 @@ int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nparts_total, 
         else if (job == 10) { nko = 8; nki = KW + 2; }
         else if (job == 11) { J.out_nat_off = 0; nko = 1; nki = 8; J.in_perm_rows = 128; J.in_nat_base = 128; }
         J.MO = (nko + 1) / 2; J.NI = nki / 2;
-        int fi, fo;
-        durf_layer_shape(W, in_dim, job, &fi, &fo);
-        hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv((size_t)fi * fo + fo, 256)), dim3(256), 0, s, W, in_dim, J,
-                           nparts_total, part + (size_t)job * pf, bpart + (size_t)job * bf, grad_mlp);
+        const int el = J.MO * J.NI * 1024 + J.MO * 32;
+        if (el > max_el) max_el = el;
     }
+    hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12), dim3(256), 0, s, W, in_dim, jobs,
+                       nparts_total, part, bpart, grad_mlp);
     DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
     return 0;
 }

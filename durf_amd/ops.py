@@ -16,6 +16,33 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+# Optional per-op timing with HIP events recorded on the launch stream (bench.py's live
+# roofline measurement).  TIMERS = None disables it (default: zero overhead).
+TIMERS = None
+
+
+class _Timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if TIMERS is not None:
+            self.e1.record()
+            TIMERS.setdefault(self.name, []).append((self.e0, self.e1))
+
+
+def timer_totals():
+    """{name: (calls, total_seconds)}; synchronises."""
+    torch.cuda.synchronize()
+    return {k: (len(v), sum(a.elapsed_time(b) for a, b in v) * 1e-3) for k, v in (TIMERS or {}).items()}
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
@@ -79,9 +106,10 @@ def encode_bkgd(t_vals, origins_s, dirs_s, radii, hit, contraction=True, tile=Tr
     dev = t_vals.device
     ot = torch.empty(tile_rows(B * N), ENC_DIM, dtype=torch.bfloat16, device=dev) if tile else None
     of = torch.empty(B * N, 60, device=dev) if f32 else None
-    _lib.check(_lib.lib().durf_encode_bkgd(_stream(), B, N, _p(_f32(t_vals)), _p(_f32(origins_s)),
-                                           _p(_f32(dirs_s)), _p(_f32(radii)), _p(hit), K,
-                                           int(contraction), _p(ot), _p(of)), 'durf_encode_bkgd')
+    with _Timed('encode_bkgd'):
+        _lib.check(_lib.lib().durf_encode_bkgd(_stream(), B, N, _p(_f32(t_vals)), _p(_f32(origins_s)),
+                                               _p(_f32(dirs_s)), _p(_f32(radii)), _p(hit), K,
+                                               int(contraction), _p(ot), _p(of)), 'durf_encode_bkgd')
     return ot, of
 
 
@@ -135,9 +163,10 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
     dev = enc_tile.device
     if raw is None:
         raw = torch.empty(rows, 4, device=dev)
-    _lib.check(_lib.lib().durf_mlp_fwd(_stream(), width, rows, N, _p(enc_tile), _p(view_bf16),
-                                       _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash)),
-               'durf_mlp_fwd')
+    with _Timed('mlp_fwd_%d%s' % (width, '_train' if stash is not None else '')):
+        _lib.check(_lib.lib().durf_mlp_fwd(_stream(), width, rows, N, _p(enc_tile), _p(view_bf16),
+                                           _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash)),
+                   'durf_mlp_fwd')
     return raw
 
 
@@ -156,10 +185,11 @@ def composite_fwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, density_bias=-1.0, bk
     t_mids = torch.empty(B, N, device=dev) if want_t else None
     t_dists = torch.empty(B, N, device=dev) if want_t else None
     ptrs = (C.c_void_p * max(K, 1))(*[r.data_ptr() for r in raw_obj])
-    _lib.check(_lib.lib().durf_composite_fwd(_stream(), B, N, K, _p(_f32(raw_bkgd)), ptrs, _p(slot),
-                                             _p(_f32(t_vals)), _p(_f32(dirs_s)), density_bias,
-                                             bkgd_mode, _p(rgb), _p(depth), _p(acc), _p(weights),
-                                             _p(t_mids), _p(t_dists)), 'durf_composite_fwd')
+    with _Timed('composite_fwd'):
+        _lib.check(_lib.lib().durf_composite_fwd(_stream(), B, N, K, _p(_f32(raw_bkgd)), ptrs, _p(slot),
+                                                 _p(_f32(t_vals)), _p(_f32(dirs_s)), density_bias,
+                                                 bkgd_mode, _p(rgb), _p(depth), _p(acc), _p(weights),
+                                                 _p(t_mids), _p(t_dists)), 'durf_composite_fwd')
     return rgb, depth, acc, weights, t_mids, t_dists
 
 
@@ -217,8 +247,9 @@ def mlp_bwd(width, rows, N, draw, wpack_bwd, stash, ray_idx=None, count=None):
     dev = draw.device
     dz = torch.empty_like(stash)
     dz_out = torch.empty(tile_rows(rows), 16, dtype=torch.bfloat16, device=dev)
-    _lib.check(_lib.lib().durf_mlp_bwd(_stream(), width, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
-                                       _p(wpack_bwd), _p(stash), _p(dz), _p(dz_out)), 'durf_mlp_bwd')
+    with _Timed('mlp_bwd_%d' % width):
+        _lib.check(_lib.lib().durf_mlp_bwd(_stream(), width, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
+                                           _p(wpack_bwd), _p(stash), _p(dz), _p(dz_out)), 'durf_mlp_bwd')
     return dz, dz_out
 
 
@@ -238,14 +269,16 @@ def dw_buffers(width, nparts_total, device):
 
 def mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, nsplit, split_off, nparts_total, part,
            bpart, count=None):
-    _lib.check(_lib.lib().durf_mlp_dw(_stream(), width, rows, N, _p(count), _p(enc_tile), _p(view_tile),
-                                      _p(stash), _p(dz), _p(dz_out), nsplit, split_off, nparts_total,
-                                      _p(part), _p(bpart)), 'durf_mlp_dw')
+    with _Timed('mlp_dw_%d' % width):
+        _lib.check(_lib.lib().durf_mlp_dw(_stream(), width, rows, N, _p(count), _p(enc_tile), _p(view_tile),
+                                          _p(stash), _p(dz), _p(dz_out), nsplit, split_off, nparts_total,
+                                          _p(part), _p(bpart)), 'durf_mlp_dw')
 
 
 def mlp_dw_finalize(width, in_dim, nparts_total, part, bpart, grad_mlp):
-    _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, nparts_total, _p(part), _p(bpart),
-                                               _p(_f32(grad_mlp))), 'durf_mlp_dw_finalize')
+    with _Timed('mlp_dw_finalize_%d' % width):
+        _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, nparts_total, _p(part), _p(bpart),
+                                                   _p(_f32(grad_mlp))), 'durf_mlp_dw_finalize')
 
 
 def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):
