@@ -1,0 +1,171 @@
+"""Host-side logic that needs no GPU: gin reader, config/type mirrors, parameter layout, the
+C-ABI library (loads, exports every symbol include/durf_hip.h declares), synthetic batches,
+layout helpers."""
+import dataclasses
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from durf_amd import _lib, obbpose_model, ops, synthetic, train_boxpose, utils
+from oracle import durf_ref as R
+from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_gin_reader_on_shipped_configs():
+    utils.clear_gin()
+    utils.parse_gin(os.path.join(ROOT, 'configs', 'waymo.gin'))
+    c = utils.configured(utils.Config)
+    assert (c.batch_size, c.far, c.grad_max_val, c.grad_max_norm) == (512, 40.0, 0.1, 1.0)
+    assert (c.depth_loss_mult, c.near_loss_mult, c.empty_loss_mult, c.sky_loss_mult) == (1e-4, 1e-2, 1.0, 1.0)
+    m = utils.configured(obbpose_model.MipNerfModel)
+    assert (m.num_samples, m.density_noise, m.no_pose_opt, m.no_yaw_opt, m.contraction) == (128, 0.0, True, True, True)
+    assert utils.configured(obbpose_model.MLP).net_width == 256
+    utils.clear_gin()
+    utils.parse_gin(os.path.join(ROOT, 'configs', 'carla_dyn.gin'))
+    assert utils.configured(utils.Config).far == 200.0
+    utils.clear_gin()
+    # defaults of the dataclasses are the reference's (internal/utils.py:93-144, obbpose_model.py:45-66)
+    d = utils.Config()
+    assert (d.batch_size, d.lr_init, d.lr_final, d.lr_delay_steps, d.coarse_loss_mult, d.rand_bkgd) == \
+        (4096, 5e-4, 5e-6, 2500, 0.1, True)
+    m = obbpose_model.MipNerfModel()
+    assert (m.num_samples, m.num_levels, m.resample_padding, m.density_bias, m.density_noise) == (128, 2, 0.01, -1., 0.1)
+
+
+def test_gin_reader_errors_and_syntax():
+    utils.clear_gin()
+    utils.parse_gin("Config.batch_size = 64  # comment\nMLP.net_activation = @flax.nn.relu\n"
+                    "Config.c2f_steps = (1, 2, 3)\ninternal.utils.Config.far = 7.5\n")
+    c = utils.configured(utils.Config)
+    assert c.batch_size == 64 and c.c2f_steps == (1, 2, 3) and c.far == 7.5
+    assert utils.configured(obbpose_model.MLP).net_activation == 'relu'
+    with pytest.raises(ValueError):
+        utils.parse_gin('this is not gin')
+    utils.clear_gin()
+    utils.parse_gin('Config.no_such_knob = 1')
+    with pytest.raises(ValueError):
+        utils.configured(utils.Config)
+    utils.clear_gin()
+
+
+def test_unsupported_knobs_fail_loudly():
+    utils.clear_gin()
+    m = obbpose_model.MipNerfModel(lindisp=True, density_noise=0.0)
+    with pytest.raises(NotImplementedError):
+        m._check()
+    m = obbpose_model.MipNerfModel(num_samples=100)
+    with pytest.raises(NotImplementedError):
+        m._check()
+    obbpose_model.MipNerfModel(num_samples=64)._check()
+
+
+def test_param_layout_matches_reference_counts():
+    lay = obbpose_model.ParamLayout(5, 3)
+    assert lay.mlp_size[256] == 594308 and lay.mlp_size[128] == 168836
+    assert lay.total == 5 * 3 * 6 + 594308 + 3 * 168836
+    flat = torch.arange(lay.total, dtype=torch.float32)
+    v = obbpose_model.Variables(flat, lay)
+    p = v['params']
+    assert p['box_centers'].shape == (5, 3, 6)
+    assert p['MLP_0']['Dense_5']['kernel'].shape == (316, 256)
+    assert p['MLP_0']['Dense_10']['kernel'].shape == (283, 128)
+    assert p['BoxMLP_2']['Dense_5']['kernel'].shape == (191, 128)
+    assert p['BoxMLP_2']['Dense_11']['bias'].shape == (3,)
+    # views alias the flat buffer, and the last leaf ends exactly at the end
+    assert p['BoxMLP_2']['Dense_11']['bias'].data_ptr() + 3 * 4 == flat.data_ptr() + lay.total * 4
+    # same order/shapes as the oracle's flax restatement
+    shapes = R.mlp_layer_shapes(60, 27, R.MLP_BKGD)
+    assert [tuple(p['MLP_0']['Dense_%d' % i]['kernel'].shape) for i in range(12)] == shapes
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    L = _lib.lib()
+    hdr = open(os.path.join(ROOT, 'include', 'durf_hip.h')).read()
+    declared = set(re.findall(r'\b(durf_[a-z0-9_]+)\s*\(', hdr))
+    assert declared, 'no declarations parsed'
+    for name in declared:
+        assert hasattr(L, name), 'libdurf_hip.so does not export %s' % name
+    assert declared == set(_lib.symbols()), declared ^ set(_lib.symbols())
+    assert L.durf_version() >= 1
+    assert L.durf_mlp_param_count(256, 60) == 594308
+    assert L.durf_mlp_param_count(128, 63) == 168836
+    for layer in range(12):
+        fi, fo = R.mlp_layer_shapes(60, 27, R.MLP_BKGD)[layer]
+        assert L.durf_mlp_layer_offset(256, 60, layer, 1) - L.durf_mlp_layer_offset(256, 60, layer, 0) == fi * fo
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libdurf_hip.so')
+    with pytest.raises(RuntimeError, match='no fallback'):
+        _lib.lib()
+
+
+def test_synthetic_batch_schema():
+    b = synthetic.make_batch(512, 3, seed=9)
+    r = b['rays']
+    assert r['origins'].shape == (512, 3) and r['radii'].shape == (512, 1) and r['far'].shape == (512, 1)
+    assert b['init'].shape == (5, 3, 6) and b['ext'].shape == (3, 3) and b['target'].shape == (3, 6)
+    assert 0 <= b['ts'] < 5 and all(v.dtype == np.float32 for v in r.values())
+    assert 0.03 <= b['hit_fraction'] <= 0.2
+    np.testing.assert_allclose(np.linalg.norm(r['viewdirs'], axis=-1), 1.0, rtol=1e-5)
+    assert abs(float(np.median(r['radii'])) - 1.1e-3) < 3e-4
+    # no ray hits two boxes (default): the oracle's dyn_mask is 0/1
+    ob = H.oracle_batch(b)
+    params = R.init_params(0, ob['init'], 3)
+    with torch.no_grad():
+        ret = R.model_apply(params, ob['rays'], b['ts'], ob['ext'], False, False, False, 10.0, cfg=dict(num_samples=4))
+    assert int(ret[0][8].max()) == 1
+    assert abs(float(ret[0][8].float().mean()) - b['hit_fraction']) < 1e-6
+
+
+def test_tile_layout_helpers_roundtrip():
+    x = torch.randn(96, 64).to(torch.bfloat16).float()
+    t = H.tile(x, 4)
+    assert torch.equal(H.untile(t, 96, 4), x)
+    # documented formula (include/durf_hip.h): elem(row,f) at (((row/32)*nks + f/16)*64 + ((f/8)&1)*32 + row%32)*8 + f%8
+    flat = t.reshape(-1).float()
+    for row, f in ((0, 0), (33, 17), (95, 63), (40, 8)):
+        off = (((row // 32) * 4 + f // 16) * 64 + ((f // 8) & 1) * 32 + row % 32) * 8 + f % 8
+        assert float(flat[off]) == float(x[row, f])
+    perm = H.cperm_cols(16)
+    assert sorted(perm.tolist()) == list(range(256))
+
+
+def test_barf_weights_host_side():
+    for alpha in (0.0, 2.5, 4.5, 10.0):
+        w = ops.barf_weights(alpha)
+        ref = R.barf_weights(alpha, 10, torch.float32).numpy()
+        np.testing.assert_allclose(w, ref, rtol=0, atol=2e-7)
+
+
+def test_level_multipliers_follow_total_loss():
+    c = utils.Config(coarse_loss_mult=0.1, sky_loss_mult=2.0, depth_loss_mult=3.0, near_loss_mult=4.0, empty_loss_mult=5.0)
+    assert train_boxpose.level_multipliers(c, 1, 2) == [1.0, 20.0, 3.0, 4.0, 5.0, 1e-6]
+    np.testing.assert_allclose(train_boxpose.level_multipliers(c, 0, 2), [0.1, 2.0, 0.3, 0.4, 0.5, 1e-6])
+    # cross-check with the oracle's total_loss on random per-level terms
+    S = {k: torch.rand(2, dtype=torch.float64) for k in ('losses', 's_losses', 'd_losses', 'n_losses', 'e_losses', 'distr_losses')}
+    S['tv_losses'] = torch.zeros(2, dtype=torch.float64)
+    want = R.total_loss(S, dict(dataclasses.asdict(c)))
+    got = 0.0
+    for lvl in range(2):
+        m = train_boxpose.level_multipliers(c, lvl, 2)
+        got = got + m[0] * S['losses'][lvl] + m[1] * S['s_losses'][lvl] + m[2] * S['d_losses'][lvl] + \
+            m[3] * S['n_losses'][lvl] + m[4] * S['e_losses'][lvl] + m[5] * S['distr_losses'][lvl]
+    assert abs(float(got) - float(want)) < 1e-12
+
+
+def test_shard_batch_errors_like_the_reference():
+    b = synthetic.make_batch(30, 1, seed=1)
+    ob = {k: (torch.tensor(v) if isinstance(v, np.ndarray) else v) for k, v in b.items() if k != 'rays'}
+    ob['rays'] = utils.BoxRays(**{k: torch.tensor(v) for k, v in b['rays'].items()})
+    with pytest.raises(ValueError, match='divisible'):
+        train_boxpose.shard_batch(ob, 0, 4)
+    s = train_boxpose.shard_batch(ob, 1, 2)
+    assert s['pixels'].shape[0] == 15 and s['rays'].origins.shape[0] == 15 and s['init'].shape == ob['init'].shape
+    assert torch.equal(s['pixels'], ob['pixels'][15:])

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz: seeded inputs + the float64 oracle's outputs for them.
+
+The reference (JAX) cannot be imported here, so these vectors are NOT reference outputs:
+they pin the float64 evaluation of the restated algorithm (oracle/durf_ref.py) so that (a) the
+fp32 oracle, (b) the HIP path and (c) any later edit of either are checked against one fixed
+truth.  Parameters are regenerated from a seed by construct_mipnerf (CPU torch generator);
+a checksum guards against RNG drift.  Run:  python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from durf_amd import obbpose_model, synthetic, utils  # noqa: E402
+from oracle import durf_ref as R  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+CASES = {   # name: (B, K, N, randomized, alpha, seed)
+    'static_K0_N64': (48, 0, 64, False, 10.0, 101),
+    'dynamic_K1_N32': (64, 1, 32, False, 10.0, 102),
+    'dynamic_K3_N32_rand_alpha': (96, 3, 32, True, 4.5, 103),
+}
+
+
+def build_case(name):
+    B, K, N, randomized, alpha, seed = CASES[name]
+    b = synthetic.make_batch(B, K, seed=seed)
+    cb = {k: (torch.tensor(v) if isinstance(v, np.ndarray) else v) for k, v in b.items() if k != 'rays'}
+    utils.clear_gin()
+    model, variables = obbpose_model.construct_mipnerf(seed, cb, device='cpu')
+    g = torch.Generator().manual_seed(seed)
+    for nm in variables.layout.mlp_names():
+        for i in range(12):
+            bias = variables['params'][nm]['Dense_%d' % i]['bias']
+            bias.copy_((torch.rand(bias.shape, generator=g) - 0.5) * 0.1)
+    noise = dict(t_rand=torch.rand(B, N + 1, generator=g), u_rand=torch.rand(B, N + 1, generator=g))
+    return b, variables, noise
+
+
+def oracle_outputs(name, dt=torch.float64):
+    B, K, N, randomized, alpha, seed = CASES[name]
+    b, variables, noise = build_case(name)
+    ob = H.oracle_batch(b, dt)
+    params = H.oracle_params_from_variables(variables, dt)
+    cfg = dict(R.CONFIG_DEFAULTS, randomized=randomized, tv_loss_mult=0.0)
+    mcfg = dict(num_samples=N)
+    nz = {k: v.to(dt) for k, v in noise.items()} if randomized else None
+    _, _, stats, grads = R.train_step(params, R.new_opt_state(params), ob, cfg, mcfg, 5e-4, 3.0, alpha,
+                                      ob['init'][0:1], noise=nz)
+    with torch.no_grad():
+        ret = R.model_apply(params, ob['rays'], b['ts'], ob['ext'], randomized, False, False, alpha, noise=nz, cfg=mcfg)
+    out = {}
+    for lvl in range(2):
+        for i, nm in enumerate(('rgb', 'depth', 'acc', 'weights', 't_vals')):
+            out['l%d_%s' % (lvl, nm)] = ret[lvl][i].numpy()
+    out['dyn_mask'] = ret[0][8].numpy()
+    for k in ('loss', 'losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses'):
+        out['stat_' + k] = stats[k].numpy()
+    leaves_g = torch.cat([x.reshape(-1) for x in grads])
+    out['grad_norm'] = np.array(float(leaves_g.norm()))
+    out['grad_head'] = leaves_g[30 * K:30 * K + 4096].numpy()        # first 4096 entries of MLP_0/Dense_0 kernel grad
+    return b, variables, noise, out
+
+
+def main():
+    gold = os.path.join(ROOT, 'tests', 'golden')
+    os.makedirs(gold, exist_ok=True)
+    for name in CASES:
+        b, variables, noise, out = oracle_outputs(name)
+        flat = variables.flat.double()
+        rec = dict(out)
+        rec['param_checksum'] = np.array([float(flat.sum()), float((flat * flat).sum())])
+        rec['t_rand'] = noise['t_rand'].numpy()
+        rec['u_rand'] = noise['u_rand'].numpy()
+        path = os.path.join(gold, name + '.npz')
+        np.savez_compressed(path, **rec)
+        print(name, '%.1f KB' % (os.path.getsize(path) / 1024), 'loss', float(out['stat_loss']))
+
+
+if __name__ == '__main__':
+    main()
