@@ -21,20 +21,25 @@ __device__ __forceinline__ void glds16b(const void* g, void* l) {
 // ---------------------------------------------------------------------------
 // backward weight stream: for fwd stage s = 10..1, tiles over INPUT features
 // ---------------------------------------------------------------------------
+// Backward stages in execution order.  b: 0..5 = fwd stages 10,9,8,7,6,5 (trunk rows),
+// 6 = input-encoding rows of Dense_5 (skip connection; only needed for box-pose gradients),
+// 7..10 = fwd stages 4,3,2,1, 11 = Dense_0 -> d encoding (box-pose gradients only).
 template <int W>
 struct BwdSpec {
     using S = MlpSpec<W>;
-    __host__ __device__ static constexpr int n_mt(int s) { return s == 10 ? S::CT : S::WT; }
-    __host__ __device__ static constexpr int n_ks(int s) {
-        return s == 10 ? 1 : (s == 9 ? S::KC : (s == 8 ? S::KW + 1 : S::KW));
+    static constexpr int NB = 12;
+    __host__ __device__ static constexpr int fwd_stage(int b) { return b <= 5 ? 10 - b : (b == 6 ? 5 : (b <= 10 ? 11 - b : 0)); }
+    __host__ __device__ static constexpr bool is_enc(int b) { return b == 6 || b == 11; }
+    __host__ __device__ static constexpr int n_mt(int b) { return is_enc(b) ? S::KE / 2 : (b == 0 ? S::CT : S::WT); }
+    __host__ __device__ static constexpr int n_ks(int b) {
+        return b == 0 ? 1 : (b == 1 ? S::KC : (b == 2 ? S::KW + 1 : S::KW));
     }
-    // chunks before fwd-stage s in execution order 10, 9, ..., 1
-    __host__ __device__ static constexpr int chunk_base(int s) {
+    __host__ __device__ static constexpr int chunk_base(int b) {
         int c = 0;
-        for (int i = 10; i > s; i--) c += n_mt(i) * n_ks(i);
+        for (int i = 0; i < b; i++) c += n_mt(i) * n_ks(i);
         return c;
     }
-    static constexpr int TOTAL_CHUNKS = chunk_base(0);
+    static constexpr int TOTAL_CHUNKS = chunk_base(NB);
     static constexpr int MAX_TILE_CHUNKS = S::KW + 1;
 };
 
@@ -46,16 +51,19 @@ k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
     const int vec = blockIdx.x * blockDim.x + threadIdx.x;
     if (vec >= Bs::TOTAL_CHUNKS * 64) return;
     const int chunk = vec >> 6, lane = vec & 63;
-    int s = 10, base = 0;
-    for (; s >= 1; s--) {
-        const int cnt = Bs::n_mt(s) * Bs::n_ks(s);
+    int b = 0, base = 0;
+    for (; b < Bs::NB; b++) {
+        const int cnt = Bs::n_mt(b) * Bs::n_ks(b);
         if (chunk < base + cnt) break;
         base += cnt;
     }
+    const int s = Bs::fwd_stage(b);
+    const bool enc_rows = Bs::is_enc(b);
     const int rel = chunk - base;
-    const int mo = rel / Bs::n_ks(s), ks = rel % Bs::n_ks(s);
+    const int mo = rel / Bs::n_ks(b), ks = rel % Bs::n_ks(b);
     const int i = lane & 31, hi = lane >> 5;
-    const int row = 32 * mo + i;                    // input feature of fwd stage s
+    // input feature (kernel row) of fwd stage s this A-fragment row stands for
+    const int row = enc_rows ? (s == 5 ? W : 0) + 32 * mo + i : 32 * mo + i;
     bf16x8 v;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -70,7 +78,7 @@ k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
         if (L >= 0) {
             int fi, fo;
             durf_layer_shape(W, in_dim, L, &fi, &fo);
-            const int row_lim = (s == 10) ? 128 : W;    // only trunk/bottleneck rows are propagated
+            const int row_lim = enc_rows ? fi : ((s == 10) ? 128 : W);   // trunk/bottleneck rows, or the encoding rows
             if (row < row_lim && row < fi && col < fo)
                 val = P[durf_layer_offset(W, in_dim, L, 0) + (size_t)row * fo + col];
         }
@@ -86,6 +94,7 @@ struct BPipe {
     const char* gnext;
     char* lds;
     int slot_bytes, par, wave, lane;
+    __device__ __forceinline__ void skip(int chunks) { gnext += (size_t)chunks * 1024; }
     __device__ __forceinline__ const char* begin(int next_chunks) {
         __syncthreads();
         char* dst = lds + (par ^ 1) * slot_bytes;
@@ -138,11 +147,12 @@ __device__ __forceinline__ void bpack_tile(const f32x16& acc, const bf16x8& m0, 
 template <int NA, int NB, int NMT, bool MASK>
 __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf16x8* inB, bf16x8* out,
                                            int next_stage_chunks, const bf16x8* mask_src,
-                                           bf16x8* dz_dst, bool valid) {
+                                           bf16x8* dz_dst, bool valid, int skip_chunks = 0) {
     constexpr int CH = NA + NB;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int mo = 0; mo < NMT; mo++) {
+        if (mo == NMT - 1) p.skip(skip_chunks);      // stages this variant does not run
         const char* slot = p.begin(mo == NMT - 1 ? next_stage_chunks : CH);
         bf16x8 m0 = zero8, m1 = zero8;
         if (MASK && valid) { m0 = mask_src[(2 * mo) * 64]; m1 = mask_src[(2 * mo + 1) * 64]; }
@@ -159,11 +169,25 @@ __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf
     }
 }
 
-template <int W>
+// d(enc) stage (box-pose gradients): 2 output tiles = the 64 encoding features, fp32 accumulators
+template <int NA>
+__device__ __forceinline__ void run_enc_stage(BPipe& p, const bf16x8* in, f32x16* denc, bool add,
+                                              int next_stage_chunks) {
+#pragma unroll
+    for (int mo = 0; mo < 2; mo++) {
+        const char* slot = p.begin(mo == 1 ? next_stage_chunks : NA);
+        const f32x16 acc = bmma_tile<NA, 0>(slot, p.lane, in, nullptr);
+#pragma unroll
+        for (int r = 0; r < 16; r++) denc[mo][r] = add ? denc[mo][r] + acc[r] : acc[r];
+    }
+}
+
+template <int W, bool POSE>
 __global__ void __launch_bounds__(512, 2)
 k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
           const int32_t* __restrict__ count, const char* __restrict__ wpack,
-          const bf16x8* __restrict__ stash, bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out) {
+          const bf16x8* __restrict__ stash, bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out,
+          float* __restrict__ d_enc) {
     using S = MlpSpec<W>;
     using Bs = BwdSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -184,9 +208,9 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     BPipe p;
     p.gnext = wpack; p.lds = smem; p.slot_bytes = Bs::MAX_TILE_CHUNKS * 1024; p.par = 0;
     p.wave = wave; p.lane = lane;
-    for (int c = wave; c < Bs::n_ks(10); c += 8)
+    for (int c = wave; c < Bs::n_ks(0); c += 8)
         glds16b(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
-    p.gnext += (size_t)Bs::n_ks(10) * 1024;
+    p.gnext += (size_t)Bs::n_ks(0) * 1024;
 
     // head gradients (fp32 [*,4]: d raw_rgb[3], d raw_density); object MLPs gather by ray
     f32x4 dr = {0.f, 0.f, 0.f, 0.f};
@@ -214,19 +238,40 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     };
     bf16x8 a[S::KW], b[S::KW], c[S::KC];
     // bwd of stage 10 (rgb head): d rgb -> d A9, masked by A9
-    run_bstage<1, 0, S::CT, true>(p, g10, nullptr, c, Bs::n_ks(9), stash_at(9), dz_at(9), tile_valid);
+    run_bstage<1, 0, S::CT, true>(p, g10, nullptr, c, S::KC, stash_at(9), dz_at(9), tile_valid);
     // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear)
-    run_bstage<S::KC, 0, S::WT, false>(p, c, nullptr, a, Bs::n_ks(8), nullptr, dz_at(8), tile_valid);
+    run_bstage<S::KC, 0, S::WT, false>(p, c, nullptr, a, S::KW + 1, nullptr, dz_at(8), tile_valid);
     // bwd of stage 8 (bottleneck + density head): -> d A7
     run_bstage<S::KW, 1, S::WT, true>(p, a, gd, b, S::KW, stash_at(7), dz_at(7), tile_valid);
-    // bwd of stages 7..1
+    // bwd of stages 7, 6 -> d Z6, d Z5
     run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(6), dz_at(6), tile_valid);
     run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(5), dz_at(5), tile_valid);
-    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(4), dz_at(4), tile_valid);
+    // bwd of stage 5: trunk rows -> d Z4 (in a); encoding rows (skip connection) only for POSE
+    constexpr int ENC_CHUNKS = (S::KE / 2) * S::KW;
+    f32x16 denc[2];
+    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(4), dz_at(4), tile_valid,
+                                      POSE ? 0 : ENC_CHUNKS);
+    if (POSE) run_enc_stage<S::KW>(p, b, denc, false, S::KW);
+    // bwd of stages 4..1
     run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(3), dz_at(3), tile_valid);
     run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(2), dz_at(2), tile_valid);
     run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(1), dz_at(1), tile_valid);
-    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, 0, stash_at(0), dz_at(0), tile_valid);
+    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, POSE ? S::KW : 0, stash_at(0), dz_at(0), tile_valid);
+    if (POSE) {
+        // Dense_0 -> d(encoding); total d enc = skip-connection part + first-layer part
+        run_enc_stage<S::KW>(p, a, denc, true, 0);
+        if (valid) {
+            const int hi = lane >> 5;
+            float* dst = d_enc + row * DURF_ENC_DIM;
+#pragma unroll
+            for (int mo = 0; mo < 2; mo++)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; g4++) {
+                    const f32x4 o = {denc[mo][4 * g4], denc[mo][4 * g4 + 1], denc[mo][4 * g4 + 2], denc[mo][4 * g4 + 3]};
+                    *(f32x4*)(dst + 32 * mo + 8 * g4 + 4 * hi) = o;
+                }
+        }
+    }
 }
 
 // view-direction features expanded per sample into tile layout [rows, 32] (dW of Dense_10)
@@ -490,18 +535,20 @@ int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_
 }
 
 int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
-                 const int32_t* count, const void* wpack_bwd, const void* stash, void* dz, void* dz_out) {
+                 const int32_t* count, const void* wpack_bwd, const void* stash, void* dz, void* dz_out,
+                 float* d_enc) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(durf_cdiv(rows, 256)), block(512);
-    if (width == 256)
-        hipLaunchKernelGGL(k_mlp_bwd<256>, grid, block, 2 * BwdSpec<256>::MAX_TILE_CHUNKS * 1024, s, rows, N, draw,
-                           ray_idx, count, (const char*)wpack_bwd, (const bf16x8*)stash, (bf16x8*)dz, (bf16x8*)dz_out);
-    else
-        hipLaunchKernelGGL(k_mlp_bwd<128>, grid, block, 2 * BwdSpec<128>::MAX_TILE_CHUNKS * 1024, s, rows, N, draw,
-                           ray_idx, count, (const char*)wpack_bwd, (const bf16x8*)stash, (bf16x8*)dz, (bf16x8*)dz_out);
+#define LAUNCH_B(WW, PP)                                                                                   \
+    hipLaunchKernelGGL((k_mlp_bwd<WW, PP>), grid, block, 2 * BwdSpec<WW>::MAX_TILE_CHUNKS * 1024, s, rows, N, \
+                       draw, ray_idx, count, (const char*)wpack_bwd, (const bf16x8*)stash, (bf16x8*)dz,    \
+                       (bf16x8*)dz_out, d_enc)
+    if (width == 256) { if (d_enc) LAUNCH_B(256, true); else LAUNCH_B(256, false); }
+    else { if (d_enc) LAUNCH_B(128, true); else LAUNCH_B(128, false); }
+#undef LAUNCH_B
     DURF_CHECK_LAUNCH("durf_mlp_bwd");
     return 0;
 }

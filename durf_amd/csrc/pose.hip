@@ -1,0 +1,218 @@
+// Box-pose gradients (part of K11): reverse-mode of the object branch of MipNerfModel.__call__
+// from d(loss)/d(object encoding) back to box_centers[ts, k, :6]:
+//   weighted_ipe (mip.py:182-223)  ->  cast_rays / conical frustum (mip.py:155-179,99-130,76-96)
+//   ->  world2object_rpy (box_helpers.py:286-341)  ->  aa2matrix (box_helpers.py:148-167).
+// `hit` is stop-gradient (obbpose_model.py:113) and level-1 t_vals are stop-gradient
+// (mip.py:413-414), so the only path is (o', d') -> sample Gaussians -> encoding.
+//
+// k_encode_obj_bwd: one wavefront per hit ray; per sample 60 sin/cos/exp (VALU-bound, but only
+// hit rays are processed); reduces over the ray's samples to d(o'), d(d'), then to the 21
+// per-ray sums that determine dL/dR and dL/dc.  Reduction over rays is a fixed-order row sum.
+#include "gauss.h"
+
+enum { POSE_ROWS = 21 };   // [0..2] sum g_o ; [3..11] sum g_o (x) o ; [12..20] sum g_u (x) d
+
+template <int P>
+__global__ void __launch_bounds__(256)
+k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+                 const float* __restrict__ d_enc, const float* __restrict__ t_vals,
+                 const float* __restrict__ origins_s, const float* __restrict__ dirs_s,
+                 const float* __restrict__ radii, const float* __restrict__ origins,
+                 const float* __restrict__ dirs, const float* __restrict__ pose, BarfW bw,
+                 float* __restrict__ rows_out /* [21][B], column j = compact ray index */) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= *count) return;
+    const int b = idx[j];
+    const float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
+    const float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
+    const float radius = radii[b];
+    const float dsum = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+    const float m = fmaxf(1e-10f, dsum);
+    float go[3] = {0.f, 0.f, 0.f}, gd[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int n = lane * P + p;
+        if (n >= N) continue;
+        const float t0 = t_vals[(size_t)b * (N + 1) + n], t1 = t_vals[(size_t)b * (N + 1) + n + 1];
+        // forward quantities (same formulas as frustum_gaussian)
+        const float mu = (t0 + t1) / 2.0f, hw = (t1 - t0) / 2.0f;
+        const float mu2 = mu * mu, hw2 = hw * hw, den = 3.0f * mu2 + hw2, hw4 = hw2 * hw2;
+        const float t_mean = mu + (2.0f * mu * hw2) / den;
+        const float t_var = hw2 / 3.0f - (4.0f / 15.0f) * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
+        const float r_var = (radius * radius) * (mu2 / 4.0f + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / den);
+        float x[3], var[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            x[i] = d[i] * t_mean + o[i];
+            var[i] = t_var * (d[i] * d[i]) + r_var * (1.0f - d[i] * (d[i] / m));
+        }
+        const float* ge = d_enc + ((size_t)j * N + n) * DURF_ENC_DIM;
+        float gx[3] = {ge[0], ge[1], ge[2]}, gv[3] = {0.f, 0.f, 0.f};     // identity features (mip.py:222)
+        for (int f = 0; f < 60; f++) {
+            const int c = f / 30, r = f - c * 30, deg = r / 3, i = r - deg * 3;
+            const float sc = (float)(1 << deg);
+            float z = x[i] * sc;
+            if (c) z = z + 1.5707963705062866f;
+            const float t = 314.15927124023438f;                          // safe_sin wrap (math.py:35-46)
+            if (!(fabsf(z) < t)) { float q = fmodf(z, t); if (q != 0.0f && q < 0.0f) q += t; z = q; }
+            const float e = expf(-0.5f * (var[i] * sc * sc));
+            const float g = ge[3 + f] * bw.w[f / 6];
+            gx[i] += g * e * sc * cosf(z);
+            gv[i] += g * (-0.5f * sc * sc) * e * sinf(z);
+        }
+        // x_i = o_i + d_i t_mean ; var_i = t_var d_i^2 + r_var (1 - d_i^2 / m)
+        float s_gv = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 3; i++) s_gv += gv[i] * r_var * (d[i] * d[i]) / (m * m);
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            go[i] += gx[i];
+            float g = gx[i] * t_mean + gv[i] * (2.0f * t_var * d[i]) - gv[i] * r_var * (2.0f * d[i] / m);
+            if (dsum > 1e-10f) g += s_gv * 2.0f * d[i];                   // through m = max(1e-10, |d|^2)
+            gd[i] += g;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { go[i] = wave_sum(go[i]); gd[i] = wave_sum(gd[i]); }
+    if (lane != 0) return;
+    // o' = R (o_w - c), u = R d_w, d' = u / |u|  (box_helpers.py:323-340)
+    const float* pk = pose + k_obj * 6;
+    const float rx = pk[3], ry = pk[4], rz = pk[5];
+    float s = rx * rx + ry * ry + rz * rz;
+    s = (s < 1e-12f) ? 1e-12f : s;
+    const float th = sqrtf(s) + 1e-12f;
+    const float a = sinf(th) / th, bb = (1.0f - cosf(th)) / (th * th);
+    const float S[9] = {0.f, -rz, ry, rz, 0.f, -rx, -ry, rx, 0.f};
+    float R[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            const float s2 = S[i * 3] * S[q] + S[i * 3 + 1] * S[3 + q] + S[i * 3 + 2] * S[6 + q];
+            R[i * 3 + q] = ((i == q) ? 1.0f : 0.0f) + a * S[i * 3 + q] + bb * s2;
+        }
+    const float ow[3] = {origins[b * 3], origins[b * 3 + 1], origins[b * 3 + 2]};
+    const float dw[3] = {dirs[b * 3], dirs[b * 3 + 1], dirs[b * 3 + 2]};
+    float u[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) u[i] = R[i * 3] * dw[0] + R[i * 3 + 1] * dw[1] + R[i * 3 + 2] * dw[2];
+    const float nrm = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+    const float dp[3] = {u[0] / nrm, u[1] / nrm, u[2] / nrm};
+    const float dot = dp[0] * gd[0] + dp[1] * gd[1] + dp[2] * gd[2];
+    float gu[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) gu[i] = (gd[i] - dp[i] * dot) / nrm;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        rows_out[(size_t)i * B + j] = go[i];
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            rows_out[(size_t)(3 + i * 3 + q) * B + j] = go[i] * ow[q];
+            rows_out[(size_t)(12 + i * 3 + q) * B + j] = gu[i] * dw[q];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(1024)
+k_pose_reduce(int n, const int32_t* __restrict__ count, const float* __restrict__ in, float* __restrict__ out) {
+    __shared__ float sh[16];
+    const int r = blockIdx.x;
+    const int c = *count < n ? *count : n;
+    const float* p = in + (size_t)r * n;
+    float v = 0.0f;
+    for (int i = threadIdx.x; i < c; i += 1024) v += p[i];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = sh[0];
+        for (int w = 1; w < 16; w++) a += sh[w];
+        out[r] += a;                       // accumulates over levels (caller zeroes)
+    }
+}
+
+// sums[K][21] -> d(loss)/d(box_centers[ts, k, 0:6]) (added into grad6[K][6])
+__global__ void k_pose_finish(int K, const float* __restrict__ pose, const float* __restrict__ sums,
+                              int want_pos, int want_rot, float* __restrict__ grad6) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const float* pk = pose + k * 6;
+    const float* sm = sums + k * POSE_ROWS;
+    const float c[3] = {pk[0], pk[1], pk[2]};
+    const float r[3] = {pk[3], pk[4], pk[5]};
+    const float s0 = r[0] * r[0] + r[1] * r[1] + r[2] * r[2];
+    const bool tiny = s0 < 1e-12f;
+    const float s = tiny ? 1e-12f : s0;
+    const float rt = sqrtf(s);
+    const float th = rt + 1e-12f;
+    const float sn = sinf(th), cs = cosf(th);
+    const float a = sn / th, b = (1.0f - cs) / (th * th);
+    const float da = (th * cs - sn) / (th * th);
+    const float db = (th * sn - 2.0f * (1.0f - cs)) / (th * th * th);
+    float Km[9] = {0.f, -r[2], r[1], r[2], 0.f, -r[0], -r[1], r[0], 0.f};
+    float K2[9], R[9], G[9];
+    for (int i = 0; i < 3; i++)
+        for (int q = 0; q < 3; q++) {
+            K2[i * 3 + q] = Km[i * 3] * Km[q] + Km[i * 3 + 1] * Km[3 + q] + Km[i * 3 + 2] * Km[6 + q];
+            R[i * 3 + q] = ((i == q) ? 1.0f : 0.0f) + a * Km[i * 3 + q] + b * K2[i * 3 + q];
+            // dL/dR = sum g_o (x) (o - c) + sum g_u (x) d
+            G[i * 3 + q] = sm[3 + i * 3 + q] - sm[i] * c[q] + sm[12 + i * 3 + q];
+        }
+    if (want_pos)
+        for (int q = 0; q < 3; q++)            // dL/dc = -R^T sum g_o
+            grad6[k * 6 + q] += -(R[q] * sm[0] + R[3 + q] * sm[1] + R[6 + q] * sm[2]);
+    if (want_rot)
+        for (int i = 0; i < 3; i++) {
+            float E[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};    // skew(e_i)
+            if (i == 0) { E[5] = -1.f; E[7] = 1.f; }
+            if (i == 1) { E[2] = 1.f; E[6] = -1.f; }
+            if (i == 2) { E[1] = -1.f; E[3] = 1.f; }
+            const float dth = tiny ? 0.0f : r[i] / rt;
+            float acc = 0.0f;
+            for (int p = 0; p < 3; p++)
+                for (int q = 0; q < 3; q++) {
+                    const float ek = E[p * 3] * Km[q] + E[p * 3 + 1] * Km[3 + q] + E[p * 3 + 2] * Km[6 + q];
+                    const float ke = Km[p * 3] * E[q] + Km[p * 3 + 1] * E[3 + q] + Km[p * 3 + 2] * E[6 + q];
+                    const float dR = da * dth * Km[p * 3 + q] + a * E[p * 3 + q] + db * dth * K2[p * 3 + q] + b * (ek + ke);
+                    acc += G[p * 3 + q] * dR;
+                }
+            grad6[k * 6 + 3 + i] += acc;
+        }
+}
+
+extern "C" {
+
+// One level, one object: d_enc [count*N, 64] -> accumulates sums[k*21 .. +21) (caller zeroes).
+// scratch: 21*B floats.
+int durf_encode_obj_bwd(void* stream, int B, int N, int k_obj, const int32_t* idx, const int32_t* count,
+                        const float* d_enc, const float* t_vals, const float* origins_s,
+                        const float* dirs_s, const float* radii, const float* origins, const float* dirs,
+                        const float* pose, const float* barf_w, float* scratch, float* sums) {
+    DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
+    if (B <= 0) return 0;
+    BarfW bw;
+    for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(durf_cdiv(B, 4)), block(256);
+#define LAUNCH_E(P)                                                                                       \
+    hipLaunchKernelGGL(k_encode_obj_bwd<P>, grid, block, 0, s, B, N, k_obj, idx, count, d_enc, t_vals,    \
+                       origins_s, dirs_s, radii, origins, dirs, pose, bw, scratch)
+    if (N <= 64) LAUNCH_E(1); else if (N <= 128) LAUNCH_E(2); else LAUNCH_E(4);
+#undef LAUNCH_E
+    hipLaunchKernelGGL(k_pose_reduce, dim3(POSE_ROWS), dim3(1024), 0, s, B, count, scratch, sums + k_obj * POSE_ROWS);
+    DURF_CHECK_LAUNCH("durf_encode_obj_bwd");
+    return 0;
+}
+
+// sums [K,21] (all levels accumulated) -> adds d(loss)/d(box_centers[ts]) into grad6 [K,6]
+int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, int want_pos, int want_rot,
+                     float* grad6) {
+    if (K <= 0) return 0;
+    hipLaunchKernelGGL(k_pose_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, K, pose, sums, want_pos, want_rot,
+                       grad6);
+    DURF_CHECK_LAUNCH("durf_pose_finish");
+    return 0;
+}
+
+}  // extern "C"

@@ -242,15 +242,17 @@ def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth
     return draw, sums
 
 
-def mlp_bwd(width, rows, N, draw, wpack_bwd, stash, ray_idx=None, count=None):
-    """-> dz (same layout as stash), dz_out tile [rows,16]"""
+def mlp_bwd(width, rows, N, draw, wpack_bwd, stash, ray_idx=None, count=None, want_d_enc=False):
+    """-> dz (same layout as stash), dz_out tile [rows,16][, d_enc [rows,64] fp32]"""
     dev = draw.device
     dz = torch.empty_like(stash)
     dz_out = torch.empty(tile_rows(rows), 16, dtype=torch.bfloat16, device=dev)
+    d_enc = torch.zeros(rows, ENC_DIM, device=dev) if want_d_enc else None
     with _Timed('mlp_bwd_%d' % width):
         _lib.check(_lib.lib().durf_mlp_bwd(_stream(), width, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
-                                           _p(wpack_bwd), _p(stash), _p(dz), _p(dz_out)), 'durf_mlp_bwd')
-    return dz, dz_out
+                                           _p(wpack_bwd), _p(stash), _p(dz), _p(dz_out), _p(d_enc)),
+                   'durf_mlp_bwd')
+    return (dz, dz_out, d_enc) if want_d_enc else (dz, dz_out)
 
 
 def expand_view(rows, N, view_bf16, ray_idx=None, count=None):
@@ -292,3 +294,23 @@ def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):
                                          _p(_f32(grad)), inv_world, max_val, max_norm, lr, int(step),
                                          _p(scratch), _p(stats)), 'durf_clip_adam')
     return stats
+
+
+def encode_obj_bwd(k_obj, idx_k, count_k, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, alpha,
+                   sums, scratch=None):
+    """accumulates the 21 pose sums of object k (one level) into sums[k] (sums: [K,21], caller-zeroed)"""
+    B, N = t_vals.shape[0], t_vals.shape[1] - 1
+    if scratch is None:
+        scratch = torch.empty(21 * B, device=t_vals.device)
+    w = barf_weights(alpha)
+    wa = (C.c_float * 10)(*[float(x) for x in w])
+    _lib.check(_lib.lib().durf_encode_obj_bwd(_stream(), B, N, k_obj, _p(idx_k), _p(count_k), _p(_f32(d_enc)),
+                                              _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
+                                              _p(_f32(radii)), _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
+                                              wa, _p(scratch), _p(_f32(sums))), 'durf_encode_obj_bwd')
+
+
+def pose_finish(pose, sums, want_pos, want_rot, grad6):
+    K = pose.shape[0]
+    _lib.check(_lib.lib().durf_pose_finish(_stream(), K, _p(_f32(pose)), _p(_f32(sums)), int(want_pos),
+                                           int(want_rot), _p(_f32(grad6))), 'durf_pose_finish')

@@ -56,9 +56,7 @@ def level_multipliers(config, level, num_levels):
 def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=None, nsplit=None):
     """value_and_grad(loss_fn) (train_boxpose.py:67-252) for this rank's shard.
     Returns (grad_flat, raw stats dict of device tensors, pose)."""
-    if not (model.no_pose_opt and model.no_yaw_opt):
-        raise NotImplementedError('box-pose gradients through the renderer are not built yet '
-                                  '(both shipped gin files set no_pose_opt = no_yaw_opt = True)')
+    pose_opt = not (model.no_pose_opt and model.no_yaw_opt)
     rays = batch['rays']
     ret, ctx = model._forward(variables, rng, rays, batch['init'], batch['ext'], batch['ts'],
                               config.randomized, config.rand_bkgd, config.white_bkgd, alpha, train=True,
@@ -83,6 +81,9 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     view_tiles_obj = [ops.expand_view(rows, N, ctx['view'], ray_idx=ctx['idx'][k], count=ctx['count'][k:k + 1])
                       for k in range(K)]
     norms, sums = [], []
+    radii = rays.radii.reshape(-1).contiguous()
+    pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
+    pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
     for lvl in range(L):
         lv = ctx['levels'][lvl]
         norm = ops.loss_prep(lv['t_vals'], lossmult, gt_depth, sky, dyn, ctx['zo'], float(eps),
@@ -99,8 +100,12 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         for k in range(K):
             nm = 'BoxMLP_%d' % k
             cnt = ctx['count'][k:k + 1]
-            dzk, dzk_out = ops.mlp_bwd(om.W_OBJ, rows, N, draw, ctx['packs'][nm][1], lv['stashes'][k],
-                                       ray_idx=ctx['idx'][k], count=cnt)
+            res = ops.mlp_bwd(om.W_OBJ, rows, N, draw, ctx['packs'][nm][1], lv['stashes'][k],
+                              ray_idx=ctx['idx'][k], count=cnt, want_d_enc=pose_opt)
+            dzk, dzk_out = res[0], res[1]
+            if pose_opt:                      # d(loss)/d(box pose) through the object encoding
+                ops.encode_obj_bwd(k, ctx['idx'][k], cnt, res[2], lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
+                                   rays.origins, rays.directions, pose_ts, alpha, pose_sums)
             ops.mlp_dw(om.W_OBJ, rows, N, lv['encs'][k], view_tiles_obj[k], lv['stashes'][k], dzk, dzk_out,
                        nsplit, lvl * nsplit, L * nsplit, *bufs[nm], count=cnt)
     for n in names:
@@ -112,6 +117,13 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     if config.weight_decay_mult != 0:                                          # :73-75
         weight_l2 = config.weight_decay_mult * (flat * flat).sum() / flat.numel()
         grad += (2.0 * config.weight_decay_mult / flat.numel()) * flat
+    if K > 0:
+        g6 = torch.zeros(K, 6, device=dev)
+        if pose_opt:
+            ops.pose_finish(pose_ts, pose_sums, not model.no_pose_opt, not model.no_yaw_opt, g6)
+        if not model.no_pose_opt and config.tv_loss_mult != 0:               # :136,:219
+            g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
+        grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)[ctx['ts']] += g6
     pose = ret[0][7][0]
     raw = dict(norms=torch.stack(norms), sums=torch.stack(sums), weight_l2=weight_l2, ret=ret, ctx=ctx)
     return grad, raw, pose

@@ -139,7 +139,8 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
  * rows through ray_idx); stash from durf_mlp_fwd; dz: same size/layout as stash, receives
  * every pre-activation gradient; dz_out: tile layout [rows,16] (slots 0-2 d rgb, 3 d density). */
 int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
-                 const int32_t* count, const void* wpack_bwd, const void* stash, void* dz, void* dz_out);
+                 const int32_t* count, const void* wpack_bwd, const void* stash, void* dz, void* dz_out,
+                 float* d_enc /* nullable: [rows,64] fp32 d(loss)/d(encoding), for box-pose gradients */);
 int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
                      const int32_t* count, void* out_tile /* tile layout [rows,32] */);
 
@@ -153,6 +154,19 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
                 int split_off, int nparts_total, float* part, float* bpart);
 int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nparts_total, const float* part,
                          const float* bpart, float* grad_mlp);
+
+/* Box-pose gradients (cfg4): reverse of weighted_ipe / cast_rays / world2object_rpy / aa2matrix
+ * (mip.py:182-223,155-179; box_helpers.py:286-341,148-167).  Per level and object:
+ * durf_mlp_bwd(..., d_enc) then durf_encode_obj_bwd accumulates 21 per-object sums
+ * (scratch: 21*B floats; sums [K,21], zeroed by the caller once per step); durf_pose_finish
+ * turns them into d(loss)/d(box_centers[ts]) added to grad6 [K,6]
+ * (want_pos = !no_pose_opt, want_rot = !no_yaw_opt, obbpose_model.py:100-104). */
+int durf_encode_obj_bwd(void* stream, int B, int N, int k_obj, const int32_t* idx, const int32_t* count,
+                        const float* d_enc, const float* t_vals, const float* origins_s,
+                        const float* dirs_s, const float* radii, const float* origins, const float* dirs,
+                        const float* pose, const float* barf_w, float* scratch, float* sums);
+int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, int want_pos, int want_rot,
+                     float* grad6);
 
 /* K12 gradient post-processing + Adam on the flat buffers (train_boxpose.py:257-289;
  * flax.optim.Adam).  grad is scaled by inv_world (pmean), scrubbed and clipped in place;

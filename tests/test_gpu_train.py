@@ -196,3 +196,93 @@ def test_train_step(cuda, K, N):
     step_got = new_state.variables.flat.cpu() - flat0.cpu()
     assert _rel(step_got, step_ref) < 0.15
     assert new_state.step == 1
+
+
+@pytest.mark.parametrize('K,alpha,tv', [(2, 4.5, 0.0), (1, 10.0, 0.01)])
+def test_box_pose_gradients(cuda, K, alpha, tv):
+    """cfg4: BARF pose optimisation on (no_pose_opt = no_yaw_opt = False).  d(loss)/d(box_centers[ts])
+    through encoding -> frustum Gaussians -> world2object -> Rodrigues vs the oracle's autograd."""
+    B, N = 1024, 32
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = False\nMipNerfModel.no_yaw_opt = False\n'
+                    'Config.randomized = False\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
+                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = %g\n' % (N, tv))
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(B, K, seed=77 + K, noise_boxes=0.05)
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
+    params = H.oracle_params_from_variables(variables)
+    prev_c, prev_d = ob['init'][0:1] + 0.01, db['init'][0:1] + 0.01
+    grad, raw, pose = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, alpha, prev_d)
+    torch.cuda.synchronize()
+    ocfg = dict(R.CONFIG_DEFAULTS, randomized=False, tv_loss_mult=tv)
+    mcfg = dict(num_samples=N, no_pose_opt=False, no_yaw_opt=False)
+    _, _, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, mcfg, 5e-4, 3.0, alpha, prev_c,
+                                        mlp_hook=R.mlp_apply_bf16)
+    lay = variables.layout
+    got = grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6).cpu()
+    want = ograds[0]
+    ts = b['ts']
+    assert float(want[ts].abs().max()) > 0
+    other = [t for t in range(lay.T) if t != ts]
+    assert float(got[other].abs().max()) == 0.0 and float(want[other].abs().max()) == 0.0
+    for k in range(K):
+        rp, rr = _rel(got[ts, k, :3], want[ts, k, :3]), _rel(got[ts, k, 3:], want[ts, k, 3:])
+        # rotation gradients are sums with heavy cancellation over rays: bf16 d(enc) noise is amplified
+        assert rp < 6e-2 and rr < 0.2, 'object %d: position rel err %g, rotation rel err %g\ngot %s\nwant %s' % (
+            k, rp, rr, got[ts, k], want[ts, k])
+    # the MLP gradients are unaffected by switching pose optimisation on
+    og = torch.cat([x.reshape(-1) for x in ograds])
+    sl = slice(lay.mlp_off['MLP_0'], lay.mlp_off['MLP_0'] + lay.mlp_size[256])
+    assert _rel(grad.cpu()[sl], og[sl]) < 5e-2
+
+
+def test_pose_chain_fp32(cuda):
+    """The fp32 part of the pose-gradient chain in isolation (tight): random d(enc) ->
+    d(box_centers[ts]) through weighted_ipe / cast_rays / world2object_rpy / aa2matrix."""
+    B, N, K, alpha = 768, 32, 2, 6.3
+    b = synthetic.make_batch(B, K, seed=123)
+    ob, db = H.oracle_batch(b, torch.float64), H.device_batch(b, cuda)
+    ts = b['ts']
+    rays = ob['rays']
+    pose = ob['init'][ts].clone().requires_grad_(True)           # [K,6]
+    box_pose = pose[:, :3].expand(B, K, 3)
+    box_mat = R.aa2matrix(pose[:, 3:]).expand(B, K, 3, 3)
+    oo, do = R.world2object_rpy(rays.origins, rays.directions, box_pose, box_mat)
+    dims = ob['ext'].expand(B, K, 3)
+    _, _, inter = R.ray_box_intersection(oo, do, -dims, dims)
+    inter = inter.detach()
+    f = inter.double()
+    bk = (inter.sum(-1) == 0).double()
+    o_s = (oo * f[..., None]).sum(-2) + bk[..., None] * rays.origins
+    d_s = (do * f[..., None]).sum(-2) + bk[..., None] * rays.directions
+    t_vals, samples = R.sample_along_rays(None, o_s, d_s, rays.radii, N, rays.near, rays.far, False)
+    g = torch.Generator().manual_seed(0)
+    # device side
+    pose_d = db['init'][ts].contiguous()
+    o_sd, d_sd, hit, zo = ops.ray_setup(db['rays'].origins, db['rays'].directions, pose_d, db['ext'])
+    idx, count, slot = ops.compact_hits(hit)
+    t_d = ops.sample_t(db['rays'].near.reshape(-1), db['rays'].far.reshape(-1), N)
+    sums = torch.zeros(K, 21, device=cuda)
+    loss = 0.0
+    for k in range(K):
+        rows = torch.nonzero(inter[:, k]).flatten()
+        d_enc = torch.randn(rows.numel() * N, 64, generator=g, dtype=torch.float64) * 0.1
+        d_enc[:, 63] = 0
+        enc = R.weighted_ipe((samples[0][rows], samples[1][rows]), 0, 10, alpha).reshape(-1, 63)
+        loss = loss + (enc * d_enc[:, :63]).sum()
+        buf = torch.zeros(B * N, 64, device=cuda)
+        buf[: rows.numel() * N] = d_enc.float().to(cuda)
+        ops.encode_obj_bwd(k, idx[k], count[k:k + 1], buf, t_d, o_sd, d_sd, db['rays'].radii.reshape(-1).contiguous(),
+                           db['rays'].origins, db['rays'].directions, pose_d, alpha, sums)
+    loss.backward()
+    g6 = torch.zeros(K, 6, device=cuda)
+    ops.pose_finish(pose_d, sums, True, True, g6)
+    want = pose.grad
+    for k in range(K):
+        assert _rel(g6[k, :3].cpu().double(), want[k, :3]) < 2e-3, (g6[k], want[k])
+        assert _rel(g6[k, 3:].cpu().double(), want[k, 3:]) < 2e-3, (g6[k], want[k])
+    g6b = torch.zeros(K, 6, device=cuda)
+    ops.pose_finish(pose_d, sums, False, True, g6b)               # no_pose_opt=True: position frozen
+    assert float(g6b[:, :3].abs().max()) == 0.0 and torch.equal(g6b[:, 3:], g6[:, 3:])
