@@ -29,7 +29,8 @@ _SIGS = {
     'durf_encode_bkgd': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
     'durf_encode_obj': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
     'durf_mlp_stash_bytes': (u64, [i32, u64]),
-    'durf_mlp_fwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_mlp_mask_bytes': (u64, [u64]),
+    'durf_mlp_fwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_composite_fwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32,
                                  vp, vp, vp, vp, vp, vp]),
     'durf_resample': (i32, [vp, i32, i32, vp, vp, f32, vp, vp]),

@@ -91,6 +91,7 @@ k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
 // fused backward data path
 // ---------------------------------------------------------------------------
 struct BPipe {
+    const char* gbase;   // start of the weight stream (persistent loop wraps around to it)
     const char* gnext;
     char* lds;
     int slot_bytes, par, wave, lane;
@@ -127,58 +128,100 @@ __device__ __forceinline__ f32x16 bmma_tile(const char* slot, int lane, const bf
     return acc;
 }
 
+// two tiles with interleaved, independent accumulators (see mma_tile2 in mlp_fwd.hip)
+template <int NA, int NB>
+__device__ __forceinline__ void bmma_tile2(const char* slot0, const char* slot1, int lane, const bf16x8* inA,
+                                           const bf16x8* inB, f32x16& acc0, f32x16& acc1) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    const char* ap0 = slot0 + lane * 16;
+    const char* ap1 = slot1 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < NA; ks++) {
+        const bf16x8 a0 = *(const bf16x8*)(ap0 + ks * 1024);
+        const bf16x8 a1 = *(const bf16x8*)(ap1 + ks * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, inA[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, inA[ks], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NB; ks++) {
+        const bf16x8 a0 = *(const bf16x8*)(ap0 + (NA + ks) * 1024);
+        const bf16x8 a1 = *(const bf16x8*)(ap1 + (NA + ks) * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, inB[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, inB[ks], acc1, 0, 0, 0);
+    }
+}
+
 // gradient wrt the pre-activation: pass where the stashed post-ReLU activation is non-zero
 template <bool MASK>
-__device__ __forceinline__ void bpack_tile(const f32x16& acc, const bf16x8& m0, const bf16x8& m1,
-                                           bf16x8& o0, bf16x8& o1) {
+__device__ __forceinline__ void bpack_tile(const f32x16& acc, unsigned bits, bf16x8& o0, bf16x8& o1) {
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float v0 = acc[e], v1 = acc[8 + e];
         if (MASK) {
-            if ((float)m0[e] == 0.0f) v0 = 0.0f;
-            if ((float)m1[e] == 0.0f) v1 = 0.0f;
+            if (!((bits >> e) & 1u)) v0 = 0.0f;
+            if (!((bits >> (8 + e)) & 1u)) v1 = 0.0f;
         }
         o0[e] = (__bf16)v0;
         o1[e] = (__bf16)v1;
     }
 }
 
-// one backward stage: NMT tiles over the fwd stage's input features
-template <int NA, int NB, int NMT, bool MASK>
+__host__ __device__ constexpr int bgroup_tiles(int nmt, int ch, int slot) {
+    int g = nmt < slot / ch ? nmt : slot / ch;
+    return (g > 1) ? (g & ~1) : g;          // even, so tiles can be processed in pairs
+}
+
+// one backward stage: NMT tiles over the fwd stage's input features, buffered in tile groups
+// (one barrier + one prefetch burst per group, see mlp_fwd.hip)
+template <int SLOT, int NA, int NB, int NMT, bool MASK>
 __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf16x8* inB, bf16x8* out,
-                                           int next_stage_chunks, const bf16x8* mask_src,
-                                           bf16x8* dz_dst, bool valid, int skip_chunks = 0) {
+                                           int next_stage_chunks, const uint4* mask_src,
+                                           bf16x8* dz_dst, bool valid, int skip_chunks = 0,
+                                           bool wrap = false) {
     constexpr int CH = NA + NB;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    constexpr int G = bgroup_tiles(NMT, CH, SLOT);
+    uint4 mk = make_uint4(0u, 0u, 0u, 0u);
+    if (MASK && valid) mk = *mask_src;            // 128 ReLU bits of this lane's sample for the whole stage
+    const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
+    static_assert(NMT % 2 == 0 && G % 2 == 0, "even tile counts");
+    const char* slot = nullptr;
 #pragma unroll
-    for (int mo = 0; mo < NMT; mo++) {
-        if (mo == NMT - 1) p.skip(skip_chunks);      // stages this variant does not run
-        const char* slot = p.begin(mo == NMT - 1 ? next_stage_chunks : CH);
-        bf16x8 m0 = zero8, m1 = zero8;
-        if (MASK && valid) { m0 = mask_src[(2 * mo) * 64]; m1 = mask_src[(2 * mo + 1) * 64]; }
-        if (mo > 0 && valid) {
-            dz_dst[(2 * mo - 2) * 64] = out[2 * mo - 2];
-            dz_dst[(2 * mo - 1) * 64] = out[2 * mo - 1];
+    for (int mo = 0; mo < NMT; mo += 2) {
+        if (mo % G == 0) {
+            const int rest = NMT - mo - G;
+            if (rest <= 0) p.skip(skip_chunks);      // stages this variant does not run
+            if (rest <= 0 && wrap) p.gnext = p.gbase; // next prefetch = first group of the next block
+            slot = p.begin(rest > 0 ? (rest < G ? rest : G) * CH : next_stage_chunks);
         }
-        const f32x16 acc = bmma_tile<NA, NB>(slot, p.lane, inA, inB);
-        bpack_tile<MASK>(acc, m0, m1, out[2 * mo], out[2 * mo + 1]);
+        if (mo > 0 && valid) {
+#pragma unroll
+            for (int q = 4; q >= 1; q--) dz_dst[(2 * mo - q) * 64] = out[2 * mo - q];
+        }
+        f32x16 acc0, acc1;
+        bmma_tile2<NA, NB>(slot + (mo % G) * CH * 1024, slot + (mo % G + 1) * CH * 1024, p.lane, inA, inB, acc0, acc1);
+        const unsigned w = mw[mo >> 1];
+        bpack_tile<MASK>(acc0, w & 0xffffu, out[2 * mo], out[2 * mo + 1]);
+        bpack_tile<MASK>(acc1, w >> 16, out[2 * mo + 2], out[2 * mo + 3]);
     }
     if (valid) {
-        dz_dst[(2 * NMT - 2) * 64] = out[2 * NMT - 2];
-        dz_dst[(2 * NMT - 1) * 64] = out[2 * NMT - 1];
+#pragma unroll
+        for (int q = 4; q >= 1; q--) dz_dst[(2 * NMT - q) * 64] = out[2 * NMT - q];
     }
 }
 
 // d(enc) stage (box-pose gradients): 2 output tiles = the 64 encoding features, fp32 accumulators
 template <int NA>
 __device__ __forceinline__ void run_enc_stage(BPipe& p, const bf16x8* in, f32x16* denc, bool add,
-                                              int next_stage_chunks) {
+                                              int next_stage_chunks, bool wrap = false) {
+    if (wrap) p.gnext = p.gbase;
+    const char* slot = p.begin(next_stage_chunks);           // both tiles arrive as one group
+    f32x16 acc0, acc1;
+    bmma_tile2<NA, 0>(slot, slot + NA * 1024, p.lane, in, nullptr, acc0, acc1);
 #pragma unroll
-    for (int mo = 0; mo < 2; mo++) {
-        const char* slot = p.begin(mo == 1 ? next_stage_chunks : NA);
-        const f32x16 acc = bmma_tile<NA, 0>(slot, p.lane, in, nullptr);
-#pragma unroll
-        for (int r = 0; r < 16; r++) denc[mo][r] = add ? denc[mo][r] + acc[r] : acc[r];
+    for (int r = 0; r < 16; r++) {
+        denc[0][r] = add ? denc[0][r] + acc0[r] : acc0[r];
+        denc[1][r] = add ? denc[1][r] + acc1[r] : acc1[r];
     }
 }
 
@@ -186,10 +229,9 @@ template <int W, bool POSE>
 __global__ void __launch_bounds__(512, 2)
 k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
           const int32_t* __restrict__ count, const char* __restrict__ wpack,
-          const bf16x8* __restrict__ stash, bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out,
+          const uint4* __restrict__ relu_mask, bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out,
           float* __restrict__ d_enc) {
     using S = MlpSpec<W>;
-    using Bs = BwdSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t nrows = rows;
     if (count) {
@@ -199,18 +241,26 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     if ((size_t)blockIdx.x * 256 >= nrows) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t tile32 = (size_t)blockIdx.x * 8 + wave;
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // stagger SIMD partners (see mlp_fwd.hip)
+    const size_t ntile32 = rows >> 5;
+    const size_t nblk = (nrows + 255) / 256;
+
+    BPipe p;
+    constexpr int SLOT = 4 * (S::KW + 1);
+    p.gbase = wpack; p.gnext = wpack; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
+    p.wave = wave; p.lane = lane;
+    constexpr int GB0 = bgroup_tiles(S::CT, 1, SLOT) * 1;                 // all tiles of the rgb-head stage
+    for (int c = wave; c < GB0; c += 8)
+        glds16b(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
+    p.gnext += (size_t)GB0 * 1024;
+
+  // persistent workgroup (see mlp_fwd.hip): loop over this CU's 256-sample blocks
+  for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const bool has_next = blk + gridDim.x < nblk;
+    const size_t tile32 = blk * 8 + wave;
     const size_t row = tile32 * 32 + (lane & 31);
     const bool valid = row < nrows;
     const bool tile_valid = tile32 * 32 < nrows;
-    const size_t ntile32 = rows >> 5;
-
-    BPipe p;
-    p.gnext = wpack; p.lds = smem; p.slot_bytes = Bs::MAX_TILE_CHUNKS * 1024; p.par = 0;
-    p.wave = wave; p.lane = lane;
-    for (int c = wave; c < Bs::n_ks(0); c += 8)
-        glds16b(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
-    p.gnext += (size_t)Bs::n_ks(0) * 1024;
 
     // head gradients (fp32 [*,4]: d raw_rgb[3], d raw_density); object MLPs gather by ray
     f32x4 dr = {0.f, 0.f, 0.f, 0.f};
@@ -230,36 +280,40 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     }
     if (tile_valid) dz_out[tile32 * 64 + lane] = gout;      // [rows,16] tile: slots 0-2 rgb, 3 density
 
-    auto stash_at = [&](int j) -> const bf16x8* {
-        return stash + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 64 + lane;
+    auto stash_at = [&](int j) -> const uint4* {      // ReLU bit-mask region: stage j (9 -> region 8)
+        return relu_mask + ((size_t)(j == 9 ? 8 : j) * ntile32 + tile32) * 64 + lane;
     };
     auto dz_at = [&](int j) -> bf16x8* {
         return dz + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 64 + lane;
     };
     bf16x8 a[S::KW], b[S::KW], c[S::KC];
     // bwd of stage 10 (rgb head): d rgb -> d A9, masked by A9
-    run_bstage<1, 0, S::CT, true>(p, g10, nullptr, c, S::KC, stash_at(9), dz_at(9), tile_valid);
+    constexpr int GC = bgroup_tiles(S::WT, S::KC, SLOT) * S::KC;           // first group of bwd stage 9
+    constexpr int G8 = bgroup_tiles(S::WT, S::KW + 1, SLOT) * (S::KW + 1);
+    constexpr int GW = bgroup_tiles(S::WT, S::KW, SLOT) * S::KW;
+    constexpr int GE = 2 * S::KW;                                             // d(enc) stage: 2 tiles, one group
+    run_bstage<SLOT, 1, 0, S::CT, true>(p, g10, nullptr, c, GC, stash_at(9), dz_at(9), tile_valid);
     // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear)
-    run_bstage<S::KC, 0, S::WT, false>(p, c, nullptr, a, S::KW + 1, nullptr, dz_at(8), tile_valid);
+    run_bstage<SLOT, S::KC, 0, S::WT, false>(p, c, nullptr, a, G8, nullptr, dz_at(8), tile_valid);
     // bwd of stage 8 (bottleneck + density head): -> d A7
-    run_bstage<S::KW, 1, S::WT, true>(p, a, gd, b, S::KW, stash_at(7), dz_at(7), tile_valid);
+    run_bstage<SLOT, S::KW, 1, S::WT, true>(p, a, gd, b, GW, stash_at(7), dz_at(7), tile_valid);
     // bwd of stages 7, 6 -> d Z6, d Z5
-    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(6), dz_at(6), tile_valid);
-    run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(5), dz_at(5), tile_valid);
+    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, b, nullptr, a, GW, stash_at(6), dz_at(6), tile_valid);
+    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, a, nullptr, b, GW, stash_at(5), dz_at(5), tile_valid);
     // bwd of stage 5: trunk rows -> d Z4 (in a); encoding rows (skip connection) only for POSE
-    constexpr int ENC_CHUNKS = (S::KE / 2) * S::KW;
     f32x16 denc[2];
-    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(4), dz_at(4), tile_valid,
-                                      POSE ? 0 : ENC_CHUNKS);
-    if (POSE) run_enc_stage<S::KW>(p, b, denc, false, S::KW);
+    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, b, nullptr, a, POSE ? GE : GW, stash_at(4), dz_at(4), tile_valid,
+                                            POSE ? 0 : GE);
+    if (POSE) run_enc_stage<S::KW>(p, b, denc, false, GW);
     // bwd of stages 4..1
-    run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(3), dz_at(3), tile_valid);
-    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, S::KW, stash_at(2), dz_at(2), tile_valid);
-    run_bstage<S::KW, 0, S::WT, true>(p, a, nullptr, b, S::KW, stash_at(1), dz_at(1), tile_valid);
-    run_bstage<S::KW, 0, S::WT, true>(p, b, nullptr, a, POSE ? S::KW : 0, stash_at(0), dz_at(0), tile_valid);
+    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, a, nullptr, b, GW, stash_at(3), dz_at(3), tile_valid);
+    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, b, nullptr, a, GW, stash_at(2), dz_at(2), tile_valid);
+    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, a, nullptr, b, GW, stash_at(1), dz_at(1), tile_valid);
+    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, b, nullptr, a, POSE ? GE : (has_next ? GB0 : 0), stash_at(0),
+                                            dz_at(0), tile_valid, 0, !POSE);
     if (POSE) {
         // Dense_0 -> d(encoding); total d enc = skip-connection part + first-layer part
-        run_enc_stage<S::KW>(p, a, denc, true, 0);
+        run_enc_stage<S::KW>(p, a, denc, true, has_next ? GB0 : 0, true);
         if (valid) {
             const int hi = lane >> 5;
             float* dst = d_enc + row * DURF_ENC_DIM;
@@ -272,6 +326,7 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
                 }
         }
     }
+  }
 }
 
 // view-direction features expanded per sample into tile layout [rows, 32] (dW of Dense_10)
@@ -535,19 +590,24 @@ int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_
 }
 
 int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
-                 const int32_t* count, const void* wpack_bwd, const void* stash, void* dz, void* dz_out,
+                 const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
                  float* d_enc) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(durf_cdiv(rows, 256)), block(512);
+    const unsigned nblk = durf_cdiv(rows, 256);
+    dim3 grid(nblk < 256u ? nblk : 256u), block(512);        // persistent: at most one workgroup per CU
 #define LAUNCH_B(WW, PP)                                                                                   \
-    hipLaunchKernelGGL((k_mlp_bwd<WW, PP>), grid, block, 2 * BwdSpec<WW>::MAX_TILE_CHUNKS * 1024, s, rows, N, \
-                       draw, ray_idx, count, (const char*)wpack_bwd, (const bf16x8*)stash, (bf16x8*)dz,    \
-                       (bf16x8*)dz_out, d_enc)
-    if (width == 256) { if (d_enc) LAUNCH_B(256, true); else LAUNCH_B(256, false); }
-    else { if (d_enc) LAUNCH_B(128, true); else LAUNCH_B(128, false); }
+    {                                                                                                      \
+        constexpr int lds = 2 * 4 * (MlpSpec<WW>::KW + 1) * 1024;                                          \
+        (void)hipFuncSetAttribute((const void*)k_mlp_bwd<WW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((k_mlp_bwd<WW, PP>), grid, block, lds, s, rows, N, draw, ray_idx, count,         \
+                           (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out,  \
+                           d_enc);                                                                         \
+    }
+    if (width == 256) { if (d_enc) LAUNCH_B(256, true) else LAUNCH_B(256, false) }
+    else { if (d_enc) LAUNCH_B(128, true) else LAUNCH_B(128, false) }
 #undef LAUNCH_B
     DURF_CHECK_LAUNCH("durf_mlp_bwd");
     return 0;

@@ -116,36 +116,92 @@ __device__ __forceinline__ f32x16 mma_tile(const char* slot, int lane, const bf1
     return acc;
 }
 
-template <bool RELU>
-__device__ __forceinline__ void pack_tile(const f32x16& acc, bf16x8& o0, bf16x8& o1) {
+// Two output tiles at once: their MFMAs alternate, so consecutive MFMAs never share an
+// accumulator (a dependent same-accumulator chain with LDS reads / waits between its links
+// pays ~43 extra cycles per link on gfx950) and each B fragment is used twice back-to-back.
+template <int NA, int NB>
+__device__ __forceinline__ void mma_tile2(const char* slot0, const char* slot1, int lane, const bf16x8* inA,
+                                          const bf16x8* inB, f32x16& acc0, f32x16& acc1) {
+    const f32x4* bp0 = (const f32x4*)(slot0 + (NA + NB) * 1024 + (lane >> 5) * 64);
+    const f32x4* bp1 = (const f32x4*)(slot1 + (NA + NB) * 1024 + (lane >> 5) * 64);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-        float v0 = acc[e], v1 = acc[8 + e];
-        if (RELU) { v0 = v0 < 0.0f ? 0.0f : v0; v1 = v1 < 0.0f ? 0.0f : v1; }   // NaN-propagating like jnp.maximum
-        o0[e] = (__bf16)v0;
-        o1[e] = (__bf16)v1;
+    for (int g = 0; g < 4; g++) {
+        const f32x4 b0 = bp0[g], b1 = bp1[g];
+        acc0[4 * g + 0] = b0[0]; acc0[4 * g + 1] = b0[1]; acc0[4 * g + 2] = b0[2]; acc0[4 * g + 3] = b0[3];
+        acc1[4 * g + 0] = b1[0]; acc1[4 * g + 1] = b1[1]; acc1[4 * g + 2] = b1[2]; acc1[4 * g + 3] = b1[3];
+    }
+    const char* ap0 = slot0 + lane * 16;
+    const char* ap1 = slot1 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < NA; ks++) {
+        const bf16x8 a0 = *(const bf16x8*)(ap0 + ks * 1024);
+        const bf16x8 a1 = *(const bf16x8*)(ap1 + ks * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, inA[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, inA[ks], acc1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NB; ks++) {
+        const bf16x8 a0 = *(const bf16x8*)(ap0 + (NA + ks) * 1024);
+        const bf16x8 a1 = *(const bf16x8*)(ap1 + (NA + ks) * 1024);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, inB[ks], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, inB[ks], acc1, 0, 0, 0);
     }
 }
 
+// returns the 16 "activation > 0" bits of this tile (bit r <-> accumulator register r)
+template <bool RELU>
+__device__ __forceinline__ unsigned pack_tile(const f32x16& acc, bf16x8& o0, bf16x8& o1) {
+    unsigned bits = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        float v0 = acc[e], v1 = acc[8 + e];
+        if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }   // one v_max_f32; NaN handled by the poison flag
+        bits |= (v0 > 0.0f ? 1u : 0u) << e;
+        bits |= (v1 > 0.0f ? 1u : 0u) << (8 + e);
+        o0[e] = (__bf16)v0;
+        o1[e] = (__bf16)v1;
+    }
+    return bits;
+}
+
+// Tiles are buffered in GROUPS: one barrier + one prefetch burst per group of up to
+// SLOT/CH output tiles (4 for a WxW layer), so the 8 waves run unsynchronised for ~64 MFMAs
+// each and the next group's weights have a whole group of compute time to arrive.
+__host__ __device__ constexpr int group_tiles(int nmt, int ch, int slot) {
+    int g = nmt < slot / ch ? nmt : slot / ch;
+    return (g > 1) ? (g & ~1) : g;          // even, so tiles can be processed in pairs
+}
+
 // One dense stage: NMT output tiles, inputs inA[NA] (C-perm) ++ inB[NB] (natural).
-template <int NA, int NB, int NMT, bool RELU, bool TRAIN>
+template <int SLOT, int NA, int NB, int NMT, bool RELU, bool TRAIN>
 __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf16x8* inB,
                                           bf16x8* out, int next_stage_chunks, bf16x8* stash_dst,
-                                          bool valid) {
+                                          bool valid, uint4* mask_dst = nullptr) {
     constexpr int CH = NA + NB + 1;
+    constexpr int G = group_tiles(NMT, CH, SLOT);
+    static_assert(NMT % 2 == 0 && G % 2 == 0, "stages processed by run_stage have an even tile count");
+    unsigned mb[4] = {0u, 0u, 0u, 0u};
+    const char* slot = nullptr;
 #pragma unroll
-    for (int mo = 0; mo < NMT; mo++) {
-        const char* slot = p.begin(mo == NMT - 1 ? next_stage_chunks : CH);
-        if (TRAIN && mo > 0 && valid) {     // delayed store of the previous tile's output
-            stash_dst[(2 * mo - 2) * 64] = out[2 * mo - 2];
-            stash_dst[(2 * mo - 1) * 64] = out[2 * mo - 1];
+    for (int mo = 0; mo < NMT; mo += 2) {
+        if (mo % G == 0) {
+            const int rest = NMT - mo - G;                       // tiles after this group
+            slot = p.begin(rest > 0 ? (rest < G ? rest : G) * CH : next_stage_chunks);
         }
-        const f32x16 acc = mma_tile<NA, NB>(slot, p.lane, inA, inB);
-        pack_tile<RELU>(acc, out[2 * mo], out[2 * mo + 1]);
+        if (TRAIN && mo > 0 && valid) {     // delayed store of the previous pair's output
+#pragma unroll
+            for (int q = 4; q >= 1; q--) stash_dst[(2 * mo - q) * 64] = out[2 * mo - q];
+        }
+        f32x16 acc0, acc1;
+        mma_tile2<NA, NB>(slot + (mo % G) * CH * 1024, slot + (mo % G + 1) * CH * 1024, p.lane, inA, inB, acc0, acc1);
+        const unsigned bits0 = pack_tile<RELU>(acc0, out[2 * mo], out[2 * mo + 1]);
+        const unsigned bits1 = pack_tile<RELU>(acc1, out[2 * mo + 2], out[2 * mo + 3]);
+        if (TRAIN && RELU) mb[mo >> 1] |= bits0 | (bits1 << 16);
     }
     if (TRAIN && valid) {
-        stash_dst[(2 * NMT - 2) * 64] = out[2 * NMT - 2];
-        stash_dst[(2 * NMT - 1) * 64] = out[2 * NMT - 1];
+#pragma unroll
+        for (int q = 4; q >= 1; q--) stash_dst[(2 * NMT - q) * 64] = out[2 * NMT - q];
+        if (RELU && mask_dst) *mask_dst = make_uint4(mb[0], mb[1], mb[2], mb[3]);
     }
 }
 
@@ -153,7 +209,8 @@ template <int W, bool TRAIN>
 __global__ void __launch_bounds__(512, 2)
 k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
           const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
-          const char* __restrict__ wpack, float* __restrict__ raw, bf16x8* __restrict__ stash) {
+          const char* __restrict__ wpack, float* __restrict__ raw, bf16x8* __restrict__ stash,
+          uint4* __restrict__ relu_mask) {
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     size_t nrows = rows;
@@ -164,48 +221,79 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     if ((size_t)blockIdx.x * 256 >= nrows) return;           // whole workgroup idle
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const size_t tile32 = (size_t)blockIdx.x * 8 + wave;
+    // Waves w and w+4 share a SIMD; static priority for the younger half staggers them so one
+    // wave's epilogue can run under its partner's MFMAs.
+    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    const size_t ntile32 = rows >> 5;
+    const size_t nblk = (nrows + 255) / 256;
+
+    WPipe p;
+    constexpr int SLOT = 4 * (S::KW + 1);            // chunks per LDS slot (two slots)
+    p.gnext = wpack; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
+    p.wave = wave; p.lane = lane;
+    // prologue: first tile group of stage 0 -> slot 0
+    constexpr int G0 = group_tiles(S::WT, S::KE + 1, SLOT) * (S::KE + 1);
+    for (int c = wave; c < G0; c += 8)
+        glds16(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
+    p.gnext += (size_t)G0 * 1024;
+
+  // Persistent workgroup: one CU holds one workgroup (136 KB of LDS), so looping over the
+  // 256-sample blocks here instead of relaunching hides every block's start-up (first weight
+  // group + encoding fetch) behind the previous block's last stages.
+  for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+    const bool has_next = blk + gridDim.x < nblk;
+    const size_t tile32 = blk * 8 + wave;
     const size_t row = tile32 * 32 + (lane & 31);
     const bool valid = row < nrows;
     const bool tile_valid = tile32 * 32 < nrows;
-    const size_t ntile32 = rows >> 5;
-
-    WPipe p;
-    p.gnext = wpack; p.lds = smem; p.slot_bytes = S::MAX_TILE_CHUNKS * 1024; p.par = 0;
-    p.wave = wave; p.lane = lane;
-    // prologue: tile 0 -> slot 0
-    for (int c = wave; c < S::tile_chunks(0); c += 8)
-        glds16(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
-    p.gnext += (size_t)S::tile_chunks(0) * 1024;
 
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 encf[S::KE];
     const bf16x8* enc_t = enc + (tile32 * S::KE) * 64 + lane;
 #pragma unroll
     for (int k = 0; k < S::KE; k++) encf[k] = tile_valid ? enc_t[k * 64] : zero8;
+    // jnp.maximum propagates NaN through every ReLU, v_max_f32 does not.  The only source of
+    // non-finite values is the encoding of a garbage (multi-hit) ray, and one non-finite
+    // feature makes the reference's MLP output NaN: detect it once here and poison the output.
+    bool poison = false;
+#pragma unroll
+    for (int k = 0; k < S::KE; k++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const float f = (float)encf[k][e];
+            poison |= !(fabsf(f) <= 3.0e38f);
+        }
+    poison |= (__shfl_xor((int)poison, 32, 64) != 0);      // the sample's other 32 features
 
     bf16x8 a[S::KW], b[S::KW];
     auto stash_at = [&](int j) -> bf16x8* {
         return stash + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 64 + lane;
     };
+    // ReLU bit-masks for the backward: region j (stages 0..7 -> 0..7, stage 9 -> 8), one uint4 per lane
+    auto mask_at = [&](int j) -> uint4* {
+        return relu_mask ? relu_mask + ((size_t)j * ntile32 + tile32) * 64 + lane : nullptr;
+    };
     constexpr int CHW = S::KW + 1;
+    constexpr int GW = group_tiles(S::WT, CHW, SLOT) * CHW;                       // first group of a WxW stage
+    constexpr int G5 = group_tiles(S::WT, S::KW + S::KE + 1, SLOT) * (S::KW + S::KE + 1);
+    constexpr int G9 = group_tiles(S::CT, S::KW + S::KV + 1, SLOT) * (S::KW + S::KV + 1);
     // stage 0: enc -> a
-    run_stage<0, S::KE, S::WT, true, TRAIN>(p, nullptr, encf, a, CHW, TRAIN ? stash_at(0) : nullptr, tile_valid);
+    run_stage<SLOT, 0, S::KE, S::WT, true, TRAIN>(p, nullptr, encf, a, GW, TRAIN ? stash_at(0) : nullptr, tile_valid, TRAIN ? mask_at(0) : nullptr);
     // stages 1-4
-    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, CHW, TRAIN ? stash_at(1) : nullptr, tile_valid);
-    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, CHW, TRAIN ? stash_at(2) : nullptr, tile_valid);
-    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, CHW, TRAIN ? stash_at(3) : nullptr, tile_valid);
-    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, S::KW + S::KE + 1, TRAIN ? stash_at(4) : nullptr, tile_valid);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, GW, TRAIN ? stash_at(1) : nullptr, tile_valid, TRAIN ? mask_at(1) : nullptr);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, GW, TRAIN ? stash_at(2) : nullptr, tile_valid, TRAIN ? mask_at(2) : nullptr);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, GW, TRAIN ? stash_at(3) : nullptr, tile_valid, TRAIN ? mask_at(3) : nullptr);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, G5, TRAIN ? stash_at(4) : nullptr, tile_valid, TRAIN ? mask_at(4) : nullptr);
     // stage 5: [a, enc] -> b
-    run_stage<S::KW, S::KE, S::WT, true, TRAIN>(p, a, encf, b, CHW, TRAIN ? stash_at(5) : nullptr, tile_valid);
+    run_stage<SLOT, S::KW, S::KE, S::WT, true, TRAIN>(p, a, encf, b, GW, TRAIN ? stash_at(5) : nullptr, tile_valid, TRAIN ? mask_at(5) : nullptr);
     // stages 6, 7
-    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, CHW, TRAIN ? stash_at(6) : nullptr, tile_valid);
-    run_stage<S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, CHW, TRAIN ? stash_at(7) : nullptr, tile_valid);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, GW, TRAIN ? stash_at(6) : nullptr, tile_valid, TRAIN ? mask_at(6) : nullptr);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, GW, TRAIN ? stash_at(7) : nullptr, tile_valid, TRAIN ? mask_at(7) : nullptr);
     // stage 8: b -> bottleneck (a, linear) + density
-    run_stage<S::KW, 0, S::WT, false, TRAIN>(p, b, nullptr, a, CHW, TRAIN ? stash_at(8) : nullptr, tile_valid);
+    run_stage<SLOT, S::KW, 0, S::WT, false, TRAIN>(p, b, nullptr, a, CHW, TRAIN ? stash_at(8) : nullptr, tile_valid);
     float dens;
     {
-        const char* slot = p.begin(S::KW + S::KV + 1);
+        const char* slot = p.begin(G9);
         const f32x16 acc = mma_tile<S::KW, 0>(slot, lane, b, nullptr);
         dens = acc[0];
     }
@@ -219,16 +307,19 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
             vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + (lane >> 5)] : zero8;
     }
     bf16x8 c[S::KC];
-    run_stage<S::KW, S::KV, S::CT, true, TRAIN>(p, a, vf, c, S::KC + 1, TRAIN ? stash_at(9) : nullptr, tile_valid);
-    // stage 10: c -> rgb
+    run_stage<SLOT, S::KW, S::KV, S::CT, true, TRAIN>(p, a, vf, c, S::KC + 1, TRAIN ? stash_at(9) : nullptr, tile_valid, TRAIN ? mask_at(8) : nullptr);
+    // stage 10: c -> rgb; meanwhile the next block's first weight group streams in
     {
-        const char* slot = p.begin(0);
+        p.gnext = wpack;
+        const char* slot = p.begin(has_next ? G0 : 0);
         const f32x16 acc = mma_tile<S::KC, 0>(slot, lane, c, nullptr);
         if (valid && lane < 32) {
-            const f32x4 o = {acc[0], acc[1], acc[2], dens};
+            const float qn = __builtin_nanf("");
+            const f32x4 o = {poison ? qn : acc[0], poison ? qn : acc[1], poison ? qn : acc[2], poison ? qn : dens};
             *(f32x4*)(raw + row * 4) = o;
         }
     }
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -241,6 +332,7 @@ size_t durf_mlp_layer_offset(int width, int in_dim, int layer, int want_bias) {
 size_t durf_wpack_fwd_bytes(int width) {
     return (size_t)(width == 256 ? MlpSpec<256>::TOTAL_CHUNKS : MlpSpec<128>::TOTAL_CHUNKS) * 1024;
 }
+size_t durf_mlp_mask_bytes(size_t rows) { return ((rows + 31) / 32) * 9 * 1024; }
 size_t durf_mlp_stash_bytes(int width, size_t rows) {
     const size_t kb = width == 256 ? MlpSpec<256>::STASH_KS_TOTAL : MlpSpec<128>::STASH_KS_TOTAL;
     return ((rows + 31) / 32) * kb * 1024;
@@ -272,18 +364,23 @@ int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_para
 
 int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
                  const void* view_bf16, const int32_t* ray_idx, const int32_t* count,
-                 const void* wpack_fwd, float* raw, void* stash) {
+                 const void* wpack_fwd, float* raw, void* stash, void* relu_mask) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(durf_cdiv(rows, 256)), block(512);
+    const unsigned nblk = durf_cdiv(rows, 256);
+    dim3 grid(nblk < 256u ? nblk : 256u), block(512);        // persistent: at most one workgroup per CU
 #define LAUNCH_F(WW, TR)                                                                          \
-    hipLaunchKernelGGL((k_mlp_fwd<WW, TR>), grid, block, 2 * MlpSpec<WW>::MAX_TILE_CHUNKS * 1024, s, \
-                       rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16, ray_idx, count, \
-                       (const char*)wpack_fwd, raw, (bf16x8*)stash)
-    if (width == 256) { if (stash) LAUNCH_F(256, true); else LAUNCH_F(256, false); }
-    else { if (stash) LAUNCH_F(128, true); else LAUNCH_F(128, false); }
+    {                                                                                             \
+        constexpr int lds = 2 * 4 * (MlpSpec<WW>::KW + 1) * 1024;                                 \
+        (void)hipFuncSetAttribute((const void*)k_mlp_fwd<WW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((k_mlp_fwd<WW, TR>), grid, block, lds, s, rows, N, (const bf16x8*)enc_tile, \
+                           (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw,  \
+                           (bf16x8*)stash, (uint4*)relu_mask);                                     \
+    }
+    if (width == 256) { if (stash) LAUNCH_F(256, true) else LAUNCH_F(256, false) }
+    else { if (stash) LAUNCH_F(128, true) else LAUNCH_F(128, false) }
 #undef LAUNCH_F
     DURF_CHECK_LAUNCH("durf_mlp_fwd");
     return 0;

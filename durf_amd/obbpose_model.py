@@ -208,22 +208,25 @@ class MipNerfModel:
                                       noise['u_rand'] if randomized else None)
             enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction)
             stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
-            raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, wf['MLP_0'], stash=stash_b)
-            raws, encs, stashes = [], [], []
+            mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
+            raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, wf['MLP_0'], stash=stash_b, relu_mask=mask_b)
+            raws, encs, stashes, masks = [], [], [], []
             for k in range(K):
                 enc_k, _ = ops.encode_obj(B, idx[k], count[k:k + 1], t_vals, o_s, d_s, radii, alpha)
                 st_k = torch.empty(ops.mlp_stash_bytes(W_OBJ, rows), dtype=torch.uint8, device=dev) if train else None
+                mk_k = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
                 raws.append(ops.mlp_fwd(W_OBJ, rows, N, enc_k, view, wf['BoxMLP_%d' % k], ray_idx=idx[k],
-                                        count=count[k:k + 1], stash=st_k))
+                                        count=count[k:k + 1], stash=st_k, relu_mask=mk_k))
                 encs.append(enc_k)
                 stashes.append(st_k)
+                masks.append(mk_k)
             rgb, depth, acc, weights, t_mids, t_dists = ops.composite_fwd(
                 raw_b, raws, slot, t_vals, d_s, self.density_bias, bk)
             ret.append((rgb, depth, acc, weights, t_vals, t_mids, t_dists, [pose[:, :3], box_rot0],
                         dyn_mask, zo))
             if train:
                 ctx['levels'].append(dict(t_vals=t_vals, enc_b=enc_b, raw_b=raw_b, stash_b=stash_b,
-                                          raws=raws, encs=encs, stashes=stashes, rgb=rgb, depth=depth,
+                                          raws=raws, encs=encs, stashes=stashes, masks=masks, mask_b=mask_b, rgb=rgb, depth=depth,
                                           acc=acc, weights=weights))
         return ret, ctx
 

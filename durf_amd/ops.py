@@ -158,14 +158,19 @@ def mlp_stash_bytes(width, rows):
     return int(_lib.lib().durf_mlp_stash_bytes(width, rows))
 
 
+def mlp_mask_bytes(rows):
+    return int(_lib.lib().durf_mlp_mask_bytes(rows))
+
+
 def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=None, stash=None,
-            raw=None):
+            raw=None, relu_mask=None):
     dev = enc_tile.device
     if raw is None:
         raw = torch.empty(rows, 4, device=dev)
     with _Timed('mlp_fwd_%d%s' % (width, '_train' if stash is not None else '')):
         _lib.check(_lib.lib().durf_mlp_fwd(_stream(), width, rows, N, _p(enc_tile), _p(view_bf16),
-                                           _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash)),
+                                           _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash),
+                                           _p(relu_mask)),
                    'durf_mlp_fwd')
     return raw
 
@@ -242,15 +247,15 @@ def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth
     return draw, sums
 
 
-def mlp_bwd(width, rows, N, draw, wpack_bwd, stash, ray_idx=None, count=None, want_d_enc=False):
-    """-> dz (same layout as stash), dz_out tile [rows,16][, d_enc [rows,64] fp32]"""
+def mlp_bwd(width, rows, N, draw, wpack_bwd, relu_mask, ray_idx=None, count=None, want_d_enc=False):
+    """-> dz (same layout as the stash), dz_out tile [rows,16][, d_enc [rows,64] fp32]"""
     dev = draw.device
-    dz = torch.empty_like(stash)
+    dz = torch.empty(mlp_stash_bytes(width, rows), dtype=torch.uint8, device=dev)
     dz_out = torch.empty(tile_rows(rows), 16, dtype=torch.bfloat16, device=dev)
     d_enc = torch.zeros(rows, ENC_DIM, device=dev) if want_d_enc else None
     with _Timed('mlp_bwd_%d' % width):
         _lib.check(_lib.lib().durf_mlp_bwd(_stream(), width, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
-                                           _p(wpack_bwd), _p(stash), _p(dz), _p(dz_out), _p(d_enc)),
+                                           _p(wpack_bwd), _p(relu_mask), _p(dz), _p(dz_out), _p(d_enc)),
                    'durf_mlp_bwd')
     return (dz, dz_out, d_enc) if want_d_enc else (dz, dz_out)
 

@@ -94,13 +94,13 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                model.density_bias, config.disable_multiscale_loss)
         norms.append(norm)
         sums.append(s)
-        dz, dz_out = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['stash_b'])
+        dz, dz_out = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
         ops.mlp_dw(om.W_BKGD, rows, N, lv['enc_b'], view_tile, lv['stash_b'], dz, dz_out, nsplit,
                    lvl * nsplit, L * nsplit, *bufs['MLP_0'])
         for k in range(K):
             nm = 'BoxMLP_%d' % k
             cnt = ctx['count'][k:k + 1]
-            res = ops.mlp_bwd(om.W_OBJ, rows, N, draw, ctx['packs'][nm][1], lv['stashes'][k],
+            res = ops.mlp_bwd(om.W_OBJ, rows, N, draw, ctx['packs'][nm][1], lv['masks'][k],
                               ray_idx=ctx['idx'][k], count=cnt, want_d_enc=pose_opt)
             dzk, dzk_out = res[0], res[1]
             if pose_opt:                      # d(loss)/d(box pose) through the object encoding

@@ -91,12 +91,15 @@ int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const
  * accumulate.  rows = number of samples (multiple of N); enc_tile: [rows,64] tile layout;
  * view_bf16 [B,32]; ray_idx nullable (object MLPs: row r belongs to ray ray_idx[r/N]);
  * count nullable device int (valid rays; rows beyond count*N are skipped);
- * raw out [rows,4] = (raw_rgb[3], raw_density).  stash (nullable, training): bf16
- * activations, durf_mlp_stash_bytes(width, rows). */
+ * raw out [rows,4] = (raw_rgb[3], raw_density).  Training (both nullable): stash = bf16
+ * activations (operands of the weight-gradient GEMMs), durf_mlp_stash_bytes(width, rows);
+ * relu_mask = one bit per activation (all the backward data path needs),
+ * durf_mlp_mask_bytes(rows). */
 size_t durf_mlp_stash_bytes(int width, size_t rows);
+size_t durf_mlp_mask_bytes(size_t rows);
 int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
                  const void* view_bf16, const int32_t* ray_idx, const int32_t* count,
-                 const void* wpack_fwd, float* raw, void* stash);
+                 const void* wpack_fwd, float* raw, void* stash, void* relu_mask);
 
 /* K8 merge + activations + volumetric_rendering (obbpose_model.py:232-254, mip.py:285-327).
  * raw_bkgd [B*N,4]; raw_obj[k] [count_k*N,4] compacted, slot from durf_compact_hits.
@@ -136,10 +139,11 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                   float* draw, float* terms, float* term_sums);
 
 /* K11 fused MLP backward (data path).  draw [*,4] fp32 head gradients (object MLPs gather
- * rows through ray_idx); stash from durf_mlp_fwd; dz: same size/layout as stash, receives
- * every pre-activation gradient; dz_out: tile layout [rows,16] (slots 0-2 d rgb, 3 d density). */
+ * rows through ray_idx); relu_mask from durf_mlp_fwd; dz: same size/layout as the stash,
+ * receives every pre-activation gradient; dz_out: tile layout [rows,16] (slots 0-2 d rgb,
+ * 3 d density). */
 int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
-                 const int32_t* count, const void* wpack_bwd, const void* stash, void* dz, void* dz_out,
+                 const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
                  float* d_enc /* nullable: [rows,64] fp32 d(loss)/d(encoding), for box-pose gradients */);
 int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
                      const int32_t* count, void* out_tile /* tile layout [rows,32] */);

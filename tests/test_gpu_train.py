@@ -92,8 +92,9 @@ def test_mlp_backward_and_weight_grads(cuda, width, in_dim):
     view = view.to(torch.bfloat16).to(cuda)
     wf, wb = ops.pack_weights(width, in_dim, flat, want_bwd=True)
     stash = torch.zeros(ops.mlp_stash_bytes(width, rows), dtype=torch.uint8, device=cuda)
-    ops.mlp_fwd(width, rows, N, enc_tile, view, wf, stash=stash)
-    dz, dz_out = ops.mlp_bwd(width, rows, N, draw.to(cuda), wb, stash)
+    mask = torch.zeros(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=cuda)
+    ops.mlp_fwd(width, rows, N, enc_tile, view, wf, stash=stash, relu_mask=mask)
+    dz, dz_out = ops.mlp_bwd(width, rows, N, draw.to(cuda), wb, mask)
     nsplit = 3
     part, bpart = ops.dw_buffers(width, 2 * nsplit, cuda)
     part.zero_(); bpart.zero_()

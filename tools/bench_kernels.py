@@ -47,7 +47,8 @@ for width, in_dim in ((256, 60), (128, 63)):
     t = timeit(lambda: ops.mlp_fwd(width, rows, N, enc_b, view, wf, raw=raw), n=10)
     print('mlp_fwd W=%d   %8.1f us  %.1f TFLOP/s (%.1f%% of 2.5 PF)' % (width, t * 1e6, 2 * macs * rows / t / 1e12, 2 * macs * rows / t / 2.5e15 * 100))
     stash = torch.empty(ops.mlp_stash_bytes(width, rows), dtype=torch.uint8, device=dev)
-    t = timeit(lambda: ops.mlp_fwd(width, rows, N, enc_b, view, wf, raw=raw, stash=stash), n=10)
+    mask = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev)
+    t = timeit(lambda: ops.mlp_fwd(width, rows, N, enc_b, view, wf, raw=raw, stash=stash, relu_mask=mask), n=10)
     print('mlp_fwd W=%d +stash %8.1f us  %.1f TFLOP/s, stash %.2f GB -> %.2f TB/s' % (width, t * 1e6, 2 * macs * rows / t / 1e12, stash.numel() / 1e9, stash.numel() / t / 1e12))
 raw_b = torch.randn(rows, 4, device=dev)
 t = timeit(lambda: ops.composite_fwd(raw_b, [], slot, t_vals, d_s, -1.0, 0, want_t=False))
