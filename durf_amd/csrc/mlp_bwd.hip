@@ -13,9 +13,9 @@
 //      (deterministic; no atomics).  HBM-bound: 1 KB read per sample per 256x256 layer.
 #include "mlp_spec.h"
 
-__device__ __forceinline__ void glds16b(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// buffer form of the LDS-DMA (descriptor + SGPR offset + one per-lane VGPR offset), see mlp_fwd.hip
+__device__ __forceinline__ void glds16b(__amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned voff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -91,17 +91,17 @@ k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
 // fused backward data path
 // ---------------------------------------------------------------------------
 struct BPipe {
-    const char* gbase;   // start of the weight stream (persistent loop wraps around to it)
-    const char* gnext;
+    __amdgpu_buffer_rsrc_t rsrc;   // the packed (transposed) weight stream
+    unsigned gnext;      // byte offset of the next tile group (the persistent loop wraps it to 0)
     char* lds;
     int slot_bytes, par, wave, lane;
-    __device__ __forceinline__ void skip(int chunks) { gnext += (size_t)chunks * 1024; }
+    __device__ __forceinline__ void skip(int chunks) { gnext += chunks * 1024u; }
     __device__ __forceinline__ const char* begin(int next_chunks) {
         __syncthreads();
         char* dst = lds + (par ^ 1) * slot_bytes;
         for (int c = wave; c < next_chunks; c += 8)
-            glds16b(gnext + (size_t)c * 1024 + lane * 16, dst + c * 1024);
-        gnext += (size_t)next_chunks * 1024;
+            glds16b(rsrc, gnext + c * 1024u, lane * 16u, dst + c * 1024);
+        gnext += next_chunks * 1024u;
         const char* cur = lds + par * slot_bytes;
         par ^= 1;
         return cur;
@@ -174,15 +174,16 @@ __host__ __device__ constexpr int bgroup_tiles(int nmt, int ch, int slot) {
 
 // one backward stage: NMT tiles over the fwd stage's input features, buffered in tile groups
 // (one barrier + one prefetch burst per group, see mlp_fwd.hip)
-template <int SLOT, int NA, int NB, int NMT, bool MASK>
+template <int SLOT, int NA, int NB, int NMT, bool MASK, int PREV_NMT>
 __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf16x8* inB, bf16x8* out,
-                                           int next_stage_chunks, const uint4* mask_src,
-                                           bf16x8* dz_dst, bool valid, int skip_chunks = 0,
-                                           bool wrap = false) {
+                                           int next_stage_chunks, const char* mask_src,
+                                           char* dz_dst, bool valid, const bf16x8* prev_out, char* prev_dst,
+                                           int skip_chunks = 0, bool wrap = false) {
+    // mask_src / dz_dst / prev_dst: wave-uniform byte pointers (+ lane*16 per lane), see mlp_fwd.hip
     constexpr int CH = NA + NB;
     constexpr int G = bgroup_tiles(NMT, CH, SLOT);
     uint4 mk = make_uint4(0u, 0u, 0u, 0u);
-    if (MASK && valid) mk = *mask_src;            // 128 ReLU bits of this lane's sample for the whole stage
+    if (MASK && valid) mk = *(const uint4*)(mask_src + p.lane * 16);   // 128 ReLU bits of this lane's sample
     const unsigned mw[4] = {mk.x, mk.y, mk.z, mk.w};
     static_assert(NMT % 2 == 0 && G % 2 == 0, "even tile counts");
     const char* slot = nullptr;
@@ -191,12 +192,18 @@ __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf
         if (mo % G == 0) {
             const int rest = NMT - mo - G;
             if (rest <= 0) p.skip(skip_chunks);      // stages this variant does not run
-            if (rest <= 0 && wrap) p.gnext = p.gbase; // next prefetch = first group of the next block
+            if (rest <= 0 && wrap) p.gnext = 0;       // next prefetch = first group of the next block
             slot = p.begin(rest > 0 ? (rest < G ? rest : G) * CH : next_stage_chunks);
         }
-        if (mo > 0 && valid) {
+        if (valid) {          // stores trail the compute by one pair, also across stages (mlp_fwd.hip)
+            if (mo > 0) {
 #pragma unroll
-            for (int q = 4; q >= 1; q--) dz_dst[(2 * mo - q) * 64] = out[2 * mo - q];
+                for (int q = 4; q >= 1; q--) *(bf16x8*)(dz_dst + (2 * mo - q) * 1024 + p.lane * 16) = out[2 * mo - q];
+            } else if (PREV_NMT > 0) {
+#pragma unroll
+                for (int q = 4; q >= 1; q--)
+                    *(bf16x8*)(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16) = prev_out[2 * PREV_NMT - q];
+            }
         }
         f32x16 acc0, acc1;
         bmma_tile2<NA, NB>(slot + (mo % G) * CH * 1024, slot + (mo % G + 1) * CH * 1024, p.lane, inA, inB, acc0, acc1);
@@ -204,17 +211,13 @@ __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf
         bpack_tile<MASK>(acc0, w & 0xffffu, out[2 * mo], out[2 * mo + 1]);
         bpack_tile<MASK>(acc1, w >> 16, out[2 * mo + 2], out[2 * mo + 3]);
     }
-    if (valid) {
-#pragma unroll
-        for (int q = 4; q >= 1; q--) dz_dst[(2 * NMT - q) * 64] = out[2 * NMT - q];
-    }
 }
 
 // d(enc) stage (box-pose gradients): 2 output tiles = the 64 encoding features, fp32 accumulators
 template <int NA>
 __device__ __forceinline__ void run_enc_stage(BPipe& p, const bf16x8* in, f32x16* denc, bool add,
                                               int next_stage_chunks, bool wrap = false) {
-    if (wrap) p.gnext = p.gbase;
+    if (wrap) p.gnext = 0;
     const char* slot = p.begin(next_stage_chunks);           // both tiles arrive as one group
     f32x16 acc0, acc1;
     bmma_tile2<NA, 0>(slot, slot + NA * 1024, p.lane, in, nullptr, acc0, acc1);
@@ -247,12 +250,13 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
 
     BPipe p;
     constexpr int SLOT = 4 * (S::KW + 1);
-    p.gbase = wpack; p.gnext = wpack; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
+    p.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, BwdSpec<W>::TOTAL_CHUNKS * 1024, 0x00020000);
+    p.gnext = 0; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
     p.wave = wave; p.lane = lane;
     constexpr int GB0 = bgroup_tiles(S::CT, 1, SLOT) * 1;                 // all tiles of the rgb-head stage
     for (int c = wave; c < GB0; c += 8)
-        glds16b(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
-    p.gnext += (size_t)GB0 * 1024;
+        glds16b(p.rsrc, c * 1024u, lane * 16u, p.lds + c * 1024);
+    p.gnext = GB0 * 1024u;
 
   // persistent workgroup (see mlp_fwd.hip): loop over this CU's 256-sample blocks
   for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -280,11 +284,11 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     }
     if (tile_valid) dz_out[tile32 * 64 + lane] = gout;      // [rows,16] tile: slots 0-2 rgb, 3 density
 
-    auto stash_at = [&](int j) -> const uint4* {      // ReLU bit-mask region: stage j (9 -> region 8)
-        return relu_mask + ((size_t)(j == 9 ? 8 : j) * ntile32 + tile32) * 64 + lane;
+    auto stash_at = [&](int j) -> const char* {      // ReLU bit-mask region: stage j (9 -> region 8); wave-uniform
+        return (const char*)relu_mask + ((size_t)(j == 9 ? 8 : j) * ntile32 + tile32) * 1024;
     };
-    auto dz_at = [&](int j) -> bf16x8* {
-        return dz + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 64 + lane;
+    auto dz_at = [&](int j) -> char* {
+        return (char*)dz + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 1024;
     };
     bf16x8 a[S::KW], b[S::KW], c[S::KC];
     // bwd of stage 10 (rgb head): d rgb -> d A9, masked by A9
@@ -292,25 +296,29 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     constexpr int G8 = bgroup_tiles(S::WT, S::KW + 1, SLOT) * (S::KW + 1);
     constexpr int GW = bgroup_tiles(S::WT, S::KW, SLOT) * S::KW;
     constexpr int GE = 2 * S::KW;                                             // d(enc) stage: 2 tiles, one group
-    run_bstage<SLOT, 1, 0, S::CT, true>(p, g10, nullptr, c, GC, stash_at(9), dz_at(9), tile_valid);
+    run_bstage<SLOT, 1, 0, S::CT, true, 0>(p, g10, nullptr, c, GC, stash_at(9), dz_at(9), tile_valid, nullptr, nullptr);
     // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear)
-    run_bstage<SLOT, S::KC, 0, S::WT, false>(p, c, nullptr, a, G8, nullptr, dz_at(8), tile_valid);
+    run_bstage<SLOT, S::KC, 0, S::WT, false, S::CT>(p, c, nullptr, a, G8, nullptr, dz_at(8), tile_valid, c, dz_at(9));
     // bwd of stage 8 (bottleneck + density head): -> d A7
-    run_bstage<SLOT, S::KW, 1, S::WT, true>(p, a, gd, b, GW, stash_at(7), dz_at(7), tile_valid);
+    run_bstage<SLOT, S::KW, 1, S::WT, true, S::WT>(p, a, gd, b, GW, stash_at(7), dz_at(7), tile_valid, a, dz_at(8));
     // bwd of stages 7, 6 -> d Z6, d Z5
-    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, b, nullptr, a, GW, stash_at(6), dz_at(6), tile_valid);
-    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, a, nullptr, b, GW, stash_at(5), dz_at(5), tile_valid);
+    run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, b, nullptr, a, GW, stash_at(6), dz_at(6), tile_valid, b, dz_at(7));
+    run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, a, nullptr, b, GW, stash_at(5), dz_at(5), tile_valid, a, dz_at(6));
     // bwd of stage 5: trunk rows -> d Z4 (in a); encoding rows (skip connection) only for POSE
     f32x16 denc[2];
-    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, b, nullptr, a, POSE ? GE : GW, stash_at(4), dz_at(4), tile_valid,
-                                            POSE ? 0 : GE);
+    run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, b, nullptr, a, POSE ? GE : GW, stash_at(4), dz_at(4), tile_valid,
+                                                   b, dz_at(5), POSE ? 0 : GE);
     if (POSE) run_enc_stage<S::KW>(p, b, denc, false, GW);
     // bwd of stages 4..1
-    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, a, nullptr, b, GW, stash_at(3), dz_at(3), tile_valid);
-    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, b, nullptr, a, GW, stash_at(2), dz_at(2), tile_valid);
-    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, a, nullptr, b, GW, stash_at(1), dz_at(1), tile_valid);
-    run_bstage<SLOT, S::KW, 0, S::WT, true>(p, b, nullptr, a, POSE ? GE : (has_next ? GB0 : 0), stash_at(0),
-                                            dz_at(0), tile_valid, 0, !POSE);
+    run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, a, nullptr, b, GW, stash_at(3), dz_at(3), tile_valid, a, dz_at(4));
+    run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, b, nullptr, a, GW, stash_at(2), dz_at(2), tile_valid, b, dz_at(3));
+    run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, a, nullptr, b, GW, stash_at(1), dz_at(1), tile_valid, a, dz_at(2));
+    run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, b, nullptr, a, POSE ? GE : (has_next ? GB0 : 0), stash_at(0),
+                                                   dz_at(0), tile_valid, b, dz_at(1), 0, !POSE);
+    if (tile_valid) {          // last stage's trailing stores
+#pragma unroll
+        for (int q = 4; q >= 1; q--) *(bf16x8*)(dz_at(0) + (2 * S::WT - q) * 1024 + lane * 16) = a[2 * S::WT - q];
+    }
     if (POSE) {
         // Dense_0 -> d(encoding); total d enc = skip-connection part + first-layer part
         run_enc_stage<S::KW>(p, a, denc, true, has_next ? GB0 : 0, true);
@@ -391,7 +399,8 @@ k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restri
             else { ks = ci - NKO - NKA; src = inB + (t * NKB + ks) * 1024; ks += NKA; }
             const int c = 2 * (ks & 1) + g_hif;
             const int n = (g_p & 16) | ((g_p - 4 * c) & 15);
-            glds16b(src + (g_hif * 32 + n) * 16, dst + ci * 1024);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g_hif * 32 + n) * 16),
+                                             (__attribute__((address_space(3))) void*)(dst + ci * 1024), 16, 0, 0);
         }
     };
     // per-lane tr-read geometry (see header comment): lane l -> group g, provider index L

@@ -8,9 +8,13 @@
 // MFMA-bound: 2*606 208 padded MAC per sample (591 872 algorithmic) for W=256.
 #include "mlp_spec.h"
 
-__device__ __forceinline__ void glds16(const void* g, void* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+// 16 bytes per lane, global -> LDS (lane-linear destination), as a BUFFER load: descriptor in
+// SGPRs, one constant per-lane VGPR offset (lane*16), the chunk offset in an SGPR.  The
+// global_load_lds form needs a 64-bit per-lane VGPR address for every tile group; hipcc
+// precomputes those, they spill, and a scratch reload next to an in-flight LDS-DMA makes it
+// drain the whole weight prefetch (s_waitcnt vmcnt(0)).
+__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned voff, void* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -73,7 +77,8 @@ k_pack_fwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
 // fused forward
 // ---------------------------------------------------------------------------
 struct WPipe {
-    const char* gnext;   // next tile to prefetch (global)
+    __amdgpu_buffer_rsrc_t rsrc;   // the packed weight stream
+    unsigned gnext;      // byte offset of the next tile group to prefetch
     char* lds;           // base of the two slots
     int slot_bytes;
     int par;             // slot that holds the tile about to be consumed
@@ -84,8 +89,8 @@ struct WPipe {
         __syncthreads();   // drains this wave's glds (vmcnt) + all waves done with the other slot
         char* dst = lds + (par ^ 1) * slot_bytes;
         for (int c = wave; c < next_chunks; c += 8)
-            glds16(gnext + (size_t)c * 1024 + lane * 16, dst + c * 1024);
-        gnext += (size_t)next_chunks * 1024;
+            glds16(rsrc, gnext + c * 1024u, lane * 16u, dst + c * 1024);
+        gnext += next_chunks * 1024u;
         const char* cur = lds + par * slot_bytes;
         par ^= 1;
         return cur;
@@ -173,10 +178,19 @@ __host__ __device__ constexpr int group_tiles(int nmt, int ch, int slot) {
 }
 
 // One dense stage: NMT output tiles, inputs inA[NA] (C-perm) ++ inB[NB] (natural).
-template <int SLOT, int NA, int NB, int NMT, bool RELU, bool TRAIN>
+// Training stores (activation stash + ReLU mask) always trail the compute by one tile pair,
+// also across stage boundaries (the previous stage's last pair is written after THIS stage's
+// first barrier): a store issued right before a barrier would expose its full HBM latency,
+// because the barrier's release waits for every outstanding memory operation of the wave.
+template <int SLOT, int NA, int NB, int NMT, bool RELU, bool TRAIN, int PREV_NMT>
 __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf16x8* inB,
-                                          bf16x8* out, int next_stage_chunks, bf16x8* stash_dst,
-                                          bool valid, uint4* mask_dst = nullptr) {
+                                          bf16x8* out, int next_stage_chunks, char* stash_dst,
+                                          bool valid, const bf16x8* prev_out, char* prev_dst,
+                                          char* prev_mask_dst, uint4& mask_carry) {
+    // stash_dst / prev_dst / prev_mask_dst are WAVE-UNIFORM byte pointers (this wave's 32-sample
+    // tile of one region); the per-lane part is lane*16.  Keeping them uniform keeps them in
+    // SGPRs: as per-lane 64-bit pointers they spill, and a scratch reload next to an in-flight
+    // global_load_lds makes hipcc drain the whole weight prefetch (vmcnt(0)).
     constexpr int CH = NA + NB + 1;
     constexpr int G = group_tiles(NMT, CH, SLOT);
     static_assert(NMT % 2 == 0 && G % 2 == 0, "stages processed by run_stage have an even tile count");
@@ -188,9 +202,16 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
             const int rest = NMT - mo - G;                       // tiles after this group
             slot = p.begin(rest > 0 ? (rest < G ? rest : G) * CH : next_stage_chunks);
         }
-        if (TRAIN && mo > 0 && valid) {     // delayed store of the previous pair's output
+        if (TRAIN && valid) {
+            if (mo > 0) {
 #pragma unroll
-            for (int q = 4; q >= 1; q--) stash_dst[(2 * mo - q) * 64] = out[2 * mo - q];
+                for (int q = 4; q >= 1; q--) *(bf16x8*)(stash_dst + (2 * mo - q) * 1024 + p.lane * 16) = out[2 * mo - q];
+            } else if (PREV_NMT > 0) {
+#pragma unroll
+                for (int q = 4; q >= 1; q--)
+                    *(bf16x8*)(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16) = prev_out[2 * PREV_NMT - q];
+                if (prev_mask_dst) *(uint4*)(prev_mask_dst + p.lane * 16) = mask_carry;
+            }
         }
         f32x16 acc0, acc1;
         mma_tile2<NA, NB>(slot + (mo % G) * CH * 1024, slot + (mo % G + 1) * CH * 1024, p.lane, inA, inB, acc0, acc1);
@@ -198,11 +219,7 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
         const unsigned bits1 = pack_tile<RELU>(acc1, out[2 * mo + 2], out[2 * mo + 3]);
         if (TRAIN && RELU) mb[mo >> 1] |= bits0 | (bits1 << 16);
     }
-    if (TRAIN && valid) {
-#pragma unroll
-        for (int q = 4; q >= 1; q--) stash_dst[(2 * NMT - q) * 64] = out[2 * NMT - q];
-        if (RELU && mask_dst) *mask_dst = make_uint4(mb[0], mb[1], mb[2], mb[3]);
-    }
+    if (TRAIN && RELU) mask_carry = make_uint4(mb[0], mb[1], mb[2], mb[3]);
 }
 
 template <int W, bool TRAIN>
@@ -229,13 +246,14 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
 
     WPipe p;
     constexpr int SLOT = 4 * (S::KW + 1);            // chunks per LDS slot (two slots)
-    p.gnext = wpack; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
+    p.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, S::TOTAL_CHUNKS * 1024, 0x00020000);
+    p.gnext = 0; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
     p.wave = wave; p.lane = lane;
     // prologue: first tile group of stage 0 -> slot 0
     constexpr int G0 = group_tiles(S::WT, S::KE + 1, SLOT) * (S::KE + 1);
     for (int c = wave; c < G0; c += 8)
-        glds16(p.gnext + (size_t)c * 1024 + lane * 16, p.lds + c * 1024);
-    p.gnext += (size_t)G0 * 1024;
+        glds16(p.rsrc, c * 1024u, lane * 16u, p.lds + c * 1024);
+    p.gnext = G0 * 1024u;
 
   // Persistent workgroup: one CU holds one workgroup (136 KB of LDS), so looping over the
   // 256-sample blocks here instead of relaunching hides every block's start-up (first weight
@@ -249,9 +267,9 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
 
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     bf16x8 encf[S::KE];
-    const bf16x8* enc_t = enc + (tile32 * S::KE) * 64 + lane;
+    const char* enc_u = (const char*)enc + tile32 * (S::KE * 1024);      // wave-uniform
 #pragma unroll
-    for (int k = 0; k < S::KE; k++) encf[k] = tile_valid ? enc_t[k * 64] : zero8;
+    for (int k = 0; k < S::KE; k++) encf[k] = tile_valid ? *(const bf16x8*)(enc_u + k * 1024 + lane * 16) : zero8;
     // jnp.maximum propagates NaN through every ReLU, v_max_f32 does not.  The only source of
     // non-finite values is the encoding of a garbage (multi-hit) ray, and one non-finite
     // feature makes the reference's MLP output NaN: detect it once here and poison the output.
@@ -266,31 +284,38 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     poison |= (__shfl_xor((int)poison, 32, 64) != 0);      // the sample's other 32 features
 
     bf16x8 a[S::KW], b[S::KW];
-    auto stash_at = [&](int j) -> bf16x8* {
-        return stash + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 64 + lane;
+    auto stash_at = [&](int j) -> char* {      // wave-uniform base of this wave's tile in region j
+        return (char*)stash + ((size_t)S::stash_ks_before(j) * ntile32 + tile32 * S::stash_ks(j)) * 1024;
     };
     // ReLU bit-masks for the backward: region j (stages 0..7 -> 0..7, stage 9 -> 8), one uint4 per lane
-    auto mask_at = [&](int j) -> uint4* {
-        return relu_mask ? relu_mask + ((size_t)j * ntile32 + tile32) * 64 + lane : nullptr;
+    auto mask_at = [&](int j) -> char* {
+        return relu_mask ? (char*)relu_mask + ((size_t)j * ntile32 + tile32) * 1024 : nullptr;
     };
     constexpr int CHW = S::KW + 1;
     constexpr int GW = group_tiles(S::WT, CHW, SLOT) * CHW;                       // first group of a WxW stage
     constexpr int G5 = group_tiles(S::WT, S::KW + S::KE + 1, SLOT) * (S::KW + S::KE + 1);
     constexpr int G9 = group_tiles(S::CT, S::KW + S::KV + 1, SLOT) * (S::KW + S::KV + 1);
+    uint4 mcarry = make_uint4(0u, 0u, 0u, 0u);
+#define ST(j) (TRAIN ? stash_at(j) : nullptr)
+#define MK(j) (TRAIN ? mask_at(j) : nullptr)
     // stage 0: enc -> a
-    run_stage<SLOT, 0, S::KE, S::WT, true, TRAIN>(p, nullptr, encf, a, GW, TRAIN ? stash_at(0) : nullptr, tile_valid, TRAIN ? mask_at(0) : nullptr);
+    run_stage<SLOT, 0, S::KE, S::WT, true, TRAIN, 0>(p, nullptr, encf, a, GW, ST(0), tile_valid, nullptr, nullptr, nullptr, mcarry);
     // stages 1-4
-    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, GW, TRAIN ? stash_at(1) : nullptr, tile_valid, TRAIN ? mask_at(1) : nullptr);
-    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, GW, TRAIN ? stash_at(2) : nullptr, tile_valid, TRAIN ? mask_at(2) : nullptr);
-    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, GW, TRAIN ? stash_at(3) : nullptr, tile_valid, TRAIN ? mask_at(3) : nullptr);
-    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, G5, TRAIN ? stash_at(4) : nullptr, tile_valid, TRAIN ? mask_at(4) : nullptr);
-    // stage 5: [a, enc] -> b
-    run_stage<SLOT, S::KW, S::KE, S::WT, true, TRAIN>(p, a, encf, b, GW, TRAIN ? stash_at(5) : nullptr, tile_valid, TRAIN ? mask_at(5) : nullptr);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, a, nullptr, b, GW, ST(1), tile_valid, a, ST(0), MK(0), mcarry);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, b, nullptr, a, GW, ST(2), tile_valid, b, ST(1), MK(1), mcarry);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, a, nullptr, b, GW, ST(3), tile_valid, a, ST(2), MK(2), mcarry);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, b, nullptr, a, G5, ST(4), tile_valid, b, ST(3), MK(3), mcarry);
+    // stage 5: [a, enc] -> b.  The encoding fragments are re-read here (L2-resident) rather than
+    // held in 16 VGPRs across stages 1-4, where the kernel sits at the 256-register cap.
+    bf16x8 encs[S::KE];
+#pragma unroll
+    for (int k = 0; k < S::KE; k++) encs[k] = tile_valid ? *(const bf16x8*)(enc_u + k * 1024 + lane * 16) : zero8;
+    run_stage<SLOT, S::KW, S::KE, S::WT, true, TRAIN, S::WT>(p, a, encs, b, GW, ST(5), tile_valid, a, ST(4), MK(4), mcarry);
     // stages 6, 7
-    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, b, nullptr, a, GW, TRAIN ? stash_at(6) : nullptr, tile_valid, TRAIN ? mask_at(6) : nullptr);
-    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN>(p, a, nullptr, b, GW, TRAIN ? stash_at(7) : nullptr, tile_valid, TRAIN ? mask_at(7) : nullptr);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, b, nullptr, a, GW, ST(6), tile_valid, b, ST(5), MK(5), mcarry);
+    run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, a, nullptr, b, GW, ST(7), tile_valid, a, ST(6), MK(6), mcarry);
     // stage 8: b -> bottleneck (a, linear) + density
-    run_stage<SLOT, S::KW, 0, S::WT, false, TRAIN>(p, b, nullptr, a, CHW, TRAIN ? stash_at(8) : nullptr, tile_valid);
+    run_stage<SLOT, S::KW, 0, S::WT, false, TRAIN, S::WT>(p, b, nullptr, a, CHW, ST(8), tile_valid, b, ST(7), MK(7), mcarry);
     float dens;
     {
         const char* slot = p.begin(G9);
@@ -307,11 +332,16 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
             vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + (lane >> 5)] : zero8;
     }
     bf16x8 c[S::KC];
-    run_stage<SLOT, S::KW, S::KV, S::CT, true, TRAIN>(p, a, vf, c, S::KC + 1, TRAIN ? stash_at(9) : nullptr, tile_valid, TRAIN ? mask_at(8) : nullptr);
+    run_stage<SLOT, S::KW, S::KV, S::CT, true, TRAIN, S::WT>(p, a, vf, c, S::KC + 1, ST(9), tile_valid, a, ST(8), nullptr, mcarry);
     // stage 10: c -> rgb; meanwhile the next block's first weight group streams in
     {
-        p.gnext = wpack;
+        p.gnext = 0;
         const char* slot = p.begin(has_next ? G0 : 0);
+        if (TRAIN && tile_valid) {               // trailing stores of stage 9
+#pragma unroll
+            for (int q = 4; q >= 1; q--) *(bf16x8*)(ST(9) + (2 * S::CT - q) * 1024 + lane * 16) = c[2 * S::CT - q];
+            if (MK(8)) *(uint4*)(MK(8) + lane * 16) = mcarry;
+        }
         const f32x16 acc = mma_tile<S::KC, 0>(slot, lane, c, nullptr);
         if (valid && lane < 32) {
             const float qn = __builtin_nanf("");
@@ -319,6 +349,8 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
             *(f32x4*)(raw + row * 4) = o;
         }
     }
+#undef ST
+#undef MK
   }
 }
 
