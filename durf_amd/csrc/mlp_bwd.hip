@@ -366,15 +366,51 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base, int off0, int off1) 
 }
 
 // NKO: k-steps (16 features) of dZ; NKA/NKB: k-steps of the two input segments.
+// The kernel streams 1 KB per sample per 256x256 layer from HBM at an arithmetic intensity of
+// 128 FLOP/B, i.e. it is HBM-bound by construction; what matters is bytes in flight per CU.
+// A DW_STAGES-deep LDS ring (32-36 KB per stage) is filled by buffer_load...lds with counted
+// s_waitcnt vmcnt(N) and raw s_barrier, so 2-3 stages (~100 KB) are always in flight per CU.
+#define DW_STAGES 4
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+// LDS-DMA issued from inline asm: hipcc orders every later ds_read behind ALL outstanding
+// buffer_load...lds it knows about (s_waitcnt vmcnt(0)), which would drain the ring on every
+// tile.  Hidden in asm, the loads are ordered only by this kernel's own counted waits.
+// (M0 = LDS byte address of the 1 KB chunk; saved/restored because hipcc owns M0.)
+__device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned soff, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+    r[2] = 0x7fffffff;          // num_records (bytes): whole address space above the base
+    r[3] = 0x00020000;          // raw buffer, dword data format (as __builtin_amdgcn_make_buffer_rsrc)
+    return r;
+}
+
 template <int NKO, int NKA, int NKB>
 __global__ void __launch_bounds__(512, 2)
 k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restrict__ dz,
      const char* __restrict__ inA, const char* __restrict__ inB, int nsplit, int split_off,
      float* __restrict__ part, float* __restrict__ bpart) {
     constexpr int NKI = NKA + NKB;
+    constexpr int NC = NKO + NKI;                 // 1 KB chunks per 32-sample stage
+    constexpr int CPW = (NC + 7) / 8;             // LDS-DMA instructions per wave per stage
     constexpr int MO = (NKO + 1) / 2, NI = NKI / 2;
     constexpr int RM = (MO + 3) / 4, RN = (NI + 1) / 2;
-    constexpr int STAGE = (NKO + NKI) * 1024;
+    constexpr int STAGE = NC * 1024;
+    constexpr int S = DW_STAGES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -386,21 +422,39 @@ k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restri
     const size_t t0 = (size_t)blockIdx.x * tps;
     size_t t1 = t0 + tps;
     if (t1 > nt_valid) t1 = nt_valid;
+    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
 
-    // glds source swizzle: LDS vector position p of half hi_f holds sample n with
+    // buffer descriptors based at this workgroup's first tile (32-bit offsets stay small)
+    const i32x4 r_dz = make_rsrc(dz + t0 * NKO * 1024);
+    const i32x4 r_a = make_rsrc(inA + t0 * NKA * 1024);
+    const i32x4 r_b = make_rsrc(NKB ? inB + t0 * (NKB ? NKB : 1) * 1024 : inA);
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // LDS-DMA source swizzle: LDS vector position p of half hi_f holds sample n with
     //   p = (n & 16) | ((n + 4*(2*(ks&1) + hi_f)) & 15)   -> conflict-free tr-reads
     const int g_hif = lane >> 5, g_p = lane & 31;
-    auto stage_load = [&](size_t t, char* dst) {
-        for (int ci = wave; ci < NKO + NKI; ci += 8) {
-            const char* src;
-            int ks;
-            if (ci < NKO) { ks = ci; src = dz + (t * NKO + ks) * 1024; }
-            else if (ci < NKO + NKA) { ks = ci - NKO; src = inA + (t * NKA + ks) * 1024; }
-            else { ks = ci - NKO - NKA; src = inB + (t * NKB + ks) * 1024; ks += NKA; }
-            const int c = 2 * (ks & 1) + g_hif;
-            const int n = (g_p & 16) | ((g_p - 4 * c) & 15);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (g_hif * 32 + n) * 16),
-                                             (__attribute__((address_space(3))) void*)(dst + ci * 1024), 16, 0, 0);
+    unsigned voff[2];
+#pragma unroll
+    for (int par = 0; par < 2; par++) {
+        const int c = 2 * par + g_hif;
+        const int n = (g_p & 16) | ((g_p - 4 * c) & 15);
+        voff[par] = (unsigned)((g_hif * 32 + n) * 16);
+    }
+    auto stage_load = [&](int ti, int slot) {        // ti = tile index relative to t0
+        ti = __builtin_amdgcn_readfirstlane(ti);
+        const unsigned dst = lds0 + (unsigned)(slot * STAGE);
+#pragma unroll
+        for (int i = 0; i < CPW; i++) {
+            int ci = wave + 8 * i;
+            if (ci >= NC) ci -= NC;                    // pad: re-load an early chunk (same bytes, same place)
+            if (ci < NKO) {
+                lds_dma16(r_dz, (unsigned)((ti * NKO + ci) * 1024), voff[ci & 1], dst + ci * 1024);
+            } else if (ci < NKO + NKA) {
+                const int ks = ci - NKO;
+                lds_dma16(r_a, (unsigned)((ti * NKA + ks) * 1024), voff[ks & 1], dst + ci * 1024);
+            } else {
+                const int ks = ci - NKO - NKA;
+                lds_dma16(r_b, (unsigned)((ti * NKB + ks) * 1024), voff[(ks + NKA) & 1], dst + ci * 1024);
+            }
         }
     };
     // per-lane tr-read geometry (see header comment): lane l -> group g, provider index L
@@ -422,13 +476,19 @@ k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restri
 #pragma unroll
     for (int rm = 0; rm < RM; rm++) bsum[rm] = 0.0f;
 
-    int par = 0;
-    if (t0 < t1) stage_load(t0, smem);
-    for (size_t t = t0; t < t1; t++) {
-        __syncthreads();
-        if (t + 1 < t1) stage_load(t + 1, smem + (par ^ 1) * STAGE);
-        const char* st = smem + par * STAGE;
-        par ^= 1;
+    // prologue: S-1 stages in flight
+#pragma unroll
+    for (int i = 0; i < S - 1; i++)
+        if (i < nt) stage_load(i, i);
+    for (int t = 0; t < nt; t++) {
+        // this wave's part of tile t has landed when at most min(S-2, nt-1-t) later stages are pending
+        const int later = nt - 1 - t;
+        if (later >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * CPW) : "memory");
+        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // every wave's part landed; everyone is done with tile t-1's slot
+        if (t + S - 1 < nt) stage_load(t + S - 1, (t + S - 1) % S);
+        const char* st = smem + (t % S) * STAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             bf16x8 af[RM], bf[RN];
@@ -573,7 +633,9 @@ k_dw_finalize(int W, int in_dim, DwJobs jobs, int nparts, const float* __restric
 template <int NKO, int NKA, int NKB>
 static int launch_dw(hipStream_t s, size_t rows, int N, const int32_t* count, const void* dz, const void* inA,
                      const void* inB, int nsplit, int split_off, float* part, float* bpart) {
-    hipLaunchKernelGGL((k_dw<NKO, NKA, NKB>), dim3(nsplit), dim3(512), 2 * (NKO + NKA + NKB) * 1024, s, rows, N,
+    constexpr int lds = DW_STAGES * (NKO + NKA + NKB) * 1024;
+    (void)hipFuncSetAttribute((const void*)k_dw<NKO, NKA, NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((k_dw<NKO, NKA, NKB>), dim3(nsplit), dim3(512), lds, s, rows, N,
                        count, (const char*)dz, (const char*)inA, (const char*)inB, nsplit, split_off, part, bpart);
     return 0;
 }
