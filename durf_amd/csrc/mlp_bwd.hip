@@ -11,6 +11,7 @@
 //      on the LDS read path (semantics verified by tools/probes/probe_tr.hip).  Split-K over
 //      workgroups with fp32 partials, summed in a fixed order by k_dw_finalize
 //      (deterministic; no atomics).  HBM-bound: 1 KB read per sample per 256x256 layer.
+#include <stdlib.h>
 #include "mlp_spec.h"
 
 // buffer form of the LDS-DMA (descriptor + SGPR offset + one per-lane VGPR offset), see mlp_fwd.hip
@@ -400,10 +401,10 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p) {
 }
 
 template <int NKO, int NKA, int NKB>
-__global__ void __launch_bounds__(512, 2)
-k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restrict__ dz,
-     const char* __restrict__ inA, const char* __restrict__ inB, int nsplit, int split_off,
-     float* __restrict__ part, float* __restrict__ bpart) {
+__device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __restrict__ count,
+                                       const char* __restrict__ dz, const char* __restrict__ inA,
+                                       const char* __restrict__ inB, int nsplit, int split_idx, int split_off,
+                                       float* __restrict__ part, float* __restrict__ bpart, char* smem) {
     constexpr int NKI = NKA + NKB;
     constexpr int NC = NKO + NKI;                 // 1 KB chunks per 32-sample stage
     constexpr int CPW = (NC + 7) / 8;             // LDS-DMA instructions per wave per stage
@@ -411,7 +412,6 @@ k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restri
     constexpr int RM = (MO + 3) / 4, RN = (NI + 1) / 2;
     constexpr int STAGE = NC * 1024;
     constexpr int S = DW_STAGES;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -419,7 +419,7 @@ k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restri
     if (count) { const size_t c = (size_t)(*count) * (size_t)N; nrows = c < rows ? c : rows; }
     const size_t nt_valid = nrows >> 5;
     const size_t tps = (nt_valid + nsplit - 1) / nsplit;     // even share of the VALID tiles
-    const size_t t0 = (size_t)blockIdx.x * tps;
+    const size_t t0 = (size_t)split_idx * tps;
     size_t t1 = t0 + tps;
     if (t1 > nt_valid) t1 = nt_valid;
     const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
@@ -528,7 +528,7 @@ k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restri
         }
     }
     // partials in fragment coordinates: [split][mo][ni][lane][16]
-    const size_t sp = (size_t)split_off + blockIdx.x;
+    const size_t sp = (size_t)split_off + split_idx;
 #pragma unroll
     for (int rm = 0; rm < RM; rm++) {
         const int mo = wm + 4 * rm;
@@ -551,6 +551,40 @@ k_dw(size_t rows, int N, const int32_t* __restrict__ count, const char* __restri
             }
         }
     }
+}
+
+// One launch for the 12 weight-gradient GEMMs of an MLP: blockIdx.y = job (= flax Dense index),
+// blockIdx.x = split within the job.  Splits are allotted in proportion to each job's bytes per
+// sample so that ~4 rounds of workgroups smooth the tail, with ~3x fewer split-K partials than one
+// 256-way launch per job.
+struct DwArgs {
+    const char* dz[12];
+    const char* inA[12];
+    const char* inB[12];
+    float* part[12];
+    float* bpart[12];
+    int nsplit[12];
+    int split_off[12];
+};
+
+template <int W>
+__global__ void __launch_bounds__(512, 2)
+k_dw_all(size_t rows, int N, const int32_t* __restrict__ count, DwArgs a) {
+    using S = MlpSpec<W>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int job = blockIdx.y, sp = blockIdx.x;
+    const int ns = a.nsplit[job];
+    if (sp >= ns) return;
+#define DW_CALL(NKO, NKA, NKB) dw_job<NKO, NKA, NKB>(rows, N, count, a.dz[job], a.inA[job], a.inB[job], ns, sp, a.split_off[job], a.part[job], a.bpart[job], smem)
+    switch (job) {
+        case 0: DW_CALL(S::KW, S::KE, 0); break;
+        case 5: DW_CALL(S::KW, S::KW, S::KE); break;
+        case 8: DW_CALL(1, S::KW, 0); break;
+        case 10: DW_CALL(S::KC, S::KW, S::KV); break;
+        case 11: DW_CALL(1, S::KC, 0); break;
+        default: DW_CALL(S::KW, S::KW, 0); break;      // Dense 1-4, 6, 7, 9
+    }
+#undef DW_CALL
 }
 
 // slot index (position in tile-layout feature order) of feature f
@@ -577,15 +611,16 @@ __host__ __device__ inline int cperm_feat(int s) {
 // partial: coalesced; 4 waves take interleaved partials with 8 loads in flight each, combined
 // in a fixed order -> deterministic), then scatter each sum to its flax [in,out] position.
 // One launch covers all 12 Dense layers of an MLP (blockIdx.y = job).
-struct DwJobs { DwJob j[12]; size_t part_stride, bpart_stride; };
+struct DwJobs { DwJob j[12]; size_t part_off[12], bpart_off[12]; int nparts[12]; };
 
 __global__ void __launch_bounds__(256)
-k_dw_finalize(int W, int in_dim, DwJobs jobs, int nparts, const float* __restrict__ part_all,
+k_dw_finalize(int W, int in_dim, DwJobs jobs, const float* __restrict__ part_all,
               const float* __restrict__ bpart_all, float* __restrict__ grad_mlp) {
     __shared__ float red[4][64];
     const DwJob job = jobs.j[blockIdx.y];
-    const float* part = part_all + (size_t)blockIdx.y * jobs.part_stride;
-    const float* bpart = bpart_all + (size_t)blockIdx.y * jobs.bpart_stride;
+    const int nparts = jobs.nparts[blockIdx.y];
+    const float* part = part_all + jobs.part_off[blockIdx.y];
+    const float* bpart = bpart_all + jobs.bpart_off[blockIdx.y];
     int fi, fo;
     durf_layer_shape(W, in_dim, job.layer, &fi, &fo);
     const int nfrag = job.MO * job.NI * 1024;
@@ -630,14 +665,41 @@ k_dw_finalize(int W, int in_dim, DwJobs jobs, int nparts, const float* __restric
     }
 }
 
-template <int NKO, int NKA, int NKB>
-static int launch_dw(hipStream_t s, size_t rows, int N, const int32_t* count, const void* dz, const void* inA,
-                     const void* inB, int nsplit, int split_off, float* part, float* bpart) {
-    constexpr int lds = DW_STAGES * (NKO + NKA + NKB) * 1024;
-    (void)hipFuncSetAttribute((const void*)k_dw<NKO, NKA, NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((k_dw<NKO, NKA, NKB>), dim3(nsplit), dim3(512), lds, s, rows, N,
-                       count, (const char*)dz, (const char*)inA, (const char*)inB, nsplit, split_off, part, bpart);
-    return 0;
+// split plan of the grouped weight-gradient launch (host side, depends on the width only)
+struct DwPlan {
+    int nko[12], nki[12], MO[12], NI[12], nsplit[12];
+    size_t part_off[12], bpart_off[12], part_total, bpart_total;
+    int max_split;
+};
+static DwPlan dw_plan(int width, int nlevels) {
+    DwPlan P;
+    const int KW = width / 16;
+    int cost = 0;
+    for (int j = 0; j < 12; j++) {
+        int nko = KW, nki = KW;
+        if (j == 0) nki = 4;
+        else if (j == 5) nki = KW + 4;
+        else if (j == 8) nko = 1;
+        else if (j == 10) { nko = 8; nki = KW + 2; }
+        else if (j == 11) { nko = 1; nki = 8; }
+        P.nko[j] = nko; P.nki[j] = nki;
+        P.MO[j] = (nko + 1) / 2; P.NI[j] = nki / 2;
+        cost += nko + nki;
+    }
+    size_t po = 0, bo = 0;
+    P.max_split = 0;
+    for (int j = 0; j < 12; j++) {
+        static const int total_wgs = getenv("DURF_DW_WGS") ? atoi(getenv("DURF_DW_WGS")) : 1024;   // tuning knob (swept 256..1024 on MI355X)
+        int ns = (total_wgs * (P.nko[j] + P.nki[j]) + cost / 2) / cost;
+        if (ns < 2) ns = 2;
+        P.nsplit[j] = ns;
+        if (ns > P.max_split) P.max_split = ns;
+        P.part_off[j] = po; P.bpart_off[j] = bo;
+        po += (size_t)nlevels * ns * P.MO[j] * P.NI[j] * 1024;
+        bo += (size_t)nlevels * ns * P.MO[j] * 32;
+    }
+    P.part_total = po; P.bpart_total = bo;
+    return P;
 }
 
 // ---------------------------------------------------------------------------
@@ -693,80 +755,76 @@ int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, co
     return 0;
 }
 
-size_t durf_dw_part_floats(int width) {     // floats per split of the largest job (256 x 320 / 128 x 192)
-    return width == 256 ? (size_t)8 * 10 * 1024 : (size_t)4 * 6 * 1024;
-}
+size_t durf_dw_part_floats(int width, int nlevels) { return dw_plan(width, nlevels).part_total; }
+size_t durf_dw_bpart_floats(int width, int nlevels) { return dw_plan(width, nlevels).bpart_total; }
 
-// All weight gradients of one MLP for one level.  Partials of this call go to split slots
-// [split_off, split_off + nsplit); durf_mlp_dw_finalize sums nparts slots in order.
-// Each of the 12 jobs has its own partial region: part + job * nparts_total * part_floats.
+// All weight gradients of one MLP for one level: ONE grouped launch of the 12 split-K GEMMs.
+// Partials of level `level` go to that level's slots; durf_mlp_dw_finalize sums all levels.
 int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, const void* enc_tile,
-                const void* view_tile, const void* stash, const void* dz, const void* dz_out, int nsplit,
-                int split_off, int nparts_total, float* part, float* bpart) {
+                const void* view_tile, const void* stash, const void* dz, const void* dz_out, int level,
+                int nlevels, float* part, float* bpart) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
+    DURF_REQUIRE(level >= 0 && level < nlevels, "0 <= level < nlevels");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    const DwPlan P = dw_plan(width, nlevels);
     const size_t nt = rows >> 5;
-    const size_t pf = durf_dw_part_floats(width) * (size_t)nparts_total;
-    const size_t bf = (size_t)8 * 32 * nparts_total;
-    auto P = [&](int job) { return part + (size_t)job * pf; };
-    auto BP = [&](int job) { return bpart + (size_t)job * bf; };
-#define REGION(base, j, KWv, KCv) ((const char*)(base) + ((size_t)(j) * (KWv) * nt) * 1024)
-    if (width == 256) {
-        constexpr int KW = 16, KC = 8, KE = 4, KV = 2;
-        launch_dw<KW, KE, 0>(s, rows, N, count, REGION(dz, 0, KW, KC), enc_tile, nullptr, nsplit, split_off, P(0), BP(0));
-        for (int j = 1; j <= 7; j++) {
-            if (j == 5) launch_dw<KW, KW, KE>(s, rows, N, count, REGION(dz, 5, KW, KC), REGION(stash, 4, KW, KC), enc_tile, nsplit, split_off, P(5), BP(5));
-            else launch_dw<KW, KW, 0>(s, rows, N, count, REGION(dz, j, KW, KC), REGION(stash, j - 1, KW, KC), nullptr, nsplit, split_off, P(j), BP(j));
-        }
-        launch_dw<1, KW, 0>(s, rows, N, count, dz_out, REGION(stash, 7, KW, KC), nullptr, nsplit, split_off, P(8), BP(8));
-        launch_dw<KW, KW, 0>(s, rows, N, count, REGION(dz, 8, KW, KC), REGION(stash, 7, KW, KC), nullptr, nsplit, split_off, P(9), BP(9));
-        launch_dw<KC, KW, KV>(s, rows, N, count, REGION(dz, 9, KW, KC), REGION(stash, 8, KW, KC), view_tile, nsplit, split_off, P(10), BP(10));
-        launch_dw<1, KC, 0>(s, rows, N, count, dz_out, REGION(stash, 9, KW, KC), nullptr, nsplit, split_off, P(11), BP(11));
-    } else {
-        constexpr int KW = 8, KC = 8, KE = 4, KV = 2;
-        launch_dw<KW, KE, 0>(s, rows, N, count, REGION(dz, 0, KW, KC), enc_tile, nullptr, nsplit, split_off, P(0), BP(0));
-        for (int j = 1; j <= 7; j++) {
-            if (j == 5) launch_dw<KW, KW, KE>(s, rows, N, count, REGION(dz, 5, KW, KC), REGION(stash, 4, KW, KC), enc_tile, nsplit, split_off, P(5), BP(5));
-            else launch_dw<KW, KW, 0>(s, rows, N, count, REGION(dz, j, KW, KC), REGION(stash, j - 1, KW, KC), nullptr, nsplit, split_off, P(j), BP(j));
-        }
-        launch_dw<1, KW, 0>(s, rows, N, count, dz_out, REGION(stash, 7, KW, KC), nullptr, nsplit, split_off, P(8), BP(8));
-        launch_dw<KW, KW, 0>(s, rows, N, count, REGION(dz, 8, KW, KC), REGION(stash, 7, KW, KC), nullptr, nsplit, split_off, P(9), BP(9));
-        launch_dw<KC, KW, KV>(s, rows, N, count, REGION(dz, 9, KW, KC), REGION(stash, 8, KW, KC), view_tile, nsplit, split_off, P(10), BP(10));
-        launch_dw<1, KC, 0>(s, rows, N, count, dz_out, REGION(stash, 9, KW, KC), nullptr, nsplit, split_off, P(11), BP(11));
+    const int KW = width / 16;
+    auto region = [&](const void* base, int j) { return (const char*)base + ((size_t)j * KW * nt) * 1024; };
+    DwArgs a;
+    for (int j = 0; j < 12; j++) {
+        a.part[j] = part + P.part_off[j];
+        a.bpart[j] = bpart + P.bpart_off[j];
+        a.nsplit[j] = P.nsplit[j];
+        a.split_off[j] = level * P.nsplit[j];
+        a.inB[j] = nullptr;
+        if (j <= 7) { a.dz[j] = region(dz, j); a.inA[j] = j == 0 ? (const char*)enc_tile : region(stash, j - 1); }
     }
-#undef REGION
+    a.inB[5] = (const char*)enc_tile;
+    a.dz[8] = (const char*)dz_out; a.inA[8] = region(stash, 7);          // density head
+    a.dz[9] = region(dz, 8); a.inA[9] = region(stash, 7);                // bottleneck
+    a.dz[10] = region(dz, 9); a.inA[10] = region(stash, 8); a.inB[10] = (const char*)view_tile;
+    a.dz[11] = (const char*)dz_out; a.inA[11] = region(stash, 9);        // rgb head
+    dim3 grid(P.max_split, 12), block(512);
+    if (width == 256) {
+        constexpr int lds = DW_STAGES * (16 + 16 + 4) * 1024;
+        (void)hipFuncSetAttribute((const void*)k_dw_all<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(k_dw_all<256>, grid, block, lds, s, rows, N, count, a);
+    } else {
+        constexpr int lds = DW_STAGES * (8 + 8 + 4) * 1024;
+        (void)hipFuncSetAttribute((const void*)k_dw_all<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(k_dw_all<128>, grid, block, lds, s, rows, N, count, a);
+    }
     DURF_CHECK_LAUNCH("durf_mlp_dw");
     return 0;
 }
 
-int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nparts_total, const float* part,
+int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nlevels, const float* part,
                          const float* bpart, float* grad_mlp) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     hipStream_t s = (hipStream_t)stream;
     const int W = width, KW = W / 16;
+    const DwPlan P = dw_plan(width, nlevels);
     DwJobs jobs;
-    jobs.part_stride = durf_dw_part_floats(width) * (size_t)nparts_total;
-    jobs.bpart_stride = (size_t)8 * 32 * nparts_total;
     int max_el = 0;
     for (int job = 0; job < 12; job++) {
         DwJob& J = jobs.j[job];
         J.layer = job;
         J.out_nat_off = -1;
         J.in_perm_rows = W; J.in_nat_base = KW * 16;
-        int nko = KW, nki = KW;
-        if (job == 0) { J.in_perm_rows = 0; J.in_nat_base = 0; nki = 4; }
-        else if (job == 5) { nki = KW + 4; }
-        else if (job == 8) { J.out_nat_off = 3; nko = 1; }                 // density head: dz_out slot 3
-        else if (job == 10) { nko = 8; nki = KW + 2; }
-        else if (job == 11) { J.out_nat_off = 0; nko = 1; nki = 8; J.in_perm_rows = 128; J.in_nat_base = 128; }
-        J.MO = (nko + 1) / 2; J.NI = nki / 2;
+        if (job == 0) { J.in_perm_rows = 0; J.in_nat_base = 0; }
+        else if (job == 8) { J.out_nat_off = 3; }                 // density head: dz_out slot 3
+        else if (job == 11) { J.out_nat_off = 0; J.in_perm_rows = 128; J.in_nat_base = 128; }
+        J.MO = P.MO[job]; J.NI = P.NI[job];
+        jobs.part_off[job] = P.part_off[job];
+        jobs.bpart_off[job] = P.bpart_off[job];
+        jobs.nparts[job] = nlevels * P.nsplit[job];
         const int el = J.MO * J.NI * 1024 + J.MO * 32;
         if (el > max_el) max_el = el;
     }
-    hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12), dim3(256), 0, s, W, in_dim, jobs,
-                       nparts_total, part, bpart, grad_mlp);
+    hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12), dim3(256), 0, s, W, in_dim, jobs, part, bpart,
+                       grad_mlp);
     DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
     return 0;
 }

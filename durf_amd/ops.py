@@ -267,24 +267,22 @@ def expand_view(rows, N, view_bf16, ray_idx=None, count=None):
     return out
 
 
-def dw_buffers(width, nparts_total, device):
-    pf = int(_lib.lib().durf_dw_part_floats(width))
-    part = torch.empty(12 * nparts_total * pf, device=device)
-    bpart = torch.empty(12 * nparts_total * 256, device=device)
+def dw_buffers(width, nlevels, device):
+    part = torch.empty(int(_lib.lib().durf_dw_part_floats(width, nlevels)), device=device)
+    bpart = torch.empty(int(_lib.lib().durf_dw_bpart_floats(width, nlevels)), device=device)
     return part, bpart
 
 
-def mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, nsplit, split_off, nparts_total, part,
-           bpart, count=None):
+def mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, level, nlevels, part, bpart, count=None):
     with _Timed('mlp_dw_%d' % width):
         _lib.check(_lib.lib().durf_mlp_dw(_stream(), width, rows, N, _p(count), _p(enc_tile), _p(view_tile),
-                                          _p(stash), _p(dz), _p(dz_out), nsplit, split_off, nparts_total,
-                                          _p(part), _p(bpart)), 'durf_mlp_dw')
+                                          _p(stash), _p(dz), _p(dz_out), level, nlevels, _p(part), _p(bpart)),
+                   'durf_mlp_dw')
 
 
-def mlp_dw_finalize(width, in_dim, nparts_total, part, bpart, grad_mlp):
+def mlp_dw_finalize(width, in_dim, nlevels, part, bpart, grad_mlp):
     with _Timed('mlp_dw_finalize_%d' % width):
-        _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, nparts_total, _p(part), _p(bpart),
+        _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, nlevels, _p(part), _p(bpart),
                                                    _p(_f32(grad_mlp))), 'durf_mlp_dw_finalize')
 
 

@@ -53,7 +53,7 @@ def level_multipliers(config, level, num_levels):
             0.000001]
 
 
-def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=None, nsplit=None):
+def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=None):
     """value_and_grad(loss_fn) (train_boxpose.py:67-252) for this rank's shard.
     Returns (grad_flat, raw stats dict of device tensors, pose)."""
     pose_opt = not (model.no_pose_opt and model.no_yaw_opt)
@@ -66,8 +66,6 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     lay = variables.layout
     dev = variables.flat.device
     rows = B * N
-    if nsplit is None:
-        nsplit = max(1, min(256, rows // 32 // 8))
     lossmult = rays.lossmult.reshape(-1).contiguous()
     gt_depth = batch['depth'].reshape(-1).contiguous()
     sky = batch['sky'].reshape(-1).contiguous()
@@ -76,7 +74,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     bg = 0.0 if config.rand_bkgd else (1.0 if config.white_bkgd else 0.5)
     grad = torch.zeros_like(variables.flat)
     names = lay.mlp_names()
-    bufs = {n: ops.dw_buffers(lay.mlp_dims(n)[0], L * nsplit, dev) for n in names}
+    bufs = {n: ops.dw_buffers(lay.mlp_dims(n)[0], L, dev) for n in names}
     view_tile = ops.expand_view(rows, N, ctx['view'])
     view_tiles_obj = [ops.expand_view(rows, N, ctx['view'], ray_idx=ctx['idx'][k], count=ctx['count'][k:k + 1])
                       for k in range(K)]
@@ -95,8 +93,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         norms.append(norm)
         sums.append(s)
         dz, dz_out = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
-        ops.mlp_dw(om.W_BKGD, rows, N, lv['enc_b'], view_tile, lv['stash_b'], dz, dz_out, nsplit,
-                   lvl * nsplit, L * nsplit, *bufs['MLP_0'])
+        ops.mlp_dw(om.W_BKGD, rows, N, lv['enc_b'], view_tile, lv['stash_b'], dz, dz_out, lvl, L, *bufs['MLP_0'])
         for k in range(K):
             nm = 'BoxMLP_%d' % k
             cnt = ctx['count'][k:k + 1]
@@ -107,11 +104,11 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                 ops.encode_obj_bwd(k, ctx['idx'][k], cnt, res[2], lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
                                    rays.origins, rays.directions, pose_ts, alpha, pose_sums)
             ops.mlp_dw(om.W_OBJ, rows, N, lv['encs'][k], view_tiles_obj[k], lv['stashes'][k], dzk, dzk_out,
-                       nsplit, lvl * nsplit, L * nsplit, *bufs[nm], count=cnt)
+                       lvl, L, *bufs[nm], count=cnt)
     for n in names:
         width, in_dim = lay.mlp_dims(n)
         off = lay.mlp_off[n]
-        ops.mlp_dw_finalize(width, in_dim, L * nsplit, *bufs[n], grad[off:off + lay.mlp_size[width]])
+        ops.mlp_dw_finalize(width, in_dim, L, *bufs[n], grad[off:off + lay.mlp_size[width]])
     flat = variables.flat
     weight_l2 = torch.zeros((), device=dev)
     if config.weight_decay_mult != 0:                                          # :73-75

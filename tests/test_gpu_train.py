@@ -95,15 +95,13 @@ def test_mlp_backward_and_weight_grads(cuda, width, in_dim):
     mask = torch.zeros(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=cuda)
     ops.mlp_fwd(width, rows, N, enc_tile, view, wf, stash=stash, relu_mask=mask)
     dz, dz_out = ops.mlp_bwd(width, rows, N, draw.to(cuda), wb, mask)
-    nsplit = 3
-    part, bpart = ops.dw_buffers(width, 2 * nsplit, cuda)
-    part.zero_(); bpart.zero_()
+    part, bpart = ops.dw_buffers(width, 2, cuda)
     view_tile = ops.expand_view(rows, N, view)
-    # two calls into disjoint split slots (as the two levels of a training step do)
-    ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, nsplit, 0, 2 * nsplit, part, bpart)
-    ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, nsplit, nsplit, 2 * nsplit, part, bpart)
+    # two calls into the two level slots (as the two levels of a training step do)
+    ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, 0, 2, part, bpart)
+    ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, 1, 2, part, bpart)
     grad = torch.zeros_like(flat)
-    ops.mlp_dw_finalize(width, in_dim, 2 * nsplit, part, bpart, grad)
+    ops.mlp_dw_finalize(width, in_dim, 2, part, bpart, grad)
     grad = grad.cpu() / 2
     # oracle
     rgb, dens = R.mlp_apply_bf16(params, x, cond, cfg)
