@@ -201,17 +201,26 @@ __device__ __forceinline__ void contract_gaussian(Gauss& g) {
     }
 }
 
-// one IPE feature f in [0,60): mip.py:273-282 with basis [2^i I3]
+// one IPE feature f in [0,60): mip.py:273-282 with basis [2^i I3].
+// FAST (bf16 output only): after the same safe_sin wrap, sin/exp use the hardware
+// transcendental units (v_sin_f32 / v_exp_f32; abs error ~1e-4 at |y| ~ 300, far below the
+// bf16 quantum 4e-3) -- the accurate libm versions make this HBM-bound kernel VALU-bound.
+template <bool FAST>
 __device__ __forceinline__ float ipe_feature(const Gauss& g, int f) {
     const int c = f / 30, r = f - c * 30, deg = r / 3, j = r - deg * 3;
     const float sc = (float)(1 << deg);
     float y = g.x[j] * sc;
     if (c) y = y + 1.5707963705062866f;
     const float yv = g.var[j] * sc * sc;
+    if (FAST) {
+        const float t = 314.15927124023438f;
+        if (!(fabsf(y) < t)) { float m = fmodf(y, t); if (m != 0.0f && m < 0.0f) m += t; y = m; }
+        return __expf(-0.5f * yv) * __sinf(y);
+    }
     return expf(-0.5f * yv) * safe_sin(y);
 }
 
-template <bool OBJ>
+template <bool OBJ, bool FAST>
 __global__ void __launch_bounds__(256)
 k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
          const float* __restrict__ t_vals, const float* __restrict__ origins_s,
@@ -253,10 +262,10 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
         float val;
         if (OBJ) {
             if (p < 3) val = g.x[p];
-            else if (p < 63) { const int f = p - 3; val = w[f / 6] * ipe_feature(g, f); }   // mip.py:217-222
+            else if (p < 63) { const int f = p - 3; val = w[f / 6] * ipe_feature<FAST>(g, f); }   // mip.py:217-222
             else val = 0.0f;
         } else {
-            val = (p < 60) ? ipe_feature(g, p) : 0.0f;
+            val = (p < 60) ? ipe_feature<FAST>(g, p) : 0.0f;
         }
         v[e] = val;
     }
@@ -321,9 +330,14 @@ int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const floa
                      int contraction, void* out_tile, float* out_f32) {
     if (B <= 0) return 0;
     DURF_REQUIRE(((size_t)B * N) % 32 == 0 || out_tile == nullptr, "B*N must be a multiple of 32");
-    hipLaunchKernelGGL(k_encode<false>, dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
-                       (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
-                       hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
+    if (out_f32)
+        hipLaunchKernelGGL((k_encode<false, false>), dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
+                           (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
+                           hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
+    else
+        hipLaunchKernelGGL((k_encode<false, true>), dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
+                           (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
+                           hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
     DURF_CHECK_LAUNCH("durf_encode_bkgd");
     return 0;
 }
@@ -334,9 +348,14 @@ int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const
     if (max_rays <= 0) return 0;
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
-    hipLaunchKernelGGL(k_encode<true>, dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
-                       (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
-                       nullptr, 0, 0, bw, (bf16x8*)out_tile, out_f32);
+    if (out_f32)
+        hipLaunchKernelGGL((k_encode<true, false>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
+                           (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
+                           nullptr, 0, 0, bw, (bf16x8*)out_tile, out_f32);
+    else
+        hipLaunchKernelGGL((k_encode<true, true>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
+                           (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
+                           nullptr, 0, 0, bw, (bf16x8*)out_tile, out_f32);
     DURF_CHECK_LAUNCH("durf_encode_obj");
     return 0;
 }

@@ -115,6 +115,12 @@ def test_encode_bkgd(cuda, K):
     ut = H.untile(ot.cpu(), 256 * N, 4)
     torch.testing.assert_close(ut[:, :60], of.cpu().to(torch.bfloat16).float(), rtol=0, atol=0)
     assert (ut[:, 60:] == 0).all()
+    # bf16-only call = the production path (hardware sin/exp): within one bf16 quantum of the accurate one
+    ot2, _ = ops.encode_bkgd(t_vals.to(cuda), o_s.to(cuda).contiguous(), d_s.to(cuda).contiguous(),
+                             db['rays'].radii.reshape(-1), hit, True, tile=True, f32=False)
+    ut2 = H.untile(ot2.cpu(), 256 * N, 4)
+    torch.testing.assert_close(ut2[ok][:, :60], ref[ok], rtol=0, atol=6e-3)
+    assert (ut2[ok][:, :60] - ref[ok]).abs().mean() < 1.5e-3
 
 
 def test_encode_obj(cuda):
