@@ -1,0 +1,75 @@
+"""Data-parallel training step with the real kernels: 2 ranks (gloo, both on cuda:0 -- the GPU
+box has one device; RCCL needs one GPU per rank) must produce exactly the parameters a single
+process gets from averaging the two shards' gradients."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+GIN = ('MipNerfModel.num_samples = 32\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
+       'MipNerfModel.no_yaw_opt = True\nConfig.randomized = False\nConfig.rand_bkgd = False\n'
+       'Config.grad_max_norm = 1.0\nConfig.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.0\n')
+
+
+def _setup(dev):
+    sys.path.insert(0, ROOT)
+    from durf_amd import obbpose_model, synthetic, utils
+    from tests import helpers as H
+    utils.clear_gin()
+    utils.parse_gin(GIN)
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(512, 1, seed=41)
+    db = H.device_batch(b, dev)
+    model, variables = obbpose_model.construct_mipnerf(3, db, device=dev)
+    return config, model, variables, db
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DURF_DIST_BACKEND='gloo')
+    sys.path.insert(0, ROOT)
+    from durf_amd import train_boxpose
+    r, w, local = train_boxpose.init_distributed()
+    dev = torch.device('cuda', local)
+    config, model, variables, db = _setup(dev)
+    shard = train_boxpose.shard_batch(db, r, w)
+    state = train_boxpose.create_train_state(variables)
+    state, stats, _, _ = train_boxpose.train_step(model, config, 0, state, shard, 5e-4, 3.0, 10.0, db['init'][0:1])
+    torch.cuda.synchronize()
+    if r == 0:
+        torch.save(dict(flat=state.variables.flat.cpu(), loss=stats.loss.cpu()), os.path.join(out_dir, 'dp.pt'))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_step_matches_shard_average(cuda, tmp_path):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(os.path.join(str(tmp_path), 'dp.pt'))
+    # single process: per-shard gradients, mean, then the same clip + Adam
+    from durf_amd import ops, train_boxpose
+    config, model, variables, db = _setup(cuda)
+    grads, losses = [], []
+    for r in range(2):
+        shard = train_boxpose.shard_batch(db, r, 2)
+        g, raw, pose = train_boxpose.loss_and_grad(model, config, 0, variables, shard, 3.0, 10.0, db['init'][0:1])
+        st = train_boxpose._assemble_stats(model, config, shard, raw, db['init'][0:1], pose, raw['ret'][0][7][1])
+        grads.append(g)
+        losses.append(st['loss'])
+    gsum = grads[0] + grads[1]
+    state = train_boxpose.create_train_state(variables)
+    ops.clip_adam(variables.flat, state.m, state.v, gsum, 0.5, float(config.grad_max_val),
+                  float(config.grad_max_norm), 5e-4, 0)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(got['flat'], variables.flat.cpu(), rtol=0, atol=0)     # deterministic kernels
+    torch.testing.assert_close(got['loss'], ((losses[0] + losses[1]) / 2).cpu(), rtol=1e-6, atol=0)

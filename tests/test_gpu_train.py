@@ -140,11 +140,11 @@ def test_clip_adam(cuda):
         torch.testing.assert_close(vd.cpu(), st['v'][0], rtol=1e-5, atol=1e-12)
 
 
-@pytest.mark.parametrize('K,N', [(1, 32), (0, 64), (3, 32)])
-def test_train_step(cuda, K, N):
+@pytest.mark.parametrize('K,N,B', [(1, 32, 256), (0, 64, 256), (3, 32, 256), (2, 32, 141)])
+def test_train_step(cuda, K, N, B):
     """One full step (forward, losses, backward, clip, Adam) vs the oracle with bf16-rounded
-    GEMM operands.  Loss terms: 1e-3 rel; gradients: 5e-2 norm-wise (bf16 backward)."""
-    B = 256
+    GEMM operands.  Loss terms: 1e-3 rel; gradients: 5e-2 norm-wise (bf16 backward).
+    B = 141: ragged sizes (partial 256-sample blocks, partial 1024-thread compaction rounds)."""
     utils.clear_gin()
     utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
                     'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
