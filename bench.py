@@ -28,6 +28,7 @@ K_OBJ = 1
 FAR = 200.0            # configs/carla_dyn.gin:13
 MAC_BKGD, MAC_OBJ = 591872, 167552
 PEAK_BF16 = 2.5e15     # dense MFMA bf16 peak, MI355X_MICROARCH.md
+PEAK_HBM = 8.0e12      # HBM3E spec peak (6.29e12 measured-achievable), MI355X_MICROARCH.md
 
 
 def gin_text():
@@ -128,19 +129,46 @@ def main():
     if rank == 0:
         rows = B * N_SAMPLES
         hit = float(batch_np['hit_fraction'])
-        # dominant kernel family: the fused background-MLP kernels (forward, backward data,
-        # weight gradient); algorithmic FLOPs = 2 * MAC * samples per launch
-        flops = {'mlp_fwd_256_train': 2.0 * MAC_BKGD * rows, 'mlp_bwd_256': 2.0 * MAC_BKGD * rows,
-                 'mlp_dw_256': 2.0 * MAC_BKGD * rows}
-        per = {k: totals[k][1] / totals[k][0] for k in flops if k in totals}
+        # Roofline of the three background-MLP kernels (96 % of the step).  Algorithmic work per
+        # launch (one level): FLOPs = 2 * 591 872 MAC * samples; bytes = what the
+        # data flow of DESIGN.md section 3 has to move: bf16 activation stash 9*W+128 features
+        # (4864 B/sample), ReLU bit-mask 288 B/sample, encoding 128 B, raw/draw 16 B, dz_out 32 B;
+        # the weight-gradient GEMMs read dz + stash + encodings = 332 KB per 32-sample tile.
+        stash_b, mask_b = 4864.0, 288.0
+        work = {
+            'mlp_fwd_256_train': (2.0 * MAC_BKGD * rows, rows * (128 + stash_b + mask_b + 16)),
+            'mlp_bwd_256': (2.0 * MAC_BKGD * rows, rows * (16 + mask_b + stash_b + 32)),
+            'mlp_dw_256': (2.0 * MAC_BKGD * rows, rows / 32.0 * 332 * 1024),
+        }
+        per = {k: totals[k][1] / totals[k][0] for k in work if k in totals}
+        info = {}
+        for k, t in per.items():
+            fl, by = work[k]
+            t_mfma, t_hbm = fl / PEAK_BF16, by / PEAK_HBM
+            bound = 'hbm' if t_hbm > t_mfma else 'mfma'
+            info[k] = dict(ms=t * 1e3, tflops=fl / t / 1e12, tbps=by / t / 1e12, bound=bound,
+                           frac=(t_hbm if bound == 'hbm' else t_mfma) / t)
         dom = max(per, key=lambda k: per[k]) if per else None
         roof = None
         if dom:
-            ach = flops[dom] / per[dom] / 1e12
-            roof = dict(bound='mfma', kernel=dom, achieved=ach, peak=PEAK_BF16 / 1e12, unit='TFLOP/s',
-                        frac=ach / (PEAK_BF16 / 1e12), traffic=None,
-                        launch_ms=per[dom] * 1e3,
-                        all={k: dict(ms=per[k] * 1e3, tflops=flops[k] / per[k] / 1e12) for k in per})
+            d = info[dom]
+            if d['bound'] == 'hbm':
+                roof = dict(bound='hbm', kernel=dom, achieved=d['tbps'] * 1e3, peak=PEAK_HBM / 1e9, unit='GB/s',
+                            frac=d['frac'], traffic=None, launch_ms=d['ms'], all=info)
+            else:
+                roof = dict(bound='mfma', kernel=dom, achieved=d['tflops'], peak=PEAK_BF16 / 1e12, unit='TFLOP/s',
+                            frac=d['frac'], traffic=None, launch_ms=d['ms'], all=info)
+            # HBM traffic of the dominant kernel from the committed PMC passes (not measurable live)
+            try:
+                with open(os.path.join(ROOT, 'profiles', 'r01b_pmc_traffic.json')) as f:
+                    tr = json.load(f)
+                if B == RAYS_PER_GPU and dom in tr:
+                    roof['traffic'] = tr[dom]['total_bytes']
+                    roof['traffic_source'] = tr['source']
+            except (OSError, ValueError):
+                pass
+            # end-to-end MFMA rate of the whole step (fwd + bwd-data + dW = 3 x fwd FLOPs, both levels)
+            roof['step_mlp_tflops'] = 3 * 2 * 2.0 * (MAC_BKGD + hit * MAC_OBJ) * rows / (dt / args.steps) / 1e12
         if args.profile_ops:
             for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
                 print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / args.steps),
