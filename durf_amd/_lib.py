@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libdurf_hip.so')
+# DURF_LIB_PATH: kernel-tuning A/B builds (tools/build_variant.sh); the default is the in-tree build
+LIB_PATH = os.environ.get('DURF_LIB_PATH') or os.path.join(_HERE, 'libdurf_hip.so')
 
 _lib = None
 

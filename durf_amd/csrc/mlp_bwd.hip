@@ -369,22 +369,37 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base, int off0, int off1) 
 // NKO: k-steps (16 features) of dZ; NKA/NKB: k-steps of the two input segments.
 // The kernel streams 1 KB per sample per 256x256 layer from HBM at an arithmetic intensity of
 // 128 FLOP/B, i.e. it is HBM-bound by construction; what matters is bytes in flight per CU.
-// A DW_STAGES-deep LDS ring (32-36 KB per stage) is filled by buffer_load...lds with counted
+// An LDS ring of dw_stages(NC) stages (9-36 KB each) is filled by buffer_load...lds with counted
 // s_waitcnt vmcnt(N) and raw s_barrier, so 2-3 stages (~100 KB) are always in flight per CU.
-#define DW_STAGES 4
+// Ring depth: 4 stages of 32 samples (measured on MI355X: 2 stages 1336 us, 3: 1209, 4: 1148,
+// 5: 1227, 6+: ~1190 per launch at cfg2 -- deeper rings do not buy bandwidth here).
+#ifndef DW_LDS_KB
+#define DW_LDS_KB 144
+#endif
+#ifndef DW_MAX_STAGES
+#define DW_MAX_STAGES 4
+#endif
+#define DW_LDS_BYTES (DW_LDS_KB * 1024)
+__host__ __device__ constexpr int dw_stages(int nc) { return DW_LDS_BYTES / (nc * 1024) > DW_MAX_STAGES ? DW_MAX_STAGES : DW_LDS_BYTES / (nc * 1024); }
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // LDS-DMA issued from inline asm: hipcc orders every later ds_read behind ALL outstanding
 // buffer_load...lds it knows about (s_waitcnt vmcnt(0)), which would drain the ring on every
 // tile.  Hidden in asm, the loads are ordered only by this kernel's own counted waits.
 // (M0 = LDS byte address of the 1 KB chunk; saved/restored because hipcc owns M0.)
+// nt: the operands are read exactly once (measured -6 % per launch vs the default cache policy)
+#if defined(DW_NO_NT)
+#define DW_DMA_POLICY ""
+#else
+#define DW_DMA_POLICY " nt"
+#endif
 __device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned soff, unsigned voff, unsigned lds_addr) {
     unsigned keep;
     asm volatile("s_nop 4\n\t"
                  "s_mov_b32 %0, m0\n\t"
                  "s_mov_b32 m0, %1\n\t"
                  "s_nop 0\n\t"
-                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen" DW_DMA_POLICY " lds\n\t"
                  "s_mov_b32 m0, %0"
                  : "=&s"(keep)
                  : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
@@ -411,7 +426,7 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
     constexpr int MO = (NKO + 1) / 2, NI = NKI / 2;
     constexpr int RM = (MO + 3) / 4, RN = (NI + 1) / 2;
     constexpr int STAGE = NC * 1024;
-    constexpr int S = DW_STAGES;
+    constexpr int S = dw_stages(NC);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -437,7 +452,11 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
     for (int par = 0; par < 2; par++) {
         const int c = 2 * par + g_hif;
         const int n = (g_p & 16) | ((g_p - 4 * c) & 15);
+#ifdef DW_PROBE_NOSWZ
+        voff[par] = (unsigned)(lane * 16);
+#else
         voff[par] = (unsigned)((g_hif * 32 + n) * 16);
+#endif
     }
     auto stage_load = [&](int ti, int slot) {        // ti = tile index relative to t0
         ti = __builtin_amdgcn_readfirstlane(ti);
@@ -484,11 +503,13 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
         // this wave's part of tile t has landed when at most min(S-2, nt-1-t) later stages are pending
         const int later = nt - 1 - t;
         if (later >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * CPW) : "memory");
-        else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(CPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tail: everything was issued, drain once
         __builtin_amdgcn_s_barrier();       // every wave's part landed; everyone is done with tile t-1's slot
         if (t + S - 1 < nt) stage_load(t + S - 1, (t + S - 1) % S);
         const char* st = smem + (t % S) * STAGE;
+#ifdef DW_PROBE_NOCOMPUTE
+        continue;
+#endif
 #pragma unroll
         for (int kk = 0; kk < 2; kk++) {
             bf16x8 af[RM], bf[RN];
@@ -527,6 +548,9 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
             }
         }
     }
+#ifdef DW_PROBE_NOSTORE
+    if (acc[0][0][0] != 1234.5f) return;
+#endif
     // partials in fragment coordinates: [split][mo][ni][lane][16]
     const size_t sp = (size_t)split_off + split_idx;
 #pragma unroll
@@ -565,16 +589,48 @@ struct DwArgs {
     float* bpart[12];
     int nsplit[12];
     int split_off[12];
+    int first_wg[13];        // workgroup ids [first_wg[i], first_wg[i+1]) run job order[i]
+    int order[12];
 };
+
+#ifdef DW_TRACE
+__device__ unsigned long long g_dw_trace[4 * 4096];
+extern "C" int durf_debug_dw_trace(void* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dw_trace), sizeof(g_dw_trace));
+}
+#endif
 
 template <int W>
 __global__ void __launch_bounds__(512, 2)
 k_dw_all(size_t rows, int N, const int32_t* __restrict__ count, DwArgs a) {
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int job = blockIdx.y, sp = blockIdx.x;
+    // 1-D grid with no idle workgroups: the dispatcher deals workgroup ids round-robin to the 8
+    // XCDs, so padding ids (a 2-D job x max_split grid) left some XCDs a fifth round of work.
+    int oi = 0;
+#pragma unroll
+    for (int i = 1; i < 12; i++) oi += ((int)blockIdx.x >= a.first_wg[i]) ? 1 : 0;
+    const int job = a.order[oi], sp = (int)blockIdx.x - a.first_wg[oi];
     const int ns = a.nsplit[job];
-    if (sp >= ns) return;
+#ifdef DW_TRACE
+    const unsigned long long t_start = wall_clock64();
+    struct TraceEnd {
+        unsigned long long t0; int job, sp;
+        __device__ ~TraceEnd() {
+            if (threadIdx.x == 0) {
+                unsigned hwid;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+                unsigned xcc;
+                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                const int slot = job * 256 + sp;
+                g_dw_trace[4 * slot] = t0;
+                g_dw_trace[4 * slot + 1] = wall_clock64();
+                g_dw_trace[4 * slot + 2] = ((unsigned long long)xcc << 32) | hwid;
+                g_dw_trace[4 * slot + 3] = ((unsigned long long)job << 32) | (unsigned)sp;
+            }
+        }
+    } trace_end{t_start, job, sp};
+#endif
 #define DW_CALL(NKO, NKA, NKB) dw_job<NKO, NKA, NKB>(rows, N, count, a.dz[job], a.inA[job], a.inB[job], ns, sp, a.split_off[job], a.part[job], a.bpart[job], smem)
     switch (job) {
         case 0: DW_CALL(S::KW, S::KE, 0); break;
@@ -674,7 +730,7 @@ struct DwPlan {
 static DwPlan dw_plan(int width, int nlevels) {
     DwPlan P;
     const int KW = width / 16;
-    int cost = 0;
+    int cost = 0, wcost[12];
     for (int j = 0; j < 12; j++) {
         int nko = KW, nki = KW;
         if (j == 0) nki = 4;
@@ -684,14 +740,32 @@ static DwPlan dw_plan(int width, int nlevels) {
         else if (j == 11) { nko = 1; nki = 8; }
         P.nko[j] = nko; P.nki[j] = nki;
         P.MO[j] = (nko + 1) / 2; P.NI[j] = nki / 2;
-        cost += nko + nki;
+        wcost[j] = nko + nki + (nko + nki < 12 ? 3 : 0);     // the 9 KB/stage job is latency-bound: +30 % time per byte (traced)
+        cost += wcost[j];
+    }
+    // splits per job in proportion to its bytes per sample, summing EXACTLY to total_wgs (largest
+    // remainder): with one resident workgroup per CU, 4 x 256 workgroups are four full rounds; two
+    // stragglers from plain rounding (1026) cost a fifth round = +25 % (measured).
+    static const int total_wgs = getenv("DURF_DW_WGS") ? atoi(getenv("DURF_DW_WGS")) : 1024;
+    int base[12], given = 0;
+    for (int j = 0; j < 12; j++) {
+        base[j] = total_wgs * wcost[j] / cost;
+        if (base[j] < 2) base[j] = 2;
+        given += base[j];
+    }
+    for (int left = total_wgs - given; left > 0; left--) {
+        int best = 0;
+        long best_rem = -1;
+        for (int j = 0; j < 12; j++) {
+            const long rem = (long)total_wgs * wcost[j] - (long)base[j] * cost;
+            if (rem > best_rem) { best_rem = rem; best = j; }
+        }
+        base[best]++;
     }
     size_t po = 0, bo = 0;
     P.max_split = 0;
     for (int j = 0; j < 12; j++) {
-        static const int total_wgs = getenv("DURF_DW_WGS") ? atoi(getenv("DURF_DW_WGS")) : 1024;   // tuning knob (swept 256..1024 on MI355X)
-        int ns = (total_wgs * (P.nko[j] + P.nki[j]) + cost / 2) / cost;
-        if (ns < 2) ns = 2;
+        const int ns = base[j];
         P.nsplit[j] = ns;
         if (ns > P.max_split) P.max_split = ns;
         P.part_off[j] = po; P.bpart_off[j] = bo;
@@ -786,13 +860,22 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
     a.dz[9] = region(dz, 8); a.inA[9] = region(stash, 7);                // bottleneck
     a.dz[10] = region(dz, 9); a.inA[10] = region(stash, 8); a.inB[10] = (const char*)view_tile;
     a.dz[11] = (const char*)dz_out; a.inA[11] = region(stash, 9);        // rgb head
-    dim3 grid(P.max_split, 12), block(512);
+    // narrow jobs first: their workgroups run longest (less data in flight per stage)
+    static const int order[12] = {11, 8, 0, 10, 5, 1, 2, 3, 4, 6, 7, 9};
+    int total = 0;
+    for (int i = 0; i < 12; i++) {
+        a.order[i] = order[i];
+        a.first_wg[i] = total;
+        total += P.nsplit[order[i]];
+    }
+    a.first_wg[12] = total;
+    dim3 grid(total), block(512);
     if (width == 256) {
-        constexpr int lds = DW_STAGES * (16 + 16 + 4) * 1024;
+        constexpr int lds = DW_LDS_BYTES;
         (void)hipFuncSetAttribute((const void*)k_dw_all<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(k_dw_all<256>, grid, block, lds, s, rows, N, count, a);
     } else {
-        constexpr int lds = DW_STAGES * (8 + 8 + 4) * 1024;
+        constexpr int lds = DW_LDS_BYTES;
         (void)hipFuncSetAttribute((const void*)k_dw_all<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(k_dw_all<128>, grid, block, lds, s, rows, N, count, a);
     }

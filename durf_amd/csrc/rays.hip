@@ -201,26 +201,18 @@ __device__ __forceinline__ void contract_gaussian(Gauss& g) {
     }
 }
 
-// one IPE feature f in [0,60): mip.py:273-282 with basis [2^i I3].
-// FAST (bf16 output only): after the same safe_sin wrap, sin/exp use the hardware
-// transcendental units (v_sin_f32 / v_exp_f32; abs error ~1e-4 at |y| ~ 300, far below the
-// bf16 quantum 4e-3) -- the accurate libm versions make this HBM-bound kernel VALU-bound.
-template <bool FAST>
+// one IPE feature f in [0,60): mip.py:273-282 with basis [2^i I3] (accurate libm path, used when
+// the caller asks for fp32 features; the bf16-only path is k_encode_lane below).
 __device__ __forceinline__ float ipe_feature(const Gauss& g, int f) {
     const int c = f / 30, r = f - c * 30, deg = r / 3, j = r - deg * 3;
     const float sc = (float)(1 << deg);
     float y = g.x[j] * sc;
     if (c) y = y + 1.5707963705062866f;
     const float yv = g.var[j] * sc * sc;
-    if (FAST) {
-        const float t = 314.15927124023438f;
-        if (!(fabsf(y) < t)) { float m = fmodf(y, t); if (m != 0.0f && m < 0.0f) m += t; y = m; }
-        return __expf(-0.5f * yv) * __sinf(y);
-    }
     return expf(-0.5f * yv) * safe_sin(y);
 }
 
-template <bool OBJ, bool FAST>
+template <bool OBJ>
 __global__ void __launch_bounds__(256)
 k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
          const float* __restrict__ t_vals, const float* __restrict__ origins_s,
@@ -262,10 +254,10 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
         float val;
         if (OBJ) {
             if (p < 3) val = g.x[p];
-            else if (p < 63) { const int f = p - 3; val = w[f / 6] * ipe_feature<FAST>(g, f); }   // mip.py:217-222
+            else if (p < 63) { const int f = p - 3; val = w[f / 6] * ipe_feature(g, f); }   // mip.py:217-222
             else val = 0.0f;
         } else {
-            val = (p < 60) ? ipe_feature<FAST>(g, p) : 0.0f;
+            val = (p < 60) ? ipe_feature(g, p) : 0.0f;
         }
         v[e] = val;
     }
@@ -282,6 +274,85 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
             const int p = q * 8 + e;
             if (p < dim) out_f32[row * dim + p] = v[e];
         }
+    }
+}
+
+// K3/K4, bf16-only fast path (sin/exp on the hardware transcendental units: abs error ~1e-4 at
+// |y| ~ 300, far below the bf16 quantum 4e-3): ONE lane per sample (the Gaussian, the contraction and the 30
+// exponentials are computed once instead of 8x), every feature index is a compile-time constant,
+// and a wave writes, per 16-byte feature vector, two contiguous 512-byte runs of the tile layout.
+// Same arithmetic as ipe_feature<true>; the safe_sin wrap is an exact fmod done with one fma
+// (y - floor(y/t)*t is representable, so the single rounding of the fma returns it exactly).
+__device__ __forceinline__ float wrap_100pi(float y) {
+    const float t = 314.15927124023438f;
+    if (!(fabsf(y) < t)) {
+        const float q = floorf(y * (1.0f / 314.15927124023438f));
+        float m = fmaf(-q, t, y);
+        if (m < 0.0f) m += t;
+        if (m >= t) m -= t;
+        y = m;
+    }
+    return y;
+}
+
+template <bool OBJ>
+__global__ void __launch_bounds__(256)
+k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
+              const float* __restrict__ t_vals, const float* __restrict__ origins_s,
+              const float* __restrict__ dirs_s, const float* __restrict__ radii,
+              const int32_t* __restrict__ hit, int K, int contraction, BarfW barf_w,
+              char* __restrict__ out_tile) {
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int j = (int)(row / N), n = (int)(row % N);
+    if (j >= rays) return;
+    int b = j;
+    if (OBJ) {
+        if (j >= *count) return;
+        b = idx[j];
+    }
+    const float t0 = t_vals[(size_t)b * (N + 1) + n], t1 = t_vals[(size_t)b * (N + 1) + n + 1];
+    float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
+    float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
+    Gauss g = frustum_gaussian(t0, t1, o, d, radii[b]);
+    if (!OBJ) {
+        int nh = 0;
+        for (int k = 0; k < K; k++) nh += hit[b * K + k];
+        if (nh != 0) {
+            const float m = 1.0f - (float)nh;
+#pragma unroll
+            for (int i = 0; i < 3; i++) { g.x[i] *= m; g.var[i] *= m; }
+        }
+        if (contraction) contract_gaussian(g);
+    }
+    float feat[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) feat[i] = 0.0f;
+    constexpr int OFF = OBJ ? 3 : 0;
+    if (OBJ) { feat[0] = g.x[0]; feat[1] = g.x[1]; feat[2] = g.x[2]; }
+#pragma unroll
+    for (int deg = 0; deg < 10; deg++) {
+        const float sc = (float)(1 << deg);
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float y = g.x[a] * sc;
+            const float yc = y + 1.5707963705062866f;
+            const float yv = g.var[a] * sc * sc;
+            const float e = __expf(-0.5f * yv);
+            float fs = e * __sinf(wrap_100pi(y));
+            float fc = e * __sinf(wrap_100pi(yc));
+            const int f = deg * 3 + a;
+            if (OBJ) { fs = barf_w.w[f / 6] * fs; fc = barf_w.w[(f + 30) / 6] * fc; }   // mip.py:217-222
+            feat[OFF + f] = fs;
+            feat[OFF + 30 + f] = fc;
+        }
+    }
+    char* base = out_tile + ((row >> 5) * 4 * 64 + (row & 31)) * 16;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        bf16x8 o8;
+#pragma unroll
+        for (int e = 0; e < 8; e++) o8[e] = (__bf16)feat[q * 8 + e];
+        *(bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16) = o8;
     }
 }
 
@@ -331,13 +402,13 @@ int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const floa
     if (B <= 0) return 0;
     DURF_REQUIRE(((size_t)B * N) % 32 == 0 || out_tile == nullptr, "B*N must be a multiple of 32");
     if (out_f32)
-        hipLaunchKernelGGL((k_encode<false, false>), dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
+        hipLaunchKernelGGL((k_encode<false>), dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
                            (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
                            hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
     else
-        hipLaunchKernelGGL((k_encode<false, true>), dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
+        hipLaunchKernelGGL((k_encode_lane<false>), dim3(durf_cdiv((size_t)B * N, 256)), dim3(256), 0,
                            (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
-                           hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
+                           hit, K, contraction, BarfW{}, (char*)out_tile);
     DURF_CHECK_LAUNCH("durf_encode_bkgd");
     return 0;
 }
@@ -349,13 +420,13 @@ int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
     if (out_f32)
-        hipLaunchKernelGGL((k_encode<true, false>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
+        hipLaunchKernelGGL((k_encode<true>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
                            nullptr, 0, 0, bw, (bf16x8*)out_tile, out_f32);
     else
-        hipLaunchKernelGGL((k_encode<true, true>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
+        hipLaunchKernelGGL((k_encode_lane<true>), dim3(durf_cdiv((size_t)max_rays * N, 256)), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
-                           nullptr, 0, 0, bw, (bf16x8*)out_tile, out_f32);
+                           nullptr, 0, 0, bw, (char*)out_tile);
     DURF_CHECK_LAUNCH("durf_encode_obj");
     return 0;
 }
