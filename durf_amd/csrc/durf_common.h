@@ -90,3 +90,54 @@ __device__ __forceinline__ float wave_incl_rscan(float v, int lane) {
 __device__ __forceinline__ size_t tile_vec_offset(size_t row, int q, int nks) {
     return ((((row >> 5) * nks + (q >> 1)) * 64) + (size_t)((q & 1) * 32) + (row & 31)) * 16;
 }
+
+// ---- LDS-DMA with explicit waits --------------------------------------------------------
+// hipcc orders every ds_read (and every __syncthreads) behind ALL outstanding buffer_load...lds
+// it knows about with s_waitcnt vmcnt(0) -- and on gfx9 stores count on vmcnt too, so that wait
+// also drains every store the wave has in flight.  Issued from inline asm the DMA is invisible
+// to the compiler and ordered only by the kernel's own counted waits (memory operations of a
+// wave retire in issue order: vmcnt <= K means everything but the newest K has completed).
+// M0 = LDS byte address of the 1 KB chunk; saved/restored because hipcc owns M0.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ i32x4 make_rsrc(const void* p) {
+    const unsigned long long a = (unsigned long long)p;
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
+    r[2] = 0x7fffffff;          // num_records (bytes): whole address space above the base
+    r[3] = 0x00020000;          // raw buffer, dword data format (as __builtin_amdgcn_make_buffer_rsrc)
+    return r;
+}
+__device__ __forceinline__ void lds_dma16_cached(i32x4 rsrc, unsigned soff, unsigned voff, unsigned lds_addr) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\t"
+                 "s_mov_b32 %0, m0\n\t"
+                 "s_mov_b32 m0, %1\n\t"
+                 "s_nop 0\n\t"
+                 "buffer_load_dwordx4 %2, %3, %4 offen lds\n\t"
+                 "s_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+// wait until at most min(n, 12) of this wave's vector-memory operations are outstanding (n wave-uniform)
+__device__ __forceinline__ void wait_vmcnt_le(int n) {
+#ifdef DURF_STRICT_WAIT
+    n = 0;
+#endif
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+    }
+}

@@ -14,10 +14,6 @@
 #include <stdlib.h>
 #include "mlp_spec.h"
 
-// buffer form of the LDS-DMA (descriptor + SGPR offset + one per-lane VGPR offset), see mlp_fwd.hip
-__device__ __forceinline__ void glds16b(__amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned voff, void* l) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
-}
 
 // ---------------------------------------------------------------------------
 // backward weight stream: for fwd stage s = 10..1, tiles over INPUT features
@@ -91,18 +87,25 @@ k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
 // ---------------------------------------------------------------------------
 // fused backward data path
 // ---------------------------------------------------------------------------
-struct BPipe {
-    __amdgpu_buffer_rsrc_t rsrc;   // the packed (transposed) weight stream
+struct BPipe {        // same protocol as WPipe (mlp_fwd.hip): asm LDS-DMA, counted wait, raw barrier
+    i32x4 rsrc;          // the packed (transposed) weight stream
     unsigned gnext;      // byte offset of the next tile group (the persistent loop wraps it to 0)
+    unsigned lds0;
     char* lds;
     int slot_bytes, par, wave, lane;
+    int since;           // stores this wave issued after its last weight DMA (lower bound)
     __device__ __forceinline__ void skip(int chunks) { gnext += chunks * 1024u; }
+    __device__ __forceinline__ void issue(int slot, int chunks) {
+        const unsigned dst = lds0 + (unsigned)(slot * slot_bytes);
+        for (int c = wave; c < chunks; c += 8)
+            lds_dma16_cached(rsrc, gnext + c * 1024u, lane * 16u, dst + c * 1024u);
+        gnext += chunks * 1024u;
+        since = 0;
+    }
     __device__ __forceinline__ const char* begin(int next_chunks) {
-        __syncthreads();
-        char* dst = lds + (par ^ 1) * slot_bytes;
-        for (int c = wave; c < next_chunks; c += 8)
-            glds16b(rsrc, gnext + c * 1024u, lane * 16u, dst + c * 1024);
-        gnext += next_chunks * 1024u;
+        wait_vmcnt_le(since);
+        __builtin_amdgcn_s_barrier();
+        issue(par ^ 1, next_chunks);
         const char* cur = lds + par * slot_bytes;
         par ^= 1;
         return cur;
@@ -159,9 +162,18 @@ __device__ __forceinline__ void bpack_tile(const f32x16& acc, unsigned bits, bf1
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float v0 = acc[e], v1 = acc[8 + e];
-        if (MASK) {
+        if (MASK) {     // v_bfe_i32 (bit -> 0 / ~0) + v_and_b32; asm: hipcc turns the C form into and + cmp + cndmask
+            int m0, m1;
+#ifdef OLD_BWD_MASK
             if (!((bits >> e) & 1u)) v0 = 0.0f;
             if (!((bits >> (8 + e)) & 1u)) v1 = 0.0f;
+            o0[e] = (__bf16)v0; o1[e] = (__bf16)v1;
+            continue;
+#endif
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(bits), "n"(e));
+            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(bits), "n"(8 + e));
+            v0 = __int_as_float(__float_as_int(v0) & m0);
+            v1 = __int_as_float(__float_as_int(v1) & m1);
         }
         o0[e] = (__bf16)v0;
         o1[e] = (__bf16)v1;
@@ -200,10 +212,12 @@ __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf
             if (mo > 0) {
 #pragma unroll
                 for (int q = 4; q >= 1; q--) *(bf16x8*)(dz_dst + (2 * mo - q) * 1024 + p.lane * 16) = out[2 * mo - q];
+                p.since += 4;
             } else if (PREV_NMT > 0) {
 #pragma unroll
                 for (int q = 4; q >= 1; q--)
                     *(bf16x8*)(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16) = prev_out[2 * PREV_NMT - q];
+                p.since += 4;
             }
         }
         f32x16 acc0, acc1;
@@ -251,13 +265,12 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
 
     BPipe p;
     constexpr int SLOT = 4 * (S::KW + 1);
-    p.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, BwdSpec<W>::TOTAL_CHUNKS * 1024, 0x00020000);
+    p.rsrc = make_rsrc(wpack);
     p.gnext = 0; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
+    p.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     p.wave = wave; p.lane = lane;
     constexpr int GB0 = bgroup_tiles(S::CT, 1, SLOT) * 1;                 // all tiles of the rgb-head stage
-    for (int c = wave; c < GB0; c += 8)
-        glds16b(p.rsrc, c * 1024u, lane * 16u, p.lds + c * 1024);
-    p.gnext = GB0 * 1024u;
+    p.issue(0, GB0);
 
   // persistent workgroup (see mlp_fwd.hip): loop over this CU's 256-sample blocks
   for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -381,7 +394,6 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* base, int off0, int off1) 
 #endif
 #define DW_LDS_BYTES (DW_LDS_KB * 1024)
 __host__ __device__ constexpr int dw_stages(int nc) { return DW_LDS_BYTES / (nc * 1024) > DW_MAX_STAGES ? DW_MAX_STAGES : DW_LDS_BYTES / (nc * 1024); }
-typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 // LDS-DMA issued from inline asm: hipcc orders every later ds_read behind ALL outstanding
 // buffer_load...lds it knows about (s_waitcnt vmcnt(0)), which would drain the ring on every
@@ -404,15 +416,6 @@ __device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned soff, unsigned vo
                  : "=&s"(keep)
                  : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
                  : "memory");
-}
-__device__ __forceinline__ i32x4 make_rsrc(const void* p) {
-    const unsigned long long a = (unsigned long long)p;
-    i32x4 r;
-    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
-    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);
-    r[2] = 0x7fffffff;          // num_records (bytes): whole address space above the base
-    r[3] = 0x00020000;          // raw buffer, dword data format (as __builtin_amdgcn_make_buffer_rsrc)
-    return r;
 }
 
 template <int NKO, int NKA, int NKB>

@@ -13,9 +13,6 @@
 // global_load_lds form needs a 64-bit per-lane VGPR address for every tile group; hipcc
 // precomputes those, they spill, and a scratch reload next to an in-flight LDS-DMA makes it
 // drain the whole weight prefetch (s_waitcnt vmcnt(0)).
-__device__ __forceinline__ void glds16(__amdgpu_buffer_rsrc_t rsrc, unsigned soff, unsigned voff, void* l) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)l, 16, voff, soff, 0, 0);
-}
 
 // ---------------------------------------------------------------------------
 // weight packer: fp32 flax params -> bf16 fragment stream (one thread per 16-byte vector)
@@ -77,20 +74,29 @@ k_pack_fwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
 // fused forward
 // ---------------------------------------------------------------------------
 struct WPipe {
-    __amdgpu_buffer_rsrc_t rsrc;   // the packed weight stream
+    i32x4 rsrc;          // the packed weight stream
     unsigned gnext;      // byte offset of the next tile group to prefetch
-    char* lds;           // base of the two slots
+    unsigned lds0;       // LDS byte address of the two slots
+    char* lds;
     int slot_bytes;
     int par;             // slot that holds the tile about to be consumed
     int wave, lane;
-    // Make the prefetched tile visible, start the prefetch of the following one (next_chunks
-    // KB, 0 = none) into the other slot, and return the slot to consume.
+    int since;           // vector-memory ops (stores) this wave issued after its last weight DMA (lower bound)
+    __device__ __forceinline__ void issue(int slot, int chunks) {
+        const unsigned dst = lds0 + (unsigned)(slot * slot_bytes);
+        for (int c = wave; c < chunks; c += 8)
+            lds_dma16_cached(rsrc, gnext + c * 1024u, lane * 16u, dst + c * 1024u);
+        gnext += chunks * 1024u;
+        since = 0;
+    }
+    // Make the prefetched tile group visible, start the prefetch of the following one
+    // (next_chunks KB, 0 = none) into the other slot, and return the slot to consume.
+    // The wait covers this wave's part of the DMA but leaves the stores issued after it in
+    // flight; the barrier then publishes every wave's part and frees the other slot.
     __device__ __forceinline__ const char* begin(int next_chunks) {
-        __syncthreads();   // drains this wave's glds (vmcnt) + all waves done with the other slot
-        char* dst = lds + (par ^ 1) * slot_bytes;
-        for (int c = wave; c < next_chunks; c += 8)
-            glds16(rsrc, gnext + c * 1024u, lane * 16u, dst + c * 1024);
-        gnext += next_chunks * 1024u;
+        wait_vmcnt_le(since);
+        __builtin_amdgcn_s_barrier();
+        issue(par ^ 1, next_chunks);
         const char* cur = lds + par * slot_bytes;
         par ^= 1;
         return cur;
@@ -153,16 +159,30 @@ __device__ __forceinline__ void mma_tile2(const char* slot0, const char* slot1, 
     }
 }
 
-// returns the 16 "activation > 0" bits of this tile (bit r <-> accumulator register r)
-template <bool RELU>
+// returns the 16 "activation > 0" bits of this tile (bit r <-> accumulator register r).
+// x > 0  <=>  clamp(int bits of x, 0, 1) == 1 for every non-NaN float (negative floats and -0
+// are negative integers): one v_med3_i32 + one v_lshl_or_b32 per element, no VCC round trip.
+template <bool RELU, bool BITS>
 __device__ __forceinline__ unsigned pack_tile(const f32x16& acc, bf16x8& o0, bf16x8& o1) {
+    static_assert(RELU || !BITS, "mask bits are taken from the ReLU output");
     unsigned bits = 0;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float v0 = acc[e], v1 = acc[8 + e];
-        if (RELU) { v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f); }   // one v_max_f32; NaN handled by the poison flag
-        bits |= (v0 > 0.0f ? 1u : 0u) << e;
-        bits |= (v1 > 0.0f ? 1u : 0u) << (8 + e);
+        if (RELU) {     // one v_med3_f32 (fmaxf costs two v_max_f32: it quiets the input first); NaN -> poison flag
+            v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, 3.0e38f);
+            v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, 3.0e38f);
+        }
+        if (BITS) {
+            // The asm reads the v_max result, never the accumulator itself: hipcc does not see
+            // inline-asm operands when it pads MFMA -> VALU read hazards with s_nop.
+            // (asm at all: hipcc rewrites the C form back into v_cmp + v_cndmask + v_or3.)
+            int b0, b1;
+            asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b0) : "v"(v0));
+            asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b1) : "v"(v1));
+            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(bits) : "v"(b0), "n"(e));
+            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(bits) : "v"(b1), "n"(8 + e));
+        }
         o0[e] = (__bf16)v0;
         o1[e] = (__bf16)v1;
     }
@@ -206,17 +226,19 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
             if (mo > 0) {
 #pragma unroll
                 for (int q = 4; q >= 1; q--) *(bf16x8*)(stash_dst + (2 * mo - q) * 1024 + p.lane * 16) = out[2 * mo - q];
+                p.since += 4;
             } else if (PREV_NMT > 0) {
 #pragma unroll
                 for (int q = 4; q >= 1; q--)
                     *(bf16x8*)(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16) = prev_out[2 * PREV_NMT - q];
+                p.since += 4;
                 if (prev_mask_dst) *(uint4*)(prev_mask_dst + p.lane * 16) = mask_carry;
             }
         }
         f32x16 acc0, acc1;
         mma_tile2<NA, NB>(slot + (mo % G) * CH * 1024, slot + (mo % G + 1) * CH * 1024, p.lane, inA, inB, acc0, acc1);
-        const unsigned bits0 = pack_tile<RELU>(acc0, out[2 * mo], out[2 * mo + 1]);
-        const unsigned bits1 = pack_tile<RELU>(acc1, out[2 * mo + 2], out[2 * mo + 3]);
+        const unsigned bits0 = pack_tile<RELU, TRAIN && RELU>(acc0, out[2 * mo], out[2 * mo + 1]);
+        const unsigned bits1 = pack_tile<RELU, TRAIN && RELU>(acc1, out[2 * mo + 2], out[2 * mo + 3]);
         if (TRAIN && RELU) mb[mo >> 1] |= bits0 | (bits1 << 16);
     }
     if (TRAIN && RELU) mask_carry = make_uint4(mb[0], mb[1], mb[2], mb[3]);
@@ -246,14 +268,13 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
 
     WPipe p;
     constexpr int SLOT = 4 * (S::KW + 1);            // chunks per LDS slot (two slots)
-    p.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)wpack, 0, S::TOTAL_CHUNKS * 1024, 0x00020000);
+    p.rsrc = make_rsrc(wpack);
     p.gnext = 0; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
+    p.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     p.wave = wave; p.lane = lane;
     // prologue: first tile group of stage 0 -> slot 0
     constexpr int G0 = group_tiles(S::WT, S::KE + 1, SLOT) * (S::KE + 1);
-    for (int c = wave; c < G0; c += 8)
-        glds16(p.rsrc, c * 1024u, lane * 16u, p.lds + c * 1024);
-    p.gnext = G0 * 1024u;
+    p.issue(0, G0);
 
   // Persistent workgroup: one CU holds one workgroup (136 KB of LDS), so looping over the
   // 256-sample blocks here instead of relaunching hides every block's start-up (first weight
@@ -340,6 +361,7 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         if (TRAIN && tile_valid) {               // trailing stores of stage 9
 #pragma unroll
             for (int q = 4; q >= 1; q--) *(bf16x8*)(ST(9) + (2 * S::CT - q) * 1024 + lane * 16) = c[2 * S::CT - q];
+            p.since += 4;
             if (MK(8)) *(uint4*)(MK(8) + lane * 16) = mcarry;
         }
         const f32x16 acc = mma_tile<S::KC, 0>(slot, lane, c, nullptr);

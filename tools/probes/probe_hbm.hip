@@ -26,6 +26,34 @@ __global__ void __launch_bounds__(256) k_plain(const u32x4* __restrict__ p, size
     if (acc == 0x12345678u) *sink = acc;
 }
 
+// streaming stores: every workgroup writes a contiguous share, 1 KB per wave instruction
+template <int MODE>
+__global__ void __launch_bounds__(256) k_store(u32x4* __restrict__ p, size_t n_vec) {
+    const size_t per = n_vec / gridDim.x;
+    u32x4* q = p + per * blockIdx.x;
+    const u32x4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
+    for (size_t i = threadIdx.x; i < per; i += 256) {
+        if (MODE == 0) q[i] = v;
+        else if (MODE == 1) __builtin_nontemporal_store(v, q + i);
+        else asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(q + i), "v"(v) : "memory");
+    }
+}
+// interleaved like the fused forward: each wave owns 32-sample blocks and writes 16 KB runs
+template <int MODE>
+__global__ void __launch_bounds__(512) k_store_waves(char* __restrict__ p, size_t bytes) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const size_t nblk = bytes / (8 * 16384);
+    const u32x4 v = {threadIdx.x, blockIdx.x, 3u, 4u};
+    for (size_t b = blockIdx.x; b < nblk; b += gridDim.x) {
+        char* base = p + (b * 8 + wave) * 16384 + lane * 16;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            if (MODE == 0) *(u32x4*)(base + k * 1024) = v;
+            else __builtin_nontemporal_store(v, (u32x4*)(base + k * 1024));
+        }
+    }
+}
+
 template <bool NT>
 __device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned soff, unsigned voff, unsigned lds_addr) {
     unsigned keep;
@@ -117,6 +145,20 @@ int main() {
     for (int wgs : {256, 512, 1024, 2048, 4096}) {
         double ms = time_ms([&] { hipLaunchKernelGGL(k_plain, dim3(wgs), dim3(256), 0, 0, (const u32x4*)d, bytes / 16, sink); });
         printf("plain 16B loads, nt, wgs=%4d: %7.1f us  %.2f TB/s\n", wgs, ms * 1e3, bytes / ms / 1e9);
+    }
+    for (int wgs : {256, 1024, 4096}) {
+        double ms = time_ms([&] { hipLaunchKernelGGL(k_store<0>, dim3(wgs), dim3(256), 0, 0, (u32x4*)d, bytes / 16); });
+        printf("plain stores          wgs=%4d: %7.1f us  %.2f TB/s\n", wgs, ms * 1e3, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_store<1>, dim3(wgs), dim3(256), 0, 0, (u32x4*)d, bytes / 16); });
+        printf("nt stores             wgs=%4d: %7.1f us  %.2f TB/s\n", wgs, ms * 1e3, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_store<2>, dim3(wgs), dim3(256), 0, 0, (u32x4*)d, bytes / 16); });
+        printf("sc0 sc1 stores        wgs=%4d: %7.1f us  %.2f TB/s\n", wgs, ms * 1e3, bytes / ms / 1e9);
+    }
+    for (int wgs : {256, 512}) {
+        double ms = time_ms([&] { hipLaunchKernelGGL(k_store_waves<0>, dim3(wgs), dim3(512), 0, 0, d, bytes); });
+        printf("wave-run stores plain wgs=%4d: %7.1f us  %.2f TB/s\n", wgs, ms * 1e3, bytes / ms / 1e9);
+        ms = time_ms([&] { hipLaunchKernelGGL(k_store_waves<1>, dim3(wgs), dim3(512), 0, 0, d, bytes); });
+        printf("wave-run stores nt    wgs=%4d: %7.1f us  %.2f TB/s\n", wgs, ms * 1e3, bytes / ms / 1e9);
     }
     for (int wgs : {256, 1024}) {
         run_ring<32, 4, 1, false>(d, bytes, sink, wgs);
