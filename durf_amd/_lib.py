@@ -35,6 +35,7 @@ _SIGS = {
     'durf_composite_fwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32,
                                  vp, vp, vp, vp, vp, vp]),
     'durf_resample': (i32, [vp, i32, i32, vp, vp, f32, vp, vp]),
+    'durf_train_stats': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'durf_loss_prep': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
     'durf_loss_bwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                             f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp]),

@@ -269,6 +269,66 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
     }
 }
 
+
+// ---------------------------------------------------------------------------
+// Scalars of utils.Stats from the per-level sums (train_boxpose.py:123-249, 291-292): one launch
+// instead of ~70 tiny elementwise/reduction kernels.  Layout of `out` (L = levels):
+//   [0] loss | 15 rows of L: losses, obj_losses, d, n, e, s, distr, tv, offsets, offset_x/y/z,
+//   offset_yaw, psnrs, obj_psnrs | 2L sampling stats (t_vals[0,0], t_vals[0,N] per level) | weight_l2
+// mode bit 0: assemble everything but the PSNRs; bit 1: PSNRs from the (possibly all-reduced) losses.
+// ---------------------------------------------------------------------------
+struct TvalPtrs { const float* p[DURF_MAX_LEVELS]; };
+struct StatMults { float coarse, sky, depth, near, empty, tv; };
+
+__global__ void k_train_stats(int L, int K, int N, const float* __restrict__ norms, const float* __restrict__ sums,
+                              const float* __restrict__ weight_l2, const float* __restrict__ pose6,
+                              const float* __restrict__ prev6, const float* __restrict__ target6, TvalPtrs tv,
+                              StatMults m, int mode, float* __restrict__ out) {
+    if (threadIdx.x != 0) return;
+    float* rows = out + 1;
+    if (mode & 1) {
+        float sq_prev = 0.f, sq_t = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, syaw = 0.f;
+        for (int k = 0; k < K; k++) {
+            for (int j = 0; j < 3; j++) {
+                const float dp = pose6[k * 6 + j] - prev6[k * 6 + j];
+                sq_prev += dp * dp;
+                const float dt = pose6[k * 6 + j] - target6[k * 6 + j];
+                sq_t += dt * dt;
+                if (j == 0) sx += dt * dt;
+                if (j == 1) sy += dt * dt;
+                if (j == 2) sz += dt * dt;
+                const float dy = pose6[3 + j] - target6[k * 6 + 3 + j];      // box_rot of object 0 vs every target
+                syaw += dy * dy;
+            }
+        }
+        const float wl2 = weight_l2 ? *weight_l2 : 0.0f;
+        float loss = wl2;
+        for (int l = 0; l < L; l++) {
+            const float* nr = norms + l * 5;
+            const float* sm = sums + l * 7;
+            const float D = fmaxf(nr[1], 1.0f), S = fmaxf(nr[2], 1.0f);
+            const float v[13] = {sm[0] / nr[0], sm[1] / nr[4], sm[2] / D, sm[3] / D, sm[4] / D, sm[5] / S, sm[6],
+                                 sq_prev, sq_t, sx, sy, sz, syaw};
+            for (int r = 0; r < 13; r++) rows[r * L + l] = (K > 0 || r < 7) ? v[r] : 0.0f;
+            if (K == 0) rows[7 * L + l] = 0.0f;
+            const bool last = l == L - 1;
+            loss += (last ? 1.0f : m.coarse) * v[0] + (last ? 10.0f : 1.0f) * m.sky * v[5]
+                  + (last ? 1.0f : 0.1f) * (m.depth * v[2] + m.near * v[3] + m.empty * v[4] + m.tv * (K > 0 ? sq_prev : 0.0f))
+                  + 0.000001f * v[6];
+            out[1 + 15 * L + 2 * l] = tv.p[l][0];
+            out[1 + 15 * L + 2 * l + 1] = tv.p[l][N];
+        }
+        out[0] = loss;
+        out[1 + 17 * L] = wl2;
+    }
+    if (mode & 2) {
+        for (int l = 0; l < L; l++) {
+            rows[13 * L + l] = -4.342944819032518f * logf(rows[0 * L + l]);      // -10/ln(10) * ln(mse)
+            rows[14 * L + l] = -4.342944819032518f * logf(rows[1 * L + l]);
+        }
+    }
+}
+
 extern "C" {
 
 int durf_loss_prep(void* stream, int B, int N, const float* t_vals, const float* lossmult,
@@ -309,6 +369,19 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
 #undef LAUNCH_L
     hipLaunchKernelGGL(k_reduce_rows, dim3(LT_ROWS), dim3(1024), 0, s, B, -1, terms, term_sums);
     DURF_CHECK_LAUNCH("durf_loss_bwd");
+    return 0;
+}
+
+int durf_train_stats(void* stream, int L, int K, int N, const float* norms, const float* sums,
+                     const float* weight_l2, const float* pose6, const float* prev6, const float* target6,
+                     const float* const* t_vals, const float* mults, int mode, float* out) {
+    DURF_REQUIRE(L >= 1 && L <= DURF_MAX_LEVELS, "1 <= num_levels <= DURF_MAX_LEVELS");
+    TvalPtrs tv;
+    for (int l = 0; l < DURF_MAX_LEVELS; l++) tv.p[l] = l < L ? t_vals[l] : nullptr;
+    const StatMults m = {mults[0], mults[1], mults[2], mults[3], mults[4], mults[5]};
+    hipLaunchKernelGGL(k_train_stats, dim3(1), dim3(64), 0, (hipStream_t)stream, L, K, N, norms, sums, weight_l2,
+                       pose6, prev6, target6, tv, m, mode, out);
+    DURF_CHECK_LAUNCH("durf_train_stats");
     return 0;
 }
 

@@ -214,12 +214,14 @@ PREP_ROWS, TERM_ROWS = 5, 7
 TERM_NAMES = ('rgb', 'obj', 'depth', 'near', 'empty', 'sky', 'dist')
 
 
-def loss_prep(t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level, disable_multiscale=False):
+def loss_prep(t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level, disable_multiscale=False,
+              norm=None):
     """-> norm[5] device floats: sum m, sum depth_mask, sum sky_mask, min near-dist^2, sum dyn."""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     dev = t_vals.device
     prep = torch.empty(PREP_ROWS, B, device=dev)
-    norm = torch.empty(PREP_ROWS, device=dev)
+    if norm is None:
+        norm = torch.empty(PREP_ROWS, device=dev)
     _lib.check(_lib.lib().durf_loss_prep(_stream(), B, N, _p(_f32(t_vals)), _p(_f32(lossmult)),
                                          _p(_f32(gt_depth)), _p(_f32(sky)), _p(dyn), _p(_f32(zo)),
                                          eps, box_loss_mult, level, int(disable_multiscale), _p(prep),
@@ -228,14 +230,15 @@ def loss_prep(t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, leve
 
 
 def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, eps,
-             mults, box_loss_mult, level, bg, density_bias=-1.0, disable_multiscale=False):
+             mults, box_loss_mult, level, bg, density_bias=-1.0, disable_multiscale=False, sums=None):
     """-> draw [B*N,4], term_sums[7] (rgb, obj, depth, near, empty, sky, dist numerators)"""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     K = len(raw_obj)
     dev = t_vals.device
     draw = torch.empty(B * N, 4, device=dev)
     terms = torch.empty(TERM_ROWS, B, device=dev)
-    sums = torch.empty(TERM_ROWS, device=dev)
+    if sums is None:
+        sums = torch.empty(TERM_ROWS, device=dev)
     ptrs = (C.c_void_p * max(K, 1))(*[r.data_ptr() for r in raw_obj])
     m = (C.c_float * 6)(*[float(x) for x in mults])
     _lib.check(_lib.lib().durf_loss_bwd(_stream(), B, N, K, _p(_f32(raw_bkgd)), ptrs, _p(slot),
@@ -245,6 +248,34 @@ def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth
                                         int(disable_multiscale), bg, density_bias, _p(draw), _p(terms),
                                         _p(sums)), 'durf_loss_bwd')
     return draw, sums
+
+
+STAT_ROWS = ('losses', 'obj_losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses', 'tv_losses',
+             'offsets', 'offset_x', 'offset_y', 'offset_z', 'offset_yaw', 'psnrs', 'obj_psnrs')
+STATS_ASSEMBLE, STATS_PSNR = 1, 2
+
+
+def train_stats(norms, sums, weight_l2, pose6, prev6, target6, t_vals_levels, mults, mode, out=None):
+    """Scalars of utils.Stats in one launch; see durf_train_stats.  -> out [2 + 17 L]"""
+    L = norms.shape[0]
+    K = 0 if pose6 is None else pose6.shape[0]
+    N = t_vals_levels[0].shape[1] - 1
+    if out is None:
+        out = torch.empty(2 + 17 * L, device=norms.device)
+    ptrs = (C.c_void_p * L)(*[t.data_ptr() for t in t_vals_levels])
+    m = (C.c_float * 6)(*[float(x) for x in mults])
+    _lib.check(_lib.lib().durf_train_stats(_stream(), L, K, N, _p(norms), _p(sums), _p(weight_l2),
+                                           _p(pose6) if K else None, _p(prev6) if K else None,
+                                           _p(target6) if K else None, ptrs, m, mode, _p(out)), 'durf_train_stats')
+    return out
+
+
+def stats_views(out, L):
+    """dict of named views into the durf_train_stats buffer"""
+    d = {'loss': out[0], 'sampling_stats': out[1 + 15 * L:1 + 17 * L], 'weight_l2': out[1 + 17 * L]}
+    for i, name in enumerate(STAT_ROWS):
+        d[name] = out[1 + i * L:1 + (i + 1) * L]
+    return d
 
 
 def mlp_bwd(width, rows, N, draw, wpack_bwd, relu_mask, ray_idx=None, count=None, want_d_enc=False):

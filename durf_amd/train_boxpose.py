@@ -78,20 +78,19 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     view_tile = ops.expand_view(rows, N, ctx['view'])
     view_tiles_obj = [ops.expand_view(rows, N, ctx['view'], ray_idx=ctx['idx'][k], count=ctx['count'][k:k + 1])
                       for k in range(K)]
-    norms, sums = [], []
+    norms = torch.empty(L, ops.PREP_ROWS, device=dev)
+    sums = torch.empty(L, ops.TERM_ROWS, device=dev)
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
     for lvl in range(L):
         lv = ctx['levels'][lvl]
         norm = ops.loss_prep(lv['t_vals'], lossmult, gt_depth, sky, dyn, ctx['zo'], float(eps),
-                             float(config.box_loss_mult), lvl, config.disable_multiscale_loss)
-        draw, s = ops.loss_bwd(lv['raw_b'], lv['raws'], ctx['slot'], lv['t_vals'], ctx['d_s'], pixels, lossmult,
+                             float(config.box_loss_mult), lvl, config.disable_multiscale_loss, norm=norms[lvl])
+        draw, _ = ops.loss_bwd(lv['raw_b'], lv['raws'], ctx['slot'], lv['t_vals'], ctx['d_s'], pixels, lossmult,
                                gt_depth, sky, dyn, ctx['zo'], norm, float(eps),
                                level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
-                               model.density_bias, config.disable_multiscale_loss)
-        norms.append(norm)
-        sums.append(s)
+                               model.density_bias, config.disable_multiscale_loss, sums=sums[lvl])
         dz, dz_out = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
         ops.mlp_dw(om.W_BKGD, rows, N, lv['enc_b'], view_tile, lv['stash_b'], dz, dz_out, lvl, L, *bufs['MLP_0'])
         for k in range(K):
@@ -110,7 +109,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         off = lay.mlp_off[n]
         ops.mlp_dw_finalize(width, in_dim, L, *bufs[n], grad[off:off + lay.mlp_size[width]])
     flat = variables.flat
-    weight_l2 = torch.zeros((), device=dev)
+    weight_l2 = None
     if config.weight_decay_mult != 0:                                          # :73-75
         weight_l2 = config.weight_decay_mult * (flat * flat).sum() / flat.numel()
         grad += (2.0 * config.weight_decay_mult / flat.numel()) * flat
@@ -122,47 +121,23 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
         grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)[ctx['ts']] += g6
     pose = ret[0][7][0]
-    raw = dict(norms=torch.stack(norms), sums=torch.stack(sums), weight_l2=weight_l2, ret=ret, ctx=ctx)
+    raw = dict(norms=norms, sums=sums, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if K > 0 else None)
     return grad, raw, pose
 
 
-def _assemble_stats(model, config, batch, raw, prev, pose, yaw0):
-    """Scalars of utils.Stats from the per-level sums (train_boxpose.py:123-249)."""
-    norms, sums = raw['norms'], raw['sums']            # [L,5], [L,7]
-    one = torch.ones((), device=norms.device)
-    D = torch.maximum(norms[:, 1], one)
-    S = torch.maximum(norms[:, 2], one)
-    losses = sums[:, 0] / norms[:, 0]
-    obj_losses = sums[:, 1] / norms[:, 4]
-    d_losses, n_losses, e_losses = sums[:, 2] / D, sums[:, 3] / D, sums[:, 4] / D
-    s_losses = sums[:, 5] / S
-    distr = sums[:, 6]
-    L = losses.shape[0]
-    target = batch['target']
-    tv = ((pose - prev[:, :, :3]) ** 2).sum().expand(L)
+def _stat_mults(config):
     c = config
-    loss = c.coarse_loss_mult * losses[:-1].sum() + losses[-1] + raw['weight_l2']
-    loss = loss + c.sky_loss_mult * s_losses[:-1].sum() + 10.0 * c.sky_loss_mult * s_losses[-1]
-    loss = loss + c.depth_loss_mult * d_losses[-1] + 0.1 * c.depth_loss_mult * d_losses[:-1].sum()
-    loss = loss + c.near_loss_mult * n_losses[-1] + 0.1 * c.near_loss_mult * n_losses[:-1].sum()
-    loss = loss + c.empty_loss_mult * e_losses[-1] + 0.1 * c.empty_loss_mult * e_losses[:-1].sum()
-    loss = loss + c.tv_loss_mult * tv[-1] + 0.1 * c.tv_loss_mult * tv[:-1].sum()
-    loss = loss + 0.000001 * distr[-1] + 0.000001 * distr[:-1].sum()
-    ret = raw['ret']
-    K = pose.shape[0]
-    if K > 0:
-        offsets = ((pose - target[:, :3]) ** 2).sum().expand(L)
-        ox = ((pose[:, 0] - target[:, 0]) ** 2).sum().expand(L)
-        oy = ((pose[:, 1] - target[:, 1]) ** 2).sum().expand(L)
-        oz = ((pose[:, 2] - target[:, 2]) ** 2).sum().expand(L)
-        oyaw = ((yaw0 - target[:, 3:]) ** 2).sum().expand(L)
-    else:
-        offsets = ox = oy = oz = oyaw = torch.zeros(L, device=norms.device)
-    sampling = torch.stack([x for r in ret for x in (r[4][0, 0], r[4][0, -1])])
-    return dict(loss=loss, obj_losses=obj_losses, losses=losses, d_losses=d_losses, n_losses=n_losses,
-                e_losses=e_losses, s_losses=s_losses, distr_losses=distr, tv_losses=tv, offsets=offsets,
-                offset_x=ox, offset_y=oy, offset_z=oz, offset_yaw=oyaw, sampling_stats=sampling,
-                weight_l2=raw['weight_l2'])
+    return [c.coarse_loss_mult, c.sky_loss_mult, c.depth_loss_mult, c.near_loss_mult, c.empty_loss_mult, c.tv_loss_mult]
+
+
+def _assemble_stats(config, batch, raw, prev, mode):
+    """Scalars of utils.Stats from the per-level sums (train_boxpose.py:123-249): one fused launch."""
+    pose6 = raw['pose6']
+    K = 0 if pose6 is None else pose6.shape[0]
+    t_levels = [r[4] for r in raw['ret']]
+    return ops.train_stats(raw['norms'], raw['sums'], raw['weight_l2'], pose6,
+                           prev[0].contiguous() if K else None, batch['target'].contiguous() if K else None,
+                           t_levels, _stat_mults(config), mode)
 
 
 def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None):
@@ -177,22 +152,19 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     if dist is not None:                                    # lax.pmean(grad) (:253)
         world = dist.get_world_size()
         dist.all_reduce(grad)
-    yaw0 = raw['ret'][0][7][1]
-    st = _assemble_stats(model, config, batch, raw, prev, pose, yaw0)
-    if dist is not None:                                    # lax.pmean(stats) (:255), scalars only
-        keys = sorted(k for k in st if torch.is_tensor(st[k]))
-        flat = torch.cat([st[k].reshape(-1).float() for k in keys])
-        dist.all_reduce(flat)
-        flat /= world
-        off = 0
-        for k in keys:
-            n = st[k].numel()
-            st[k] = flat[off:off + n].reshape(st[k].shape)
-            off += n
+    L = model.num_levels
+    if dist is None:
+        out = _assemble_stats(config, batch, raw, prev, ops.STATS_ASSEMBLE | ops.STATS_PSNR)
+    else:                                                   # lax.pmean(stats) (:255), then the PSNRs (:291-292)
+        out = _assemble_stats(config, batch, raw, prev, ops.STATS_ASSEMBLE)
+        dist.all_reduce(out)
+        out /= world
+        ops.train_stats(raw['norms'], raw['sums'], None, None, None, None, [r[4] for r in raw['ret']],
+                        _stat_mults(config), ops.STATS_PSNR, out=out)
+    st = ops.stats_views(out, L)
     gs = ops.clip_adam(variables.flat, state.m, state.v, grad, 1.0 / world, float(config.grad_max_val),
                        float(config.grad_max_norm), float(lr), state.step)
     new_state = TrainState(variables, state.m, state.v, state.step + 1)
-    psnrs = dmath.mse_to_psnr(st['losses'])
     ret = raw['ret']
     stats = utils.Stats(
         loss=st['loss'], obj_losses=st['obj_losses'], losses=st['losses'], d_losses=st['d_losses'],
@@ -200,7 +172,7 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
         distr_losses=st['distr_losses'], tv_losses=st['tv_losses'], sampling_stats=st['sampling_stats'],
         offsets=st['offsets'], offset_x=st['offset_x'], offset_y=st['offset_y'], offset_z=st['offset_z'],
         offset_yaw=st['offset_yaw'], pose=pose, weights=[r[3] for r in ret], samples=[r[4] for r in ret],
-        weight_l2=st['weight_l2'], psnr=psnrs[-1], psnrs=psnrs, obj_psnr=dmath.mse_to_psnr(st['obj_losses'])[-1],
+        weight_l2=st['weight_l2'], psnr=st['psnrs'][-1], psnrs=st['psnrs'], obj_psnr=st['obj_psnrs'][-1],
         grad_norm=gs[0], grad_abs_max=gs[1], grad_norm_clipped=gs[3])
     new_rng = (int(rng) + 1) if isinstance(rng, int) else rng
     return new_state, stats, new_rng, pose.clone()

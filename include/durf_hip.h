@@ -29,6 +29,7 @@ extern "C" {
 #endif
 
 #define DURF_MAX_OBJ 16
+#define DURF_MAX_LEVELS 8
 #define DURF_ENC_DIM 64      /* 60 (bkgd IPE) / 63 (object IPE) features padded to 64 */
 #define DURF_VIEW_DIM 32     /* 27 view-direction features padded to 32 */
 
@@ -137,6 +138,17 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                   const float* zo, const float* norm, float eps, const float* mults,
                   float box_loss_mult, int level, int disable_multiscale, float bg, float density_bias,
                   float* draw, float* terms, float* term_sums);
+
+/* Scalars of utils.Stats from the per-level sums (train_boxpose.py:123-249,291-292) in one launch.
+ * norms [L,5] (durf_loss_prep), sums [L,7] (durf_loss_bwd), weight_l2 nullable device scalar,
+ * pose6/prev6/target6 [K,6] (box_centers[ts], prev[0], batch target), t_vals: L host-side device
+ * pointers, mults (host) {coarse, sky, depth, near, empty, tv}_loss_mult.
+ * out [2 + 17 L]: loss | 15 rows of L (losses, obj_losses, d, n, e, s, distr, tv, offsets,
+ * offset_x, offset_y, offset_z, offset_yaw, psnrs, obj_psnrs) | 2L sampling stats | weight_l2.
+ * mode bit 0: everything but the PSNRs; bit 1: PSNRs from out's (possibly all-reduced) losses. */
+int durf_train_stats(void* stream, int L, int K, int N, const float* norms, const float* sums,
+                     const float* weight_l2, const float* pose6, const float* prev6, const float* target6,
+                     const float* const* t_vals, const float* mults, int mode, float* out);
 
 /* K11 fused MLP backward (data path).  draw [*,4] fp32 head gradients (object MLPs gather
  * rows through ray_idx); relu_mask from durf_mlp_fwd; dz: same size/layout as the stash,

@@ -285,3 +285,44 @@ def test_pose_chain_fp32(cuda):
     g6b = torch.zeros(K, 6, device=cuda)
     ops.pose_finish(pose_d, sums, False, True, g6b)               # no_pose_opt=True: position frozen
     assert float(g6b[:, :3].abs().max()) == 0.0 and torch.equal(g6b[:, 3:], g6[:, 3:])
+
+
+@pytest.mark.parametrize('K,L', [(0, 2), (3, 2), (1, 3)])
+def test_train_stats_kernel(cuda, K, L):
+    """durf_train_stats against the stat formulas of train_boxpose.py:123-249,291-292 written in torch."""
+    g = torch.Generator().manual_seed(11)
+    N = 16
+    norms = torch.rand(L, 5, generator=g) * 100 + 0.5
+    norms[0, 1] = 0.0                                         # no depth rays on level 0 -> max(., 1)
+    sums = torch.rand(L, 7, generator=g) * 10
+    wl2 = torch.rand((), generator=g)
+    pose6, prev6, target6 = (torch.randn(K, 6, generator=g) for _ in range(3))
+    t_levels = [torch.rand(4, N + 1, generator=g) for _ in range(L)]
+    mults = [0.1, 0.5, 0.7, 0.3, 0.2, 0.05]
+    out = ops.train_stats(norms.to(cuda), sums.to(cuda), wl2.to(cuda), pose6.to(cuda) if K else None,
+                          prev6.to(cuda) if K else None, target6.to(cuda) if K else None,
+                          [t.to(cuda) for t in t_levels], mults, ops.STATS_ASSEMBLE | ops.STATS_PSNR)
+    st = {k: v.cpu() for k, v in ops.stats_views(out, L).items()}
+    one = torch.ones(())
+    D, S = torch.maximum(norms[:, 1], one), torch.maximum(norms[:, 2], one)
+    ref = dict(losses=sums[:, 0] / norms[:, 0], obj_losses=sums[:, 1] / norms[:, 4], d_losses=sums[:, 2] / D,
+               n_losses=sums[:, 3] / D, e_losses=sums[:, 4] / D, s_losses=sums[:, 5] / S, distr_losses=sums[:, 6])
+    pose = pose6[:, :3]
+    ref['tv_losses'] = ((pose - prev6[:, :3]) ** 2).sum().expand(L)
+    ref['offsets'] = ((pose - target6[:, :3]) ** 2).sum().expand(L)
+    for j, nm in enumerate(('offset_x', 'offset_y', 'offset_z')):
+        ref[nm] = ((pose[:, j] - target6[:, j]) ** 2).sum().expand(L)
+    ref['offset_yaw'] = ((pose6[0, 3:] - target6[:, 3:]) ** 2).sum().expand(L) if K else torch.zeros(L)
+    coarse, sky, dep, near, emp, tv = mults
+    loss = coarse * ref['losses'][:-1].sum() + ref['losses'][-1] + wl2
+    loss = loss + sky * ref['s_losses'][:-1].sum() + 10.0 * sky * ref['s_losses'][-1]
+    for m, nm in ((dep, 'd_losses'), (near, 'n_losses'), (emp, 'e_losses'), (tv, 'tv_losses')):
+        loss = loss + m * ref[nm][-1] + 0.1 * m * ref[nm][:-1].sum()
+    loss = loss + 0.000001 * ref['distr_losses'].sum()
+    ref['loss'] = loss
+    ref['psnrs'] = R.mse_to_psnr(ref['losses'])
+    ref['obj_psnrs'] = R.mse_to_psnr(ref['obj_losses'])
+    ref['sampling_stats'] = torch.stack([x for t in t_levels for x in (t[0, 0], t[0, -1])])
+    ref['weight_l2'] = wl2
+    for k, v in ref.items():
+        torch.testing.assert_close(st[k], v.float(), rtol=2e-6, atol=1e-7, msg=lambda m: k + ': ' + m)
