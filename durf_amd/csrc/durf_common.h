@@ -141,3 +141,11 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
         default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
     }
 }
+
+// 16-byte store of a streamed-once tensor (activation stash, dz): non-temporal, so the stream does
+// not compete with the packed weights for L2 (measured -3 % on the fused forward and backward)
+#if defined(STREAM_NO_NT)
+#define STREAM_STORE(ptr, val) (*(bf16x8*)(ptr) = (val))
+#else
+#define STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (bf16x8*)(ptr))
+#endif

@@ -211,12 +211,12 @@ __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf
         if (valid) {          // stores trail the compute by one pair, also across stages (mlp_fwd.hip)
             if (mo > 0) {
 #pragma unroll
-                for (int q = 4; q >= 1; q--) *(bf16x8*)(dz_dst + (2 * mo - q) * 1024 + p.lane * 16) = out[2 * mo - q];
+                for (int q = 4; q >= 1; q--) STREAM_STORE(dz_dst + (2 * mo - q) * 1024 + p.lane * 16, out[2 * mo - q]);
                 p.since += 4;
             } else if (PREV_NMT > 0) {
 #pragma unroll
                 for (int q = 4; q >= 1; q--)
-                    *(bf16x8*)(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16) = prev_out[2 * PREV_NMT - q];
+                    STREAM_STORE(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16, prev_out[2 * PREV_NMT - q]);
                 p.since += 4;
             }
         }
@@ -331,7 +331,7 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
                                                    dz_at(0), tile_valid, b, dz_at(1), 0, !POSE);
     if (tile_valid) {          // last stage's trailing stores
 #pragma unroll
-        for (int q = 4; q >= 1; q--) *(bf16x8*)(dz_at(0) + (2 * S::WT - q) * 1024 + lane * 16) = a[2 * S::WT - q];
+        for (int q = 4; q >= 1; q--) STREAM_STORE(dz_at(0) + (2 * S::WT - q) * 1024 + lane * 16, a[2 * S::WT - q]);
     }
     if (POSE) {
         // Dense_0 -> d(encoding); total d enc = skip-connection part + first-layer part
@@ -418,11 +418,26 @@ __device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned soff, unsigned vo
                  : "memory");
 }
 
+// One launch for the 12 weight-gradient GEMMs of an MLP: blockIdx.y = job (= flax Dense index),
+// blockIdx.x = split within the job.  Splits are allotted in proportion to each job's bytes per
+// sample so that ~4 rounds of workgroups smooth the tail, with ~3x fewer split-K partials than one
+// 256-way launch per job.
+struct DwArgs {
+    const char* dz[DURF_MAX_LEVELS][12];      // per level (the sample axis of the GEMMs runs over all levels)
+    const char* inA[DURF_MAX_LEVELS][12];
+    const char* inB[DURF_MAX_LEVELS][12];
+    int nlevels;
+    float* part[12];
+    float* bpart[12];
+    int nsplit[12];
+    int first_wg[13];        // workgroup ids [first_wg[i], first_wg[i+1]) run job order[i]
+    int order[12];
+};
+
 template <int NKO, int NKA, int NKB>
-__device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __restrict__ count,
-                                       const char* __restrict__ dz, const char* __restrict__ inA,
-                                       const char* __restrict__ inB, int nsplit, int split_idx, int split_off,
-                                       float* __restrict__ part, float* __restrict__ bpart, char* smem) {
+__device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __restrict__ count, const DwArgs& a, int job,
+                                       int nsplit, int split_idx, float* __restrict__ part,
+                                       float* __restrict__ bpart, char* smem) {
     constexpr int NKI = NKA + NKB;
     constexpr int NC = NKO + NKI;                 // 1 KB chunks per 32-sample stage
     constexpr int CPW = (NC + 7) / 8;             // LDS-DMA instructions per wave per stage
@@ -435,17 +450,12 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
     const int wm = wave >> 1, wn = wave & 1;
     size_t nrows = rows;
     if (count) { const size_t c = (size_t)(*count) * (size_t)N; nrows = c < rows ? c : rows; }
-    const size_t nt_valid = nrows >> 5;
-    const size_t tps = (nt_valid + nsplit - 1) / nsplit;     // even share of the VALID tiles
-    const size_t t0 = (size_t)split_idx * tps;
-    size_t t1 = t0 + tps;
-    if (t1 > nt_valid) t1 = nt_valid;
-    const int nt = t1 > t0 ? (int)(t1 - t0) : 0;
-
-    // buffer descriptors based at this workgroup's first tile (32-bit offsets stay small)
-    const i32x4 r_dz = make_rsrc(dz + t0 * NKO * 1024);
-    const i32x4 r_a = make_rsrc(inA + t0 * NKA * 1024);
-    const i32x4 r_b = make_rsrc(NKB ? inB + t0 * (NKB ? NKB : 1) * 1024 : inA);
+    const size_t nt_valid = nrows >> 5;                       // valid 32-sample tiles per level
+    const size_t nt_all = nt_valid * (size_t)a.nlevels;       // the K axis: every level's samples
+    const size_t tps = (nt_all + nsplit - 1) / nsplit;        // even share of the VALID tiles
+    const size_t g0 = (size_t)split_idx * tps;
+    size_t g1 = g0 + tps;
+    if (g1 > nt_all) g1 = nt_all;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     // LDS-DMA source swizzle: LDS vector position p of half hi_f holds sample n with
     //   p = (n & 16) | ((n + 4*(2*(ks&1) + hi_f)) & 15)   -> conflict-free tr-reads
@@ -461,6 +471,7 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
         voff[par] = (unsigned)((g_hif * 32 + n) * 16);
 #endif
     }
+    i32x4 r_dz, r_a, r_b;                             // descriptors based at the current segment's first tile
     auto stage_load = [&](int ti, int slot) {        // ti = tile index relative to t0
         ti = __builtin_amdgcn_readfirstlane(ti);
         const unsigned dst = lds0 + (unsigned)(slot * STAGE);
@@ -498,54 +509,67 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
 #pragma unroll
     for (int rm = 0; rm < RM; rm++) bsum[rm] = 0.0f;
 
-    // prologue: S-1 stages in flight
+    // The samples of every level form one K axis; a split that straddles a level boundary runs one
+    // segment per level (the ring drains and refills at the boundary, the accumulators carry on).
+    for (int lvl = 0; lvl < a.nlevels; lvl++) {
+        const size_t lo = (size_t)lvl * nt_valid, hi_t = lo + nt_valid;
+        const size_t b0 = g0 > lo ? g0 : lo, b1 = g1 < hi_t ? g1 : hi_t;
+        if (b1 <= b0) continue;
+        const size_t t0 = b0 - lo;                    // first tile of the segment within its level
+        const int nt = (int)(b1 - b0);
+        r_dz = make_rsrc(a.dz[lvl][job] + t0 * NKO * 1024);
+        r_a = make_rsrc(a.inA[lvl][job] + t0 * NKA * 1024);
+        r_b = make_rsrc(NKB ? a.inB[lvl][job] + t0 * (NKB ? NKB : 1) * 1024 : a.inA[lvl][job]);
+        __builtin_amdgcn_s_barrier();                 // everyone is done reading the previous segment's slots
+        // prologue: S-1 stages in flight
 #pragma unroll
-    for (int i = 0; i < S - 1; i++)
-        if (i < nt) stage_load(i, i);
-    for (int t = 0; t < nt; t++) {
-        // this wave's part of tile t has landed when at most min(S-2, nt-1-t) later stages are pending
-        const int later = nt - 1 - t;
-        if (later >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * CPW) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tail: everything was issued, drain once
-        __builtin_amdgcn_s_barrier();       // every wave's part landed; everyone is done with tile t-1's slot
-        if (t + S - 1 < nt) stage_load(t + S - 1, (t + S - 1) % S);
-        const char* st = smem + (t % S) * STAGE;
+        for (int i = 0; i < S - 1; i++)
+            if (i < nt) stage_load(i, i);
+        for (int t = 0; t < nt; t++) {
+            // this wave's part of tile t has landed when at most min(S-2, nt-1-t) later stages are pending
+            const int later = nt - 1 - t;
+            if (later >= S - 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * CPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // tail: everything was issued, drain once
+            __builtin_amdgcn_s_barrier();       // every wave's part landed; everyone is done with tile t-1's slot
+            if (t + S - 1 < nt) stage_load(t + S - 1, (t + S - 1) % S);
+            const char* st = smem + (t % S) * STAGE;
 #ifdef DW_PROBE_NOCOMPUTE
-        continue;
+            continue;
 #endif
 #pragma unroll
-        for (int kk = 0; kk < 2; kk++) {
-            bf16x8 af[RM], bf[RN];
+            for (int kk = 0; kk < 2; kk++) {
+                bf16x8 af[RM], bf[RN];
 #pragma unroll
-            for (int rm = 0; rm < RM; rm++) {
-                const int mo = wm + 4 * rm;
-                if (mo < MO) {
-                    int ks = 2 * mo + ksp;
-                    if (ks > NKO - 1) ks = NKO - 1;            // odd NKO: duplicate, ignored later
-                    const char* base = st + ks * 1024 + lane_off + kk * 256;
-                    af[rm] = tr_frag(base, poff0, poff1);
+                for (int rm = 0; rm < RM; rm++) {
+                    const int mo = wm + 4 * rm;
+                    if (mo < MO) {
+                        int ks = 2 * mo + ksp;
+                        if (ks > NKO - 1) ks = NKO - 1;            // odd NKO: duplicate, ignored later
+                        const char* base = st + ks * 1024 + lane_off + kk * 256;
+                        af[rm] = tr_frag(base, poff0, poff1);
+                    }
                 }
-            }
 #pragma unroll
-            for (int rn = 0; rn < RN; rn++) {
-                const int ni = wn + 2 * rn;
-                if (ni < NI) {
-                    const char* base = st + (NKO + 2 * ni + ksp) * 1024 + lane_off + kk * 256;
-                    bf[rn] = tr_frag(base, poff0, poff1);
+                for (int rn = 0; rn < RN; rn++) {
+                    const int ni = wn + 2 * rn;
+                    if (ni < NI) {
+                        const char* base = st + (NKO + 2 * ni + ksp) * 1024 + lane_off + kk * 256;
+                        bf[rn] = tr_frag(base, poff0, poff1);
+                    }
                 }
-            }
 #pragma unroll
-            for (int rm = 0; rm < RM; rm++) {
-                if (wm + 4 * rm < MO) {
+                for (int rm = 0; rm < RM; rm++) {
+                    if (wm + 4 * rm < MO) {
 #pragma unroll
-                    for (int rn = 0; rn < RN; rn++)
-                        if (wn + 2 * rn < NI)
-                            acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm], bf[rn], acc[rm][rn], 0, 0, 0);
-                    if (wn == 0) {
-                        float s = 0.0f;
+                        for (int rn = 0; rn < RN; rn++)
+                            if (wn + 2 * rn < NI)
+                                acc[rm][rn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[rm], bf[rn], acc[rm][rn], 0, 0, 0);
+                        if (wn == 0) {
+                            float s = 0.0f;
 #pragma unroll
-                        for (int e = 0; e < 8; e++) s += (float)af[rm][e];
-                        bsum[rm] += s;
+                            for (int e = 0; e < 8; e++) s += (float)af[rm][e];
+                            bsum[rm] += s;
+                        }
                     }
                 }
             }
@@ -555,7 +579,7 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
     if (acc[0][0][0] != 1234.5f) return;
 #endif
     // partials in fragment coordinates: [split][mo][ni][lane][16]
-    const size_t sp = (size_t)split_off + split_idx;
+    const size_t sp = (size_t)split_idx;
 #pragma unroll
     for (int rm = 0; rm < RM; rm++) {
         const int mo = wm + 4 * rm;
@@ -580,21 +604,6 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
     }
 }
 
-// One launch for the 12 weight-gradient GEMMs of an MLP: blockIdx.y = job (= flax Dense index),
-// blockIdx.x = split within the job.  Splits are allotted in proportion to each job's bytes per
-// sample so that ~4 rounds of workgroups smooth the tail, with ~3x fewer split-K partials than one
-// 256-way launch per job.
-struct DwArgs {
-    const char* dz[12];
-    const char* inA[12];
-    const char* inB[12];
-    float* part[12];
-    float* bpart[12];
-    int nsplit[12];
-    int split_off[12];
-    int first_wg[13];        // workgroup ids [first_wg[i], first_wg[i+1]) run job order[i]
-    int order[12];
-};
 
 #ifdef DW_TRACE
 __device__ unsigned long long g_dw_trace[4 * 4096];
@@ -634,7 +643,7 @@ k_dw_all(size_t rows, int N, const int32_t* __restrict__ count, DwArgs a) {
         }
     } trace_end{t_start, job, sp};
 #endif
-#define DW_CALL(NKO, NKA, NKB) dw_job<NKO, NKA, NKB>(rows, N, count, a.dz[job], a.inA[job], a.inB[job], ns, sp, a.split_off[job], a.part[job], a.bpart[job], smem)
+#define DW_CALL(NKO, NKA, NKB) dw_job<NKO, NKA, NKB>(rows, N, count, a, job, ns, sp, a.part[job], a.bpart[job], smem)
     switch (job) {
         case 0: DW_CALL(S::KW, S::KE, 0); break;
         case 5: DW_CALL(S::KW, S::KW, S::KE); break;
@@ -730,7 +739,7 @@ struct DwPlan {
     size_t part_off[12], bpart_off[12], part_total, bpart_total;
     int max_split;
 };
-static DwPlan dw_plan(int width, int nlevels) {
+static DwPlan dw_plan(int width) {
     DwPlan P;
     const int KW = width / 16;
     int cost = 0, wcost[12];
@@ -772,8 +781,8 @@ static DwPlan dw_plan(int width, int nlevels) {
         P.nsplit[j] = ns;
         if (ns > P.max_split) P.max_split = ns;
         P.part_off[j] = po; P.bpart_off[j] = bo;
-        po += (size_t)nlevels * ns * P.MO[j] * P.NI[j] * 1024;
-        bo += (size_t)nlevels * ns * P.MO[j] * 32;
+        po += (size_t)ns * P.MO[j] * P.NI[j] * 1024;
+        bo += (size_t)ns * P.MO[j] * 32;
     }
     P.part_total = po; P.bpart_total = bo;
     return P;
@@ -832,37 +841,45 @@ int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, co
     return 0;
 }
 
-size_t durf_dw_part_floats(int width, int nlevels) { return dw_plan(width, nlevels).part_total; }
-size_t durf_dw_bpart_floats(int width, int nlevels) { return dw_plan(width, nlevels).bpart_total; }
+size_t durf_dw_part_floats(int width) { return dw_plan(width).part_total; }
+size_t durf_dw_bpart_floats(int width) { return dw_plan(width).bpart_total; }
 
-// All weight gradients of one MLP for one level: ONE grouped launch of the 12 split-K GEMMs.
-// Partials of level `level` go to that level's slots; durf_mlp_dw_finalize sums all levels.
-int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, const void* enc_tile,
-                const void* view_tile, const void* stash, const void* dz, const void* dz_out, int level,
-                int nlevels, float* part, float* bpart) {
+// All weight gradients of one MLP: ONE grouped launch of the 12 split-K GEMMs whose K axis runs over
+// the samples of every level (per-level operand buffers, one set of fp32 partials).
+int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
+                const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
+                const void* const* dz, const void* const* dz_out, float* part, float* bpart) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
-    DURF_REQUIRE(level >= 0 && level < nlevels, "0 <= level < nlevels");
+    DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
     if (rows == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const DwPlan P = dw_plan(width, nlevels);
+    const DwPlan P = dw_plan(width);
     const size_t nt = rows >> 5;
     const int KW = width / 16;
     auto region = [&](const void* base, int j) { return (const char*)base + ((size_t)j * KW * nt) * 1024; };
     DwArgs a;
+    a.nlevels = nlevels;
     for (int j = 0; j < 12; j++) {
         a.part[j] = part + P.part_off[j];
         a.bpart[j] = bpart + P.bpart_off[j];
         a.nsplit[j] = P.nsplit[j];
-        a.split_off[j] = level * P.nsplit[j];
-        a.inB[j] = nullptr;
-        if (j <= 7) { a.dz[j] = region(dz, j); a.inA[j] = j == 0 ? (const char*)enc_tile : region(stash, j - 1); }
     }
-    a.inB[5] = (const char*)enc_tile;
-    a.dz[8] = (const char*)dz_out; a.inA[8] = region(stash, 7);          // density head
-    a.dz[9] = region(dz, 8); a.inA[9] = region(stash, 7);                // bottleneck
-    a.dz[10] = region(dz, 9); a.inA[10] = region(stash, 8); a.inB[10] = (const char*)view_tile;
-    a.dz[11] = (const char*)dz_out; a.inA[11] = region(stash, 9);        // rgb head
+    for (int l = 0; l < DURF_MAX_LEVELS; l++) {
+        const int ll = l < nlevels ? l : 0;
+        for (int j = 0; j < 12; j++) {
+            a.inB[l][j] = nullptr;
+            if (j <= 7) {
+                a.dz[l][j] = region(dz[ll], j);
+                a.inA[l][j] = j == 0 ? (const char*)enc_tile[ll] : region(stash[ll], j - 1);
+            }
+        }
+        a.inB[l][5] = (const char*)enc_tile[ll];
+        a.dz[l][8] = (const char*)dz_out[ll]; a.inA[l][8] = region(stash[ll], 7);          // density head
+        a.dz[l][9] = region(dz[ll], 8); a.inA[l][9] = region(stash[ll], 7);                // bottleneck
+        a.dz[l][10] = region(dz[ll], 9); a.inA[l][10] = region(stash[ll], 8); a.inB[l][10] = (const char*)view_tile[ll];
+        a.dz[l][11] = (const char*)dz_out[ll]; a.inA[l][11] = region(stash[ll], 9);        // rgb head
+    }
     // narrow jobs first: their workgroups run longest (less data in flight per stage)
     static const int order[12] = {11, 8, 0, 10, 5, 1, 2, 3, 4, 6, 7, 9};
     int total = 0;
@@ -886,12 +903,12 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
     return 0;
 }
 
-int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nlevels, const float* part,
-                         const float* bpart, float* grad_mlp) {
+int durf_mlp_dw_finalize(void* stream, int width, int in_dim, const float* part, const float* bpart,
+                         float* grad_mlp) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     hipStream_t s = (hipStream_t)stream;
     const int W = width, KW = W / 16;
-    const DwPlan P = dw_plan(width, nlevels);
+    const DwPlan P = dw_plan(width);
     DwJobs jobs;
     int max_el = 0;
     for (int job = 0; job < 12; job++) {
@@ -905,7 +922,7 @@ int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nlevels, const
         J.MO = P.MO[job]; J.NI = P.NI[job];
         jobs.part_off[job] = P.part_off[job];
         jobs.bpart_off[job] = P.bpart_off[job];
-        jobs.nparts[job] = nlevels * P.nsplit[job];
+        jobs.nparts[job] = P.nsplit[job];
         const int el = J.MO * J.NI * 1024 + J.MO * 32;
         if (el > max_el) max_el = el;
     }

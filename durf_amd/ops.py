@@ -298,23 +298,25 @@ def expand_view(rows, N, view_bf16, ray_idx=None, count=None):
     return out
 
 
-def dw_buffers(width, nlevels, device):
-    part = torch.empty(int(_lib.lib().durf_dw_part_floats(width, nlevels)), device=device)
-    bpart = torch.empty(int(_lib.lib().durf_dw_bpart_floats(width, nlevels)), device=device)
+def dw_buffers(width, device):
+    part = torch.empty(int(_lib.lib().durf_dw_part_floats(width)), device=device)
+    bpart = torch.empty(int(_lib.lib().durf_dw_bpart_floats(width)), device=device)
     return part, bpart
 
 
-def mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, level, nlevels, part, bpart, count=None):
+def mlp_dw(width, rows, N, enc_tiles, view_tiles, stashes, dzs, dz_outs, part, bpart, count=None):
+    """Weight-gradient partials of one MLP over the samples of every level (lists: one entry per level)."""
+    L = len(stashes)
+    arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])
     with _Timed('mlp_dw_%d' % width):
-        _lib.check(_lib.lib().durf_mlp_dw(_stream(), width, rows, N, _p(count), _p(enc_tile), _p(view_tile),
-                                          _p(stash), _p(dz), _p(dz_out), level, nlevels, _p(part), _p(bpart)),
-                   'durf_mlp_dw')
+        _lib.check(_lib.lib().durf_mlp_dw(_stream(), width, rows, N, _p(count), L, arr(enc_tiles), arr(view_tiles),
+                                          arr(stashes), arr(dzs), arr(dz_outs), _p(part), _p(bpart)), 'durf_mlp_dw')
 
 
-def mlp_dw_finalize(width, in_dim, nlevels, part, bpart, grad_mlp):
+def mlp_dw_finalize(width, in_dim, part, bpart, grad_mlp):
     with _Timed('mlp_dw_finalize_%d' % width):
-        _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, nlevels, _p(part), _p(bpart),
-                                                   _p(_f32(grad_mlp))), 'durf_mlp_dw_finalize')
+        _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, _p(part), _p(bpart), _p(grad_mlp)),
+                   'durf_mlp_dw_finalize')
 
 
 def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):

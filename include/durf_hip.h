@@ -160,17 +160,19 @@ int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw,
 int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
                      const int32_t* count, void* out_tile /* tile layout [rows,32] */);
 
-/* K11 weight gradients of one MLP over `rows` samples of one level: ONE grouped launch of the 12
- * split-K GEMMs (one per Dense), fp32 partials per (job, level, split); the finalize call sums
- * every level and split in a fixed order into grad_mlp (flax layout of one MLP, overwritten).
- * part / bpart: durf_dw_part_floats / durf_dw_bpart_floats (width, nlevels) floats. */
-size_t durf_dw_part_floats(int width, int nlevels);
-size_t durf_dw_bpart_floats(int width, int nlevels);
-int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, const void* enc_tile,
-                const void* view_tile, const void* stash, const void* dz, const void* dz_out, int level,
-                int nlevels, float* part, float* bpart);
-int durf_mlp_dw_finalize(void* stream, int width, int in_dim, int nlevels, const float* part,
-                         const float* bpart, float* grad_mlp);
+/* K11 weight gradients of one MLP: ONE grouped launch of the 12 split-K GEMMs (one per Dense)
+ * whose K axis runs over the `rows` samples of EVERY level; enc_tile/view_tile/stash/dz/dz_out
+ * are host arrays of nlevels device pointers (the per-level buffers of durf_mlp_fwd /
+ * durf_mlp_bwd / durf_expand_view).  fp32 partials per (job, split); the finalize call sums
+ * the splits in a fixed order into grad_mlp (flax layout of one MLP, overwritten).
+ * part / bpart: durf_dw_part_floats / durf_dw_bpart_floats (width) floats. */
+size_t durf_dw_part_floats(int width);
+size_t durf_dw_bpart_floats(int width);
+int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
+                const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
+                const void* const* dz, const void* const* dz_out, float* part, float* bpart);
+int durf_mlp_dw_finalize(void* stream, int width, int in_dim, const float* part, const float* bpart,
+                         float* grad_mlp);
 
 /* Box-pose gradients (cfg4): reverse of weighted_ipe / cast_rays / world2object_rpy / aa2matrix
  * (mip.py:182-223,155-179; box_helpers.py:286-341,148-167).  Per level and object:

@@ -95,13 +95,13 @@ def test_mlp_backward_and_weight_grads(cuda, width, in_dim):
     mask = torch.zeros(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=cuda)
     ops.mlp_fwd(width, rows, N, enc_tile, view, wf, stash=stash, relu_mask=mask)
     dz, dz_out = ops.mlp_bwd(width, rows, N, draw.to(cuda), wb, mask)
-    part, bpart = ops.dw_buffers(width, 2, cuda)
+    part, bpart = ops.dw_buffers(width, cuda)
     view_tile = ops.expand_view(rows, N, view)
-    # two calls into the two level slots (as the two levels of a training step do)
-    ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, 0, 2, part, bpart)
-    ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, 1, 2, part, bpart)
+    # the K axis runs over two levels (here: the same buffers twice, as two separate allocations would be)
+    ops.mlp_dw(width, rows, N, [enc_tile] * 2, [view_tile] * 2, [stash, stash.clone()], [dz, dz.clone()],
+               [dz_out] * 2, part, bpart)
     grad = torch.zeros_like(flat)
-    ops.mlp_dw_finalize(width, in_dim, 2, part, bpart, grad)
+    ops.mlp_dw_finalize(width, in_dim, part, bpart, grad)
     grad = grad.cpu() / 2
     # oracle
     rgb, dens = R.mlp_apply_bf16(params, x, cond, cfg)

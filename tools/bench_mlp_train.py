@@ -48,11 +48,14 @@ dz, dz_out = ops.mlp_bwd(W, rows, N, draw, wb, mask)
 by = dz.numel() * dz.element_size() + dz_out.numel() * dz_out.element_size() + mask.numel()
 print('bwd             %8.1f us  %6.1f TFLOP/s  %.2f GB -> %.2f TB/s' % (t * 1e6, flops / t / 1e12, by / 1e9, by / t / 1e12))
 view_tile = ops.expand_view(rows, N, view)
-part, bpart = ops.dw_buffers(W, 1, dev)
-t = timeit(lambda: ops.mlp_dw(W, rows, N, enc, view_tile, stash, dz, dz_out, 0, 1, part, bpart))
+part, bpart = ops.dw_buffers(W, dev)
+t = timeit(lambda: ops.mlp_dw(W, rows, N, [enc], [view_tile], [stash], [dz], [dz_out], part, bpart))
 by = (stash.numel() + dz.numel() * dz.element_size() + dz_out.numel() * dz_out.element_size()
       + enc.numel() * 2 + view_tile.numel() * view_tile.element_size())
 print('dW              %8.1f us  %6.1f TFLOP/s  %.2f GB -> %.2f TB/s' % (t * 1e6, flops / t / 1e12, by / 1e9, by / t / 1e12))
 grad = torch.empty(ops.mlp_param_count(W, IN), device=dev)
-t = timeit(lambda: ops.mlp_dw_finalize(W, IN, 1, part, bpart, grad))
+t = timeit(lambda: ops.mlp_dw_finalize(W, IN, part, bpart, grad))
 print('dW finalize     %8.1f us' % (t * 1e6))
+stash2, dz2 = stash.clone(), dz.clone()
+t = timeit(lambda: ops.mlp_dw(W, rows, N, [enc, enc], [view_tile] * 2, [stash, stash2], [dz, dz2], [dz_out] * 2, part, bpart))
+print('dW (2 levels)   %8.1f us  %6.1f TFLOP/s  %.2f GB -> %.2f TB/s' % (t * 1e6, 2 * flops / t / 1e12, 2 * by / 1e9, 2 * by / t / 1e12))

@@ -33,11 +33,11 @@ stash = torch.zeros(ops.mlp_stash_bytes(width, rows), dtype=torch.uint8, device=
 mask = torch.zeros(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=cuda)
 ops.mlp_fwd(width, rows, N, enc_tile, view, wf, stash=stash, relu_mask=mask)
 dz, dz_out = ops.mlp_bwd(width, rows, N, draw.to(cuda), wb, mask)
-part, bpart = ops.dw_buffers(width, 1, cuda)
+part, bpart = ops.dw_buffers(width, cuda)
 view_tile = ops.expand_view(rows, N, view)
-ops.mlp_dw(width, rows, N, enc_tile, view_tile, stash, dz, dz_out, 0, 1, part, bpart)
+ops.mlp_dw(width, rows, N, [enc_tile], [view_tile], [stash], [dz], [dz_out], part, bpart)
 grad = torch.zeros_like(flat)
-ops.mlp_dw_finalize(width, in_dim, 1, part, bpart, grad)
+ops.mlp_dw_finalize(width, in_dim, part, bpart, grad)
 grad = grad.cpu()
 rgb, dens = R.mlp_apply_bf16(params, x, cond, cfg)
 out = torch.cat([rgb.reshape(rows, 3), dens.reshape(rows, 1)], -1)

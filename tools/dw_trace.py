@@ -24,9 +24,9 @@ ops.mlp_fwd(W, rows, N, enc, view, wf, raw=raw, stash=stash, relu_mask=mask)
 draw = torch.randn(rows, 4, device=dev) * 1e-3
 dz, dz_out = ops.mlp_bwd(W, rows, N, draw, wb, mask)
 view_tile = ops.expand_view(rows, N, view)
-part, bpart = ops.dw_buffers(W, 1, dev)
+part, bpart = ops.dw_buffers(W, dev)
 for _ in range(3):
-    ops.mlp_dw(W, rows, N, enc, view_tile, stash, dz, dz_out, 0, 1, part, bpart)
+    ops.mlp_dw(W, rows, N, [enc], [view_tile], [stash], [dz], [dz_out], part, bpart)
 torch.cuda.synchronize()
 buf = np.zeros(4 * 4096, dtype=np.uint64)
 L = _lib.lib()
