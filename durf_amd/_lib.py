@@ -25,10 +25,10 @@ _SIGS = {
     'durf_pack_weights': (i32, [vp, i32, i32, vp, vp, vp]),
     'durf_ray_setup': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_compact_hits': (i32, [vp, i32, i32, vp, vp, vp, vp]),
-    'durf_sample_t': (i32, [vp, i32, i32, vp, vp, vp, vp]),
+    'durf_sample_t': (i32, [vp, i32, i32, vp, vp, vp, i32, vp]),
     'durf_view_enc': (i32, [vp, i32, vp, vp, vp]),
     'durf_encode_bkgd': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
-    'durf_encode_obj': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
+    'durf_encode_obj': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp, vp]),
     'durf_mlp_stash_bytes': (u64, [i32, u64]),
     'durf_mlp_mask_bytes': (u64, [u64]),
     'durf_mlp_fwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]),

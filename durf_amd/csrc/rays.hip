@@ -134,7 +134,7 @@ k_compact_hits(int B, int K, const int32_t* __restrict__ hit, int32_t* __restric
 // ---------------------------------------------------------------------------
 __global__ void __launch_bounds__(256)
 k_sample_t(int B, int N, const float* __restrict__ near, const float* __restrict__ far,
-           const float* __restrict__ t_rand, float* __restrict__ t_vals) {
+           const float* __restrict__ t_rand, int lindisp, float* __restrict__ t_vals) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t tot = (size_t)B * (N + 1);
     if (i >= tot) return;
@@ -142,7 +142,8 @@ k_sample_t(int B, int N, const float* __restrict__ near, const float* __restrict
     const float nr = near[b], fr = far[b];
     auto tv = [&](int m) {
         const float s = (m == N) ? 1.0f : (float)m / (float)N;
-        return nr * (1.0f - s) + fr * s;
+        const float t = nr * (1.0f - s) + fr * s;
+        return lindisp ? 1.0f / t : t;                                  // mip.py:354-356
     };
     float t = tv(n);
     if (t_rand) {                                                       // :360-365
@@ -233,6 +234,7 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
     float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
     float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
     Gauss g = frustum_gaussian(t0, t1, o, d, radii[b]);
+    if (contraction & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
     float w[10];
     if (OBJ) {
 #pragma unroll
@@ -245,7 +247,7 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
 #pragma unroll
             for (int i = 0; i < 3; i++) { g.x[i] *= m; g.var[i] *= m; }
         }
-        if (contraction) contract_gaussian(g);
+        if (contraction & DURF_ENC_CONTRACT) contract_gaussian(g);
     }
     float v[8];
 #pragma unroll
@@ -314,6 +316,7 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
     float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
     float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
     Gauss g = frustum_gaussian(t0, t1, o, d, radii[b]);
+    if (contraction & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
     if (!OBJ) {
         int nh = 0;
         for (int k = 0; k < K; k++) nh += hit[b * K + k];
@@ -322,7 +325,7 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
 #pragma unroll
             for (int i = 0; i < 3; i++) { g.x[i] *= m; g.var[i] *= m; }
         }
-        if (contraction) contract_gaussian(g);
+        if (contraction & DURF_ENC_CONTRACT) contract_gaussian(g);
     }
     float feat[64];
 #pragma unroll
@@ -380,10 +383,10 @@ int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* i
 }
 
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
-                  const float* t_rand, float* t_vals) {
+                  const float* t_rand, int lindisp, float* t_vals) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(k_sample_t, dim3(durf_cdiv((size_t)B * (N + 1), 256)), dim3(256), 0,
-                       (hipStream_t)stream, B, N, near, far, t_rand, t_vals);
+                       (hipStream_t)stream, B, N, near, far, t_rand, lindisp, t_vals);
     DURF_CHECK_LAUNCH("durf_sample_t");
     return 0;
 }
@@ -415,18 +418,18 @@ int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const floa
 
 int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const int32_t* count,
                     const float* t_vals, const float* origins_s, const float* dirs_s,
-                    const float* radii, const float* barf_w, void* out_tile, float* out_f32) {
+                    const float* radii, const float* barf_w, int flags, void* out_tile, float* out_f32) {
     if (max_rays <= 0) return 0;
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
     if (out_f32)
         hipLaunchKernelGGL((k_encode<true>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
-                           nullptr, 0, 0, bw, (bf16x8*)out_tile, out_f32);
+                           nullptr, 0, flags & DURF_ENC_NO_INTEGRATION, bw, (bf16x8*)out_tile, out_f32);
     else
         hipLaunchKernelGGL((k_encode_lane<true>), dim3(durf_cdiv((size_t)max_rays * N, 256)), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
-                           nullptr, 0, 0, bw, (char*)out_tile);
+                           nullptr, 0, flags & DURF_ENC_NO_INTEGRATION, bw, (char*)out_tile);
     DURF_CHECK_LAUNCH("durf_encode_obj");
     return 0;
 }

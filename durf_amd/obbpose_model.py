@@ -154,11 +154,10 @@ class MipNerfModel:
     def _check(self):
         bad = []
         if self.ray_shape != 'cone': bad.append('ray_shape')
-        if self.lindisp: bad.append('lindisp')
         if not self.use_viewdirs: bad.append('use_viewdirs=False')
         if (self.min_deg_point, self.max_deg_point, self.deg_view) != (0, 10, 4): bad.append('degrees')
-        if self.disable_integration: bad.append('disable_integration')
-        if not self.dynamics: bad.append('dynamics=False')
+        if (self.disable_integration or not self.dynamics) and not (self.no_pose_opt and self.no_yaw_opt):
+            bad.append('disable_integration / dynamics=False with box-pose optimisation')
         if not self.stop_level_grad: bad.append('stop_level_grad=False')
         if self.num_samples % 32 or not (32 <= self.num_samples <= 256): bad.append('num_samples')
         if bad:
@@ -174,6 +173,7 @@ class MipNerfModel:
             raise NotImplementedError('density_noise > 0 (both shipped gin files set 0.0)')
         lay = variables.layout
         K, N = lay.K, self.num_samples
+        Kd = K if self.dynamics else 0         # dynamics=False: boxes only select rays (obbpose_model.py:167,232,257-260)
         B = rays.origins.shape[0]
         dev = rays.origins.device
         ts = int(ts)
@@ -195,24 +195,26 @@ class MipNerfModel:
                          u_rand=torch.rand(B, N + 1, device=dev, generator=g))
         rows = B * N
         ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,
-                   packs=packs, levels=[], B=B, N=N, K=K, ts=ts, bkgd_mode=bk)
+                   packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk)
         ret = []
         t_vals = weights = None
         box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
         dyn_mask = hit.sum(dim=-1, keepdim=True) if K > 0 else torch.zeros(B, 1, dtype=torch.int32, device=dev)
         for lvl in range(self.num_levels):
             if lvl == 0:
-                t_vals = ops.sample_t(near, far, N, noise['t_rand'] if randomized else None)
+                t_vals = ops.sample_t(near, far, N, noise['t_rand'] if randomized else None, self.lindisp)
             else:
                 t_vals = ops.resample(t_vals, weights, self.resample_padding,
                                       noise['u_rand'] if randomized else None)
-            enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction)
+            enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
+                                       disable_integration=self.disable_integration)
             stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
             mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
             raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, wf['MLP_0'], stash=stash_b, relu_mask=mask_b)
             raws, encs, stashes, masks = [], [], [], []
-            for k in range(K):
-                enc_k, _ = ops.encode_obj(B, idx[k], count[k:k + 1], t_vals, o_s, d_s, radii, alpha)
+            for k in range(Kd):
+                enc_k, _ = ops.encode_obj(B, idx[k], count[k:k + 1], t_vals, o_s, d_s, radii, alpha,
+                                          disable_integration=self.disable_integration)
                 st_k = torch.empty(ops.mlp_stash_bytes(W_OBJ, rows), dtype=torch.uint8, device=dev) if train else None
                 mk_k = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
                 raws.append(ops.mlp_fwd(W_OBJ, rows, N, enc_k, view, wf['BoxMLP_%d' % k], ray_idx=idx[k],

@@ -78,11 +78,11 @@ def compact_hits(hit):
     return idx, count, slot
 
 
-def sample_t(near, far, N, t_rand=None):
+def sample_t(near, far, N, t_rand=None, lindisp=False):
     B = near.shape[0]
     t = torch.empty(B, N + 1, device=near.device)
     _lib.check(_lib.lib().durf_sample_t(_stream(), B, N, _p(_f32(near)), _p(_f32(far)),
-                                        _p(None if t_rand is None else _f32(t_rand)), _p(t)),
+                                        _p(None if t_rand is None else _f32(t_rand)), int(lindisp), _p(t)),
                'durf_sample_t')
     return t
 
@@ -100,16 +100,22 @@ def tile_rows(rows):
     return (rows + 31) // 32 * 32
 
 
-def encode_bkgd(t_vals, origins_s, dirs_s, radii, hit, contraction=True, tile=True, f32=False):
+ENC_CONTRACT, ENC_NO_INTEGRATION = 1, 2
+
+
+def encode_bkgd(t_vals, origins_s, dirs_s, radii, hit, contraction=True, tile=True, f32=False,
+                disable_integration=False):
+    """hit=None: no object masking of the samples (MipNerfModel.dynamics=False)"""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
-    K = hit.shape[1]
+    K = 0 if hit is None else hit.shape[1]
     dev = t_vals.device
     ot = torch.empty(tile_rows(B * N), ENC_DIM, dtype=torch.bfloat16, device=dev) if tile else None
     of = torch.empty(B * N, 60, device=dev) if f32 else None
     with _Timed('encode_bkgd'):
         _lib.check(_lib.lib().durf_encode_bkgd(_stream(), B, N, _p(_f32(t_vals)), _p(_f32(origins_s)),
                                                _p(_f32(dirs_s)), _p(_f32(radii)), _p(hit), K,
-                                               int(contraction), _p(ot), _p(of)), 'durf_encode_bkgd')
+                                               (ENC_CONTRACT if contraction else 0) | (ENC_NO_INTEGRATION if disable_integration else 0),
+                                               _p(ot), _p(of)), 'durf_encode_bkgd')
     return ot, of
 
 
@@ -121,7 +127,8 @@ def barf_weights(alpha, max_deg=10):
     return ((np.float32(1) - np.cos(a, dtype=np.float32)) / np.float32(2)).astype(np.float32)
 
 
-def encode_obj(max_rays, idx_k, count_k, t_vals, origins_s, dirs_s, radii, alpha, tile=True, f32=False):
+def encode_obj(max_rays, idx_k, count_k, t_vals, origins_s, dirs_s, radii, alpha, tile=True, f32=False,
+               disable_integration=False):
     N = t_vals.shape[1] - 1
     dev = t_vals.device
     ot = torch.empty(tile_rows(max_rays * N), ENC_DIM, dtype=torch.bfloat16, device=dev) if tile else None
@@ -130,7 +137,8 @@ def encode_obj(max_rays, idx_k, count_k, t_vals, origins_s, dirs_s, radii, alpha
     wa = (C.c_float * 10)(*[float(x) for x in w])
     _lib.check(_lib.lib().durf_encode_obj(_stream(), max_rays, N, _p(idx_k), _p(count_k),
                                           _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
-                                          _p(_f32(radii)), wa, _p(ot), _p(of)), 'durf_encode_obj')
+                                          _p(_f32(radii)), wa, ENC_NO_INTEGRATION if disable_integration else 0,
+                                          _p(ot), _p(of)), 'durf_encode_obj')
     return ot, of
 
 

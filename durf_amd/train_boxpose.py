@@ -110,7 +110,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         ops.mlp_dw(om.W_OBJ, rows, N, [lv['encs'][k] for lv in levels], [view_tiles_obj[k]] * L,
                    [lv['stashes'][k] for lv in levels], [d[0] for d in dzs[nm]], [d[1] for d in dzs[nm]],
                    *bufs[nm], count=ctx['count'][k:k + 1])
-    for n in names:
+    for n in (names if K == lay.K else names[:1]):          # dynamics=False: the object MLPs are not evaluated
         width, in_dim = lay.mlp_dims(n)
         off = lay.mlp_off[n]
         ops.mlp_dw_finalize(width, in_dim, *bufs[n], grad[off:off + lay.mlp_size[width]])
@@ -127,7 +127,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
         grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)[ctx['ts']] += g6
     pose = ret[0][7][0]
-    raw = dict(norms=norms, sums=sums, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if K > 0 else None)
+    raw = dict(norms=norms, sums=sums, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if lay.K > 0 else None)
     return grad, raw, pose
 
 

@@ -30,6 +30,9 @@ extern "C" {
 
 #define DURF_MAX_OBJ 16
 #define DURF_MAX_LEVELS 8
+/* flags of durf_encode_bkgd (`contraction` argument) / durf_encode_obj */
+#define DURF_ENC_CONTRACT 1        /* MipNerfModel.contraction (mip360.new_space) */
+#define DURF_ENC_NO_INTEGRATION 2  /* MipNerfModel.disable_integration: PE instead of IPE (covariances zeroed) */
 #define DURF_ENC_DIM 64      /* 60 (bkgd IPE) / 63 (object IPE) features padded to 64 */
 #define DURF_VIEW_DIM 32     /* 27 view-direction features padded to 32 */
 
@@ -67,7 +70,7 @@ int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* i
 
 /* mip.sample_along_rays t_vals (mip.py:353-368). t_rand nullable (randomized=False). */
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
-                  const float* t_rand, float* t_vals);
+                  const float* t_rand, int lindisp /* MipNerfModel.lindisp, mip.py:354-356 */, float* t_vals);
 
 /* view-direction encoding mip.pos_enc(viewdirs,0,4,True) (mip.py:36-45) -> [B,32]
  * bf16 (27 features, zero padded) and/or fp32 [B,27]. */
@@ -79,14 +82,15 @@ int durf_view_enc(void* stream, int B, const float* viewdirs, void* out_bf16, fl
  * out_f32: [B*N, 60] row-major (either may be null). */
 int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const float* origins_s,
                      const float* dirs_s, const float* radii, const int32_t* hit, int K,
-                     int contraction, void* out_tile, float* out_f32);
+                     int contraction /* DURF_ENC_* flags */, void* out_tile, float* out_f32);
 
 /* K4 object encoding for compacted hit rays of object k: weighted_ipe (mip.py:182-223),
  * no contraction, xyz prepended -> 63 features.  idx/count from durf_compact_hits
  * (device-side count; launch covers max_rays).  barf_w: 10 host floats (mip.py:217-218). */
 int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const int32_t* count,
                     const float* t_vals, const float* origins_s, const float* dirs_s,
-                    const float* radii, const float* barf_w, void* out_tile, float* out_f32);
+                    const float* radii, const float* barf_w, int flags /* DURF_ENC_NO_INTEGRATION */,
+                    void* out_tile, float* out_f32);
 
 /* K6/K7 fused MLP forward (obbpose_model.py:305-354 / :369-418), bf16 MFMA, fp32
  * accumulate.  rows = number of samples (multiple of N); enc_tile: [rows,64] tile layout;

@@ -525,7 +525,9 @@ def model_apply(params, rays, ts, ext, randomized, rand_bkgd, white_bkgd, alpha,
         raw_densities = torch.zeros(Bn, N, 1, dtype=dt)
         masks_sum = torch.zeros(Bn, N, 1, dtype=dt)
         ret_masks = torch.zeros(Bn, 1, dtype=torch.int64)
-        for i in range(K):                                                # :174-201
+        if not c['dynamics']:                                             # :257-260: mask from the hit test only
+            ret_masks = intersection.sum(dim=-1, keepdim=True)
+        for i in range(K if c['dynamics'] else 0):                        # :167,:174-201
             mask_i = intersection[:, i].reshape(-1, 1)
             ret_masks = ret_masks + mask_i
             mask = mask_i.to(dt)[:, None, :].expand(Bn, N, 1)
@@ -537,8 +539,9 @@ def model_apply(params, rays, ts, ext, randomized, rand_bkgd, white_bkgd, alpha,
             obj_rgb, obj_density = mlp(params['BoxMLP_%d' % i], enc, viewdirs_enc, MLP_BOX)
             raw_rgbs = raw_rgbs + mask * obj_rgb
             raw_densities = raw_densities + mask * obj_density
-        bkgd_mask_s = (1 - masks_sum).detach()                            # :205-206
-        samples = (bkgd_mask_s * samples[0], bkgd_mask_s[..., None] * samples[1])
+        if c['dynamics']:
+            bkgd_mask_s = (1 - masks_sum).detach()                        # :205-206
+            samples = (bkgd_mask_s * samples[0], bkgd_mask_s[..., None] * samples[1])
 
         if c['contraction']:
             samples = new_space(samples)                                  # :212-213

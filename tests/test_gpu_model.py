@@ -16,11 +16,14 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _run(cuda, B, K, N, randomized, seed, alpha=10.0, far=40.0):
+def _run(cuda, B, K, N, randomized, seed, alpha=10.0, far=40.0, knobs=None, near=None):
     utils.clear_gin()
     utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
-                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n' % N)
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n' % N +
+                    ''.join('MipNerfModel.%s = %r\n' % kv for kv in (knobs or {}).items()))
     b = synthetic.make_batch(B, K, seed=seed, far=far, allow_multi_hit=True)
+    if near is not None:
+        b['rays']['near'][:] = near
     ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
     model, variables = obbpose_model.construct_mipnerf(seed, db, device=cuda)
     # non-zero biases so bias packing is exercised
@@ -35,7 +38,7 @@ def _run(cuda, B, K, N, randomized, seed, alpha=10.0, far=40.0):
                       rand_bkgd=False, white_bkgd=False, alpha=alpha, noise=noise_d if randomized else None)
     torch.cuda.synchronize()
     params = H.oracle_params_from_variables(variables)
-    mcfg = dict(num_samples=N)
+    mcfg = dict(num_samples=N, **(knobs or {}))
     with torch.no_grad():
         ref_bf = R.model_apply(params, ob['rays'], b['ts'], ob['ext'], randomized, False, False, alpha,
                                noise=noise_c if randomized else None, cfg=mcfg, mlp_hook=R.mlp_apply_bf16)
@@ -71,6 +74,31 @@ def test_forward_parity(cuda, K, N, randomized):
         torch.testing.assert_close(got[7][0].cpu(), rb[7][0])
     if K > 0:
         assert 0.02 < b['hit_fraction'] < 0.3
+
+
+@pytest.mark.parametrize('knobs', [dict(lindisp=True), dict(disable_integration=True), dict(dynamics=False),
+                                   dict(contraction=False)])
+def test_forward_knobs(cuda, knobs):
+    """gin knobs off their shipped values: lindisp (mip.py:354-356; near > 0 so 1/t is finite),
+    disable_integration (obbpose_model.py:164-165), dynamics=False (:167,232,257-260), contraction=False."""
+    far = 40.0
+    b, ret, ref_bf, _ = _run(cuda, 256, 2, 32, False, seed=31, far=far, knobs=knobs,
+                             near=0.05 if knobs.get('lindisp') else None)
+    single = torch.tensor(b['_multi'] == 0)
+    scale = 1.0 / 0.05 if knobs.get('lindisp') else far           # lindisp: t runs over [1/far, 1/near]
+    if knobs.get('lindisp'):
+        # lindisp makes t_vals DEcreasing (1/near -> 1/far, mip.py:354-356): deltas, alphas and weights go negative
+        # and the colours blow up on both sides, so the sample positions of level 0 are the meaningful comparison.
+        for i in (4, 5, 6):
+            torch.testing.assert_close(ret[0][i].cpu(), ref_bf[0][i], rtol=1e-6, atol=1e-6)
+        assert bool((ret[0][4][:, 1:] < ret[0][4][:, :-1]).all())
+        return
+    for lvl in range(2):
+        got, rb = ret[lvl], ref_bf[lvl]
+        for i, tol in ((0, 3e-3), (1, 3e-3 * scale), (2, 3e-3), (3, 3e-3), (4, 2e-3 * scale)):
+            torch.testing.assert_close(got[i].cpu()[single], rb[i][single], rtol=0, atol=tol,
+                                       msg=lambda m: 'output %d l%d: %s' % (i, lvl, m))
+        assert torch.equal(got[8].cpu().long().reshape(-1), rb[8].reshape(-1)), 'dyn_mask'
 
 
 def test_forward_alpha_ramp(cuda):
