@@ -25,7 +25,6 @@ sys.path.insert(0, ROOT)
 RAYS_PER_GPU = 4096
 N_LEVELS = 2
 N_SAMPLES = 128
-K_OBJ = 1
 FAR = 200.0            # configs/carla_dyn.gin:13
 MAC_BKGD, MAC_OBJ = 591872, 167552
 PEAK_BF16 = 2.5e15     # dense MFMA bf16 peak, MI355X_MICROARCH.md
@@ -41,7 +40,7 @@ def gin_text():
             'Config.sky_loss_mult = 1.0\nConfig.box_loss_mult = 0\nConfig.far = %g\n' % (N_SAMPLES, FAR))
 
 
-def cpu_baseline(batch_np, seconds_budget=15.0):
+def cpu_baseline(batch_np, seconds_budget=15.0, K_OBJ=1):
     """The oracle's train_step (fp32 torch-CPU restatement of the reference step) timed on the
     host cores on a bounded sample of the same workload.  A reported baseline, not a target."""
     import numpy as np
@@ -79,6 +78,7 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--rays', type=int, default=RAYS_PER_GPU, help='rays per GPU')
+    ap.add_argument('--objects', type=int, default=1, help='dynamic boxes K (default: cfg2; 3 = cfg3, 8 = cfg5)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-op time table to stderr')
     args = ap.parse_args()
@@ -97,6 +97,7 @@ def main():
     utils.parse_gin(gin_text())
     config = utils.configured(utils.Config)
     B = args.rays
+    K_OBJ = args.objects
     batch_np = synthetic.make_batch(B * world, K_OBJ, far=FAR, seed=synthetic.SEED)
     full = H.device_batch(batch_np, dev)
     batch = train_boxpose.shard_batch(full, rank, world)
@@ -175,11 +176,11 @@ def main():
             for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
                 print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / args.steps),
                       file=sys.stderr)
-        cb = None if args.no_cpu_baseline else cpu_baseline(batch_np)
+        cb = None if args.no_cpu_baseline else cpu_baseline(batch_np, K_OBJ=K_OBJ)
         out = dict(metric='train_rays_per_sec', value=B * world * args.steps / dt, unit='rays/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload='cfg2: CARLA-like dynamic scene, K=1 OBB, 128 samples/ray x 2 levels, '
+                   config=dict(workload=('cfg2: CARLA-like dynamic scene, K=1 OBB' if K_OBJ == 1 else 'K=%d OBBs' % K_OBJ) + ', 128 samples/ray x 2 levels, '
                                         '8x256 bkgd MLP + 8x128 object MLP, full train step',
                                rays_per_gpu=B, global_batch=B * world, num_samples=N_SAMPLES, num_levels=2,
                                objects=K_OBJ, far=FAR, hit_fraction=hit, randomized=True,

@@ -35,6 +35,13 @@ _SIGS = {
     'durf_composite_fwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32,
                                  vp, vp, vp, vp, vp, vp]),
     'durf_resample': (i32, [vp, i32, i32, vp, vp, f32, vp, vp]),
+    'durf_obj_enc_stride': (u64, [i32, i32]),
+    'durf_obj_view_stride': (u64, [i32, i32]),
+    'durf_obj_dzout_stride': (u64, [i32, i32]),
+    'durf_pack_weights_batch': (i32, [vp, i32, i32, i32, vp, u64, vp, vp]),
+    'durf_obj_fwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_obj_bwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_obj_dw_batch': (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64]),
     'durf_train_stats': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'durf_loss_prep': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
     'durf_loss_bwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,

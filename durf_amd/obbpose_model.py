@@ -185,17 +185,21 @@ class MipNerfModel:
         view = ops.view_enc(rays.viewdirs)
         radii = rays.radii.reshape(-1).contiguous()
         near, far = rays.near.reshape(-1).contiguous(), rays.far.reshape(-1).contiguous()
-        packs = {n: ops.pack_weights(*lay.mlp_dims(n), variables.mlp_flat(n), want_bwd=train)
-                 for n in lay.mlp_names()}
-        wf = {n: (p[0] if train else p) for n, p in packs.items()}
+        pk = ops.pack_weights(W_BKGD, IN_BKGD, variables.mlp_flat('MLP_0'), want_bwd=train)
+        packs = {'MLP_0': pk if train else (pk, None)}
+        if Kd:                                       # the K object MLPs sit back to back in the flat buffer
+            o0 = lay.mlp_off['BoxMLP_0']
+            packs['obj'] = ops.pack_weights_batch(Kd, variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]],
+                                                  lay.mlp_size[W_OBJ], want_bwd=train)
         bk = ops.BKGD_RAND if rand_bkgd else (ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY)
         if randomized and noise is None:
             g = _make_generator(rng, dev)
             noise = dict(t_rand=torch.rand(B, N + 1, device=dev, generator=g),
                          u_rand=torch.rand(B, N + 1, device=dev, generator=g))
         rows = B * N
+        view_tiles_obj = ops.obj_view_tiles(Kd, B, N, dev) if (train and Kd) else None
         ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,
-                   packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk)
+                   packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk, view_tiles_obj=view_tiles_obj)
         ret = []
         t_vals = weights = None
         box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
@@ -210,25 +214,21 @@ class MipNerfModel:
                                        disable_integration=self.disable_integration)
             stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
             mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
-            raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, wf['MLP_0'], stash=stash_b, relu_mask=mask_b)
-            raws, encs, stashes, masks = [], [], [], []
-            for k in range(Kd):
-                enc_k, _ = ops.encode_obj(B, idx[k], count[k:k + 1], t_vals, o_s, d_s, radii, alpha,
-                                          disable_integration=self.disable_integration)
-                st_k = torch.empty(ops.mlp_stash_bytes(W_OBJ, rows), dtype=torch.uint8, device=dev) if train else None
-                mk_k = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
-                raws.append(ops.mlp_fwd(W_OBJ, rows, N, enc_k, view, wf['BoxMLP_%d' % k], ray_idx=idx[k],
-                                        count=count[k:k + 1], stash=st_k, relu_mask=mk_k))
-                encs.append(enc_k)
-                stashes.append(st_k)
-                masks.append(mk_k)
+            raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
+            slabs = None
+            if Kd:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
+                slabs = ops.ObjSlabs(Kd, B, N, dev, train)
+                ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
+                                  view_tile=view_tiles_obj if lvl == 0 else None,
+                                  disable_integration=self.disable_integration)
+            raws = slabs.raws() if Kd else []
             rgb, depth, acc, weights, t_mids, t_dists = ops.composite_fwd(
                 raw_b, raws, slot, t_vals, d_s, self.density_bias, bk)
             ret.append((rgb, depth, acc, weights, t_vals, t_mids, t_dists, [pose[:, :3], box_rot0],
                         dyn_mask, zo))
             if train:
                 ctx['levels'].append(dict(t_vals=t_vals, enc_b=enc_b, raw_b=raw_b, stash_b=stash_b,
-                                          raws=raws, encs=encs, stashes=stashes, masks=masks, mask_b=mask_b, rgb=rgb, depth=depth,
+                                          raws=raws, slabs=slabs, mask_b=mask_b, rgb=rgb, depth=depth,
                                           acc=acc, weights=weights))
         return ret, ctx
 

@@ -327,6 +327,85 @@ def mlp_dw_finalize(width, in_dim, part, bpart, grad_mlp):
                    'durf_mlp_dw_finalize')
 
 
+# ---------------------------------------------------------------------------
+# the K object MLPs of one level as one call each (csrc/objects.hip)
+# ---------------------------------------------------------------------------
+W_OBJ_, IN_OBJ_ = 128, 63
+
+
+class ObjSlabs:
+    """[K, ...] slabs of one level for the batched object calls (strides fixed by the library)."""
+
+    def __init__(self, K, B, N, device, train):
+        L = _lib.lib()
+        rows = B * N
+        u8 = lambda n: torch.empty(K * int(n), dtype=torch.uint8, device=device)
+        self.K, self.B, self.N = K, B, N
+        self.enc = u8(L.durf_obj_enc_stride(B, N))
+        self.raw = torch.empty(K, rows, 4, device=device)
+        self.stash = u8(mlp_stash_bytes(W_OBJ_, rows)) if train else None
+        self.mask = u8(mlp_mask_bytes(rows)) if train else None
+        self.dz = self.dz_out = self.d_enc = None
+
+    def raws(self):
+        return [self.raw[k] for k in range(self.K)]
+
+
+def pack_weights_batch(K, obj_params, param_stride, want_bwd=False):
+    """obj_params: flat fp32 params of BoxMLP_0 .. BoxMLP_{K-1}, back to back"""
+    L = _lib.lib()
+    dev = obj_params.device
+    wf = torch.empty(K * int(L.durf_wpack_fwd_bytes(W_OBJ_)), dtype=torch.uint8, device=dev)
+    wb = torch.empty(K * int(L.durf_wpack_bwd_bytes(W_OBJ_)), dtype=torch.uint8, device=dev) if want_bwd else None
+    _lib.check(L.durf_pack_weights_batch(_stream(), W_OBJ_, IN_OBJ_, K, _p(obj_params), param_stride, _p(wf), _p(wb)),
+               'durf_pack_weights_batch')
+    return wf, wb
+
+
+def obj_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha, view_bf16, wf, view_tile=None,
+                  disable_integration=False):
+    w = barf_weights(alpha)
+    wa = (C.c_float * 10)(*[float(x) for x in w])
+    with _Timed('obj_fwd_batch'):
+        _lib.check(_lib.lib().durf_obj_fwd_batch(
+            _stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(_f32(t_vals)), _p(_f32(origins_s)),
+            _p(_f32(dirs_s)), _p(_f32(radii)), wa, ENC_NO_INTEGRATION if disable_integration else 0, _p(view_bf16),
+            _p(wf), _p(slabs.enc), _p(slabs.raw), _p(slabs.stash), _p(slabs.mask), _p(view_tile)), 'durf_obj_fwd_batch')
+
+
+def obj_view_tiles(K, B, N, device):
+    return torch.empty(K * int(_lib.lib().durf_obj_view_stride(B, N)), dtype=torch.uint8, device=device)
+
+
+def obj_bwd_batch(slabs, idx, count, draw, wb, want_d_enc=False):
+    L = _lib.lib()
+    dev = draw.device
+    K, B, N = slabs.K, slabs.B, slabs.N
+    slabs.dz = torch.empty(K * mlp_stash_bytes(W_OBJ_, B * N), dtype=torch.uint8, device=dev)
+    slabs.dz_out = torch.empty(K * int(L.durf_obj_dzout_stride(B, N)), dtype=torch.uint8, device=dev)
+    slabs.d_enc = torch.zeros(K, B * N, ENC_DIM, device=dev) if want_d_enc else None
+    with _Timed('obj_bwd_batch'):
+        _lib.check(L.durf_obj_bwd_batch(_stream(), K, B, N, _p(idx), _p(count), _p(_f32(draw)), _p(wb), _p(slabs.mask),
+                                        _p(slabs.dz), _p(slabs.dz_out), _p(slabs.d_enc)), 'durf_obj_bwd_batch')
+
+
+def obj_dw_batch(slabs_levels, view_tile, count, grad_obj, grad_stride):
+    """weight gradients of all K object MLPs over every level -> grad_obj (flat, K x grad_stride floats)"""
+    L = _lib.lib()
+    s0 = slabs_levels[0]
+    K, B, N = s0.K, s0.B, s0.N
+    nl = len(slabs_levels)
+    dev = grad_obj.device
+    part = torch.empty(K * int(L.durf_dw_part_floats(W_OBJ_)), device=dev)
+    bpart = torch.empty(K * int(L.durf_dw_bpart_floats(W_OBJ_)), device=dev)
+    arr = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    with _Timed('obj_dw_batch'):
+        _lib.check(L.durf_obj_dw_batch(_stream(), K, B, N, _p(count), nl, arr([s.enc for s in slabs_levels]),
+                                       arr([view_tile] * nl), arr([s.stash for s in slabs_levels]),
+                                       arr([s.dz for s in slabs_levels]), arr([s.dz_out for s in slabs_levels]),
+                                       IN_OBJ_, _p(part), _p(bpart), _p(grad_obj), grad_stride), 'durf_obj_dw_batch')
+
+
 def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):
     """In-place Adam step on the flat buffers; returns stats[4] (grad_norm, grad_abs_max,
     clip multiplier, grad_norm_clipped) as a device tensor."""

@@ -73,12 +73,9 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     dyn = ret[0][8].reshape(-1).to(torch.int32).contiguous()
     bg = 0.0 if config.rand_bkgd else (1.0 if config.white_bkgd else 0.5)
     grad = torch.zeros_like(variables.flat)
-    names = lay.mlp_names()
-    bufs = {n: ops.dw_buffers(lay.mlp_dims(n)[0], dev) for n in names}
-    dzs = {n: [] for n in names}                # per-level (dz, dz_out) of every MLP, consumed by ONE dW launch each
+    bufs = ops.dw_buffers(om.W_BKGD, dev)
+    dzs = []                                    # per-level (dz, dz_out) of the bkgd MLP, consumed by ONE dW launch
     view_tile = ops.expand_view(rows, N, ctx['view'])
-    view_tiles_obj = [ops.expand_view(rows, N, ctx['view'], ray_idx=ctx['idx'][k], count=ctx['count'][k:k + 1])
-                      for k in range(K)]
     norms = torch.empty(L, ops.PREP_ROWS, device=dev)
     sums = torch.empty(L, ops.TERM_ROWS, device=dev)
     radii = rays.radii.reshape(-1).contiguous()
@@ -92,28 +89,21 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                gt_depth, sky, dyn, ctx['zo'], norm, float(eps),
                                level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
                                model.density_bias, config.disable_multiscale_loss, sums=sums[lvl])
-        dzs['MLP_0'].append(ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b']))
-        for k in range(K):
-            nm = 'BoxMLP_%d' % k
-            cnt = ctx['count'][k:k + 1]
-            res = ops.mlp_bwd(om.W_OBJ, rows, N, draw, ctx['packs'][nm][1], lv['masks'][k],
-                              ray_idx=ctx['idx'][k], count=cnt, want_d_enc=pose_opt)
-            dzs[nm].append((res[0], res[1]))
-            if pose_opt:                      # d(loss)/d(box pose) through the object encoding
-                ops.encode_obj_bwd(k, ctx['idx'][k], cnt, res[2], lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
-                                   rays.origins, rays.directions, pose_ts, alpha, pose_sums)
+        dzs.append(ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b']))
+        if K:                                 # all K object MLPs: one call (csrc/objects.hip)
+            ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
+            for k in range(K if pose_opt else 0):   # d(loss)/d(box pose) through the object encoding
+                ops.encode_obj_bwd(k, ctx['idx'][k], ctx['count'][k:k + 1], lv['slabs'].d_enc[k], lv['t_vals'],
+                                   ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
+                                   pose_sums)
     levels = ctx['levels']
     ops.mlp_dw(om.W_BKGD, rows, N, [lv['enc_b'] for lv in levels], [view_tile] * L, [lv['stash_b'] for lv in levels],
-               [d[0] for d in dzs['MLP_0']], [d[1] for d in dzs['MLP_0']], *bufs['MLP_0'])
-    for k in range(K):
-        nm = 'BoxMLP_%d' % k
-        ops.mlp_dw(om.W_OBJ, rows, N, [lv['encs'][k] for lv in levels], [view_tiles_obj[k]] * L,
-                   [lv['stashes'][k] for lv in levels], [d[0] for d in dzs[nm]], [d[1] for d in dzs[nm]],
-                   *bufs[nm], count=ctx['count'][k:k + 1])
-    for n in (names if K == lay.K else names[:1]):          # dynamics=False: the object MLPs are not evaluated
-        width, in_dim = lay.mlp_dims(n)
-        off = lay.mlp_off[n]
-        ops.mlp_dw_finalize(width, in_dim, *bufs[n], grad[off:off + lay.mlp_size[width]])
+               [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
+    off = lay.mlp_off['MLP_0']
+    ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
+    if K:
+        o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
+        ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)
     flat = variables.flat
     weight_l2 = None
     if config.weight_decay_mult != 0:                                          # :73-75

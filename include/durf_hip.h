@@ -30,6 +30,8 @@ extern "C" {
 
 #define DURF_MAX_OBJ 16
 #define DURF_MAX_LEVELS 8
+#define DURF_W_BKGD 256      /* MLP.net_width (obbpose_model.py:296) */
+#define DURF_W_OBJ 128       /* BoxMLP.net_width (:360) */
 /* flags of durf_encode_bkgd (`contraction` argument) / durf_encode_obj */
 #define DURF_ENC_CONTRACT 1        /* MipNerfModel.contraction (mip360.new_space) */
 #define DURF_ENC_NO_INTEGRATION 2  /* MipNerfModel.disable_integration: PE instead of IPE (covariances zeroed) */
@@ -177,6 +179,31 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
                 const void* const* dz, const void* const* dz_out, float* part, float* bpart);
 int durf_mlp_dw_finalize(void* stream, int width, int in_dim, const float* part, const float* bpart,
                          float* grad_mlp);
+
+/* The K per-object BoxMLPs of one level as one call each (obbpose_model.py:174-201): loops over the
+ * objects inside the library and spreads them over side streams forked from / joined to `stream`.
+ * Slabs are [K, ...] with per-object strides: enc durf_obj_enc_stride, view_tile durf_obj_view_stride,
+ * dz_out durf_obj_dzout_stride, stash/dz durf_mlp_stash_bytes(128, B*N), mask durf_mlp_mask_bytes(B*N),
+ * raw B*N*4 floats, d_enc B*N*64 floats, weight packs durf_wpack_{fwd,bwd}_bytes(128), params / grads
+ * `*_stride` floats (the flat buffer keeps BoxMLP_0, BoxMLP_1, ... back to back).  idx [K,B], count [K]
+ * from durf_compact_hits.  The kernels are the ones the per-object entry points launch. */
+size_t durf_obj_enc_stride(int B, int N);
+size_t durf_obj_view_stride(int B, int N);
+size_t durf_obj_dzout_stride(int B, int N);
+int durf_pack_weights_batch(void* stream, int width, int in_dim, int K, const float* mlp_params,
+                            size_t param_stride, void* wpack_fwd, void* wpack_bwd /* nullable */);
+int durf_obj_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
+                       const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
+                       const float* barf_w, int flags, const void* view_bf16, const void* wpack_fwd,
+                       void* enc, float* raw, void* stash /* nullable */, void* relu_mask /* nullable */,
+                       void* view_tile /* nullable: durf_expand_view per object */);
+int durf_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
+                       const float* draw, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
+                       float* d_enc /* nullable */);
+int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
+                      const void* const* enc, const void* const* view_tile, const void* const* stash,
+                      const void* const* dz, const void* const* dz_out, int in_dim, float* part, float* bpart,
+                      float* grad_mlp, size_t grad_stride);
 
 /* Box-pose gradients (cfg4): reverse of weighted_ipe / cast_rays / world2object_rpy / aa2matrix
  * (mip.py:182-223,155-179; box_helpers.py:286-341,148-167).  Per level and object:

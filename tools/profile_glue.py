@@ -15,7 +15,7 @@ from tests import helpers as H
 dev = torch.device('cuda:0')
 utils.clear_gin(); utils.parse_gin(bench.gin_text())
 config = utils.configured(utils.Config)
-batch_np = synthetic.make_batch(4096, bench.K_OBJ, far=bench.FAR, seed=synthetic.SEED)
+batch_np = synthetic.make_batch(4096, 1, far=bench.FAR, seed=synthetic.SEED)
 batch = H.device_batch(batch_np, dev)
 model, variables = obbpose_model.construct_mipnerf(0, batch, device=dev)
 state = train_boxpose.create_train_state(variables)
