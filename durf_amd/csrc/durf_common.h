@@ -122,9 +122,6 @@ __device__ __forceinline__ void lds_dma16_cached(i32x4 rsrc, unsigned soff, unsi
 }
 // wait until at most min(n, 12) of this wave's vector-memory operations are outstanding (n wave-uniform)
 __device__ __forceinline__ void wait_vmcnt_le(int n) {
-#ifdef DURF_STRICT_WAIT
-    n = 0;
-#endif
     switch (n) {
         case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;

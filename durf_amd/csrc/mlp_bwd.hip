@@ -164,12 +164,6 @@ __device__ __forceinline__ void bpack_tile(const f32x16& acc, unsigned bits, bf1
         float v0 = acc[e], v1 = acc[8 + e];
         if (MASK) {     // v_bfe_i32 (bit -> 0 / ~0) + v_and_b32; asm: hipcc turns the C form into and + cmp + cndmask
             int m0, m1;
-#ifdef OLD_BWD_MASK
-            if (!((bits >> e) & 1u)) v0 = 0.0f;
-            if (!((bits >> (8 + e)) & 1u)) v1 = 0.0f;
-            o0[e] = (__bf16)v0; o1[e] = (__bf16)v1;
-            continue;
-#endif
             asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(bits), "n"(e));
             asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(bits), "n"(8 + e));
             v0 = __int_as_float(__float_as_int(v0) & m0);
@@ -465,11 +459,7 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
     for (int par = 0; par < 2; par++) {
         const int c = 2 * par + g_hif;
         const int n = (g_p & 16) | ((g_p - 4 * c) & 15);
-#ifdef DW_PROBE_NOSWZ
-        voff[par] = (unsigned)(lane * 16);
-#else
         voff[par] = (unsigned)((g_hif * 32 + n) * 16);
-#endif
     }
     i32x4 r_dz, r_a, r_b;                             // descriptors based at the current segment's first tile
     auto stage_load = [&](int ti, int slot) {        // ti = tile index relative to t0
@@ -533,9 +523,6 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
             __builtin_amdgcn_s_barrier();       // every wave's part landed; everyone is done with tile t-1's slot
             if (t + S - 1 < nt) stage_load(t + S - 1, (t + S - 1) % S);
             const char* st = smem + (t % S) * STAGE;
-#ifdef DW_PROBE_NOCOMPUTE
-            continue;
-#endif
 #pragma unroll
             for (int kk = 0; kk < 2; kk++) {
                 bf16x8 af[RM], bf[RN];
@@ -575,9 +562,6 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
             }
         }
     }
-#ifdef DW_PROBE_NOSTORE
-    if (acc[0][0][0] != 1234.5f) return;
-#endif
     // partials in fragment coordinates: [split][mo][ni][lane][16]
     const size_t sp = (size_t)split_idx;
 #pragma unroll

@@ -224,28 +224,20 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
         }
         if (TRAIN && valid) {
             if (mo > 0) {
-#ifndef FWD_PROBE_NOSTORE
 #pragma unroll
                 for (int q = 4; q >= 1; q--) STREAM_STORE(stash_dst + (2 * mo - q) * 1024 + p.lane * 16, out[2 * mo - q]);
                 p.since += 4;
-#endif
             } else if (PREV_NMT > 0) {
-#ifndef FWD_PROBE_NOSTORE
 #pragma unroll
                 for (int q = 4; q >= 1; q--)
                     STREAM_STORE(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16, prev_out[2 * PREV_NMT - q]);
                 p.since += 4;
-#endif
                 if (prev_mask_dst) *(uint4*)(prev_mask_dst + p.lane * 16) = mask_carry;
             }
         }
         f32x16 acc0, acc1;
         mma_tile2<NA, NB>(slot + (mo % G) * CH * 1024, slot + (mo % G + 1) * CH * 1024, p.lane, inA, inB, acc0, acc1);
-#ifdef FWD_PROBE_NOMASK
-        constexpr bool BITS = false;
-#else
         constexpr bool BITS = TRAIN && RELU;
-#endif
         const unsigned bits0 = pack_tile<RELU, BITS>(acc0, out[2 * mo], out[2 * mo + 1]);
         const unsigned bits1 = pack_tile<RELU, BITS>(acc1, out[2 * mo + 2], out[2 * mo + 3]);
         if (TRAIN && RELU) mb[mo >> 1] |= bits0 | (bits1 << 16);
