@@ -51,7 +51,7 @@ _SIGS = {
     'durf_dw_part_floats': (u64, [i32]),
     'durf_dw_bpart_floats': (u64, [i32]),
     'durf_mlp_dw': (i32, [vp, i32, u64, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
-    'durf_mlp_dw_finalize': (i32, [vp, i32, i32, vp, vp, vp]),
+    'durf_mlp_dw_finalize': (i32, [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp]),
     'durf_encode_obj_bwd': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
     'durf_pose_finish': (i32, [vp, i32, vp, vp, i32, i32, vp]),
     'durf_optim_scratch_floats': (u64, [u64]),

@@ -146,3 +146,35 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 #else
 #define STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (bf16x8*)(ptr))
 #endif
+
+// ---- batched (per-object) launches ---------------------------------------------------------
+// The K object MLPs use [K, ...] slabs with uniform strides (include/durf_hip.h, durf_obj_*): the
+// kernels take the object index from blockIdx.y (k_dw_finalize: blockIdx.z) and offset their
+// pointers by these strides (bytes, except idx in int32 elements and params/grads in floats).
+// Strides of 0 with gridDim.y == 1 are the plain per-MLP launches.
+struct FwdStrides { size_t enc, idx, wpack, raw, stash, mask; };
+struct BwdStrides { size_t idx, wpack, mask, dz, dz_out, d_enc; };
+struct DwStrides { size_t enc, view, stash, dz_out, part, bpart; };      // stash stride also applies to dz
+
+namespace durf {
+int launch_pack(void* stream, int width, int in_dim, int K, const float* params, size_t param_stride,
+                void* wpack_fwd, void* wpack_bwd);
+int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* idx, const int32_t* count,
+                      const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
+                      const float* barf_w, int flags, void* out_tile, size_t out_stride, float* out_f32);
+int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile, const void* view_bf16,
+                   const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
+                   void* relu_mask, int K, const FwdStrides& st);
+int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
+                   const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
+                   float* d_enc, int K, const BwdStrides& st);
+int launch_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
+                       const int32_t* count, void* out_tile, int K, size_t idx_stride, size_t out_stride);
+int launch_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
+                  const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
+                  const void* const* dz, const void* const* dz_out, float* part, float* bpart, int K,
+                  const DwStrides& st);
+int launch_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count, int nlevels,
+                       const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
+                       size_t bpart_stride, size_t grad_stride);
+}  // namespace durf

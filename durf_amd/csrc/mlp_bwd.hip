@@ -42,9 +42,11 @@ struct BwdSpec {
 
 template <int W>
 __global__ void __launch_bounds__(256)
-k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
+k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out, size_t p_stride, size_t out_stride) {
     using S = MlpSpec<W>;
     using Bs = BwdSpec<W>;
+    P += blockIdx.y * p_stride;                                  // object index (0 for a single MLP)
+    out = (bf16x8*)((char*)out + blockIdx.y * out_stride);
     const int vec = blockIdx.x * blockDim.x + threadIdx.x;
     if (vec >= Bs::TOTAL_CHUNKS * 64) return;
     const int chunk = vec >> 6, lane = vec & 63;
@@ -242,9 +244,19 @@ __global__ void __launch_bounds__(512, 2)
 k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
           const int32_t* __restrict__ count, const char* __restrict__ wpack,
           const uint4* __restrict__ relu_mask, bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out,
-          float* __restrict__ d_enc) {
+          float* __restrict__ d_enc, BwdStrides bs) {
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gridDim.y > 1) {                             // batched object MLPs: this workgroup's object slab
+        const size_t k = blockIdx.y;
+        ray_idx += k * bs.idx;
+        count += k;
+        wpack += k * bs.wpack;
+        relu_mask = (const uint4*)((const char*)relu_mask + k * bs.mask);
+        dz = (bf16x8*)((char*)dz + k * bs.dz);
+        dz_out = (bf16x8*)((char*)dz_out + k * bs.dz_out);
+        if (POSE) d_enc = (float*)((char*)d_enc + k * bs.d_enc);
+    }
     size_t nrows = rows;
     if (count) {
         const size_t c = (size_t)(*count) * (size_t)N;
@@ -348,7 +360,12 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
 // view-direction features expanded per sample into tile layout [rows, 32] (dW of Dense_10)
 __global__ void __launch_bounds__(256)
 k_expand_view(size_t rows, int N, const bf16x8* __restrict__ view, const int32_t* __restrict__ ray_idx,
-              const int32_t* __restrict__ count, bf16x8* __restrict__ out) {
+              const int32_t* __restrict__ count, bf16x8* __restrict__ out, size_t idx_stride, size_t out_stride) {
+    if (gridDim.y > 1) {
+        ray_idx += blockIdx.y * idx_stride;
+        count += blockIdx.y;
+        out = (bf16x8*)((char*)out + blockIdx.y * out_stride);
+    }
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;     // one 16-byte vector each
     const size_t row = gid >> 2;
     const int q = (int)(gid & 3);
@@ -421,12 +438,23 @@ struct DwArgs {
     const char* inA[DURF_MAX_LEVELS][12];
     const char* inB[DURF_MAX_LEVELS][12];
     int nlevels;
+    size_t ks_dz[12], ks_a[12], ks_b[12];      // per-object strides of the three operand streams (batched object MLPs)
+    size_t ks_part, ks_bpart;                  // ... and of the partial buffers (floats)
     float* part[12];
     float* bpart[12];
     int nsplit[12];
     int first_wg[13];        // workgroup ids [first_wg[i], first_wg[i+1]) run job order[i]
     int order[12];
 };
+
+// Tiles per split: an even share, but at least DW_MIN_TPS, so that a sparsely hit object (a few hundred
+// valid tiles) uses a few dozen splits instead of ~100 per GEMM -- the unused workgroups exit at once and
+// neither write nor get summed (k_dw_finalize derives the same count from the device-side ray count).
+#define DW_MIN_TPS 48
+__host__ __device__ inline size_t dw_tiles_per_split(size_t nt_all, int nsplit) {
+    const size_t even = (nt_all + nsplit - 1) / nsplit;
+    return even > DW_MIN_TPS ? even : DW_MIN_TPS;
+}
 
 template <int NKO, int NKA, int NKB>
 __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __restrict__ count, const DwArgs& a, int job,
@@ -442,12 +470,15 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
+    const size_t obj = blockIdx.y;                            // batched object MLPs (0 for a single MLP)
+    if (gridDim.y > 1) { count += obj; part += obj * a.ks_part; bpart += obj * a.ks_bpart; }
     size_t nrows = rows;
     if (count) { const size_t c = (size_t)(*count) * (size_t)N; nrows = c < rows ? c : rows; }
     const size_t nt_valid = nrows >> 5;                       // valid 32-sample tiles per level
     const size_t nt_all = nt_valid * (size_t)a.nlevels;       // the K axis: every level's samples
-    const size_t tps = (nt_all + nsplit - 1) / nsplit;        // even share of the VALID tiles
+    const size_t tps = dw_tiles_per_split(nt_all, nsplit);    // even share of the VALID tiles
     const size_t g0 = (size_t)split_idx * tps;
+    if (g0 >= nt_all) return;                                 // unused split: k_dw_finalize skips it too
     size_t g1 = g0 + tps;
     if (g1 > nt_all) g1 = nt_all;
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
@@ -507,9 +538,9 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
         if (b1 <= b0) continue;
         const size_t t0 = b0 - lo;                    // first tile of the segment within its level
         const int nt = (int)(b1 - b0);
-        r_dz = make_rsrc(a.dz[lvl][job] + t0 * NKO * 1024);
-        r_a = make_rsrc(a.inA[lvl][job] + t0 * NKA * 1024);
-        r_b = make_rsrc(NKB ? a.inB[lvl][job] + t0 * (NKB ? NKB : 1) * 1024 : a.inA[lvl][job]);
+        r_dz = make_rsrc(a.dz[lvl][job] + obj * a.ks_dz[job] + t0 * NKO * 1024);
+        r_a = make_rsrc(a.inA[lvl][job] + obj * a.ks_a[job] + t0 * NKA * 1024);
+        r_b = make_rsrc(NKB ? a.inB[lvl][job] + obj * a.ks_b[job] + t0 * (NKB ? NKB : 1) * 1024 : a.inA[lvl][job]);
         __builtin_amdgcn_s_barrier();                 // everyone is done reading the previous segment's slots
         // prologue: S-1 stages in flight
 #pragma unroll
@@ -667,10 +698,19 @@ struct DwJobs { DwJob j[12]; size_t part_off[12], bpart_off[12]; int nparts[12];
 
 __global__ void __launch_bounds__(256)
 k_dw_finalize(int W, int in_dim, DwJobs jobs, const float* __restrict__ part_all,
-              const float* __restrict__ bpart_all, float* __restrict__ grad_mlp) {
+              const float* __restrict__ bpart_all, float* __restrict__ grad_mlp, size_t part_stride,
+              size_t bpart_stride, size_t grad_stride, size_t rows, int N, int nlevels,
+              const int32_t* __restrict__ count) {
     __shared__ float red[4][64];
+    part_all += blockIdx.z * part_stride;            // batched object MLPs: blockIdx.z = object
+    bpart_all += blockIdx.z * bpart_stride;
+    grad_mlp += blockIdx.z * grad_stride;
+    size_t nrows = rows;                             // the splits k_dw_all actually wrote (see dw_tiles_per_split)
+    if (count) { const size_t c = (size_t)count[blockIdx.z] * (size_t)N; nrows = c < rows ? c : rows; }
+    const size_t nt_all = (nrows >> 5) * (size_t)nlevels;
     const DwJob job = jobs.j[blockIdx.y];
-    const int nparts = jobs.nparts[blockIdx.y];
+    const size_t tps_ = dw_tiles_per_split(nt_all, jobs.nparts[blockIdx.y]);
+    const int nparts = (int)((nt_all + tps_ - 1) / tps_);
     const float* part = part_all + jobs.part_off[blockIdx.y];
     const float* bpart = bpart_all + jobs.bpart_off[blockIdx.y];
     int fi, fo;
@@ -780,34 +820,70 @@ size_t durf_wpack_bwd_bytes(int width) {
 }
 
 int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_bwd) {
-    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
-    hipStream_t s = (hipStream_t)stream;
-    if (width == 256)
-        hipLaunchKernelGGL(k_pack_bwd<256>, dim3(durf_cdiv(BwdSpec<256>::TOTAL_CHUNKS * 64, 256)), dim3(256), 0, s,
-                           in_dim, mlp_params, (bf16x8*)wpack_bwd);
-    else
-        hipLaunchKernelGGL(k_pack_bwd<128>, dim3(durf_cdiv(BwdSpec<128>::TOTAL_CHUNKS * 64, 256)), dim3(256), 0, s,
-                           in_dim, mlp_params, (bf16x8*)wpack_bwd);
-    DURF_CHECK_LAUNCH("durf_pack_weights_bwd");
-    return 0;
+    return durf::launch_pack(stream, width, in_dim, 1, mlp_params, 0, nullptr, wpack_bwd);
 }
 
 int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
                  const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
                  float* d_enc) {
+    return durf::launch_mlp_bwd(stream, width, rows, N, draw, ray_idx, count, wpack_bwd, relu_mask, dz, dz_out, d_enc,
+                                1, BwdStrides{});
+}
+
+int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
+                     const int32_t* count, void* out_tile) {
+    return durf::launch_expand_view(stream, rows, N, view_bf16, ray_idx, count, out_tile, 1, 0, 0);
+}
+
+size_t durf_dw_part_floats(int width) { return dw_plan(width).part_total; }
+size_t durf_dw_bpart_floats(int width) { return dw_plan(width).bpart_total; }
+
+int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
+                const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
+                const void* const* dz, const void* const* dz_out, float* part, float* bpart) {
+    return durf::launch_mlp_dw(stream, width, rows, N, count, nlevels, enc_tile, view_tile, stash, dz, dz_out, part,
+                               bpart, 1, DwStrides{});
+}
+
+int durf_mlp_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count,
+                         int nlevels, const float* part, const float* bpart, float* grad_mlp) {
+    return durf::launch_dw_finalize(stream, width, in_dim, rows, N, count, nlevels, part, bpart, grad_mlp, 1, 0, 0, 0);
+}
+
+}  // extern "C"
+
+namespace durf {
+
+int pack_bwd_launch(void* stream, int width, int in_dim, int K, const float* params, size_t param_stride, void* wpack_bwd) {
+    hipStream_t s = (hipStream_t)stream;
+    const size_t ostride = durf_wpack_bwd_bytes(width);
+    if (width == 256)
+        hipLaunchKernelGGL(k_pack_bwd<256>, dim3(durf_cdiv(BwdSpec<256>::TOTAL_CHUNKS * 64, 256), K), dim3(256), 0, s,
+                           in_dim, params, (bf16x8*)wpack_bwd, param_stride, ostride);
+    else
+        hipLaunchKernelGGL(k_pack_bwd<128>, dim3(durf_cdiv(BwdSpec<128>::TOTAL_CHUNKS * 64, 256), K), dim3(256), 0, s,
+                           in_dim, params, (bf16x8*)wpack_bwd, param_stride, ostride);
+    DURF_CHECK_LAUNCH("durf_pack_weights (bwd)");
+    return 0;
+}
+
+int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
+                   const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
+                   float* d_enc, int K, const BwdStrides& st) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
-    if (rows == 0) return 0;
+    DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
+    if (rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const unsigned nblk = durf_cdiv(rows, 256);
-    dim3 grid(nblk < 256u ? nblk : 256u), block(512);        // persistent: at most one workgroup per CU
+    dim3 grid(nblk < 256u ? nblk : 256u, K), block(512);     // persistent: at most one workgroup per CU and object
 #define LAUNCH_B(WW, PP)                                                                                   \
     {                                                                                                      \
         constexpr int lds = 2 * 4 * (MlpSpec<WW>::KW + 1) * 1024;                                          \
         (void)hipFuncSetAttribute((const void*)k_mlp_bwd<WW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((k_mlp_bwd<WW, PP>), grid, block, lds, s, rows, N, draw, ray_idx, count,         \
                            (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out,  \
-                           d_enc);                                                                         \
+                           d_enc, st);                                                                     \
     }
     if (width == 256) { if (d_enc) LAUNCH_B(256, true) else LAUNCH_B(256, false) }
     else { if (d_enc) LAUNCH_B(128, true) else LAUNCH_B(128, false) }
@@ -816,27 +892,26 @@ int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw,
     return 0;
 }
 
-int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
-                     const int32_t* count, void* out_tile) {
-    if (rows == 0) return 0;
-    hipLaunchKernelGGL(k_expand_view, dim3(durf_cdiv(rows * 4, 256)), dim3(256), 0, (hipStream_t)stream, rows, N,
-                       (const bf16x8*)view_bf16, ray_idx, count, (bf16x8*)out_tile);
+int launch_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
+                       const int32_t* count, void* out_tile, int K, size_t idx_stride, size_t out_stride) {
+    if (rows == 0 || K <= 0) return 0;
+    hipLaunchKernelGGL(k_expand_view, dim3(durf_cdiv(rows * 4, 256), K), dim3(256), 0, (hipStream_t)stream, rows, N,
+                       (const bf16x8*)view_bf16, ray_idx, count, (bf16x8*)out_tile, idx_stride, out_stride);
     DURF_CHECK_LAUNCH("durf_expand_view");
     return 0;
 }
 
-size_t durf_dw_part_floats(int width) { return dw_plan(width).part_total; }
-size_t durf_dw_bpart_floats(int width) { return dw_plan(width).bpart_total; }
-
 // All weight gradients of one MLP: ONE grouped launch of the 12 split-K GEMMs whose K axis runs over
 // the samples of every level (per-level operand buffers, one set of fp32 partials).
-int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
-                const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
-                const void* const* dz, const void* const* dz_out, float* part, float* bpart) {
+int launch_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
+                  const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
+                  const void* const* dz, const void* const* dz_out, float* part, float* bpart, int K,
+                  const DwStrides& st) {
+    DURF_REQUIRE(K == 1 || count, "batched launches are for compacted object rays");
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
-    if (rows == 0) return 0;
+    if (rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const DwPlan P = dw_plan(width);
     const size_t nt = rows >> 5;
@@ -844,6 +919,12 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
     auto region = [&](const void* base, int j) { return (const char*)base + ((size_t)j * KW * nt) * 1024; };
     DwArgs a;
     a.nlevels = nlevels;
+    a.ks_part = st.part; a.ks_bpart = st.bpart;
+    for (int j = 0; j < 12; j++) {
+        a.ks_dz[j] = (j == 8 || j == 11) ? st.dz_out : st.stash;
+        a.ks_a[j] = j == 0 ? st.enc : st.stash;
+        a.ks_b[j] = j == 5 ? st.enc : (j == 10 ? st.view : 0);
+    }
     for (int j = 0; j < 12; j++) {
         a.part[j] = part + P.part_off[j];
         a.bpart[j] = bpart + P.bpart_off[j];
@@ -873,7 +954,7 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
         total += P.nsplit[order[i]];
     }
     a.first_wg[12] = total;
-    dim3 grid(total), block(512);
+    dim3 grid(total, K), block(512);
     if (width == 256) {
         constexpr int lds = DW_LDS_BYTES;
         (void)hipFuncSetAttribute((const void*)k_dw_all<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -887,8 +968,10 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
     return 0;
 }
 
-int durf_mlp_dw_finalize(void* stream, int width, int in_dim, const float* part, const float* bpart,
-                         float* grad_mlp) {
+int launch_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count, int nlevels,
+                       const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
+                       size_t bpart_stride, size_t grad_stride) {
+    if (K <= 0) return 0;
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     hipStream_t s = (hipStream_t)stream;
     const int W = width, KW = W / 16;
@@ -910,10 +993,11 @@ int durf_mlp_dw_finalize(void* stream, int width, int in_dim, const float* part,
         const int el = J.MO * J.NI * 1024 + J.MO * 32;
         if (el > max_el) max_el = el;
     }
-    hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12), dim3(256), 0, s, W, in_dim, jobs, part, bpart,
-                       grad_mlp);
+    hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12, K), dim3(256), 0, s, W, in_dim, jobs, part, bpart,
+                       grad_mlp, part_stride, bpart_stride, grad_stride, rows, N, nlevels, count);
     DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
     return 0;
 }
 
-}  // extern "C"
+
+}  // namespace durf

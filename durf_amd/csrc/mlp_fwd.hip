@@ -19,8 +19,10 @@
 // ---------------------------------------------------------------------------
 template <int W>
 __global__ void __launch_bounds__(256)
-k_pack_fwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out) {
+k_pack_fwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out, size_t p_stride, size_t out_stride) {
     using S = MlpSpec<W>;
+    P += blockIdx.y * p_stride;                                  // object index (0 for a single MLP)
+    out = (bf16x8*)((char*)out + blockIdx.y * out_stride);
     const int vec = blockIdx.x * blockDim.x + threadIdx.x;
     if (vec >= S::TOTAL_CHUNKS * 64) return;
     const int chunk = vec >> 6, lane = vec & 63;
@@ -257,9 +259,21 @@ __global__ void __launch_bounds__(512, 2)
 k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
           const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
           const char* __restrict__ wpack, float* __restrict__ raw, bf16x8* __restrict__ stash,
-          uint4* __restrict__ relu_mask) {
+          uint4* __restrict__ relu_mask, FwdStrides bs) {
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    if (gridDim.y > 1) {                             // batched object MLPs: this workgroup's object slab
+        const size_t k = blockIdx.y;
+        enc = (const bf16x8*)((const char*)enc + k * bs.enc);
+        ray_idx += k * bs.idx;
+        count += k;
+        wpack += k * bs.wpack;
+        raw = (float*)((char*)raw + k * bs.raw);
+        if (TRAIN) {
+            stash = (bf16x8*)((char*)stash + k * bs.stash);
+            relu_mask = (uint4*)((char*)relu_mask + k * bs.mask);
+        }
+    }
     size_t nrows = rows;
     if (count) {
         const size_t c = (size_t)(*count) * (size_t)N;
@@ -410,46 +424,68 @@ size_t durf_mlp_stash_bytes(int width, size_t rows) {
     return ((rows + 31) / 32) * kb * 1024;
 }
 
-int durf_pack_weights_fwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_fwd) {
-    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
-    DURF_REQUIRE(in_dim > 0 && in_dim <= DURF_ENC_DIM, "in_dim <= 64");
-    hipStream_t s = (hipStream_t)stream;
-    if (width == 256) {
-        hipLaunchKernelGGL(k_pack_fwd<256>, dim3(durf_cdiv(MlpSpec<256>::TOTAL_CHUNKS * 64, 256)), dim3(256),
-                           0, s, in_dim, mlp_params, (bf16x8*)wpack_fwd);
-    } else {
-        hipLaunchKernelGGL(k_pack_fwd<128>, dim3(durf_cdiv(MlpSpec<128>::TOTAL_CHUNKS * 64, 256)), dim3(256),
-                           0, s, in_dim, mlp_params, (bf16x8*)wpack_fwd);
-    }
-    DURF_CHECK_LAUNCH("durf_pack_weights_fwd");
-    return 0;
-}
-
 int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_bwd);
+
+int durf_pack_weights_fwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_fwd) {
+    return durf::launch_pack(stream, width, in_dim, 1, mlp_params, 0, wpack_fwd, nullptr);
+}
 
 int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_fwd,
                       void* wpack_bwd) {
-    int rc = durf_pack_weights_fwd(stream, width, in_dim, mlp_params, wpack_fwd);
-    if (rc == 0 && wpack_bwd) rc = durf_pack_weights_bwd(stream, width, in_dim, mlp_params, wpack_bwd);
-    return rc;
+    return durf::launch_pack(stream, width, in_dim, 1, mlp_params, 0, wpack_fwd, wpack_bwd);
 }
 
 int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
                  const void* view_bf16, const int32_t* ray_idx, const int32_t* count,
                  const void* wpack_fwd, float* raw, void* stash, void* relu_mask) {
+    return durf::launch_mlp_fwd(stream, width, rows, N, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash,
+                                relu_mask, 1, FwdStrides{});
+}
+
+}  // extern "C"
+
+namespace durf {
+
+int pack_bwd_launch(void* stream, int width, int in_dim, int K, const float* params, size_t param_stride, void* wpack_bwd);
+
+// fp32 flax params -> bf16 fragment streams for K MLPs laid out `param_stride` floats apart
+int launch_pack(void* stream, int width, int in_dim, int K, const float* params, size_t param_stride,
+                void* wpack_fwd, void* wpack_bwd) {
+    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+    DURF_REQUIRE(in_dim > 0 && in_dim <= DURF_ENC_DIM, "in_dim <= 64");
+    if (K <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (wpack_fwd) {
+        const size_t ostride = durf_wpack_fwd_bytes(width);
+        if (width == 256)
+            hipLaunchKernelGGL(k_pack_fwd<256>, dim3(durf_cdiv(MlpSpec<256>::TOTAL_CHUNKS * 64, 256), K), dim3(256), 0, s,
+                               in_dim, params, (bf16x8*)wpack_fwd, param_stride, ostride);
+        else
+            hipLaunchKernelGGL(k_pack_fwd<128>, dim3(durf_cdiv(MlpSpec<128>::TOTAL_CHUNKS * 64, 256), K), dim3(256), 0, s,
+                               in_dim, params, (bf16x8*)wpack_fwd, param_stride, ostride);
+        DURF_CHECK_LAUNCH("durf_pack_weights (fwd)");
+    }
+    if (wpack_bwd) return pack_bwd_launch(stream, width, in_dim, K, params, param_stride, wpack_bwd);
+    return 0;
+}
+
+int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile, const void* view_bf16,
+                   const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
+                   void* relu_mask, int K, const FwdStrides& st) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
-    if (rows == 0) return 0;
+    DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
+    if (rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const unsigned nblk = durf_cdiv(rows, 256);
-    dim3 grid(nblk < 256u ? nblk : 256u), block(512);        // persistent: at most one workgroup per CU
+    dim3 grid(nblk < 256u ? nblk : 256u, K), block(512);     // persistent: at most one workgroup per CU and object
 #define LAUNCH_F(WW, TR)                                                                          \
     {                                                                                             \
         constexpr int lds = 2 * 4 * (MlpSpec<WW>::KW + 1) * 1024;                                 \
         (void)hipFuncSetAttribute((const void*)k_mlp_fwd<WW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((k_mlp_fwd<WW, TR>), grid, block, lds, s, rows, N, (const bf16x8*)enc_tile, \
                            (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw,  \
-                           (bf16x8*)stash, (uint4*)relu_mask);                                     \
+                           (bf16x8*)stash, (uint4*)relu_mask, st);                                 \
     }
     if (width == 256) { if (stash) LAUNCH_F(256, true) else LAUNCH_F(256, false) }
     else { if (stash) LAUNCH_F(128, true) else LAUNCH_F(128, false) }
@@ -458,4 +494,4 @@ int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_ti
     return 0;
 }
 
-}  // extern "C"
+}  // namespace durf

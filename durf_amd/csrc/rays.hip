@@ -303,7 +303,12 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
               const float* __restrict__ t_vals, const float* __restrict__ origins_s,
               const float* __restrict__ dirs_s, const float* __restrict__ radii,
               const int32_t* __restrict__ hit, int K, int contraction, BarfW barf_w,
-              char* __restrict__ out_tile) {
+              char* __restrict__ out_tile, size_t idx_stride, size_t out_stride) {
+    if (OBJ && gridDim.y > 1) {                      // batched objects: blockIdx.y = object
+        idx += blockIdx.y * idx_stride;
+        count += blockIdx.y;
+        out_tile += blockIdx.y * out_stride;
+    }
     const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int j = (int)(row / N), n = (int)(row % N);
     if (j >= rays) return;
@@ -411,7 +416,7 @@ int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const floa
     else
         hipLaunchKernelGGL((k_encode_lane<false>), dim3(durf_cdiv((size_t)B * N, 256)), dim3(256), 0,
                            (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
-                           hit, K, contraction, BarfW{}, (char*)out_tile);
+                           hit, K, contraction, BarfW{}, (char*)out_tile, (size_t)0, (size_t)0);
     DURF_CHECK_LAUNCH("durf_encode_bkgd");
     return 0;
 }
@@ -419,7 +424,19 @@ int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const floa
 int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const int32_t* count,
                     const float* t_vals, const float* origins_s, const float* dirs_s,
                     const float* radii, const float* barf_w, int flags, void* out_tile, float* out_f32) {
-    if (max_rays <= 0) return 0;
+    return durf::launch_encode_obj(stream, 1, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags,
+                                   out_tile, 0, out_f32);
+}
+
+}  // extern "C"
+
+namespace durf {
+
+int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* idx, const int32_t* count,
+                      const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
+                      const float* barf_w, int flags, void* out_tile, size_t out_stride, float* out_f32) {
+    if (max_rays <= 0 || K <= 0) return 0;
+    DURF_REQUIRE(K == 1 || out_f32 == nullptr, "batched object encoding writes bf16 tiles only");
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
     if (out_f32)
@@ -427,11 +444,11 @@ int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
                            nullptr, 0, flags & DURF_ENC_NO_INTEGRATION, bw, (bf16x8*)out_tile, out_f32);
     else
-        hipLaunchKernelGGL((k_encode_lane<true>), dim3(durf_cdiv((size_t)max_rays * N, 256)), dim3(256), 0,
+        hipLaunchKernelGGL((k_encode_lane<true>), dim3(durf_cdiv((size_t)max_rays * N, 256), K), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
-                           nullptr, 0, flags & DURF_ENC_NO_INTEGRATION, bw, (char*)out_tile);
+                           nullptr, 0, flags & DURF_ENC_NO_INTEGRATION, bw, (char*)out_tile, (size_t)max_rays, out_stride);
     DURF_CHECK_LAUNCH("durf_encode_obj");
     return 0;
 }
 
-}  // extern "C"
+}  // namespace durf

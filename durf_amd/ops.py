@@ -321,10 +321,11 @@ def mlp_dw(width, rows, N, enc_tiles, view_tiles, stashes, dzs, dz_outs, part, b
                                           arr(stashes), arr(dzs), arr(dz_outs), _p(part), _p(bpart)), 'durf_mlp_dw')
 
 
-def mlp_dw_finalize(width, in_dim, part, bpart, grad_mlp):
+def mlp_dw_finalize(width, in_dim, rows, N, nlevels, part, bpart, grad_mlp, count=None):
+    """rows, N, nlevels, count: as in the mlp_dw call that wrote the partials"""
     with _Timed('mlp_dw_finalize_%d' % width):
-        _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, _p(part), _p(bpart), _p(grad_mlp)),
-                   'durf_mlp_dw_finalize')
+        _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, rows, N, _p(count), nlevels, _p(part),
+                                                   _p(bpart), _p(grad_mlp)), 'durf_mlp_dw_finalize')
 
 
 # ---------------------------------------------------------------------------

@@ -100,7 +100,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     ops.mlp_dw(om.W_BKGD, rows, N, [lv['enc_b'] for lv in levels], [view_tile] * L, [lv['stash_b'] for lv in levels],
                [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
     off = lay.mlp_off['MLP_0']
-    ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
+    ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, rows, N, L, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
     if K:
         o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
         ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)

@@ -177,8 +177,9 @@ size_t durf_dw_bpart_floats(int width);
 int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
                 const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
                 const void* const* dz, const void* const* dz_out, float* part, float* bpart);
-int durf_mlp_dw_finalize(void* stream, int width, int in_dim, const float* part, const float* bpart,
-                         float* grad_mlp);
+int durf_mlp_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count,
+                         int nlevels /* the same rows, N, count, nlevels as the durf_mlp_dw call */,
+                         const float* part, const float* bpart, float* grad_mlp);
 
 /* The K per-object BoxMLPs of one level as one call each (obbpose_model.py:174-201): loops over the
  * objects inside the library and spreads them over side streams forked from / joined to `stream`.
