@@ -42,6 +42,9 @@ _SIGS = {
     'durf_obj_fwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp, vp, vp, vp, vp, vp, vp]),
     'durf_obj_bwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_obj_dw_batch': (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64]),
+    'durf_gen_batch': (i32, [vp, i32, i32, C.POINTER(f32), vp, f32, f32, vp, vp, vp, i32] + [vp] * 10),
+    'durf_ssim_scratch_floats': (u64, [i32, i32, i32, i32]),
+    'durf_ssim': (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, f32, f32, vp, vp, vp]),
     'durf_train_stats': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'durf_loss_prep': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
     'durf_loss_bwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,

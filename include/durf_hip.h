@@ -30,6 +30,7 @@ extern "C" {
 
 #define DURF_MAX_OBJ 16
 #define DURF_MAX_LEVELS 8
+#define DURF_MAX_CAMS 8        /* cameras of one timestep (Waymo rig: 5) */
 #define DURF_W_BKGD 256      /* MLP.net_width (obbpose_model.py:296) */
 #define DURF_W_OBJ 128       /* BoxMLP.net_width (:360) */
 /* flags of durf_encode_bkgd (`contraction` argument) / durf_encode_obj */
@@ -225,6 +226,24 @@ int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, 
 size_t durf_optim_scratch_floats(size_t n);
 int durf_clip_adam(void* stream, size_t n, float* params, float* m, float* v, float* grad, float inv_world,
                    float max_val, float max_norm, float lr, int step, float* scratch, float* stats);
+
+/* ---- callers / data either side of the hot path ---------------------------------
+ * Rays of a 'timestep' batch generated on the device (obbpose_dataset.py:1868-1916 pinhole rays with
+ * un-normalised directions and row-neighbour radii; :1551-1583 gather from the timestep's concatenated
+ * cameras).  cams_host: n_cams x 17 HOST floats {camtoworld 3x4 row-major, focal, cx, cy, h, w};
+ * ray_idx [B] device indices into the concatenation (NULL: 0..B-1); images [P,img_channels] / depth [P] /
+ * sky [P] device arrays of the same concatenation (nullable, with their outputs). */
+int durf_gen_batch(void* stream, int B, int n_cams, const float* cams_host, const int32_t* ray_idx, float near,
+                   float far, const float* images, const float* depth, const float* sky, int img_channels,
+                   float* origins, float* directions, float* viewdirs, float* radii, float* lossmult,
+                   float* near_out, float* far_out, float* pixels, float* depth_out, float* sky_out);
+/* SSIM of two [H,W,C] fp32 images (internal/math.py:66-137): filt_dev = the normalised 1-D Gaussian
+ * window (filter_size device floats), scratch durf_ssim_scratch_floats floats, ssim_map nullable
+ * [(H-fs+1),(W-fs+1),C], ssim_mean 1 device float. */
+size_t durf_ssim_scratch_floats(int H, int W, int C, int filter_size);
+int durf_ssim(void* stream, int H, int W, int C, const float* img0, const float* img1, float max_val,
+              int filter_size, const float* filt_dev, float k1, float k2, float* ssim_map, float* scratch,
+              float* ssim_mean);
 
 #ifdef __cplusplus
 }
