@@ -48,7 +48,8 @@ def _run(cuda, B, K, N, randomized, seed, alpha=10.0, far=40.0, knobs=None, near
     return b, ret, ref_bf, ref_32
 
 
-@pytest.mark.parametrize('K,N,randomized', [(0, 64, False), (1, 32, False), (3, 64, True), (8, 32, False)])
+@pytest.mark.parametrize('K,N,randomized', [(0, 64, False), (1, 32, False), (3, 64, True), (8, 32, False),
+                                            (1, 96, True), (2, 256, False)])     # odd multiple of 32, and the maximum N
 def test_forward_parity(cuda, K, N, randomized):
     far = 40.0
     b, ret, ref_bf, ref_32 = _run(cuda, 256, K, N, randomized, seed=21 + K, far=far)
