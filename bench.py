@@ -98,9 +98,13 @@ def main():
     config = utils.configured(utils.Config)
     B = args.rays
     K_OBJ = args.objects
-    batch_np = synthetic.make_batch(B * world, K_OBJ, far=FAR, seed=synthetic.SEED)
+    # Weak scaling: every rank trains on the same synthetic B-ray batch (same boxes / poses / timestep, as one
+    # 'timestep' batch of the reference has) with rank-dependent stratified-sampling noise, so the per-GPU work --
+    # including the fraction of rays that hit a box -- does not change with the number of GPUs.  The gradient
+    # all-reduce and the stats all-reduce run exactly as with distinct shards.
+    batch_np = synthetic.make_batch(B, K_OBJ, far=FAR, seed=synthetic.SEED)
     full = H.device_batch(batch_np, dev)
-    batch = train_boxpose.shard_batch(full, rank, world)
+    batch = full
     model, variables = obbpose_model.construct_mipnerf(0, full, device=dev)
     state = train_boxpose.create_train_state(variables)
     prev = full['init'][0:1]
@@ -111,7 +115,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    rng = 0
+    rng = 1000 * rank                                  # stratified-sampling noise differs per rank
     for _ in range(args.warmup):
         state, stats, rng, _ = train_boxpose.train_step(model, config, rng, state, batch, lr, eps, alpha, prev)
     sync()
