@@ -194,8 +194,8 @@ class MipNerfModel:
         bk = ops.BKGD_RAND if rand_bkgd else (ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY)
         if randomized and noise is None:
             g = _make_generator(rng, dev)
-            noise = dict(t_rand=torch.rand(B, N + 1, device=dev, generator=g),
-                         u_rand=torch.rand(B, N + 1, device=dev, generator=g))
+            u = torch.rand(2, B, N + 1, device=dev, generator=g)          # one launch for both levels' noise
+            noise = dict(t_rand=u[0], u_rand=u[1])
         rows = B * N
         view_tiles_obj = ops.obj_view_tiles(Kd, B, N, dev) if (train and Kd) else None
         ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,

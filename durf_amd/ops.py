@@ -70,9 +70,13 @@ def compact_hits(hit):
     """-> idx[K,B] int32, count[K] int32, slot[B,K] int32"""
     B, K = hit.shape
     dev = hit.device
-    idx = torch.zeros(max(K, 1), B, dtype=torch.int32, device=dev)
-    count = torch.zeros(max(K, 1), dtype=torch.int32, device=dev)
-    slot = torch.full((B, max(K, 1)), -1, dtype=torch.int32, device=dev)
+    if K == 0:
+        return (torch.zeros(1, B, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
+                torch.full((B, 1), -1, dtype=torch.int32, device=dev))
+    # the kernel writes every slot and count entry, and idx[k, :count[k]] is all anyone reads
+    idx = torch.empty(K, B, dtype=torch.int32, device=dev)
+    count = torch.empty(K, dtype=torch.int32, device=dev)
+    slot = torch.empty(B, K, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().durf_compact_hits(_stream(), B, K, _p(hit), _p(idx), _p(count), _p(slot)),
                'durf_compact_hits')
     return idx, count, slot
