@@ -233,7 +233,7 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
     const float t0 = t_vals[(size_t)b * (N + 1) + n], t1 = t_vals[(size_t)b * (N + 1) + n + 1];
     float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
     float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
-    Gauss g = frustum_gaussian(t0, t1, o, d, radii[b]);
+    Gauss g = frustum_gaussian(t0, t1, o, d, radii[b], (contraction & DURF_ENC_CYLINDER) != 0);
     if (contraction & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
     float w[10];
     if (OBJ) {
@@ -320,7 +320,7 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
     const float t0 = t_vals[(size_t)b * (N + 1) + n], t1 = t_vals[(size_t)b * (N + 1) + n + 1];
     float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
     float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
-    Gauss g = frustum_gaussian(t0, t1, o, d, radii[b]);
+    Gauss g = frustum_gaussian(t0, t1, o, d, radii[b], (contraction & DURF_ENC_CYLINDER) != 0);
     if (contraction & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
     if (!OBJ) {
         int nh = 0;
@@ -442,11 +442,11 @@ int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* i
     if (out_f32)
         hipLaunchKernelGGL((k_encode<true>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
-                           nullptr, 0, flags & DURF_ENC_NO_INTEGRATION, bw, (bf16x8*)out_tile, out_f32);
+                           nullptr, 0, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), bw, (bf16x8*)out_tile, out_f32);
     else
         hipLaunchKernelGGL((k_encode_lane<true>), dim3(durf_cdiv((size_t)max_rays * N, 256), K), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
-                           nullptr, 0, flags & DURF_ENC_NO_INTEGRATION, bw, (char*)out_tile, (size_t)max_rays, out_stride);
+                           nullptr, 0, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), bw, (char*)out_tile, (size_t)max_rays, out_stride);
     DURF_CHECK_LAUNCH("durf_encode_obj");
     return 0;
 }

@@ -153,11 +153,12 @@ class MipNerfModel:
 
     def _check(self):
         bad = []
-        if self.ray_shape != 'cone': bad.append('ray_shape')
+        if self.ray_shape not in ('cone', 'cylinder'): bad.append('ray_shape')
         if not self.use_viewdirs: bad.append('use_viewdirs=False')
         if (self.min_deg_point, self.max_deg_point, self.deg_view) != (0, 10, 4): bad.append('degrees')
-        if (self.disable_integration or not self.dynamics) and not (self.no_pose_opt and self.no_yaw_opt):
-            bad.append('disable_integration / dynamics=False with box-pose optimisation')
+        if ((self.disable_integration or not self.dynamics or self.ray_shape != 'cone') and
+                not (self.no_pose_opt and self.no_yaw_opt)):
+            bad.append('disable_integration / dynamics=False / cylinder rays with box-pose optimisation')
         if not self.stop_level_grad: bad.append('stop_level_grad=False')
         if self.num_samples % 32 or not (32 <= self.num_samples <= 256): bad.append('num_samples')
         if bad:
@@ -169,8 +170,6 @@ class MipNerfModel:
     def _forward(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
                  train=False, noise=None):
         self._check()
-        if randomized and self.density_noise > 0:
-            raise NotImplementedError('density_noise > 0 (both shipped gin files set 0.0)')
         lay = variables.layout
         K, N = lay.K, self.num_samples
         Kd = K if self.dynamics else 0         # dynamics=False: boxes only select rays (obbpose_model.py:167,232,257-260)
@@ -192,11 +191,12 @@ class MipNerfModel:
             packs['obj'] = ops.pack_weights_batch(Kd, variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]],
                                                   lay.mlp_size[W_OBJ], want_bwd=train)
         bk = ops.BKGD_RAND if rand_bkgd else (ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY)
+        g = _make_generator(rng, dev) if randomized else None
         if randomized and noise is None:
-            g = _make_generator(rng, dev)
             u = torch.rand(2, B, N + 1, device=dev, generator=g)          # one launch for both levels' noise
             noise = dict(t_rand=u[0], u_rand=u[1])
         rows = B * N
+        cyl = self.ray_shape == 'cylinder'
         view_tiles_obj = ops.obj_view_tiles(Kd, B, N, dev) if (train and Kd) else None
         ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,
                    packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk, view_tiles_obj=view_tiles_obj)
@@ -211,7 +211,7 @@ class MipNerfModel:
                 t_vals = ops.resample(t_vals, weights, self.resample_padding,
                                       noise['u_rand'] if randomized else None)
             enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
-                                       disable_integration=self.disable_integration)
+                                       disable_integration=self.disable_integration, cylinder=cyl)
             stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
             mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
             raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
@@ -220,8 +220,11 @@ class MipNerfModel:
                 slabs = ops.ObjSlabs(Kd, B, N, dev, train)
                 ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
                                   view_tile=view_tiles_obj if lvl == 0 else None,
-                                  disable_integration=self.disable_integration)
+                                  disable_integration=self.disable_integration, cylinder=cyl)
             raws = slabs.raws() if Kd else []
+            if randomized and self.density_noise > 0:    # :236-240 (added once to the merged raw density)
+                dn = noise['density'][lvl] if 'density' in noise else torch.randn(B, N, device=dev, generator=g)
+                raw_b[:, 3] += self.density_noise * dn.reshape(-1)
             rgb, depth, acc, weights, t_mids, t_dists = ops.composite_fwd(
                 raw_b, raws, slot, t_vals, d_s, self.density_bias, bk)
             ret.append((rgb, depth, acc, weights, t_vals, t_mids, t_dists, [pose[:, :3], box_rot0],

@@ -104,11 +104,11 @@ def tile_rows(rows):
     return (rows + 31) // 32 * 32
 
 
-ENC_CONTRACT, ENC_NO_INTEGRATION = 1, 2
+ENC_CONTRACT, ENC_NO_INTEGRATION, ENC_CYLINDER = 1, 2, 4
 
 
 def encode_bkgd(t_vals, origins_s, dirs_s, radii, hit, contraction=True, tile=True, f32=False,
-                disable_integration=False):
+                disable_integration=False, cylinder=False):
     """hit=None: no object masking of the samples (MipNerfModel.dynamics=False)"""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     K = 0 if hit is None else hit.shape[1]
@@ -118,7 +118,8 @@ def encode_bkgd(t_vals, origins_s, dirs_s, radii, hit, contraction=True, tile=Tr
     with _Timed('encode_bkgd'):
         _lib.check(_lib.lib().durf_encode_bkgd(_stream(), B, N, _p(_f32(t_vals)), _p(_f32(origins_s)),
                                                _p(_f32(dirs_s)), _p(_f32(radii)), _p(hit), K,
-                                               (ENC_CONTRACT if contraction else 0) | (ENC_NO_INTEGRATION if disable_integration else 0),
+                                               (ENC_CONTRACT if contraction else 0) | (ENC_NO_INTEGRATION if disable_integration else 0) |
+                                               (ENC_CYLINDER if cylinder else 0),
                                                _p(ot), _p(of)), 'durf_encode_bkgd')
     return ot, of
 
@@ -132,7 +133,7 @@ def barf_weights(alpha, max_deg=10):
 
 
 def encode_obj(max_rays, idx_k, count_k, t_vals, origins_s, dirs_s, radii, alpha, tile=True, f32=False,
-               disable_integration=False):
+               disable_integration=False, cylinder=False):
     N = t_vals.shape[1] - 1
     dev = t_vals.device
     ot = torch.empty(tile_rows(max_rays * N), ENC_DIM, dtype=torch.bfloat16, device=dev) if tile else None
@@ -141,7 +142,8 @@ def encode_obj(max_rays, idx_k, count_k, t_vals, origins_s, dirs_s, radii, alpha
     wa = (C.c_float * 10)(*[float(x) for x in w])
     _lib.check(_lib.lib().durf_encode_obj(_stream(), max_rays, N, _p(idx_k), _p(count_k),
                                           _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
-                                          _p(_f32(radii)), wa, ENC_NO_INTEGRATION if disable_integration else 0,
+                                          _p(_f32(radii)), wa,
+                                          (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0),
                                           _p(ot), _p(of)), 'durf_encode_obj')
     return ot, of
 
@@ -368,13 +370,14 @@ def pack_weights_batch(K, obj_params, param_stride, want_bwd=False):
 
 
 def obj_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha, view_bf16, wf, view_tile=None,
-                  disable_integration=False):
+                  disable_integration=False, cylinder=False):
     w = barf_weights(alpha)
     wa = (C.c_float * 10)(*[float(x) for x in w])
     with _Timed('obj_fwd_batch'):
         _lib.check(_lib.lib().durf_obj_fwd_batch(
             _stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(_f32(t_vals)), _p(_f32(origins_s)),
-            _p(_f32(dirs_s)), _p(_f32(radii)), wa, ENC_NO_INTEGRATION if disable_integration else 0, _p(view_bf16),
+            _p(_f32(dirs_s)), _p(_f32(radii)), wa,
+            (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0), _p(view_bf16),
             _p(wf), _p(slabs.enc), _p(slabs.raw), _p(slabs.stash), _p(slabs.mask), _p(view_tile)), 'durf_obj_fwd_batch')
 
 

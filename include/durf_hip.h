@@ -36,6 +36,7 @@ extern "C" {
 /* flags of durf_encode_bkgd (`contraction` argument) / durf_encode_obj */
 #define DURF_ENC_CONTRACT 1        /* MipNerfModel.contraction (mip360.new_space) */
 #define DURF_ENC_NO_INTEGRATION 2  /* MipNerfModel.disable_integration: PE instead of IPE (covariances zeroed) */
+#define DURF_ENC_CYLINDER 4        /* MipNerfModel.ray_shape == 'cylinder' (mip.cylinder_to_gaussian) */
 #define DURF_ENC_DIM 64      /* 60 (bkgd IPE) / 63 (object IPE) features padded to 64 */
 #define DURF_VIEW_DIM 32     /* 27 view-direction features padded to 32 */
 
@@ -92,7 +93,7 @@ int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const floa
  * (device-side count; launch covers max_rays).  barf_w: 10 host floats (mip.py:217-218). */
 int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const int32_t* count,
                     const float* t_vals, const float* origins_s, const float* dirs_s,
-                    const float* radii, const float* barf_w, int flags /* DURF_ENC_NO_INTEGRATION */,
+                    const float* radii, const float* barf_w, int flags /* DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER */,
                     void* out_tile, float* out_f32);
 
 /* K6/K7 fused MLP forward (obbpose_model.py:305-354 / :369-418), bf16 MFMA, fp32

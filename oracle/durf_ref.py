@@ -246,11 +246,24 @@ def conical_frustum_to_gaussian(d, t0, t1, base_radius):
     return lift_gaussian(d, t_mean, t_var, r_var)
 
 
-def cast_rays(t_vals, origins, directions, radii):
-    """internal/mip.py:155-179, ray_shape='cone', diag=False."""
+def cylinder_to_gaussian(d, t0, t1, radius):
+    """internal/mip.py:133-152."""
+    t_mean = (t0 + t1) / 2
+    r_var = radius ** 2 / 4
+    t_var = (t1 - t0) ** 2 / 12
+    return lift_gaussian(d, t_mean, t_var, r_var)
+
+
+def cast_rays(t_vals, origins, directions, radii, ray_shape='cone'):
+    """internal/mip.py:155-179, diag=False."""
     t0 = t_vals[..., :-1]
     t1 = t_vals[..., 1:]
-    means, covs = conical_frustum_to_gaussian(directions, t0, t1, radii)
+    if ray_shape == 'cone':
+        means, covs = conical_frustum_to_gaussian(directions, t0, t1, radii)
+    elif ray_shape == 'cylinder':
+        means, covs = cylinder_to_gaussian(directions, t0, t1, radii)
+    else:
+        raise ValueError(ray_shape)
     means = means + origins[..., None, :]
     return means, covs
 
@@ -313,7 +326,7 @@ def volumetric_rendering(rgb, density, t_vals, dirs, white_bkgd, rand_bkgd):
 
 
 def sample_along_rays(t_rand, origins, directions, radii, num_samples, near, far,
-                      randomized, lindisp=False):
+                      randomized, lindisp=False, ray_shape='cone'):
     """internal/mip.py:330-370.  `t_rand` [B,N+1] U[0,1) replaces the PRNG key."""
     batch_size = origins.shape[0]
     dt = origins.dtype
@@ -329,12 +342,12 @@ def sample_along_rays(t_rand, origins, directions, radii, num_samples, near, far
         t_vals = lower + (upper - lower) * t_rand.to(dt)
     else:
         t_vals = t_vals.expand(batch_size, num_samples + 1)
-    means, covs = cast_rays(t_vals, origins, directions, radii)
+    means, covs = cast_rays(t_vals, origins, directions, radii, ray_shape)
     return t_vals, (means, covs)
 
 
 def resample_along_rays(u_rand, origins, directions, radii, t_vals, weights,
-                        randomized, stop_grad, resample_padding):
+                        randomized, stop_grad, resample_padding, ray_shape='cone'):
     """internal/mip.py:373-416."""
     weights_pad = torch.cat([weights[..., :1], weights, weights[..., -1:]], dim=-1)
     weights_max = torch.maximum(weights_pad[..., :-1], weights_pad[..., 1:])
@@ -344,7 +357,7 @@ def resample_along_rays(u_rand, origins, directions, radii, t_vals, weights,
                                                t_vals.shape[-1], randomized)
     if stop_grad:
         new_t_vals = new_t_vals.detach()
-    means, covs = cast_rays(new_t_vals, origins, directions, radii)
+    means, covs = cast_rays(new_t_vals, origins, directions, radii, ray_shape)
     return new_t_vals, (means, covs)
 
 
@@ -468,7 +481,8 @@ def model_apply(params, rays, ts, ext, randomized, rand_bkgd, white_bkgd, alpha,
     c = dict(MODEL_DEFAULTS)
     if cfg:
         c.update(cfg)
-    assert c['density_noise'] == 0.0 or not randomized, 'density noise needs jax PRNG'
+    assert c['density_noise'] == 0.0 or not randomized or (noise is not None and 'density' in noise), \
+        'density noise: pass noise["density"] = per-level N(0,1) draws [B,N,1] (they replace the jax PRNG key)'
     mlp = mlp_hook or mlp_apply
     pose_offsets = params['box_centers']
     K = pose_offsets.shape[1]
@@ -511,12 +525,12 @@ def model_apply(params, rays, ts, ext, randomized, rand_bkgd, white_bkgd, alpha,
             t_vals, samples = sample_along_rays(
                 None if noise is None else noise['t_rand'], origins_s, dirs_s,
                 rays.radii, c['num_samples'], rays.near, rays.far, randomized,
-                c['lindisp'])
+                c['lindisp'], c['ray_shape'])
         else:
             t_vals, samples = resample_along_rays(
                 None if noise is None else noise['u_rand'], origins_s, dirs_s,
                 rays.radii, t_vals, weights, randomized, c['stop_level_grad'],
-                c['resample_padding'])
+                c['resample_padding'], c['ray_shape'])
         if c['disable_integration']:
             samples = (samples[0], torch.zeros_like(samples[1]))
 
@@ -550,6 +564,8 @@ def model_apply(params, rays, ts, ext, randomized, rand_bkgd, white_bkgd, alpha,
         raw_rgb = raw_rgb + raw_rgbs                                      # :232-234
         raw_density = raw_density + raw_densities
 
+        if randomized and c['density_noise'] > 0:                         # :236-240
+            raw_density = raw_density + c['density_noise'] * noise['density'][i_level].to(dt)
         rgb = torch.sigmoid(raw_rgb)                                      # :243
         density = torch.nn.functional.softplus(raw_density + c['density_bias'])  # :245
         comp_rgb, distance, acc, weights, t_vals, t_mids, t_dists = volumetric_rendering(

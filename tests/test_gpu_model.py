@@ -78,7 +78,7 @@ def test_forward_parity(cuda, K, N, randomized):
 
 
 @pytest.mark.parametrize('knobs', [dict(lindisp=True), dict(disable_integration=True), dict(dynamics=False),
-                                   dict(contraction=False)])
+                                   dict(contraction=False), dict(ray_shape='cylinder')])
 def test_forward_knobs(cuda, knobs):
     """gin knobs off their shipped values: lindisp (mip.py:354-356; near > 0 so 1/t is finite),
     disable_integration (obbpose_model.py:164-165), dynamics=False (:167,232,257-260), contraction=False."""
@@ -100,6 +100,39 @@ def test_forward_knobs(cuda, knobs):
             torch.testing.assert_close(got[i].cpu()[single], rb[i][single], rtol=0, atol=tol,
                                        msg=lambda m: 'output %d l%d: %s' % (i, lvl, m))
         assert torch.equal(got[8].cpu().long().reshape(-1), rb[8].reshape(-1)), 'dyn_mask'
+
+
+def test_density_noise(cuda):
+    """density_noise > 0 with randomized=True (obbpose_model.py:236-240; the class default is 0.1, both shipped
+    gin files set 0): the same N(0,1) draws on both sides."""
+    B, K, N, far = 256, 1, 32, 40.0
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.1\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n' % N)
+    b = synthetic.make_batch(B, K, seed=12, far=far)
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+    g = torch.Generator().manual_seed(5)
+    noise_c = dict(t_rand=torch.rand(B, N + 1, generator=g), u_rand=torch.rand(B, N + 1, generator=g),
+                   density=[torch.randn(B, N, 1, generator=g) for _ in range(2)])
+    noise_d = dict(t_rand=noise_c['t_rand'].to(cuda), u_rand=noise_c['u_rand'].to(cuda),
+                   density=[d.to(cuda) for d in noise_c['density']])
+    ret = model.apply(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], randomized=True, rand_bkgd=False,
+                      white_bkgd=False, alpha=10.0, noise=noise_d)
+    params = H.oracle_params_from_variables(variables)
+    with torch.no_grad():
+        ref = R.model_apply(params, ob['rays'], b['ts'], ob['ext'], True, False, False, 10.0, noise=noise_c,
+                            cfg=dict(num_samples=N, density_noise=0.1), mlp_hook=R.mlp_apply_bf16)
+        ref0 = R.model_apply(params, ob['rays'], b['ts'], ob['ext'], True, False, False, 10.0, noise=noise_c,
+                             cfg=dict(num_samples=N, density_noise=0.0), mlp_hook=R.mlp_apply_bf16)
+    for lvl in range(2):
+        for i, tol in ((0, 3e-3), (2, 3e-3), (3, 3e-3), (4, 2e-3 * far)):
+            torch.testing.assert_close(ret[lvl][i].cpu(), ref[lvl][i], rtol=0, atol=tol)
+    assert (ref[1][3] - ref0[1][3]).abs().max() > 1e-3, 'the noise must matter in this test'
+    # without explicit draws the model makes its own (and still runs)
+    ret2 = model.apply(variables, 7, db['rays'], db['init'], db['ext'], b['ts'], randomized=True, rand_bkgd=False,
+                       white_bkgd=False, alpha=10.0)
+    assert torch.isfinite(ret2[1][0]).all()
 
 
 def test_forward_alpha_ramp(cuda):

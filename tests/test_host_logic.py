@@ -55,7 +55,7 @@ def test_gin_reader_errors_and_syntax():
 
 def test_unsupported_knobs_fail_loudly():
     utils.clear_gin()
-    m = obbpose_model.MipNerfModel(ray_shape='cylinder', density_noise=0.0)
+    m = obbpose_model.MipNerfModel(use_viewdirs=False, density_noise=0.0)
     with pytest.raises(NotImplementedError):
         m._check()
     m = obbpose_model.MipNerfModel(num_samples=100)
