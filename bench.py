@@ -167,7 +167,7 @@ def main():
                             frac=d['frac'], traffic=None, launch_ms=d['ms'], all=info)
             # HBM traffic of the dominant kernel from the committed PMC passes (not measurable live)
             try:
-                with open(os.path.join(ROOT, 'profiles', 'r01c_pmc_traffic.json')) as f:
+                with open(os.path.join(ROOT, 'profiles', 'r01d_pmc_traffic.json')) as f:
                     tr = json.load(f)
                 if B == RAYS_PER_GPU and dom in tr:
                     roof['traffic'] = tr[dom]['total_bytes']
