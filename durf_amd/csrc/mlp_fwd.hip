@@ -132,9 +132,13 @@ __device__ __forceinline__ f32x16 mma_tile(const char* slot, int lane, const bf1
 // Two output tiles at once: their MFMAs alternate, so consecutive MFMAs never share an
 // accumulator (a dependent same-accumulator chain with LDS reads / waits between its links
 // pays ~43 extra cycles per link on gfx950) and each B fragment is used twice back-to-back.
-template <int NA, int NB>
+template <int NA, int NB, bool SPREAD = false>
 __device__ __forceinline__ void mma_tile2(const char* slot0, const char* slot1, int lane, const bf16x8* inA,
-                                          const bf16x8* inB, f32x16& acc0, f32x16& acc1) {
+                                          const bf16x8* inB, f32x16& acc0, f32x16& acc1,
+                                          const bf16x8* sv = nullptr, char* sp = nullptr, bool do_store = false) {
+    // SPREAD: the four 16-byte stores of the previous tile pair (sv[0..3] -> sp + q KB) are issued between the
+    // k-steps instead of in one burst before them, so a store that waits for queue space has MFMAs ahead of it.
+    constexpr int T = NA + NB;
     const f32x4* bp0 = (const f32x4*)(slot0 + (NA + NB) * 1024 + (lane >> 5) * 64);
     const f32x4* bp1 = (const f32x4*)(slot1 + (NA + NB) * 1024 + (lane >> 5) * 64);
 #pragma unroll
@@ -146,18 +150,21 @@ __device__ __forceinline__ void mma_tile2(const char* slot0, const char* slot1, 
     const char* ap0 = slot0 + lane * 16;
     const char* ap1 = slot1 + lane * 16;
 #pragma unroll
-    for (int ks = 0; ks < NA; ks++) {
+    for (int ks = 0; ks < T; ks++) {
         const bf16x8 a0 = *(const bf16x8*)(ap0 + ks * 1024);
         const bf16x8 a1 = *(const bf16x8*)(ap1 + ks * 1024);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, inA[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, inA[ks], acc1, 0, 0, 0);
-    }
+        const bf16x8 b = ks < NA ? inA[ks < NA ? ks : 0] : inB[ks < NA ? 0 : ks - NA];
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc1, 0, 0, 0);
+        if (SPREAD) {
 #pragma unroll
-    for (int ks = 0; ks < NB; ks++) {
-        const bf16x8 a0 = *(const bf16x8*)(ap0 + (NA + ks) * 1024);
-        const bf16x8 a1 = *(const bf16x8*)(ap1 + (NA + ks) * 1024);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, inB[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, inB[ks], acc1, 0, 0, 0);
+            for (int q = 0; q < 4; q++)
+                if (ks == (q + 1) * T / 4 - 1) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (do_store) STREAM_STORE(sp + q * 1024, sv[q]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
     }
 }
 
@@ -224,21 +231,27 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
             const int rest = NMT - mo - G;                       // tiles after this group
             slot = p.begin(rest > 0 ? (rest < G ? rest : G) * CH : next_stage_chunks);
         }
-        if (TRAIN && valid) {
-            if (mo > 0) {
-#pragma unroll
-                for (int q = 4; q >= 1; q--) STREAM_STORE(stash_dst + (2 * mo - q) * 1024 + p.lane * 16, out[2 * mo - q]);
-                p.since += 4;
-            } else if (PREV_NMT > 0) {
-#pragma unroll
-                for (int q = 4; q >= 1; q--)
-                    STREAM_STORE(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16, prev_out[2 * PREV_NMT - q]);
-                p.since += 4;
-                if (prev_mask_dst) *(uint4*)(prev_mask_dst + p.lane * 16) = mask_carry;
-            }
-        }
         f32x16 acc0, acc1;
-        mma_tile2<NA, NB>(slot + (mo % G) * CH * 1024, slot + (mo % G + 1) * CH * 1024, p.lane, inA, inB, acc0, acc1);
+        const char* s0 = slot + (mo % G) * CH * 1024;
+        const char* s1 = slot + (mo % G + 1) * CH * 1024;
+        if (TRAIN) {          // the previous pair's stores (this stage's, or the previous stage's last pair) ride inside the k-loop
+            if (mo > 0) {
+                mma_tile2<NA, NB, true>(s0, s1, p.lane, inA, inB, acc0, acc1, out + 2 * mo - 4,
+                                        stash_dst + (2 * mo - 4) * 1024 + p.lane * 16, valid);
+                if (valid) p.since += 4;
+            } else if (PREV_NMT > 0) {
+                mma_tile2<NA, NB, true>(s0, s1, p.lane, inA, inB, acc0, acc1, prev_out + 2 * PREV_NMT - 4,
+                                        prev_dst + (2 * PREV_NMT - 4) * 1024 + p.lane * 16, valid);
+                if (valid) {
+                    p.since += 4;
+                    if (prev_mask_dst) *(uint4*)(prev_mask_dst + p.lane * 16) = mask_carry;
+                }
+            } else {
+                mma_tile2<NA, NB>(s0, s1, p.lane, inA, inB, acc0, acc1);
+            }
+        } else {
+            mma_tile2<NA, NB>(s0, s1, p.lane, inA, inB, acc0, acc1);
+        }
         constexpr bool BITS = TRAIN && RELU;
         const unsigned bits0 = pack_tile<RELU, BITS>(acc0, out[2 * mo], out[2 * mo + 1]);
         const unsigned bits1 = pack_tile<RELU, BITS>(acc1, out[2 * mo + 2], out[2 * mo + 3]);
