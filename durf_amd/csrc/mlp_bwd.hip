@@ -159,15 +159,22 @@ __device__ __forceinline__ void bmma_tile2(const char* slot0, const char* slot1,
 }
 
 // gradient wrt the pre-activation: pass where the stashed post-ReLU activation is non-zero
+// `word`: the pair's 32 ReLU flags as the forward filed them (pack_tile in mlp_fwd.hip): tile t of the pair,
+// accumulator register r -> bit 8t + (r < 8 ? r/2 : 4 + (r-8)/2) + 16 (r & 1)
 template <bool MASK>
-__device__ __forceinline__ void bpack_tile(const f32x16& acc, unsigned bits, bf16x8& o0, bf16x8& o1) {
+__device__ __forceinline__ void bpack_tile(const f32x16& acc, unsigned word, int t, bf16x8& o0, bf16x8& o1) {
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float v0 = acc[e], v1 = acc[8 + e];
         if (MASK) {     // v_bfe_i32 (bit -> 0 / ~0) + v_and_b32; asm: hipcc turns the C form into and + cmp + cndmask
             int m0, m1;
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(bits), "n"(e));
-            asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(bits), "n"(8 + e));
+            if (t == 0) {
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(word), "n"(e / 2 + 16 * (e & 1)));
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(word), "n"(4 + e / 2 + 16 * (e & 1)));
+            } else {
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m0) : "v"(word), "n"(8 + e / 2 + 16 * (e & 1)));
+                asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m1) : "v"(word), "n"(12 + e / 2 + 16 * (e & 1)));
+            }
             v0 = __int_as_float(__float_as_int(v0) & m0);
             v1 = __int_as_float(__float_as_int(v1) & m1);
         }
@@ -219,8 +226,8 @@ __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf
         f32x16 acc0, acc1;
         bmma_tile2<NA, NB>(slot + (mo % G) * CH * 1024, slot + (mo % G + 1) * CH * 1024, p.lane, inA, inB, acc0, acc1);
         const unsigned w = mw[mo >> 1];
-        bpack_tile<MASK>(acc0, w & 0xffffu, out[2 * mo], out[2 * mo + 1]);
-        bpack_tile<MASK>(acc1, w >> 16, out[2 * mo + 2], out[2 * mo + 3]);
+        bpack_tile<MASK>(acc0, w, 0, out[2 * mo], out[2 * mo + 1]);
+        bpack_tile<MASK>(acc1, w, 1, out[2 * mo + 2], out[2 * mo + 3]);
     }
 }
 

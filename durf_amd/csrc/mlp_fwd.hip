@@ -174,7 +174,6 @@ __device__ __forceinline__ void mma_tile2(const char* slot0, const char* slot1, 
 template <bool RELU, bool BITS>
 __device__ __forceinline__ unsigned pack_tile(const f32x16& acc, bf16x8& o0, bf16x8& o1) {
     static_assert(RELU || !BITS, "mask bits are taken from the ReLU output");
-    unsigned bits = 0;
 #pragma unroll
     for (int e = 0; e < 8; e++) {
         float v0 = acc[e], v1 = acc[8 + e];
@@ -182,20 +181,27 @@ __device__ __forceinline__ unsigned pack_tile(const f32x16& acc, bf16x8& o0, bf1
             v0 = __builtin_amdgcn_fmed3f(v0, 0.0f, 3.0e38f);
             v1 = __builtin_amdgcn_fmed3f(v1, 0.0f, 3.0e38f);
         }
-        if (BITS) {
-            // The asm reads the v_max result, never the accumulator itself: hipcc does not see
-            // inline-asm operands when it pads MFMA -> VALU read hazards with s_nop.
-            // (asm at all: hipcc rewrites the C form back into v_cmp + v_cndmask + v_or3.)
-            int b0, b1;
-            asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b0) : "v"(v0));
-            asm("v_med3_i32 %0, %1, 0, 1" : "=v"(b1) : "v"(v1));
-            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(bits) : "v"(b0), "n"(e));
-            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(bits) : "v"(b1), "n"(8 + e));
-        }
         o0[e] = (__bf16)v0;
         o1[e] = (__bf16)v1;
     }
-    return bits;
+    unsigned bits = 0;
+    if (BITS) {
+        // "activation != 0" of two bf16 at a time: v_pk_min_u16(pair, {1,1}) puts the flags at bits 0 and 16,
+        // v_lshl_or_b32 files them at bits j and 16+j (j = dword 0..7 of o0 ++ o1).  One op per activation
+        // instead of the v_cmp + v_cndmask + v_or3 (+ VCC stalls) hipcc makes of any C form.  The asm reads
+        // the v_cvt_pk results, never an accumulator: hipcc does not pad MFMA -> VALU hazards for asm operands.
+        typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+        const u32x4_ d0 = __builtin_bit_cast(u32x4_, o0), d1 = __builtin_bit_cast(u32x4_, o1);
+        const unsigned ones = 0x00010001u;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            unsigned t;
+            const unsigned d = j < 4 ? d0[j & 3] : d1[j & 3];
+            asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(d), "s"(ones));
+            asm("v_lshl_or_b32 %0, %1, %2, %0" : "+v"(bits) : "v"(t), "n"(j));
+        }
+    }
+    return bits;     // tile-local: flags of acc[2j] at bit j, of acc[2j+1] at bit 16+j (acc[8..15]: j = 4..7)
 }
 
 // Tiles are buffered in GROUPS: one barrier + one prefetch burst per group of up to
@@ -255,7 +261,7 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
         constexpr bool BITS = TRAIN && RELU;
         const unsigned bits0 = pack_tile<RELU, BITS>(acc0, out[2 * mo], out[2 * mo + 1]);
         const unsigned bits1 = pack_tile<RELU, BITS>(acc1, out[2 * mo + 2], out[2 * mo + 3]);
-        if (TRAIN && RELU) mb[mo >> 1] |= bits0 | (bits1 << 16);
+        if (TRAIN && RELU) mb[mo >> 1] |= bits0 | (bits1 << 8);      // second tile of the pair: bits 8-15 and 24-31
     }
     if (TRAIN && RELU) mask_carry = make_uint4(mb[0], mb[1], mb[2], mb[3]);
 }
