@@ -168,9 +168,7 @@ __device__ __forceinline__ void mma_tile2(const char* slot0, const char* slot1, 
     }
 }
 
-// returns the 16 "activation > 0" bits of this tile (bit r <-> accumulator register r).
-// x > 0  <=>  clamp(int bits of x, 0, 1) == 1 for every non-NaN float (negative floats and -0
-// are negative integers): one v_med3_i32 + one v_lshl_or_b32 per element, no VCC round trip.
+// packs one output tile to bf16 (ReLU optional) and returns its 16 "activation != 0" flags
 template <bool RELU, bool BITS>
 __device__ __forceinline__ unsigned pack_tile(const f32x16& acc, bf16x8& o0, bf16x8& o1) {
     static_assert(RELU || !BITS, "mask bits are taken from the ReLU output");
