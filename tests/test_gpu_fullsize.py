@@ -107,3 +107,29 @@ def test_weight_gradient_checksum_full_size(cuda):
     want = sum(d.to(torch.bfloat16).double().sum(0) for d in draws)
     torch.testing.assert_close(grad[off_b11:off_b11 + 3].double(), want[:3], rtol=1e-4, atol=1e-4)     # rgb head bias
     torch.testing.assert_close(grad[off_b8:off_b8 + 1].double(), want[3:4], rtol=1e-4, atol=1e-4)       # density head bias
+
+
+@pytest.mark.parametrize('Bs,K', [(1, 1), (33, 2), (1000, 16)])
+def test_odd_batch_sizes_and_max_objects(cuda, Bs, K):
+    """Edge shapes: a single ray, a batch that fills neither a 256-sample block nor a compaction round, and the
+    maximum object count (DURF_MAX_OBJ = 16): a full training step runs, stays finite and matches the oracle's loss."""
+    from oracle import durf_ref as R
+    Ns = 32
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
+                    'Config.randomized = False\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
+                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.0\n' % Ns)
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(Bs, K, seed=5 + K, far=40.0)
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(2, db, device=cuda)
+    params = H.oracle_params_from_variables(variables)
+    state = train_boxpose.create_train_state(variables)
+    state, stats, _, _ = train_boxpose.train_step(model, config, 0, state, db, 5e-4, 3.0, 10.0, db['init'][0:1])
+    torch.cuda.synchronize()
+    assert torch.isfinite(state.variables.flat).all() and torch.isfinite(stats.loss)
+    ocfg = dict(R.CONFIG_DEFAULTS, randomized=False, tv_loss_mult=0.0)
+    _, _, ostats, _ = R.train_step(params, R.new_opt_state(params), ob, ocfg, dict(num_samples=Ns), 5e-4, 3.0, 10.0,
+                                   ob['init'][0:1], mlp_hook=R.mlp_apply_bf16)
+    torch.testing.assert_close(stats.loss.cpu(), ostats['loss'], rtol=3e-3, atol=1e-6)
