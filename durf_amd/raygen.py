@@ -50,3 +50,36 @@ def generate_batch(ts_data, ray_indices, near, far):
                                          _p(img), _p(ts_data.depth), _p(ts_data.sky), ch, _p(o), _p(d), _p(v), _p(r),
                                          _p(lm), _p(nr), _p(fr), _p(px), _p(dp), _p(sk)), 'durf_gen_batch')
     return utils.BoxRays(o, d, v, r, lm, nr, fr), px, dp, sk
+
+
+# ---------------------------------------------------------------------------
+# coarse-to-fine multi-resolution schedule (c2f_obb_dataset.py:306-313, 843-891)
+# ---------------------------------------------------------------------------
+C2F_FACTORS = (16, 12, 8, 4)
+
+
+def c2f_factor(train_it, c2f_steps):
+    """Downsampling factor of training iteration `train_it` (c2f_obb_dataset.py:306-313): 16 up to
+    c2f_steps[0], 12 up to c2f_steps[1], 8 up to c2f_steps[2], then 4."""
+    if train_it <= c2f_steps[0]:
+        return 16
+    if train_it <= c2f_steps[1]:
+        return 12
+    if train_it <= c2f_steps[2]:
+        return 8
+    return 4
+
+
+class C2FTimestepData:
+    """One timestep at the four C2F resolutions.  `levels`: {factor: dict(h, w, focal, images, depth, sky)};
+    the C2F loader centres the principal point at (w/2, h/2) (c2f_obb_dataset.py:861-864)."""
+
+    def __init__(self, camtoworlds, levels, device='cuda'):
+        self.data = {}
+        for f, lv in levels.items():
+            pp = [(w * 0.5, h * 0.5) for h, w in zip(lv['h'], lv['w'])]
+            self.data[int(f)] = TimestepData(camtoworlds, lv['focal'], pp, lv['h'], lv['w'], lv.get('images'),
+                                             lv.get('depth'), lv.get('sky'), device=device)
+
+    def at(self, train_it, c2f_steps):
+        return self.data[c2f_factor(train_it, c2f_steps)]

@@ -169,3 +169,10 @@ def test_shard_batch_errors_like_the_reference():
     s = train_boxpose.shard_batch(ob, 1, 2)
     assert s['pixels'].shape[0] == 15 and s['rays'].origins.shape[0] == 15 and s['init'].shape == ob['init'].shape
     assert torch.equal(s['pixels'], ob['pixels'][15:])
+
+
+def test_c2f_schedule():
+    from durf_amd import raygen
+    steps = (1000, 2000, 3000)
+    got = [raygen.c2f_factor(i, steps) for i in (0, 1000, 1001, 2000, 2001, 3000, 3001, 10 ** 6)]
+    assert got == [16, 16, 12, 12, 8, 8, 4, 4]          # c2f_obb_dataset.py:306-313 (inclusive upper bounds)
