@@ -203,7 +203,10 @@ class MipNerfModel:
         ret = []
         t_vals = weights = None
         box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
-        dyn_mask = hit.sum(dim=-1, keepdim=True) if K > 0 else torch.zeros(B, 1, dtype=torch.int32, device=dev)
+        if K > 1:
+            dyn_mask = hit.sum(dim=-1, keepdim=True, dtype=torch.int32)
+        else:
+            dyn_mask = hit if K == 1 else torch.zeros(B, 1, dtype=torch.int32, device=dev)
         for lvl in range(self.num_levels):
             if lvl == 0:
                 t_vals = ops.sample_t(near, far, N, noise['t_rand'] if randomized else None, self.lindisp)

@@ -109,7 +109,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     if config.weight_decay_mult != 0:                                          # :73-75
         weight_l2 = config.weight_decay_mult * (flat * flat).sum() / flat.numel()
         grad += (2.0 * config.weight_decay_mult / flat.numel()) * flat
-    if K > 0:
+    if K > 0 and pose_opt:                      # no_pose_opt and no_yaw_opt: box_centers get no gradient (:100-104)
         g6 = torch.zeros(K, 6, device=dev)
         if pose_opt:
             ops.pose_finish(pose_ts, pose_sums, not model.no_pose_opt, not model.no_yaw_opt, g6)
