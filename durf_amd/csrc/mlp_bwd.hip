@@ -967,7 +967,9 @@ int launch_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* co
         (void)hipFuncSetAttribute((const void*)k_dw_all<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(k_dw_all<256>, grid, block, lds, s, rows, N, count, a);
     } else {
-        constexpr int lds = DW_LDS_BYTES;
+        // widest W=128 job: 20 KB per stage x 4 stages = 80 KB, so two workgroups share a CU (80 VGPRs per lane):
+        // the object GEMMs are per-tile-latency-bound with one resident workgroup
+        constexpr int lds = dw_stages(20) * 20 * 1024;
         (void)hipFuncSetAttribute((const void*)k_dw_all<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(k_dw_all<128>, grid, block, lds, s, rows, N, count, a);
     }
