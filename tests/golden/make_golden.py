@@ -5,7 +5,7 @@ The reference (JAX) cannot be imported here, so these vectors are NOT reference 
 they pin the float64 evaluation of the restated algorithm (oracle/durf_ref.py) so that (a) the
 fp32 oracle, (b) the HIP path and (c) any later edit of either are checked against one fixed
 truth.  Parameters are regenerated from a seed by construct_mipnerf (CPU torch generator);
-a checksum guards against RNG drift.  Run:  python tools/make_golden.py
+a checksum guards against RNG drift.  Run:  python tests/golden/make_golden.py
 """
 import os
 import sys
@@ -13,7 +13,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from durf_amd import obbpose_model, synthetic, utils  # noqa: E402
 from oracle import durf_ref as R  # noqa: E402

@@ -10,7 +10,7 @@ consume IDENTICAL batches for S steps:
 and both are evaluated on the same held-out rays:  PSNR = mse_to_psnr(mean((pred - gt)^2))
 (train_boxpose.py:562).  Target: |delta| <= 0.1 dB.
 
-    python tools/psnr_experiment.py --steps 300 [--skip-cpu] [--out profiles/r01_psnr.json]
+    python tests/psnr_experiment.py --steps 300 [--skip-cpu] [--out profiles/r01_psnr.json]
 """
 import argparse
 import json

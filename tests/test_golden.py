@@ -1,4 +1,4 @@
-"""Golden vectors (tests/golden/*.npz, made by tools/make_golden.py from the float64 oracle).
+"""Golden vectors (tests/golden/*.npz, made by tests/golden/make_golden.py from the float64 oracle).
 CPU: the float32 oracle ("reference-precision twin") reproduces them -- this bounds what an fp32
 evaluation of the reference may differ by.  GPU: the HIP path reproduces them within the bf16
 tolerance SURVEY.md 8c states (rgb <= 2e-2 abs, loss terms <= 2 % rel)."""
@@ -10,8 +10,8 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(ROOT, 'tools'))
-import make_golden as MG  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+import make_golden as MG  # noqa: E402  (the committed generator of the fixtures; imports the oracle, so it lives under tests/)
 
 from durf_amd import obbpose_model, train_boxpose, utils  # noqa: E402
 from tests import helpers as H  # noqa: E402
@@ -19,6 +19,19 @@ from tests import helpers as H  # noqa: E402
 
 def _load(name):
     return np.load(os.path.join(ROOT, 'tests', 'golden', name + '.npz'))
+
+
+@pytest.mark.parametrize('name', list(MG.CASES))
+def test_generator_reproduces_committed_fixture(name):
+    """Re-running the generator (float64 oracle) gives the committed vectors EXACTLY: an oracle edit that moves
+    the default path fails here instead of being re-pinned silently by the next `make_golden.py` run."""
+    gold = _load(name)
+    _, variables, noise, out = MG.oracle_outputs(name)
+    for k, v in out.items():
+        np.testing.assert_array_equal(np.asarray(v), gold[k], err_msg=k)
+    np.testing.assert_array_equal(noise['t_rand'].numpy(), gold['t_rand'])
+    np.testing.assert_array_equal(noise['u_rand'].numpy(), gold['u_rand'])
+    assert set(gold.files) == set(out) | {'param_checksum', 't_rand', 'u_rand'}
 
 
 @pytest.mark.parametrize('name', list(MG.CASES))
