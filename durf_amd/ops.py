@@ -19,6 +19,7 @@ def _stream():
 # Optional per-op timing with HIP events recorded on the launch stream (bench.py's live
 # roofline measurement).  TIMERS = None disables it (default: zero overhead).
 TIMERS = None
+TIMED_NAMES = None       # optional set of op names to time (None: every wrapped op)
 
 
 class _Timed:
@@ -26,13 +27,14 @@ class _Timed:
         self.name = name
 
     def __enter__(self):
-        if TIMERS is not None:
+        self.on = TIMERS is not None and (TIMED_NAMES is None or self.name in TIMED_NAMES)
+        if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
             self.e0.record()
 
     def __exit__(self, *a):
-        if TIMERS is not None:
+        if self.on:
             self.e1.record()
             TIMERS.setdefault(self.name, []).append((self.e0, self.e1))
 
