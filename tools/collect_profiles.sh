@@ -1,13 +1,15 @@
 #!/bin/bash
 # End-of-milestone evidence run (on the GPU box):  tools/collect_profiles.sh <tag>
 #   gpurun_out/<tag>/bench.json            default bench.py line (with cpu_baseline)
+#   gpurun_out/<tag>/bench_op_times.txt    per-op table of a separate --profile-ops run
 #   gpurun_out/<tag>/rocprofv3_stats.txt   rocprofv3 --kernel-trace --stats of bench.py --steps 10
 #   gpurun_out/<tag>/rocprofv3_{fetch,write,mfma}.txt   separate --pmc passes (bench.py --steps 2)
 tag=${1:-rXX}
 out=/root/repo/gpurun_out/$tag
 mkdir -p $out
 cd /root/repo
-python3 bench.py --profile-ops > $out/bench.json 2> $out/bench_op_times.txt
+python3 bench.py > $out/bench.json 2> $out/bench.err                     # the default line, exactly as the driver runs it
+python3 bench.py --profile-ops --no-cpu-baseline > $out/bench_all_ops_timed.json 2> $out/bench_op_times.txt   # full per-op table (every op timed: ~1.4 % slower)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stats -- python3 /root/repo/bench.py --steps 10 --warmup 2 --no-cpu-baseline > $out/bench_under_rocprof.json 2>/dev/null
