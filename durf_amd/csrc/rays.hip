@@ -337,21 +337,53 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
     for (int i = 0; i < 64; i++) feat[i] = 0.0f;
     constexpr int OFF = OBJ ? 3 : 0;
     if (OBJ) { feat[0] = g.x[0]; feat[1] = g.x[1]; feat[2] = g.x[2]; }
+    // Range reduction of the 60 sine arguments.  safe_sin wraps |y| >= 100 pi by an exact fmod (wrap_100pi below the
+    // sine).  v_sin_f32 works in revolutions and any integer may be dropped, so v_fract(y / 2 pi) does the same job in
+    // one op when the arguments are moderate.  Differences from the exact wrap: it ignores that the reference's 100 pi
+    // is rounded to fp32 (5.9e-6 rad per wrap) and it rounds y / 2 pi in fp32 (<= 2e-4 rad at |y| = 2048); both are far
+    // below the bf16 quantum 4e-3 this path writes (measured: max / mean abs error vs the oracle unchanged to three
+    // digits, tests/encode_error.py).  A wave in which ANY sample has max|x| * 512 + pi/2 >= 2048 takes the exact
+    // wrap, unchanged -- that covers uncontracted coordinates (|y| up to 1e5, where the fp32 rounding of y / 2 pi
+    // would reach the quantum), object-frame rays, and also contracted points: the reference's contraction switches
+    // at norm 0.1, so norms just above 0.1 map to |2 - 1/n| up to 8, not <= 2.  How many waves that is depends on
+    // the scene (level 0 of the bench.py batch: none of 8192).
+    const float amax = fmaxf(fmaxf(fabsf(g.x[0]), fabsf(g.x[1])), fabsf(g.x[2]));
+    const bool big = !(amax * 512.0f + 1.5707963705062866f < 2048.0f);         // also true for NaN
+    if (__builtin_amdgcn_ballot_w64(big) != 0) {
 #pragma unroll
-    for (int deg = 0; deg < 10; deg++) {
-        const float sc = (float)(1 << deg);
+        for (int deg = 0; deg < 10; deg++) {
+            const float sc = (float)(1 << deg);
 #pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const float y = g.x[a] * sc;
-            const float yc = y + 1.5707963705062866f;
-            const float yv = g.var[a] * sc * sc;
-            const float e = __expf(-0.5f * yv);
-            float fs = e * __sinf(wrap_100pi(y));
-            float fc = e * __sinf(wrap_100pi(yc));
-            const int f = deg * 3 + a;
-            if (OBJ) { fs = barf_w.w[f / 6] * fs; fc = barf_w.w[(f + 30) / 6] * fc; }   // mip.py:217-222
-            feat[OFF + f] = fs;
-            feat[OFF + 30 + f] = fc;
+            for (int a = 0; a < 3; a++) {
+                const float y = g.x[a] * sc;
+                const float yc = y + 1.5707963705062866f;
+                const float yv = g.var[a] * sc * sc;
+                const float e = __expf(-0.5f * yv);
+                float fs = e * __sinf(wrap_100pi(y));
+                float fc = e * __sinf(wrap_100pi(yc));
+                const int f = deg * 3 + a;
+                if (OBJ) { fs = barf_w.w[f / 6] * fs; fc = barf_w.w[(f + 30) / 6] * fc; }   // mip.py:217-222
+                feat[OFF + f] = fs;
+                feat[OFF + 30 + f] = fc;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int deg = 0; deg < 10; deg++) {
+            const float sc = (float)(1 << deg);
+#pragma unroll
+            for (int a = 0; a < 3; a++) {
+                const float y = g.x[a] * sc;
+                const float yc = y + 1.5707963705062866f;
+                const float yv = g.var[a] * sc * sc;
+                const float e = __expf(-0.5f * yv);
+                float fs = e * __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(y * 0.15915494309189535f));
+                float fc = e * __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(yc * 0.15915494309189535f));
+                const int f = deg * 3 + a;
+                if (OBJ) { fs = barf_w.w[f / 6] * fs; fc = barf_w.w[(f + 30) / 6] * fc; }   // mip.py:217-222
+                feat[OFF + f] = fs;
+                feat[OFF + 30 + f] = fc;
+            }
         }
     }
     char* base = out_tile + ((row >> 5) * 4 * 64 + (row & 31)) * 16;
