@@ -2,56 +2,130 @@
 """Headline benchmark: train rays/sec of the durf ray pipeline on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: launched by torch.distributed.run, one rank per GPU, RCCL over xGMI)
 
-A "step" is one full training step (forward 2 levels, losses, backward, one gradient
-all-reduce, clip + Adam) of MipNerfModel over one synthetic random-pose ray batch that is
-already resident in HBM.  Workload = BASELINE.json configs[1] (SURVEY.md 8d "cfg2"):
-CARLA-like dynamic scene, K=1 moving OBB, 128 samples/ray x 2 levels, 8x256 background MLP +
-8x128 object MLP, bf16 MFMA GEMMs (fp32 accumulate, fp32 everywhere else), 4096 rays per GPU
-(weak scaling: the global batch is 4096*N rays).  Prints ONE JSON line on rank 0.
+N > 1 needs no launcher: with WORLD_SIZE unset this process only spawns N children (one rank per
+GPU, RCCL over xGMI) and never touches the GPU itself -- the counterpart of the reference's
+`jax.pmap`, which needs no launcher either (train_boxpose.py:370-374).  Under
+`python -m torch.distributed.run ... bench.py --gpus N` the RANK / LOCAL_RANK / WORLD_SIZE /
+MASTER_* of the environment are used as they are.
+
+A "step" is one full training step (forward 2 levels, losses, backward, ONE gradient all-reduce,
+clip + Adam) of MipNerfModel over this rank's shard of one synthetic random-pose ray batch that is
+already resident in HBM.  Default workload = BASELINE.json configs[2] (SURVEY.md 8d "cfg3"), the
+1-GPU configuration the metric is quoted on: Waymo knobs (configs/waymo.gin), K=3 dynamic OBBs,
+far=40, LIDAR depth / near / empty / sky losses on, 128 samples/ray x 2 levels, 8x256 background
+MLP + 3 8x128 object MLPs, bf16 MFMA GEMMs (fp32 accumulate, fp32 everywhere else), 4096 rays per
+GPU (weak scaling: the global batch is 4096*N rays, sharded contiguously).  `--config` selects
+cfg2 (CARLA, K=1, far=200), cfg4 (Waymo + box-pose optimisation, 1024 rays/GPU) or cfg5 (K=8,
+1024 rays/GPU).  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-RAYS_PER_GPU = 4096
 N_LEVELS = 2
 N_SAMPLES = 128
-FAR = 200.0            # configs/carla_dyn.gin:13
 MAC_BKGD, MAC_OBJ = 591872, 167552      # SURVEY.md App. C
 PEAK_BF16 = 2.5e15     # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12      # HBM3E spec peak (6.29e12 measured-achievable), MI355X_MICROARCH.md
+ENC_BYTES, COMPOSITE_BYTES = 15928, 3108    # algorithmic bytes per ray-level, SURVEY.md 8(d) (bf16 features)
+
+# name -> (gin file, K objects, far, rays per GPU, extra gin bindings, box noise, alpha)
+WORKLOADS = {
+    'cfg2': ('carla_dyn.gin', 1, 200.0, 4096, (), 0.0, 10.0,
+             'cfg2: CARLA-like dynamic scene (configs/carla_dyn.gin), K=1 OBB, far=200'),
+    'cfg3': ('waymo.gin', 3, 40.0, 4096, (), 0.0, 10.0,
+             'cfg3: Waymo segment (configs/waymo.gin), K=3 dynamic OBBs, far=40, LIDAR depth/near/empty + sky losses'),
+    'cfg4': ('waymo.gin', 3, 40.0, 1024, ('MipNerfModel.no_pose_opt = False', 'MipNerfModel.no_yaw_opt = False'),
+             0.5, 3.3, 'cfg4: Waymo + BARF coarse-to-fine box-pose optimisation (alpha=3.3, box noise 0.5), K=3'),
+    'cfg5': ('waymo.gin', 8, 40.0, 1024, (), 0.0, 10.0,
+             'cfg5: full Waymo rig, K=8 dynamic OBBs, far=40'),
+}
 
 
-def gin_text():
-    return ('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
-            'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
-            'Config.randomized = True\nConfig.rand_bkgd = False\nConfig.white_bkgd = False\n'
-            'Config.grad_max_norm = 1.0\nConfig.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.0\n'
-            'Config.depth_loss_mult = 0.0001\nConfig.near_loss_mult = 0.01\nConfig.empty_loss_mult = 1.0\n'
-            'Config.sky_loss_mult = 1.0\nConfig.box_loss_mult = 0\nConfig.far = %g\n' % (N_SAMPLES, FAR))
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--config', default='cfg3', choices=sorted(WORKLOADS))
+    ap.add_argument('--rays', type=int, default=0, help='rays per GPU (default: the workload\'s)')
+    ap.add_argument('--objects', type=int, default=-1, help='override the number of dynamic boxes K')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-ops', action='store_true', help='print the per-op time table to stderr')
+    ap.add_argument('--selftest-launch', action='store_true',
+                    help='CPU/gloo check of the spawn + rendezvous + shard + all-reduce plumbing (no HIP kernels)')
+    return ap.parse_args()
 
 
-def cpu_baseline(batch_np, seconds_budget=15.0, K_OBJ=1):
+# ---------------------------------------------------------------------------------------------
+# self-launch: one child per GPU, started BEFORE anything in this process touches the GPU
+# ---------------------------------------------------------------------------------------------
+def spawn_ranks(n):
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    pending = set(range(n))
+    while pending:                              # a failed rank would leave the others in a collective forever
+        for r in sorted(pending):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            pending.discard(r)
+            if c != 0:
+                rc = rc or c
+                for q in pending:
+                    procs[q].kill()             # exactly the PIDs started above
+        time.sleep(0.05)
+    return rc
+
+
+def setup_workload(name, dev, rank=0, world=1, rays=0, objects=-1):
+    """Config, model, train state and this rank's shard of the named workload (also used by tools/)."""
+    from durf_amd import obbpose_model, synthetic, train_boxpose, utils
+    gin, K_OBJ, far, wl_rays, extra, noise, alpha, label = WORKLOADS[name]
+    if objects >= 0:
+        K_OBJ = objects
+    B = rays or wl_rays
+    utils.clear_gin()
+    config = utils.load_config([os.path.join(ROOT, 'configs', gin)], list(extra))
+    # Weak scaling over distinct shards: every rank builds the same seeded GLOBAL batch of B*world rays (one
+    # 'timestep' batch of the reference: same boxes / poses / timestep for all rays) and keeps its contiguous
+    # shard, exactly what utils.shard + pmap do (internal/utils.py:193-196, train_boxpose.py:370-374).
+    batch_np = synthetic.make_batch(B * world, K_OBJ, far=far, seed=synthetic.SEED, noise_boxes=noise)
+    full = synthetic.device_batch(batch_np, dev)
+    batch = train_boxpose.shard_batch(full, rank, world)
+    model, variables = obbpose_model.construct_mipnerf(0, full, device=dev)
+    state = train_boxpose.create_train_state(variables)
+    return dict(config=config, model=model, state=state, batch=batch, batch_np=batch_np, prev=full['init'][0:1],
+                B=B, K=K_OBJ, far=far, alpha=alpha, label=label)
+
+
+def cpu_baseline(batch_np, K_OBJ, seconds_budget=15.0):
     """The oracle's train_step (fp32 torch-CPU restatement of the reference step) timed on the
     host cores on a bounded sample of the same workload.  A reported baseline, not a target."""
-    import numpy as np
+    import torch
     from oracle import durf_ref as R
-    from tests import helpers as H
     Bc = 256
     sub = dict(batch_np)
     sub['rays'] = {k: v[:Bc] for k, v in batch_np['rays'].items()}
     for k in ('pixels', 'depth', 'sky'):
         sub[k] = batch_np[k][:Bc]
-    ob = H.oracle_batch(sub)
+    ob = R.batch_from_numpy(sub)
     # torch-CPU scales poorly past a few tens of threads on these small GEMMs (256 threads
     # were 50x slower than 16 on the GPU box): use at most 16 and report what was used.
     cores = min(os.cpu_count() or 1, 16)
@@ -72,60 +146,111 @@ def cpu_baseline(batch_np, seconds_budget=15.0, K_OBJ=1):
                        'of the same workload (N=%d, K=%d), %.2f s/step' % (n, Bc, N_SAMPLES, K_OBJ, dt))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--rays', type=int, default=RAYS_PER_GPU, help='rays per GPU')
-    ap.add_argument('--objects', type=int, default=1, help='dynamic boxes K (default: cfg2; 3 = cfg3, 8 = cfg5)')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--profile-ops', action='store_true', help='print the per-op time table to stderr')
-    args = ap.parse_args()
+def pmc_traffic(lib_version, workload, rays, kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (not measurable live).  Only
+    quoted when the passes were collected on THIS library version, workload and shard size."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                tr = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if (tr.get('lib_version') == lib_version and tr.get('workload') == workload and
+                tr.get('rays_per_gpu') == rays and kernel in tr):
+            return tr[kernel]['total_bytes'], '%s: %s' % (os.path.basename(path), tr.get('source', ''))
+    return None, None
 
-    from durf_amd import obbpose_model, ops, synthetic, train_boxpose, utils
-    from tests import helpers as H
+
+def selftest_launch(args):
+    """CPU/gloo: rendezvous, contiguous shard of the global synthetic batch, one all-reduce of a flat
+    fp32 buffer the size of the gradient, barrier, max-over-ranks timing -- the plumbing of the real
+    run without a HIP kernel (this container has no GPU)."""
+    import numpy as np
+    import torch
     import torch.distributed as dist
+    from durf_amd import obbpose_model, synthetic, train_boxpose
+    os.environ['DURF_DIST_BACKEND'] = 'gloo'
+    rank, world, _ = train_boxpose.init_distributed()
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if os.environ.get('DURF_SELFTEST_FAIL_RANK') == str(rank):      # tests: a rank that dies before the collective
+        os._exit(3)
+    gin, K, far, rays, extra, noise, alpha, label = WORKLOADS[args.config]
+    B = 64
+    b = synthetic.make_batch(B * world, K, far=far, seed=synthetic.SEED)
+    n = B
+    lo = rank * n
+    shard_first = float(b['pixels'][lo, 0])
+    lay = obbpose_model.ParamLayout(b['init'].shape[0], K)
+    g = torch.full((lay.total,), float(rank + 1))
+    t0 = time.perf_counter()
+    if world > 1:
+        dist.all_reduce(g)
+        dist.barrier()
+    dt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    firsts = torch.zeros(world, dtype=torch.float64)
+    firsts[rank] = shard_first
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(firsts)
+    ok = bool(torch.all(g == world * (world + 1) / 2)) and \
+        bool(np.allclose(firsts.numpy(), b['pixels'][::n, 0][:world]))
+    if rank == 0:
+        print(json.dumps(dict(selftest='launch', n_gpus=world, backend='gloo', grad_floats=lay.total,
+                              shard_rays=n, ok=ok)))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))        # parent: spawns and waits; no GPU call in this process
+    if args.selftest_launch:
+        raise SystemExit(selftest_launch(args))
+
+    import torch
+    import torch.distributed as dist
+    from durf_amd import _lib, obbpose_model, ops, synthetic, train_boxpose, utils
 
     rank, world, local = train_boxpose.init_distributed()
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)' % (args.gpus, world))
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if world > torch.cuda.device_count():
+        raise SystemExit('--gpus %d but only %d visible' % (world, torch.cuda.device_count()))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
-    utils.clear_gin()
-    utils.parse_gin(gin_text())
-    config = utils.configured(utils.Config)
-    B = args.rays
-    K_OBJ = args.objects
-    # Weak scaling: every rank trains on the same synthetic B-ray batch (same boxes / poses / timestep, as one
-    # 'timestep' batch of the reference has) with rank-dependent stratified-sampling noise, so the per-GPU work --
-    # including the fraction of rays that hit a box -- does not change with the number of GPUs.  The gradient
-    # all-reduce and the stats all-reduce run exactly as with distinct shards.
-    batch_np = synthetic.make_batch(B, K_OBJ, far=FAR, seed=synthetic.SEED)
-    full = H.device_batch(batch_np, dev)
-    batch = full
-    model, variables = obbpose_model.construct_mipnerf(0, full, device=dev)
-    state = train_boxpose.create_train_state(variables)
-    prev = full['init'][0:1]
-    lr, eps, alpha = 5e-4, 3.0, 10.0
+    w = setup_workload(args.config, dev, rank, world, rays=args.rays, objects=args.objects)
+    config, model, state, batch, batch_np, prev = (w[k] for k in ('config', 'model', 'state', 'batch', 'batch_np', 'prev'))
+    B, K_OBJ, far, alpha, label = w['B'], w['K'], w['far'], w['alpha'], w['label']
+    lr, eps = 5e-4, 3.0
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step(state, rng, i):
+        # the logged scalars are all-reduced only every print_every steps (SURVEY.md 8e, C2)
+        return train_boxpose.train_step(model, config, rng, state, batch, lr, eps, alpha, prev,
+                                        reduce_stats=(i % config.print_every == 0))
+
     rng = 1000 * rank                                  # stratified-sampling noise differs per rank
-    for _ in range(args.warmup):
-        state, stats, rng, _ = train_boxpose.train_step(model, config, rng, state, batch, lr, eps, alpha, prev)
+    for i in range(args.warmup):
+        state, stats, rng, _ = step(state, rng, i)
     sync()
-    # live HIP-event timers over the timed region: only the three kernels the roofline reports, unless the full
-    # per-op table is asked for (every timed op costs two event records)
-    ops.TIMED_NAMES = None if args.profile_ops else {'mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256'}
+    # live HIP-event timers over the timed region (recorded on the launch stream): the kernels the roofline
+    # reports, or every wrapped op with --profile-ops (every timed op costs two event records; DESIGN.md 6)
+    timed = {'mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256', 'encode_bkgd', 'composite_fwd'}
+    ops.TIMED_NAMES = None if args.profile_ops else timed
     ops.TIMERS = {}
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        state, stats, rng, _ = train_boxpose.train_step(model, config, rng, state, batch, lr, eps, alpha, prev)
+    for i in range(args.steps):
+        state, stats, rng, _ = step(state, rng, i + 1)
     sync()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -138,60 +263,50 @@ def main():
     if rank == 0:
         rows = B * N_SAMPLES
         hit = float(batch_np['hit_fraction'])
-        # Roofline of the three background-MLP kernels (96 % of the step).  Algorithmic work per
-        # launch (one level): FLOPs = 2 * 591 872 MAC * samples; bytes = what the
-        # data flow of DESIGN.md section 3 has to move: bf16 activation stash 9*W+128 features
-        # (4864 B/sample), ReLU bit-mask 288 B/sample, encoding 128 B, raw/draw 16 B, dz_out 32 B;
-        # the weight-gradient GEMMs read dz + stash + encodings = 332 KB per 32-sample tile.
-        stash_b, mask_b = 4864.0, 288.0
-        work = {
-            'mlp_fwd_256_train': (2.0 * MAC_BKGD * rows, rows * (128 + stash_b + mask_b + 16)),
-            'mlp_bwd_256': (2.0 * MAC_BKGD * rows, rows * (16 + mask_b + stash_b + 32)),
-            # ONE launch covers the samples of both levels
-            'mlp_dw_256': (N_LEVELS * 2.0 * MAC_BKGD * rows, N_LEVELS * rows / 32.0 * 332 * 1024),
-        }
-        per = {k: totals[k][1] / totals[k][0] for k in work if k in totals}
+        # Roofline.  MLP kernels: MFMA-bound by definition -- algorithmic FLOPs per launch
+        # = 2 * 591 872 MAC * samples (one level; the dW launch covers both levels) / live HIP-event time /
+        # 2.5 PFLOP/s.  Encode / composite: HBM-bound -- algorithmic bytes per ray-level / time / 8 TB/s.
+        mfma = {'mlp_fwd_256_train': 2.0 * MAC_BKGD * rows, 'mlp_bwd_256': 2.0 * MAC_BKGD * rows,
+                'mlp_dw_256': N_LEVELS * 2.0 * MAC_BKGD * rows}
+        hbm = {'encode_bkgd': float(ENC_BYTES) * B, 'composite_fwd': float(COMPOSITE_BYTES) * B}
         info = {}
-        for k, t in per.items():
-            fl, by = work[k]
-            t_mfma, t_hbm = fl / PEAK_BF16, by / PEAK_HBM
-            bound = 'hbm' if t_hbm > t_mfma else 'mfma'
-            info[k] = dict(ms=t * 1e3, tflops=fl / t / 1e12, tbps=by / t / 1e12, bound=bound,
-                           frac=(t_hbm if bound == 'hbm' else t_mfma) / t)
-        dom = max(per, key=lambda k: per[k]) if per else None
+        for k, (n, s) in totals.items():
+            t = s / n
+            if k in mfma:
+                info[k] = dict(us=t * 1e6, bound='mfma', achieved=mfma[k] / t / 1e12, unit='TFLOP/s',
+                               frac=mfma[k] / t / PEAK_BF16)
+            elif k in hbm:
+                info[k] = dict(us=t * 1e6, bound='hbm', achieved=hbm[k] / t / 1e9, unit='GB/s',
+                               frac=hbm[k] / t / PEAK_HBM)
+        mlp = [k for k in info if k in mfma]
         roof = None
-        if dom:
+        if mlp:
+            dom = max(mlp, key=lambda k: info[k]['us'])      # the dominant kernel: longest launch
             d = info[dom]
-            if d['bound'] == 'hbm':
-                roof = dict(bound='hbm', kernel=dom, achieved=d['tbps'] * 1e3, peak=PEAK_HBM / 1e9, unit='GB/s',
-                            frac=d['frac'], traffic=None, launch_ms=d['ms'], all=info)
-            else:
-                roof = dict(bound='mfma', kernel=dom, achieved=d['tflops'], peak=PEAK_BF16 / 1e12, unit='TFLOP/s',
-                            frac=d['frac'], traffic=None, launch_ms=d['ms'], all=info)
-            # HBM traffic of the dominant kernel from the committed PMC passes (not measurable live)
-            try:
-                with open(os.path.join(ROOT, 'profiles', 'r01d_pmc_traffic.json')) as f:
-                    tr = json.load(f)
-                if B == RAYS_PER_GPU and dom in tr:
-                    roof['traffic'] = tr[dom]['total_bytes']
-                    roof['traffic_source'] = tr['source']
-            except (OSError, ValueError):
-                pass
-            # end-to-end MFMA rate of the whole step (fwd + bwd-data + dW = 3 x fwd FLOPs, both levels)
-            roof['step_mlp_tflops'] = 3 * 2 * 2.0 * (MAC_BKGD + hit * MAC_OBJ) * rows / (dt / args.steps) / 1e12
+            tr, src = pmc_traffic(int(_lib.lib().durf_version()), args.config, B, dom)
+            roof = dict(bound='mfma', kernel=dom, achieved=d['achieved'], peak=PEAK_BF16 / 1e12, unit='TFLOP/s',
+                        frac=d['frac'], traffic=tr, traffic_source=src, launch_us=d['us'], all=info)
+            # end-to-end MFMA rate of the whole step (fwd + bwd-data + dW = 3 x fwd FLOPs, both levels, incl.
+            # the object MLPs on the measured fraction of hit rays) and the time outside the three MLP kernels
+            step_s = dt / args.steps
+            fl = 3 * N_LEVELS * 2.0 * (MAC_BKGD + hit * MAC_OBJ) * rows
+            roof['step_mlp_tflops'] = fl / step_s / 1e12
+            roof['step_mlp_frac'] = fl / step_s / PEAK_BF16
+            per_step = {k: totals[k][1] / args.steps for k in mlp}
+            roof['non_mlp_ms_per_step'] = (step_s - sum(per_step.values())) * 1e3
         if args.profile_ops:
             for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
                 print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / args.steps),
                       file=sys.stderr)
-        cb = None if args.no_cpu_baseline else cpu_baseline(batch_np, K_OBJ=K_OBJ)
+        cb = None if args.no_cpu_baseline else cpu_baseline(batch_np, K_OBJ)
         out = dict(metric='train_rays_per_sec', value=B * world * args.steps / dt, unit='rays/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload=('cfg2: CARLA-like dynamic scene, K=1 OBB' if K_OBJ == 1 else 'K=%d OBBs' % K_OBJ) + ', 128 samples/ray x 2 levels, '
-                                        '8x256 bkgd MLP + 8x128 object MLP, full train step',
-                               rays_per_gpu=B, global_batch=B * world, num_samples=N_SAMPLES, num_levels=2,
-                               objects=K_OBJ, far=FAR, hit_fraction=hit, randomized=True,
-                               parallelism='dp%d' % world),
+                   config=dict(workload=label + ', 128 samples/ray x 2 levels, 8x256 bkgd MLP + %d 8x128 object MLPs, '
+                                                'full train step' % K_OBJ,
+                               name=args.config, rays_per_gpu=B, global_batch=B * world, num_samples=N_SAMPLES,
+                               num_levels=N_LEVELS, objects=K_OBJ, far=far, hit_fraction=hit, randomized=True,
+                               pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world),
                    loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb)
         print(json.dumps(out))
     if world > 1:

@@ -7,7 +7,7 @@ format is restated from its published serializer and is UNPINNED against a real 
   * file  <dir>/checkpoint_<step>  = msgpack of `flax.serialization.to_state_dict(state)`;
   * state dict of utils.TrainState(optimizer=flax.optim.Optimizer):
         {'optimizer': {'target': {'params': {box_centers, MLP_0/Dense_i/{kernel,bias}, BoxMLP_k/...}},
-                       'state': {'step': int,
+                       'state': {'step': 0-d int32 ndarray (flax.optim keeps OptimizerState.step as an array),
                                  'param_states': {'params': {<same tree>: {'grad_ema', 'grad_sq_ema'}}}}}}
   * every ndarray is msgpack ExtType(1, packb((shape, dtype.name, bytes))), numpy scalars ExtType(3, same).
 Only tests/ exercise it today; train scripts call save_checkpoint / restore_checkpoint like the
@@ -78,7 +78,7 @@ def to_state_dict(state):
             return {k: zip_states(a[k], b[k]) for k in a}
         return {'grad_ema': a, 'grad_sq_ema': b}
     return {'optimizer': {'target': {'params': params},
-                          'state': {'step': int(state.step), 'param_states': {'params': zip_states(m, v)}}}}
+                          'state': {'step': np.asarray(int(state.step), np.int32), 'param_states': {'params': zip_states(m, v)}}}}
 
 
 def _fill(variables_like, tree, what):

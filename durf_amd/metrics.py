@@ -23,7 +23,11 @@ def compute_ssim(img0, img1, max_val, filter_size=11, filter_sigma=1.5, k1=0.01,
     scratch = torch.empty(int(L.durf_ssim_scratch_floats(H, W, Cc, filter_size)), device=dev)
     smap = torch.empty(H - filter_size + 1, W - filter_size + 1, Cc, device=dev) if return_map else None
     out = torch.empty((), device=dev)
-    _lib.check(L.durf_ssim(_stream(), H, W, Cc, _p(img0.float().contiguous()), _p(img1.float().contiguous()),
+    # bind the converted images to locals: a temporary made inside the call expression is freed as soon as its
+    # address has been taken, and the caching allocator would hand the second conversion the same block
+    a = img0.to(torch.float32).contiguous()
+    b = img1.to(torch.float32).contiguous()
+    _lib.check(L.durf_ssim(_stream(), H, W, Cc, _p(a), _p(b),
                            float(max_val), filter_size, _p(fd), float(k1), float(k2), _p(smap), _p(scratch), _p(out)),
                'durf_ssim')
     return smap if return_map else out

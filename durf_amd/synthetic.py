@@ -144,3 +144,14 @@ def make_image_rays(H, W, focal=515.0, far=40.0, yaw=0.1, origin=(0.0, 0.0, 0.0)
                 viewdirs=f32(d / np.linalg.norm(d, axis=-1, keepdims=True)),
                 radii=f32((dx * 2 / np.sqrt(12))[..., None]), lossmult=f32(one),
                 near=f32(0 * one), far=f32(far * one))
+
+
+def device_batch(b, dev):
+    """numpy batch of make_batch -> the product's batch of device tensors (rays as utils.BoxRays)."""
+    import torch
+    from . import utils
+    rays = utils.BoxRays(**{k: torch.tensor(v, dtype=torch.float32, device=dev) for k, v in b['rays'].items()})
+    out = {k: (torch.tensor(v, dtype=torch.float32, device=dev) if isinstance(v, np.ndarray) else v)
+           for k, v in b.items() if k != 'rays'}
+    out['rays'] = rays
+    return out

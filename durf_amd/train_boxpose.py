@@ -136,20 +136,27 @@ def _assemble_stats(config, batch, raw, prev, mode):
                            t_levels, _stat_mults(config), mode)
 
 
-def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None):
+def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, reduce_stats=True):
     """One optimization step (train_boxpose.py:49-321).
 
     batch: dict(rays=BoxRays, pixels[B,3], depth[B,1], sky[B,1], init[T,K,6], ext[K,3], ts, target[K,6])
-    of device tensors for THIS rank's shard.  Returns (new_state, stats, rng, pose)."""
+    of device tensors for THIS rank's shard.  Returns (new_state, stats, rng, pose).
+
+    Data-parallel exchange: ONE all-reduce of the flat gradient buffer (lax.pmean(grad), :253), issued
+    asynchronously so that the stats assembly overlaps it.  `reduce_stats=False` skips the second, ~40-float
+    all-reduce of the logged scalars (lax.pmean(stats), :255): the reference only reads them every
+    `print_every` steps (:440), so a driver passes `step % print_every == 0`; the scalars returned on the other
+    steps are this rank's shard-local values."""
     variables = state.variables
     grad, raw, pose = loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=noise)
     dist = _dist()
     world = 1
+    pending = None
     if dist is not None:                                    # lax.pmean(grad) (:253)
         world = dist.get_world_size()
-        dist.all_reduce(grad)
+        pending = dist.all_reduce(grad, async_op=True)
     L = model.num_levels
-    if dist is None:
+    if dist is None or not reduce_stats:
         out = _assemble_stats(config, batch, raw, prev, ops.STATS_ASSEMBLE | ops.STATS_PSNR)
     else:                                                   # lax.pmean(stats) (:255), then the PSNRs (:291-292)
         out = _assemble_stats(config, batch, raw, prev, ops.STATS_ASSEMBLE)
@@ -157,6 +164,8 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
         out /= world
         ops.train_stats(raw['norms'], raw['sums'], None, None, None, None, [r[4] for r in raw['ret']],
                         _stat_mults(config), ops.STATS_PSNR, out=out)
+    if pending is not None:
+        pending.wait()                                      # orders the current stream behind the collective
     st = ops.stats_views(out, L)
     gs = ops.clip_adam(variables.flat, state.m, state.v, grad, 1.0 / world, float(config.grad_max_val),
                        float(config.grad_max_norm), float(lr), state.step)

@@ -33,6 +33,18 @@ Rays = namedtuple('Rays', ('origins', 'directions', 'viewdirs', 'radii',
 BoxRays = namedtuple('BoxRays', ('origins', 'directions', 'viewdirs', 'radii',
                                  'lossmult', 'near', 'far'))
 
+
+
+def batch_from_numpy(b, dt=torch.float32):
+    """numpy batch (durf_amd.synthetic.make_batch schema) -> the oracle's batch."""
+    import numpy as np
+    rays = BoxRays(**{k: torch.tensor(v, dtype=dt) for k, v in b['rays'].items()})
+    out = {k: (torch.tensor(v, dtype=dt) if isinstance(v, np.ndarray) else v)
+           for k, v in b.items() if k != 'rays'}
+    out['rays'] = rays
+    return out
+
+
 F32_EPS = 1.1920928955078125e-07  # jnp.finfo('float32').eps
 F32_MAX = 3.4028234663852886e+38
 

@@ -6,20 +6,10 @@ from durf_amd import synthetic, utils
 from oracle import durf_ref as R
 
 
-def oracle_batch(b, dt=torch.float32):
-    rays = R.BoxRays(**{k: torch.tensor(v, dtype=dt) for k, v in b['rays'].items()})
-    out = {k: (torch.tensor(v, dtype=dt) if isinstance(v, np.ndarray) else v)
-           for k, v in b.items() if k != 'rays'}
-    out['rays'] = rays
-    return out
+oracle_batch = R.batch_from_numpy
 
 
-def device_batch(b, dev):
-    rays = utils.BoxRays(**{k: torch.tensor(v, dtype=torch.float32, device=dev) for k, v in b['rays'].items()})
-    out = {k: (torch.tensor(v, dtype=torch.float32, device=dev) if isinstance(v, np.ndarray) else v)
-           for k, v in b.items() if k != 'rays'}
-    out['rays'] = rays
-    return out
+device_batch = synthetic.device_batch
 
 
 def oracle_params_from_variables(variables, dt=torch.float32):

@@ -61,3 +61,22 @@ def test_ssim_matches_reference(cuda, shape):
     assert abs(float(got) - want) < 2e-5
     np.testing.assert_allclose(got_map.cpu().numpy(), want_map, rtol=0, atol=5e-5)
     assert abs(float(metrics.compute_ssim(ta, ta, 1.0)) - 1.0) < 1e-6
+
+
+@pytest.mark.gpu
+def test_ssim_converted_inputs(cuda):
+    """Inputs that need a dtype / layout conversion (RGBA slice, float64, bf16): both converted images must stay
+    alive for the call (a freed temporary's block is reused by the next conversion -> SSIM(img1, img1) = 1)."""
+    rs = np.random.default_rng(6)
+    a4 = rs.uniform(0, 1, (24, 40, 4)).astype(np.float32)
+    b4 = np.clip(a4 + rs.normal(0, 0.15, a4.shape), 0, 1).astype(np.float32)
+    want = D.compute_ssim(a4[..., :3], b4[..., :3], 1.0)
+    assert want < 0.95
+    ta, tb = torch.tensor(a4, device=cuda), torch.tensor(b4, device=cuda)
+    got = metrics.compute_ssim(ta[..., :3], tb[..., :3], 1.0)            # non-contiguous views
+    assert abs(float(got) - want) < 2e-5
+    got64 = metrics.compute_ssim(ta[..., :3].double(), tb[..., :3].double(), 1.0)
+    assert abs(float(got64) - want) < 2e-5
+    gotbf = metrics.compute_ssim(ta[..., :3].bfloat16(), tb[..., :3].bfloat16(), 1.0)
+    wantbf = D.compute_ssim(ta[..., :3].bfloat16().float().cpu().numpy(), tb[..., :3].bfloat16().float().cpu().numpy(), 1.0)
+    assert abs(float(gotbf) - wantbf) < 2e-5

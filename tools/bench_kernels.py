@@ -3,7 +3,6 @@ import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from durf_amd import ops, synthetic
-from tests import helpers as H
 
 dev = torch.device('cuda:0')
 B, N, K = int(os.environ.get('B', 4096)), 128, 1
@@ -23,7 +22,7 @@ def timeit(fn, n=20, warm=3):
 
 
 b = synthetic.make_batch(B, K, seed=1)
-db = H.device_batch(b, dev)
+db = synthetic.device_batch(b, dev)
 rays = db['rays']
 pose = db['init'][b['ts']].contiguous()
 o_s, d_s, hit, zo = ops.ray_setup(rays.origins, rays.directions, pose, db['ext'])

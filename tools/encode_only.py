@@ -8,13 +8,12 @@ import torch
 
 import bench
 from durf_amd import ops, synthetic
-from tests import helpers as H
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else bench.RAYS_PER_GPU
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device('cuda:0')
-b = synthetic.make_batch(B, 1, far=bench.FAR, seed=synthetic.SEED)
-db = H.device_batch(b, dev)
+b = synthetic.make_batch(B, 1, far=40.0, seed=synthetic.SEED)
+db = synthetic.device_batch(b, dev)
 rays = db['rays']
 pose = db['init'][b['ts']].contiguous()
 o_s, d_s, hit, zo = ops.ray_setup(rays.origins, rays.directions, pose, db['ext'])

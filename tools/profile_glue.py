@@ -9,17 +9,11 @@ import torch
 from torch.profiler import ProfilerActivity, profile
 
 import bench
-from durf_amd import obbpose_model, synthetic, train_boxpose, utils
-from tests import helpers as H
+from durf_amd import train_boxpose
 
 dev = torch.device('cuda:0')
-utils.clear_gin(); utils.parse_gin(bench.gin_text())
-config = utils.configured(utils.Config)
-batch_np = synthetic.make_batch(4096, 1, far=bench.FAR, seed=synthetic.SEED)
-batch = H.device_batch(batch_np, dev)
-model, variables = obbpose_model.construct_mipnerf(0, batch, device=dev)
-state = train_boxpose.create_train_state(variables)
-prev = batch['init'][0:1]
+w = bench.setup_workload(os.environ.get('DURF_BENCH_CONFIG', 'cfg3'), dev)
+config, model, state, batch, prev = w['config'], w['model'], w['state'], w['batch'], w['prev']
 rng = 0
 for _ in range(3):
     state, stats, rng, _ = train_boxpose.train_step(model, config, rng, state, batch, 5e-4, 3.0, 10.0, prev)

@@ -11,18 +11,13 @@ import numpy as np
 import torch
 
 import bench
-from durf_amd import obbpose_model, synthetic, train_boxpose, utils
-from tests import helpers as H
+from durf_amd import train_boxpose
 
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 warmup = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 dev = torch.device('cuda:0')
-utils.clear_gin(); utils.parse_gin(bench.gin_text())
-config = utils.configured(utils.Config)
-batch = H.device_batch(synthetic.make_batch(bench.RAYS_PER_GPU, 1, far=bench.FAR, seed=synthetic.SEED), dev)
-model, variables = obbpose_model.construct_mipnerf(0, batch, device=dev)
-state = train_boxpose.create_train_state(variables)
-prev = batch['init'][0:1]
+w = bench.setup_workload(os.environ.get('DURF_BENCH_CONFIG', 'cfg3'), dev)
+config, model, state, batch, prev, alpha = w['config'], w['model'], w['state'], w['batch'], w['prev'], w['alpha']
 rng = 0
 host = []
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(warmup + steps + 1)]
@@ -30,7 +25,7 @@ torch.cuda.synchronize()
 ev[0].record()
 t_prev = time.perf_counter()
 for i in range(warmup + steps):
-    state, stats, rng, _ = train_boxpose.train_step(model, config, rng, state, batch, 5e-4, 3.0, 10.0, prev)
+    state, stats, rng, _ = train_boxpose.train_step(model, config, rng, state, batch, 5e-4, 3.0, alpha, prev)
     ev[i + 1].record()
     t = time.perf_counter(); host.append((t - t_prev) * 1e3); t_prev = t        # host time to ISSUE the step
 torch.cuda.synchronize()
@@ -41,7 +36,7 @@ for i in range(min(warmup + steps, 12)):
     print('%4d  %7.3f  %7.3f%s' % (i, gpu[i], host[i], '   (warm-up)' if i < warmup else ''))
 g = gpu[warmup:]
 print('timed steps: mean %.3f  median %.3f  min %.3f  max %.3f  p90 %.3f  -> %.0f rays/s (mean)' % (
-    g.mean(), np.median(g), g.min(), g.max(), np.percentile(g, 90), bench.RAYS_PER_GPU / g.mean() * 1e3))
+    g.mean(), np.median(g), g.min(), g.max(), np.percentile(g, 90), w['B'] / g.mean() * 1e3))
 print('host issue time per step: mean %.3f  max %.3f ms (GPU-bound while this stays below the GPU step time)' % (
     host[warmup:].mean(), host[warmup:].max()))
 slow = np.nonzero(g > 1.1 * np.median(g))[0]
