@@ -34,6 +34,9 @@ _SIGS = {
     'durf_mlp_fwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_composite_fwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32,
                                  vp, vp, vp, vp, vp, vp]),
+    'durf_composite_resample': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32,
+                                      vp, vp, vp, vp, vp, vp, f32, vp, vp,
+                                      vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp]),
     'durf_resample': (i32, [vp, i32, i32, vp, vp, f32, vp, vp]),
     'durf_obj_enc_stride': (u64, [i32, i32]),
     'durf_obj_view_stride': (u64, [i32, i32]),
@@ -41,19 +44,19 @@ _SIGS = {
     'durf_pack_weights_batch': (i32, [vp, i32, i32, i32, vp, u64, vp, vp]),
     'durf_obj_fwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp, vp, vp, vp, vp, vp, vp]),
     'durf_obj_bwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
-    'durf_obj_dw_batch': (i32, [vp, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64]),
+    'durf_obj_dw_batch': (i32, [vp, i32, i32, i32, vp, i32] + [C.POINTER(vp)] * 5 + [i32, vp, vp, vp, u64]),
     'durf_gen_batch': (i32, [vp, i32, i32, C.POINTER(f32), vp, f32, f32, vp, vp, vp, i32] + [vp] * 10),
     'durf_ssim_scratch_floats': (u64, [i32, i32, i32, i32]),
     'durf_ssim': (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, f32, f32, vp, vp, vp]),
-    'durf_train_stats': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
+    'durf_train_stats': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(f32), i32, vp]),
     'durf_loss_prep': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
     'durf_loss_bwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                            f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp]),
+                            f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_mlp_bwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_expand_view': (i32, [vp, u64, i32, vp, vp, vp, vp]),
     'durf_dw_part_floats': (u64, [i32]),
     'durf_dw_bpart_floats': (u64, [i32]),
-    'durf_mlp_dw': (i32, [vp, i32, u64, i32, vp, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_mlp_dw': (i32, [vp, i32, u64, i32, vp, i32] + [C.POINTER(vp)] * 5 + [vp, vp]),
     'durf_mlp_dw_finalize': (i32, [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp]),
     'durf_encode_obj_bwd': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
     'durf_pose_finish': (i32, [vp, i32, vp, vp, i32, i32, vp]),

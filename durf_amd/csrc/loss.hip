@@ -9,39 +9,10 @@
 //
 // Flow per level:  durf_loss_prep  -> per-ray {m, dm, sm, min dist^2, dyn}  -> durf_reduce_rows
 //                  -> norm[] (device)  -> durf_loss_bwd -> d(raw) [B*N,4] + per-ray loss terms
-#include "durf_common.h"
+#include "loss_common.h"
 
 struct ObjPtrsL { const float* p[DURF_MAX_OBJ]; };
 
-struct LossCfg {
-    float eps;              // near-loss half width (schedule value)
-    float c_rgb, c_sky, c_depth, c_near, c_empty, c_dist;   // multipliers of this level's terms
-    float box_loss_mult;
-    int level;              // depth_mask accumulates box_loss_mult*dyn*box once per level (:140)
-    float bg;               // background colour added with (1-acc): 0.5 / 1 / 0
-    float density_bias;
-    int disable_multiscale;
-};
-
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
-
-// per-ray masks (train_boxpose.py:94-102,138-140)
-struct RayMasks { float m, dm, sm, box; };
-__device__ __forceinline__ RayMasks ray_masks(const LossCfg& c, float lossmult, float gt, float sky,
-                                              float dyn, float zo) {
-    RayMasks r;
-    r.m = c.disable_multiscale ? 1.0f : lossmult;
-    const float dm0 = gt > 0.0f ? 1.0f : 0.0f;
-    const float s0 = sky > 0.0f ? 1.0f : 0.0f;
-    r.sm = s0 - dm0 * s0;
-    r.box = gt < zo ? 1.0f : 0.0f;
-    r.dm = dm0 + (float)(c.level + 1) * (c.box_loss_mult * dyn * r.box);
-    return r;
-}
-
-// rows of the per-ray prep buffer
-enum { PREP_M = 0, PREP_DM = 1, PREP_SM = 2, PREP_MIND2 = 3, PREP_DYN = 4, PREP_ROWS = 5 };
 // rows of the per-ray loss-term buffer
 enum { LT_RGB = 0, LT_OBJ = 1, LT_DEPTH = 2, LT_NEAR = 3, LT_EMPTY = 4, LT_SKY = 5, LT_DIST = 6, LT_ROWS = 7 };
 
@@ -57,29 +28,17 @@ k_loss_prep(int B, int N, const float* __restrict__ t_vals, const float* __restr
     const float dynf = (float)dyn[b];
     const RayMasks r = ray_masks(c, lossmult[b], gt, sky[b], dynf, zo[b]);
     float mind2 = __builtin_inff();
-    for (int n = lane; n < N; n += 64) {
-        const float t = t_vals[(size_t)b * (N + 1) + n];
-        const float ind = (t > gt - c.eps && t < gt + c.eps) ? 1.0f : 0.0f;
-        const float d = (ind * r.dm) * (t - gt);
-        mind2 = fminf(mind2, d * d);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mind2 = fminf(mind2, __shfl_xor(mind2, o, 64));
-    if (lane == 0) {
-        prep[(size_t)PREP_M * B + b] = r.m;
-        prep[(size_t)PREP_DM * B + b] = r.dm;
-        prep[(size_t)PREP_SM * B + b] = r.sm;
-        prep[(size_t)PREP_MIND2 * B + b] = mind2;
-        prep[(size_t)PREP_DYN * B + b] = dynf;
-    }
+    for (int n = lane; n < N; n += 64) mind2 = fminf(mind2, near_d2(t_vals[(size_t)b * (N + 1) + n], gt, c.eps, r.dm));
+    mind2 = wave_min(mind2);
+    if (lane == 0) write_prep(prep, B, b, r, mind2, dynf);
 }
 
-// deterministic row reduction: out[r] = sum (or min if r == min_row) of in[r*n .. r*n+n)
+// deterministic row reduction: out[r] = sum (or min if r % PREP_ROWS == min_row) of in[r*n .. r*n+n)
 __global__ void __launch_bounds__(1024)
 k_reduce_rows(int n, int min_row, const float* __restrict__ in, float* __restrict__ out) {
     __shared__ float s[16];
     const int r = blockIdx.x;
-    const bool is_min = (r == min_row);
+    const bool is_min = (min_row >= 0 && r % PREP_ROWS == min_row);
     const float* p = in + (size_t)r * n;
     float v = is_min ? __builtin_inff() : 0.0f;
     for (int i = threadIdx.x; i < n; i += 1024) v = is_min ? fminf(v, p[i]) : v + p[i];
@@ -105,7 +64,9 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
            const float* __restrict__ lossmult, const float* __restrict__ gt_depth,
            const float* __restrict__ sky, const int32_t* __restrict__ dyn,
            const float* __restrict__ zo, const float* __restrict__ norm, LossCfg c,
-           float* __restrict__ draw, float* __restrict__ terms) {
+           float* __restrict__ draw, float* __restrict__ terms, float* __restrict__ rgb_out,
+           float* __restrict__ depth_out, float* __restrict__ acc_out, float* __restrict__ weights_out,
+           float* __restrict__ t_mids_out, float* __restrict__ t_dists_out) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -174,6 +135,24 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
     const float rem = 1.0f - s_acc;
     const float rgb[3] = {s_rgb[0] + c.bg * rem, s_rgb[1] + c.bg * rem, s_rgb[2] + c.bg * rem};
     const float depth = s_dep;
+    // the level's rendered outputs (what k_composite_fwd would write: same arithmetic), so that a training step
+    // needs no separate composite launch for a level that is not resampled from
+    if (weights_out) {
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const int n = lane * P + p;
+            if (n < N) {
+                weights_out[(size_t)b * N + n] = w[p];
+                if (t_mids_out) t_mids_out[(size_t)b * N + n] = tm[p];
+                if (t_dists_out) t_dists_out[(size_t)b * N + n] = td[p];
+            }
+        }
+    }
+    if (lane == 0) {
+        if (rgb_out) { rgb_out[b * 3 + 0] = rgb[0]; rgb_out[b * 3 + 1] = rgb[1]; rgb_out[b * 3 + 2] = rgb[2]; }
+        if (depth_out) depth_out[b] = depth;
+        if (acc_out) acc_out[b] = s_acc;
+    }
 
     // ---- per-ray loss terms and their gradients wrt rgb / depth ----
     const float m_eff = rm.m + c.box_loss_mult * dynf * rm.box;                     // :191
@@ -329,6 +308,12 @@ __global__ void k_train_stats(int L, int K, int N, const float* __restrict__ nor
     }
 }
 
+namespace durf {
+void launch_reduce_rows(hipStream_t s, int rows, int n, int min_row, const float* in, float* out) {
+    hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(1024), 0, s, n, min_row, in, out);
+}
+}  // namespace durf
+
 extern "C" {
 
 int durf_loss_prep(void* stream, int B, int N, const float* t_vals, const float* lossmult,
@@ -341,7 +326,7 @@ int durf_loss_prep(void* stream, int B, int N, const float* t_vals, const float*
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(k_loss_prep, dim3(durf_cdiv(B, 4)), dim3(256), 0, s, B, N, t_vals, lossmult, gt_depth,
                        sky, dyn, zo, c, prep);
-    hipLaunchKernelGGL(k_reduce_rows, dim3(PREP_ROWS), dim3(1024), 0, s, B, (int)PREP_MIND2, prep, norm);
+    durf::launch_reduce_rows(s, PREP_ROWS, B, (int)PREP_MIND2, prep, norm);
     DURF_CHECK_LAUNCH("durf_loss_prep");
     return 0;
 }
@@ -351,7 +336,8 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                   const float* lossmult, const float* gt_depth, const float* sky, const int32_t* dyn,
                   const float* zo, const float* norm, float eps, const float* mults /*6: rgb,sky,depth,near,empty,dist*/,
                   float box_loss_mult, int level, int disable_multiscale, float bg, float density_bias,
-                  float* draw, float* terms, float* term_sums) {
+                  float* draw, float* terms, float* term_sums, float* rgb_out, float* depth_out, float* acc_out,
+                  float* weights_out, float* t_mids_out, float* t_dists_out) {
     DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
     if (B <= 0) return 0;
     LossCfg c;
@@ -364,7 +350,8 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
     dim3 grid(durf_cdiv(B, 4)), block(256);
 #define LAUNCH_L(P)                                                                                   \
     hipLaunchKernelGGL(k_loss_bwd<P>, grid, block, 0, s, B, N, K, raw_bkgd, op, slot, t_vals, dirs_s,  \
-                       pixels, lossmult, gt_depth, sky, dyn, zo, norm, c, draw, terms)
+                       pixels, lossmult, gt_depth, sky, dyn, zo, norm, c, draw, terms, rgb_out, depth_out, acc_out, \
+                       weights_out, t_mids_out, t_dists_out)
     if (N <= 64) LAUNCH_L(1); else if (N <= 128) LAUNCH_L(2); else LAUNCH_L(4);
 #undef LAUNCH_L
     hipLaunchKernelGGL(k_reduce_rows, dim3(LT_ROWS), dim3(1024), 0, s, B, -1, terms, term_sums);

@@ -337,6 +337,39 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
     for (int i = 0; i < 64; i++) feat[i] = 0.0f;
     constexpr int OFF = OBJ ? 3 : 0;
     if (OBJ) { feat[0] = g.x[0]; feat[1] = g.x[1]; feat[2] = g.x[2]; }
+    char* base = out_tile + ((row >> 5) * 4 * 64 + (row & 31)) * 16;
+    // Degrees are the OUTER loop and every 16-byte output vector is stored as soon as its last feature exists
+    // (all indices are compile-time constants): the stores are spread through the arithmetic instead of bursting
+    // at the end of the wave, and at most ~3 vectors of features are live at a time, so the kernel fits 64 VGPRs
+    // (8 waves per SIMD: the 8192 waves of a 4096-ray launch are all resident at once).
+    auto flush = [&](int deg) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            // last degree that contributes to features [8q, 8q+8): sin features OFF + 3 deg + a, cos OFF + 30 + 3 deg + a
+            int last = 0;
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                const int f = q * 8 + e - OFF;
+                if (f >= 0 && f < 60) { const int d = (f % 30) / 3; last = d > last ? d : last; }
+            }
+#if defined(ENC_EXP) && ENC_EXP == 2      // tuning experiment: the arithmetic with 1/8 of the stores
+            if (q != 0) continue;
+#endif
+            if (last == deg) {
+                bf16x8 o8;
+#pragma unroll
+                for (int e = 0; e < 8; e++) o8[e] = (__bf16)feat[q * 8 + e];
+                *(bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16) = o8;
+            }
+        }
+    };
+#if defined(ENC_EXP) && ENC_EXP == 1      // tuning experiment: the stores without the arithmetic
+#pragma unroll
+    for (int i = 0; i < 64; i++) feat[i] = t0 + (float)i;
+#pragma unroll
+    for (int deg = 0; deg < 10; deg++) flush(deg);
+    return;
+#endif
     // Range reduction of the 60 sine arguments.  safe_sin wraps |y| >= 100 pi by an exact fmod (wrap_100pi below the
     // sine).  v_sin_f32 works in revolutions and any integer may be dropped, so v_fract(y / 2 pi) does the same job in
     // one op when the arguments are moderate.  Differences from the exact wrap: it ignores that the reference's 100 pi
@@ -366,33 +399,49 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
                 feat[OFF + f] = fs;
                 feat[OFF + 30 + f] = fc;
             }
+            flush(deg);
         }
     } else {
+        // Octave recurrences (the arithmetic is transcendental-heavy: 60 v_sin + 30 v_exp at quarter rate): per axis
+        // the sine / cosine of degree 0 and of degree 5 come from the hardware (v_sin / v_cos of v_fract(y / 2 pi)),
+        // the degrees in between from the double-angle formulas s' = 2 s c, c' = 1 - 2 s^2, so an angle or amplitude
+        // error at most doubles per octave (<= 16 x the hardware error ~1e-6, far below the bf16 quantum 4e-3 this
+        // path writes).  cos(y) stands in for the reference's sin(y + fl(pi/2)) (they differ by the fp32 rounding of
+        // the sum, <= 3e-5 rad at |y| = 1000).  The Gaussian damping exp(-0.5 var 4^deg) is evaluated at degrees
+        // 0, 3, 6, 9 and raised to the 4th power in between (the relative error quadruples per octave: two chained
+        // steps stay below 2e-6).  12 + 12 transcendentals instead of 90.  The exact fp32 path (k_encode, libm) is
+        // untouched; error vs the oracle: tests/encode_error.py.
+        const float inv2pi = 0.15915494309189535f;
+        float sn[3], cs[3], ev[3];
 #pragma unroll
         for (int deg = 0; deg < 10; deg++) {
             const float sc = (float)(1 << deg);
 #pragma unroll
             for (int a = 0; a < 3; a++) {
-                const float y = g.x[a] * sc;
-                const float yc = y + 1.5707963705062866f;
-                const float yv = g.var[a] * sc * sc;
-                const float e = __expf(-0.5f * yv);
-                float fs = e * __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(y * 0.15915494309189535f));
-                float fc = e * __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(yc * 0.15915494309189535f));
+                if (deg % 5 == 0) {
+                    const float r = __builtin_amdgcn_fractf((g.x[a] * sc) * inv2pi);
+                    sn[a] = __builtin_amdgcn_sinf(r);
+                    cs[a] = __builtin_amdgcn_cosf(r);
+                } else {
+                    const float s2 = sn[a] + sn[a];
+                    const float cn = fmaf(-s2, sn[a], 1.0f);
+                    sn[a] = s2 * cs[a];
+                    cs[a] = cn;
+                }
+                if (deg % 3 == 0) {
+                    ev[a] = __expf(-0.5f * (g.var[a] * sc * sc));
+                } else {
+                    const float e2 = ev[a] * ev[a];
+                    ev[a] = e2 * e2;
+                }
+                float fs = ev[a] * sn[a], fc = ev[a] * cs[a];
                 const int f = deg * 3 + a;
                 if (OBJ) { fs = barf_w.w[f / 6] * fs; fc = barf_w.w[(f + 30) / 6] * fc; }   // mip.py:217-222
                 feat[OFF + f] = fs;
                 feat[OFF + 30 + f] = fc;
             }
+            flush(deg);
         }
-    }
-    char* base = out_tile + ((row >> 5) * 4 * 64 + (row & 31)) * 16;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-        bf16x8 o8;
-#pragma unroll
-        for (int e = 0; e < 8; e++) o8[e] = (__bf16)feat[q * 8 + e];
-        *(bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16) = o8;
     }
 }
 

@@ -2,32 +2,23 @@
 // One 64-lane wavefront owns one ray; samples are split into contiguous runs of P per
 // lane, so the transmittance prefix is a lane-local scan plus one wave-level scan.
 // Both kernels are HBM-bound (3.1 KB / 1.5 KB per ray-level) and read each input once.
-#include "durf_common.h"
+#include "loss_common.h"
 
 struct ObjPtrs { const float* p[DURF_MAX_OBJ]; };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-// jax.nn.softplus = logaddexp(x, 0)
-__device__ __forceinline__ float softplusf_(float x) { return fmaxf(x, 0.0f) + log1pf(expf(-fabsf(x))); }
 
 // ---------------------------------------------------------------------------
 // K8 composite forward: obbpose_model.py:232-245 + mip.volumetric_rendering (mip.py:285-327)
+// One ray per wave; lane l owns samples [l*P, l*P+P).  Shared by k_composite_fwd and the fused
+// k_composite_resample, so both produce the same bits.
 // ---------------------------------------------------------------------------
 template <int P>
-__global__ void __launch_bounds__(256)
-k_composite_fwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrs raw_obj,
-                const int32_t* __restrict__ slot, const float* __restrict__ t_vals,
-                const float* __restrict__ dirs_s, float density_bias, int bkgd_mode,
-                float* __restrict__ rgb_out, float* __restrict__ depth_out,
-                float* __restrict__ acc_out, float* __restrict__ weights,
-                float* __restrict__ t_mids, float* __restrict__ t_dists) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    if (b >= B) return;
-    const float dx = dirs_s[b * 3], dy = dirs_s[b * 3 + 1], dz = dirs_s[b * 3 + 2];
-    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
-    const float* tv = t_vals + (size_t)b * (N + 1);
-    float a[P], c[P][3], tm[P], td[P];
+__device__ __forceinline__ void composite_ray(int b, int lane, int N, int K, const float* __restrict__ raw_bkgd,
+                                              const ObjPtrs& raw_obj, const int32_t* __restrict__ slot,
+                                              const float* __restrict__ tv, float dnorm, float density_bias,
+                                              float (&w)[P], float (&tm)[P], float (&td)[P], float (&s_rgb)[3],
+                                              float& s_acc, float& s_dep) {
+    float a[P], c[P][3];
     float run = 0.0f;
 #pragma unroll
     for (int p = 0; p < P; p++) {
@@ -57,26 +48,41 @@ k_composite_fwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrs
     // exclusive prefix of a over the whole ray
     const float incl = wave_incl_scan(run, lane);
     float pre = incl - run;
-    float s_rgb[3] = {0.f, 0.f, 0.f}, s_acc = 0.f, s_dep = 0.f;
+    s_rgb[0] = s_rgb[1] = s_rgb[2] = 0.f; s_acc = 0.f; s_dep = 0.f;
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const int n = lane * P + p;
         const float alpha = 1.0f - expf(-a[p]);
         const float trans = expf(-pre);
-        const float w = nan_to_num(alpha * trans);
+        w[p] = nan_to_num(alpha * trans);
         pre += a[p];
         if (n < N) {
-            weights[(size_t)b * N + n] = w;
-            if (t_mids) t_mids[(size_t)b * N + n] = tm[p];
-            if (t_dists) t_dists[(size_t)b * N + n] = td[p];
-            s_rgb[0] += w * c[p][0]; s_rgb[1] += w * c[p][1]; s_rgb[2] += w * c[p][2];
-            s_acc += w;
-            s_dep += w * tm[p];
+            s_rgb[0] += w[p] * c[p][0]; s_rgb[1] += w[p] * c[p][1]; s_rgb[2] += w[p] * c[p][2];
+            s_acc += w[p];
+            s_dep += w[p] * tm[p];
         }
     }
     s_rgb[0] = wave_sum(s_rgb[0]); s_rgb[1] = wave_sum(s_rgb[1]); s_rgb[2] = wave_sum(s_rgb[2]);
     s_acc = wave_sum(s_acc);
     s_dep = wave_sum(s_dep);
+}
+
+template <int P>
+__device__ __forceinline__ void composite_store(int b, int lane, int N, int bkgd_mode, const float (&w)[P],
+                                                const float (&tm)[P], const float (&td)[P], const float (&s_rgb)[3],
+                                                float s_acc, float s_dep, float* __restrict__ rgb_out,
+                                                float* __restrict__ depth_out, float* __restrict__ acc_out,
+                                                float* __restrict__ weights, float* __restrict__ t_mids,
+                                                float* __restrict__ t_dists) {
+#pragma unroll
+    for (int p = 0; p < P; p++) {
+        const int n = lane * P + p;
+        if (n < N) {
+            if (weights) weights[(size_t)b * N + n] = w[p];
+            if (t_mids) t_mids[(size_t)b * N + n] = tm[p];
+            if (t_dists) t_dists[(size_t)b * N + n] = td[p];
+        }
+    }
     if (lane == 0) {
         float bg = 0.0f;                       // rand_bkgd: randint(key,(1,3),0,1) == 0 (mip.py:324)
         if (bkgd_mode == 0) bg = 0.5f;
@@ -92,30 +98,39 @@ k_composite_fwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrs
     }
 }
 
+template <int P>
+__global__ void __launch_bounds__(256)
+k_composite_fwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrs raw_obj,
+                const int32_t* __restrict__ slot, const float* __restrict__ t_vals,
+                const float* __restrict__ dirs_s, float density_bias, int bkgd_mode,
+                float* __restrict__ rgb_out, float* __restrict__ depth_out,
+                float* __restrict__ acc_out, float* __restrict__ weights,
+                float* __restrict__ t_mids, float* __restrict__ t_dists) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const float dx = dirs_s[b * 3], dy = dirs_s[b * 3 + 1], dz = dirs_s[b * 3 + 2];
+    const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+    float w[P], tm[P], td[P], s_rgb[3], s_acc, s_dep;
+    composite_ray<P>(b, lane, N, K, raw_bkgd, raw_obj, slot, t_vals + (size_t)b * (N + 1), dnorm, density_bias,
+                     w, tm, td, s_rgb, s_acc, s_dep);
+    composite_store<P>(b, lane, N, bkgd_mode, w, tm, td, s_rgb, s_acc, s_dep, rgb_out, depth_out, acc_out, weights,
+                       t_mids, t_dists);
+}
+
 // ---------------------------------------------------------------------------
 // K9 resample: blur-pool + padding (mip.py:393-404), sorted_piecewise_constant_pdf
 // (math.py:222-284).  The reference's [B,N+1,N+1] mask compare is a search in a sorted
 // CDF; here each lane binary-searches the wave's CDF held in LDS.
+// sw (the ray's weights) and bins (its t_vals) are in LDS when this is entered (all four waves of the
+// workgroup call it: it synchronises).  Returns, when gt_eps_dm is given, the minimum of near_d2 over the
+// first N resampled values (the NEXT level's interval starts, loss_common.h).
 // ---------------------------------------------------------------------------
 #define RS_MAXN 256
 template <int P>
-__global__ void __launch_bounds__(256)
-k_resample(int B, int N, const float* __restrict__ t_vals, const float* __restrict__ w_in,
-           float padding, const float* __restrict__ u_rand, float* __restrict__ t_out) {
-    __shared__ float s_w[4][RS_MAXN + 2];
-    __shared__ float s_cdf[4][RS_MAXN + 2];
-    __shared__ float s_bins[4][RS_MAXN + 2];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int b = blockIdx.x * 4 + wv;
-    const bool active = b < B;
-    float* sw = s_w[wv];
-    float* cdf = s_cdf[wv];
-    float* bins = s_bins[wv];
-    if (active) {
-        for (int n = lane; n < N; n += 64) sw[n] = w_in[(size_t)b * N + n];
-        for (int n = lane; n <= N; n += 64) bins[n] = t_vals[(size_t)b * (N + 1) + n];
-    }
-    __syncthreads();
+__device__ __forceinline__ float resample_ray(bool active, int b, int lane, int N, const float* sw, float* cdf,
+                                              const float* bins, float padding, const float* __restrict__ u_rand,
+                                              float* __restrict__ t_out, const float* gt_eps_dm) {
     float pw[P];
     float tot = 0.0f;
 #pragma unroll
@@ -149,7 +164,8 @@ k_resample(int B, int N, const float* __restrict__ t_vals, const float* __restri
         if (lane == 0) { cdf[0] = 0.0f; cdf[N] = 1.0f; }
     }
     __syncthreads();
-    if (!active) return;
+    float mind2 = __builtin_inff();
+    if (!active) return mind2;
     const float one_m_eps = 0.99999988079071045f;                        // 1 - finfo(float32).eps
     const int num = N + 1;
     for (int j = lane; j < num; j += 64) {
@@ -171,7 +187,103 @@ k_resample(int B, int N, const float* __restrict__ t_vals, const float* __restri
         float t = nan_to_num((u - c0) / (c1 - c0));
         t = fminf(fmaxf(t, 0.0f), 1.0f);
         const float b0 = bins[lo], b1 = bins[lo + 1];
-        t_out[(size_t)b * num + j] = b0 + t * (b1 - b0);
+        const float tn = b0 + t * (b1 - b0);
+        t_out[(size_t)b * num + j] = tn;
+        if (gt_eps_dm && j < N) mind2 = fminf(mind2, near_d2(tn, gt_eps_dm[0], gt_eps_dm[1], gt_eps_dm[2]));
+    }
+    return mind2;
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+k_resample(int B, int N, const float* __restrict__ t_vals, const float* __restrict__ w_in,
+           float padding, const float* __restrict__ u_rand, float* __restrict__ t_out) {
+    __shared__ float s_w[4][RS_MAXN + 2];
+    __shared__ float s_cdf[4][RS_MAXN + 2];
+    __shared__ float s_bins[4][RS_MAXN + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    const bool active = b < B;
+    float* sw = s_w[wv];
+    float* bins = s_bins[wv];
+    if (active) {
+        for (int n = lane; n < N; n += 64) sw[n] = w_in[(size_t)b * N + n];
+        for (int n = lane; n <= N; n += 64) bins[n] = t_vals[(size_t)b * (N + 1) + n];
+    }
+    __syncthreads();
+    resample_ray<P>(active, b, lane, N, sw, s_cdf[wv], bins, padding, u_rand, t_out, nullptr);
+}
+
+// ---------------------------------------------------------------------------
+// K8 + K9 (+ the per-ray part of loss_fn's normalisers) in ONE launch for a level that is followed by
+// another: composite, hand the ray's weights to the resampler through LDS, emit the next level's t_vals.
+// With `lossmult` given it also writes the loss-prep rows (loss_common.h) of the NEXT level (from the
+// resampled t_vals) and, if prep_this is given, of this level -- what durf_loss_prep computes, so a
+// training step needs no separate launch for them.
+// ---------------------------------------------------------------------------
+struct PrepArgs {
+    const float* lossmult; const float* gt_depth; const float* sky; const int32_t* dyn; const float* zo;
+    float eps, box_loss_mult; int level, disable_multiscale;
+    float* prep_this; float* prep_next;
+};
+
+template <int P>
+__global__ void __launch_bounds__(256)
+k_composite_resample(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrs raw_obj,
+                     const int32_t* __restrict__ slot, const float* __restrict__ t_vals,
+                     const float* __restrict__ dirs_s, float density_bias, int bkgd_mode,
+                     float* __restrict__ rgb_out, float* __restrict__ depth_out, float* __restrict__ acc_out,
+                     float* __restrict__ weights, float* __restrict__ t_mids, float* __restrict__ t_dists,
+                     float padding, const float* __restrict__ u_rand, float* __restrict__ t_out, PrepArgs pa) {
+    __shared__ float s_w[4][RS_MAXN + 2];
+    __shared__ float s_cdf[4][RS_MAXN + 2];
+    __shared__ float s_bins[4][RS_MAXN + 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int b = blockIdx.x * 4 + wv;
+    const bool active = b < B;
+    float* sw = s_w[wv];
+    float* bins = s_bins[wv];
+    float gt_eps_dm[3] = {0.f, 0.f, 0.f};
+    RayMasks rm_next = {};
+    float dynf = 0.0f;
+    if (active) {
+        const float dx = dirs_s[b * 3], dy = dirs_s[b * 3 + 1], dz = dirs_s[b * 3 + 2];
+        const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
+        const float* tv = t_vals + (size_t)b * (N + 1);
+        float w[P], tm[P], td[P], s_rgb[3], s_acc, s_dep;
+        composite_ray<P>(b, lane, N, K, raw_bkgd, raw_obj, slot, tv, dnorm, density_bias, w, tm, td, s_rgb, s_acc, s_dep);
+        composite_store<P>(b, lane, N, bkgd_mode, w, tm, td, s_rgb, s_acc, s_dep, rgb_out, depth_out, acc_out, weights,
+                           t_mids, t_dists);
+#pragma unroll
+        for (int p = 0; p < P; p++) {
+            const int n = lane * P + p;
+            if (n < N) sw[n] = w[p];
+        }
+        for (int n = lane; n <= N; n += 64) bins[n] = tv[n];
+        if (pa.lossmult) {
+            LossCfg c = {};
+            c.eps = pa.eps; c.box_loss_mult = pa.box_loss_mult; c.disable_multiscale = pa.disable_multiscale;
+            const float gt = pa.gt_depth[b];
+            dynf = (float)pa.dyn[b];
+            if (pa.prep_this) {
+                c.level = pa.level;
+                const RayMasks r = ray_masks(c, pa.lossmult[b], gt, pa.sky[b], dynf, pa.zo[b]);
+                float mind2 = __builtin_inff();
+                for (int n = lane; n < N; n += 64) mind2 = fminf(mind2, near_d2(tv[n], gt, c.eps, r.dm));
+                mind2 = wave_min(mind2);
+                if (lane == 0) write_prep(pa.prep_this, B, b, r, mind2, dynf);
+            }
+            c.level = pa.level + 1;
+            rm_next = ray_masks(c, pa.lossmult[b], gt, pa.sky[b], dynf, pa.zo[b]);
+            gt_eps_dm[0] = gt; gt_eps_dm[1] = c.eps; gt_eps_dm[2] = rm_next.dm;
+        }
+    }
+    __syncthreads();
+    float mind2 = resample_ray<P>(active, b, lane, N, sw, s_cdf[wv], bins, padding, u_rand, t_out,
+                                  pa.lossmult ? gt_eps_dm : nullptr);
+    if (active && pa.lossmult) {
+        mind2 = wave_min(mind2);
+        if (lane == 0) write_prep(pa.prep_next, B, b, rm_next, mind2, dynf);
     }
 }
 
@@ -194,6 +306,42 @@ int durf_composite_fwd(void* stream, int B, int N, int K, const float* raw_bkgd,
     if (N <= 64) LAUNCH_C(1); else if (N <= 128) LAUNCH_C(2); else LAUNCH_C(4);
 #undef LAUNCH_C
     DURF_CHECK_LAUNCH("durf_composite_fwd");
+    return 0;
+}
+
+int durf_composite_resample(void* stream, int B, int N, int K, const float* raw_bkgd, const float* const* raw_obj,
+                            const int32_t* slot, const float* t_vals, const float* dirs_s, float density_bias,
+                            int bkgd_mode, float* rgb, float* depth, float* acc, float* weights, float* t_mids,
+                            float* t_dists, float resample_padding, const float* u_rand, float* t_vals_out,
+                            const float* lossmult, const float* gt_depth, const float* sky, const int32_t* dyn,
+                            const float* zo, float eps, float box_loss_mult, int level, int disable_multiscale,
+                            float* prep_this, float* norm_this, float* prep_next, float* norm_next) {
+    DURF_REQUIRE(N >= 2 && N <= RS_MAXN, "2 <= N <= 256");
+    DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "K <= DURF_MAX_OBJ");
+    DURF_REQUIRE(!lossmult || (gt_depth && sky && dyn && zo && prep_next && norm_next), "loss prep needs all its inputs");
+    DURF_REQUIRE(!prep_this || (lossmult && norm_this), "prep_this needs the loss-prep inputs and norm_this");
+    if (B <= 0) return 0;
+    ObjPtrs op;
+    for (int k = 0; k < DURF_MAX_OBJ; k++) op.p[k] = (k < K) ? raw_obj[k] : nullptr;
+    const PrepArgs pa = {lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level, disable_multiscale, prep_this, prep_next};
+    dim3 grid(durf_cdiv(B, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_CR(P)                                                                                       \
+    hipLaunchKernelGGL(k_composite_resample<P>, grid, block, 0, s, B, N, K, raw_bkgd, op, slot, t_vals, dirs_s, \
+                       density_bias, bkgd_mode, rgb, depth, acc, weights, t_mids, t_dists, resample_padding, \
+                       u_rand, t_vals_out, pa)
+    if (N <= 64) LAUNCH_CR(1); else if (N <= 128) LAUNCH_CR(2); else LAUNCH_CR(4);
+#undef LAUNCH_CR
+    if (lossmult) {
+        // prep_this and prep_next may be adjacent ([2, PREP_ROWS, B]) with adjacent norms: one reduction launch
+        if (prep_this && prep_next == prep_this + (size_t)PREP_ROWS * B && norm_next == norm_this + PREP_ROWS) {
+            durf::launch_reduce_rows(s, 2 * PREP_ROWS, B, (int)PREP_MIND2, prep_this, norm_this);
+        } else {
+            if (prep_this) durf::launch_reduce_rows(s, PREP_ROWS, B, (int)PREP_MIND2, prep_this, norm_this);
+            durf::launch_reduce_rows(s, PREP_ROWS, B, (int)PREP_MIND2, prep_next, norm_next);
+        }
+    }
+    DURF_CHECK_LAUNCH("durf_composite_resample");
     return 0;
 }
 

@@ -168,7 +168,9 @@ class MipNerfModel:
 
     # -- forward -------------------------------------------------------------
     def _forward(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
-                 train=False, noise=None):
+                 train=False, noise=None, loss_prep=None):
+        """loss_prep (training, num_levels >= 2): dict(lossmult, gt_depth, sky, eps, box_loss_mult, disable_multiscale,
+        norms [L,5]) -- the inputs of durf_loss_prep; the fused per-ray launches then fill `norms` for every level."""
         self._check()
         lay = variables.layout
         K, N = lay.K, self.num_samples
@@ -207,9 +209,23 @@ class MipNerfModel:
             dyn_mask = hit.sum(dim=-1, keepdim=True, dtype=torch.int32)
         else:
             dyn_mask = hit if K == 1 else torch.zeros(B, 1, dtype=torch.int32, device=dev)
+        if loss_prep is not None:
+            if self.num_levels < 2:
+                loss_prep = None
+            else:
+                loss_prep = dict(loss_prep, dyn=dyn_mask.reshape(-1).to(torch.int32).contiguous(), zo=zo)
+        # Training fuses the per-ray stages (composite / resample are launch-bound at 4096 rays): a level
+        # that is followed by another runs composite + resample + the loss normalisers of both levels as ONE launch
+        # (durf_composite_resample); the last level launches no composite at all -- durf_loss_bwd recomputes it
+        # anyway and fills this level's rgb / depth / acc / weights (`deferred`).  Inference keeps the plain calls.
+        fused = train and loss_prep is not None
+        t_next = None
         for lvl in range(self.num_levels):
+            last = lvl == self.num_levels - 1
             if lvl == 0:
                 t_vals = ops.sample_t(near, far, N, noise['t_rand'] if randomized else None, self.lindisp)
+            elif t_next is not None:
+                t_vals = t_next
             else:
                 t_vals = ops.resample(t_vals, weights, self.resample_padding,
                                       noise['u_rand'] if randomized else None)
@@ -228,14 +244,26 @@ class MipNerfModel:
             if randomized and self.density_noise > 0:    # :236-240 (added once to the merged raw density)
                 dn = noise['density'][lvl] if 'density' in noise else torch.randn(B, N, device=dev, generator=g)
                 raw_b[:, 3] += self.density_noise * dn.reshape(-1)
-            rgb, depth, acc, weights, t_mids, t_dists = ops.composite_fwd(
-                raw_b, raws, slot, t_vals, d_s, self.density_bias, bk)
+            deferred = False
+            if fused and not last:
+                rgb, depth, acc, weights, t_mids, t_dists, t_next = ops.composite_resample(
+                    raw_b, raws, slot, t_vals, d_s, self.density_bias, bk, self.resample_padding,
+                    noise['u_rand'] if randomized else None, prep=dict(loss_prep, level=lvl))
+            elif fused:
+                t_next = None
+                rgb, depth, acc = torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
+                weights, t_mids, t_dists = (torch.empty(B, N, device=dev) for _ in range(3))
+                deferred = True
+            else:
+                t_next = None
+                rgb, depth, acc, weights, t_mids, t_dists = ops.composite_fwd(
+                    raw_b, raws, slot, t_vals, d_s, self.density_bias, bk)
             ret.append((rgb, depth, acc, weights, t_vals, t_mids, t_dists, [pose[:, :3], box_rot0],
                         dyn_mask, zo))
             if train:
                 ctx['levels'].append(dict(t_vals=t_vals, enc_b=enc_b, raw_b=raw_b, stash_b=stash_b,
                                           raws=raws, slabs=slabs, mask_b=mask_b, rgb=rgb, depth=depth,
-                                          acc=acc, weights=weights))
+                                          acc=acc, weights=weights, t_mids=t_mids, t_dists=t_dists, deferred=deferred))
         return ret, ctx
 
     def apply(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,

@@ -214,6 +214,40 @@ def composite_fwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, density_bias=-1.0, bk
     return rgb, depth, acc, weights, t_mids, t_dists
 
 
+def composite_resample(raw_bkgd, raw_obj, slot, t_vals, dirs_s, density_bias=-1.0, bkgd_mode=BKGD_GREY,
+                       padding=0.01, u_rand=None, want_t=True, prep=None):
+    """composite_fwd + resample in one launch (bit-identical to the two calls) -> (rgb, depth, acc, weights,
+    t_mids, t_dists, t_vals_next).  prep = dict(lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level,
+    disable_multiscale, norms [L,5]) also fills norms[level] (when level == 0) and norms[level + 1]: durf_loss_prep's
+    job for both levels."""
+    B, N = t_vals.shape[0], t_vals.shape[1] - 1
+    K = len(raw_obj)
+    dev = t_vals.device
+    rgb = torch.empty(B, 3, device=dev)
+    depth = torch.empty(B, device=dev)
+    acc = torch.empty(B, device=dev)
+    weights = torch.empty(B, N, device=dev)
+    t_mids = torch.empty(B, N, device=dev) if want_t else None
+    t_dists = torch.empty(B, N, device=dev) if want_t else None
+    t_next = torch.empty(B, N + 1, device=dev)
+    ptrs = (C.c_void_p * max(K, 1))(*[r.data_ptr() for r in raw_obj])
+    pa = [None] * 5 + [0.0, 0.0, 0, 0] + [None] * 4
+    if prep is not None:
+        lvl = int(prep['level'])
+        norms = prep['norms']
+        buf = torch.empty(2, PREP_ROWS, B, device=dev)
+        pa = [_p(_f32(prep['lossmult'])), _p(_f32(prep['gt_depth'])), _p(_f32(prep['sky'])), _p(prep['dyn']),
+              _p(_f32(prep['zo'])), float(prep['eps']), float(prep['box_loss_mult']), lvl,
+              int(prep['disable_multiscale']),
+              _p(buf[0]) if lvl == 0 else None, _p(norms[lvl]) if lvl == 0 else None, _p(buf[1]), _p(norms[lvl + 1])]
+    with _Timed('composite_resample'):
+        _lib.check(_lib.lib().durf_composite_resample(
+            _stream(), B, N, K, _p(_f32(raw_bkgd)), ptrs, _p(slot), _p(_f32(t_vals)), _p(_f32(dirs_s)), density_bias,
+            bkgd_mode, _p(rgb), _p(depth), _p(acc), _p(weights), _p(t_mids), _p(t_dists), padding,
+            _p(None if u_rand is None else _f32(u_rand)), _p(t_next), *pa), 'durf_composite_resample')
+    return rgb, depth, acc, weights, t_mids, t_dists, t_next
+
+
 def resample(t_vals, weights, padding=0.01, u_rand=None):
     B, N = weights.shape
     out = torch.empty(B, N + 1, device=t_vals.device)
@@ -246,8 +280,10 @@ def loss_prep(t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, leve
 
 
 def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, eps,
-             mults, box_loss_mult, level, bg, density_bias=-1.0, disable_multiscale=False, sums=None):
-    """-> draw [B*N,4], term_sums[7] (rgb, obj, depth, near, empty, sky, dist numerators)"""
+             mults, box_loss_mult, level, bg, density_bias=-1.0, disable_multiscale=False, sums=None, render_out=None):
+    """-> draw [B*N,4], term_sums[7] (rgb, obj, depth, near, empty, sky, dist numerators).
+    render_out = (rgb [B,3], depth [B], acc [B], weights [B,N], t_mids [B,N], t_dists [B,N]) tensors to fill with the level's rendered
+    outputs (what composite_fwd returns; a training step then skips that launch for the last level)."""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     K = len(raw_obj)
     dev = t_vals.device
@@ -262,7 +298,7 @@ def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth
                                         _p(_f32(lossmult)), _p(_f32(gt_depth)), _p(_f32(sky)), _p(dyn),
                                         _p(_f32(zo)), _p(norm), eps, m, box_loss_mult, level,
                                         int(disable_multiscale), bg, density_bias, _p(draw), _p(terms),
-                                        _p(sums)), 'durf_loss_bwd')
+                                        _p(sums), *[_p(t) for t in (render_out or (None,) * 6)]), 'durf_loss_bwd')
     return draw, sums
 
 

@@ -58,38 +58,45 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     Returns (grad_flat, raw stats dict of device tensors, pose)."""
     pose_opt = not (model.no_pose_opt and model.no_yaw_opt)
     rays = batch['rays']
-    ret, ctx = model._forward(variables, rng, rays, batch['init'], batch['ext'], batch['ts'],
-                              config.randomized, config.rand_bkgd, config.white_bkgd, alpha, train=True,
-                              noise=noise)
-    B, N, K = ctx['B'], ctx['N'], ctx['K']
     L = model.num_levels
-    lay = variables.layout
     dev = variables.flat.device
-    rows = B * N
     lossmult = rays.lossmult.reshape(-1).contiguous()
     gt_depth = batch['depth'].reshape(-1).contiguous()
     sky = batch['sky'].reshape(-1).contiguous()
+    norms = torch.empty(L, ops.PREP_ROWS, device=dev)
+    # with >= 2 levels the forward's fused per-ray launches also compute the loss normalisers (durf_loss_prep's job)
+    prep = dict(lossmult=lossmult, gt_depth=gt_depth, sky=sky, eps=float(eps), box_loss_mult=float(config.box_loss_mult),
+                disable_multiscale=config.disable_multiscale_loss, norms=norms) if L >= 2 else None
+    ret, ctx = model._forward(variables, rng, rays, batch['init'], batch['ext'], batch['ts'],
+                              config.randomized, config.rand_bkgd, config.white_bkgd, alpha, train=True,
+                              noise=noise, loss_prep=prep)
+    B, N, K = ctx['B'], ctx['N'], ctx['K']
+    lay = variables.layout
+    rows = B * N
     pixels = batch['pixels'][..., :3].contiguous()
     dyn = ret[0][8].reshape(-1).to(torch.int32).contiguous()
     bg = 0.0 if config.rand_bkgd else (1.0 if config.white_bkgd else 0.5)
     grad = torch.zeros_like(variables.flat)
     bufs = ops.dw_buffers(om.W_BKGD, dev)
-    dzs = []                                    # per-level (dz, dz_out) of the bkgd MLP, consumed by ONE dW launch
+    dzs = [None] * L                            # per-level (dz, dz_out) of the bkgd MLP, consumed by ONE dW launch
     view_tile = ops.expand_view(rows, N, ctx['view'])
-    norms = torch.empty(L, ops.PREP_ROWS, device=dev)
     sums = torch.empty(L, ops.TERM_ROWS, device=dev)
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
-    for lvl in range(L):
+    # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
+    for lvl in reversed(range(L)):
         lv = ctx['levels'][lvl]
-        norm = ops.loss_prep(lv['t_vals'], lossmult, gt_depth, sky, dyn, ctx['zo'], float(eps),
-                             float(config.box_loss_mult), lvl, config.disable_multiscale_loss, norm=norms[lvl])
+        if prep is None:
+            ops.loss_prep(lv['t_vals'], lossmult, gt_depth, sky, dyn, ctx['zo'], float(eps),
+                          float(config.box_loss_mult), lvl, config.disable_multiscale_loss, norm=norms[lvl])
+        norm = norms[lvl]
+        out = (lv['rgb'], lv['depth'], lv['acc'], lv['weights'], lv['t_mids'], lv['t_dists']) if lv['deferred'] else None
         draw, _ = ops.loss_bwd(lv['raw_b'], lv['raws'], ctx['slot'], lv['t_vals'], ctx['d_s'], pixels, lossmult,
                                gt_depth, sky, dyn, ctx['zo'], norm, float(eps),
                                level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
-                               model.density_bias, config.disable_multiscale_loss, sums=sums[lvl])
-        dzs.append(ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b']))
+                               model.density_bias, config.disable_multiscale_loss, sums=sums[lvl], render_out=out)
+        dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
         if K:                                 # all K object MLPs: one call (csrc/objects.hip)
             ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
             for k in range(K if pose_opt else 0):   # d(loss)/d(box pose) through the object encoding

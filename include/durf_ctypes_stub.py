@@ -1,56 +1,3 @@
-# INTEGRATION — dropping the MI355X ray pipeline into FelTris/durf
-
-The reference hot path is plain Python calling `jax.numpy`; there is no FFI to re-bind. A maintainer
-integrates at one of two levels.
-
-## A. Python level (what `train_boxpose.py` calls)
-
-Replace three imports; everything the train script and the notebooks call keeps its name, argument
-order and return structure (torch tensors stand in for `jnp` arrays):
-
-```python
-# train_boxpose.py:34-38
-from durf_amd import obbpose_model          # construct_mipnerf, MipNerfModel, render_image
-from durf_amd import utils                  # Config, Rays/BoxRays, Stats, load_config (gin subset)
-from durf_amd import math                   # learning_rate_decay, freq_alpha_rate, mse_to_psnr
-from durf_amd.train_boxpose import train_step, create_train_state, init_distributed, shard_batch
-
-rank, world, local = init_distributed()                 # replaces jax.pmap (:370-374): 1 process / GPU
-model, variables = obbpose_model.construct_mipnerf(key, dataset.peek())          # :339
-state = create_train_state(variables)                                            # :343-344
-for step, batch in zip(range(init_step, config.max_steps + 1), dataset):         # :420
-    lr, eps, alpha = learning_rate_fn(step), eps_rate_fn(step), alpha_rate_fn(step)
-    batch = shard_batch(to_device(batch), rank, world)
-    state, stats, keys, pose = train_step(model, config, keys, state, batch, lr, eps, alpha, prev)   # :434
-    prevs[ts, :, :3] = pose.cpu().numpy()                                        # :437
-```
-
-`render_image(render_fn, rays, init, ext, ts, rng, alpha, chunk)` (`obbpose_model.py:421`) takes a
-`render_fn(rng, batch)` exactly like the pmapped `render_eval_fn` (`train_boxpose.py:377-390`):
-
-```python
-def render_fn(rng, batch):
-    return model.apply(variables, rng, batch['rays'], batch['init'], batch['ext'], batch['ts'],
-                       randomized=False, rand_bkgd=False, white_bkgd=config.white_bkgd, alpha=batch['alpha'])
-```
-
-Error behaviour mirrors the reference where it has any: `ValueError('Batch size must be divisible by the
-number of devices.')` (`train_boxpose.py:332-333`); unsupported knob values raise `NotImplementedError`
-instead of silently computing something else.
-
-## B. C-ABI level (`include/durf_hip.h`, `durf_amd/libdurf_hip.so`)
-
-If the JAX program is kept and only the device work is swapped (e.g. behind `jax.pure_callback` or a
-dlpack hand-off), this is the ctypes stub a maintainer adds next to `internal/obbpose_model.py`; it
-replaces the body of `MipNerfModel.__call__` (`obbpose_model.py:94-261`). All pointers are device
-pointers of caller-owned buffers, every call is asynchronous on `stream`:
-
-The binding below is GENERATED from `include/durf_hip.h` (`tools/gen_integration_stub.py`; the same text is
-committed as `include/durf_ctypes_stub.py`, and `tests/test_host_logic.py` fails when either copy or
-`durf_amd/_lib.py`'s table drifts from the header):
-
-<!-- BEGIN GENERATED: tools/gen_integration_stub.py -->
-```python
 """ctypes binding of libdurf_hip.so for a reference-side caller -- GENERATED from include/durf_hip.h by
 tools/gen_integration_stub.py (do not edit; `--check` runs in the CPU test-suite).  All `vp` arguments are
 DEVICE pointers of caller-owned buffers except `stream` (hipStream_t); C.POINTER(...) arguments are host
@@ -187,61 +134,3 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_ssim.argtypes = [vp, i32, i32, i32, vp, vp, f32, i32, vp, f32, f32, vp, vp, vp]
     #   (stream, H, W, C, img0, img1, max_val, filter_size, filt_dev, k1, k2, ssim_map, scratch, ssim_mean)
     return L
-```
-<!-- END GENERATED -->
-
-One level of `obbpose_model.py:134-258` through it (inference; `bufs.*` are device pointers the caller owns):
-
-```python
-from include.durf_ctypes_stub import bind
-L = bind()
-
-def render_level0(stream, B, N, K, rays, pose_ts, ext, params_bkgd, bufs, barf_w):
-    L.durf_ray_setup(stream, B, K, rays.origins, rays.directions, pose_ts, ext,
-                     bufs.o_s, bufs.d_s, bufs.hit, bufs.zo)
-    L.durf_compact_hits(stream, B, K, bufs.hit, bufs.idx, bufs.count, bufs.slot)
-    L.durf_view_enc(stream, B, rays.viewdirs, bufs.view, None)
-    L.durf_sample_t(stream, B, N, rays.near, rays.far, None, 0, bufs.t_vals)     # t_rand=None, lindisp=0
-    L.durf_encode_bkgd(stream, B, N, bufs.t_vals, bufs.o_s, bufs.d_s, rays.radii, bufs.hit, K,
-                       1, bufs.enc, None)                                         # DURF_ENC_CONTRACT
-    L.durf_pack_weights(stream, 256, 60, params_bkgd, bufs.wf, None)
-    L.durf_mlp_fwd(stream, 256, B * N, N, bufs.enc, bufs.view, None, None, bufs.wf, bufs.raw, None, None)
-    for k in range(K):                      # or durf_obj_fwd_batch: all K objects in one call
-        L.durf_encode_obj(stream, B, N, bufs.idx[k], bufs.count[k], bufs.t_vals, bufs.o_s, bufs.d_s, rays.radii,
-                          barf_w, 0, bufs.enc_obj[k], None)                       # barf_w: 10 host floats, flags = 0
-        L.durf_mlp_fwd(stream, 128, B * N, N, bufs.enc_obj[k], bufs.view, bufs.idx[k], bufs.count[k],
-                       bufs.wf_obj[k], bufs.raw_obj[k], None, None)
-    # a level that is followed by another: composite + resample in one launch (t_vals of level 1 out)
-    L.durf_composite_resample(stream, B, N, K, bufs.raw, bufs.raw_obj_ptrs, bufs.slot, bufs.t_vals, bufs.d_s,
-                              -1.0, 0, bufs.rgb, bufs.depth, bufs.acc, bufs.weights, None, None,
-                              0.01, None, bufs.t_vals1,
-                              None, None, None, None, None, 0.0, 0.0, 0, 0, None, None, None, None)
-```
-
-Training adds `durf_loss_prep` (or the loss-prep arguments of `durf_composite_resample`), `durf_loss_bwd` (`train_boxpose.py:94-220` + reverse of compositing),
-`durf_mlp_bwd(…, relu_mask, dz, dz_out, d_enc)` per level, `durf_expand_view`, then ONE `durf_mlp_dw(…, nlevels,
-enc[], view[], stash[], dz[], dz_out[], part, bpart)` over the samples of every level and one `durf_mlp_dw_finalize` per MLP (together the `jax.value_and_grad` of
-`:251-252`), `durf_encode_obj_bwd` + `durf_pose_finish` when `no_pose_opt`/`no_yaw_opt` are off
-(`obbpose_model.py:100-104`), `durf_train_stats` (the `Stats` scalars of `:123-249,291-292` in one launch) and `durf_clip_adam` (`:257-289`, takes `inv_world` so the DP mean is folded
-into the update after one RCCL all-reduce of the flat gradient); the complete call sequence is
-`durf_amd/train_boxpose.py:loss_and_grad`. `durf_amd/_lib.py` holds the product's own `argtypes` table and is
-checked against the header by `tests/test_host_logic.py`.
-
-Parameter exchange: flax `params/{box_centers, MLP_0/Dense_i/{kernel,bias}, BoxMLP_k/...}` ↔ one flat
-fp32 buffer in the order documented at the top of `include/durf_hip.h`
-(`durf_mlp_layer_offset(width, in_dim, layer, want_bias)` gives every offset), kernels `[in,out]`
-row-major exactly as flax stores them — a checkpoint converts with one `np.concatenate`.
-
-## Data side (optional)
-
-`durf_amd.raygen.TimestepData(camtoworlds, focal, principal_point, h, w, images, depth, sky)` keeps one timestep's
-cameras and images in HBM; `raygen.generate_batch(ts_data, ray_indices, near, far)` returns the `BoxRays` plus the
-gathered pixels / depth / sky that `Waymo._next_train` (`obbpose_dataset.py:1551-1587`) assembles on the host, so
-the train loop can feed `train_step` without a per-step H2D copy. `durf_amd.metrics.compute_ssim` /
-`mse_to_psnr` replace `math.compute_ssim` / `math.mse_to_psnr` in the test loop (`train_boxpose.py:398,562-575`),
-`durf_amd.checkpoints.{save,restore}_checkpoint` replace `flax.training.checkpoints` (`:404,531,580`).
-
-## Build
-
-`python -c "import __graft_entry__ as g; g.build()"` (or `make -C durf_amd/csrc`): `hipcc
---offload-arch=gfx950`, 10 translation units, ~40 s; the `.so` is built in-tree (git-ignored).

@@ -120,6 +120,20 @@ int durf_composite_fwd(void* stream, int B, int N, int K, const float* raw_bkgd,
                        float density_bias, int bkgd_mode, float* rgb, float* depth, float* acc,
                        float* weights, float* t_mids, float* t_dists);
 
+/* K8 + K9 in one launch for a level that is followed by another (obbpose_model.py:143-151,232-254):
+ * durf_composite_fwd, then durf_resample of its weights (handed over through LDS) -> t_vals_out [B,N+1];
+ * outputs bit-identical to the two separate calls.  With lossmult != NULL it also does durf_loss_prep's job
+ * for level+1 (from t_vals_out) into prep_next/norm_next and, if prep_this != NULL, for `level` (from t_vals)
+ * into prep_this/norm_this, so that a training step launches nothing else for the normalisers. */
+int durf_composite_resample(void* stream, int B, int N, int K, const float* raw_bkgd, const float* const* raw_obj,
+                            const int32_t* slot, const float* t_vals, const float* dirs_s, float density_bias,
+                            int bkgd_mode, float* rgb, float* depth, float* acc, float* weights, float* t_mids,
+                            float* t_dists, float resample_padding, const float* u_rand, float* t_vals_out,
+                            const float* lossmult /* nullable: no loss prep */, const float* gt_depth, const float* sky,
+                            const int32_t* dyn, const float* zo, float eps, float box_loss_mult, int level,
+                            int disable_multiscale, float* prep_this /* nullable */, float* norm_this,
+                            float* prep_next, float* norm_next);
+
 /* K9 resample: mip.resample_along_rays + math.sorted_piecewise_constant_pdf
  * (mip.py:373-416, math.py:222-284). u_rand nullable. */
 int durf_resample(void* stream, int B, int N, const float* t_vals, const float* weights,
@@ -145,7 +159,11 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                   const float* lossmult, const float* gt_depth, const float* sky, const int32_t* dyn,
                   const float* zo, const float* norm, float eps, const float* mults,
                   float box_loss_mult, int level, int disable_multiscale, float bg, float density_bias,
-                  float* draw, float* terms, float* term_sums);
+                  float* draw, float* terms, float* term_sums,
+                  float* rgb_out /* nullable [B,3] */, float* depth_out /* nullable [B] */,
+                  float* acc_out /* nullable [B] */, float* weights_out /* nullable [B,N] */,
+                  float* t_mids_out, float* t_dists_out /* nullable [B,N], written with weights_out: the level's
+                  rendered outputs, bit-identical to durf_composite_fwd's, for a level nothing is resampled from */);
 
 /* Scalars of utils.Stats from the per-level sums (train_boxpose.py:123-249,291-292) in one launch.
  * norms [L,5] (durf_loss_prep), sums [L,7] (durf_loss_bwd), weight_l2 nullable device scalar,
@@ -183,8 +201,8 @@ int durf_mlp_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N
                          int nlevels /* the same rows, N, count, nlevels as the durf_mlp_dw call */,
                          const float* part, const float* bpart, float* grad_mlp);
 
-/* The K per-object BoxMLPs of one level as one call each (obbpose_model.py:174-201): loops over the
- * objects inside the library and spreads them over side streams forked from / joined to `stream`.
+/* The K per-object BoxMLPs of one level as one call each (obbpose_model.py:174-201): every kernel of the
+ * per-object path runs ONCE with the object index in blockIdx.y (csrc/objects.hip), on `stream`.
  * Slabs are [K, ...] with per-object strides: enc durf_obj_enc_stride, view_tile durf_obj_view_stride,
  * dz_out durf_obj_dzout_stride, stash/dz durf_mlp_stash_bytes(128, B*N), mask durf_mlp_mask_bytes(B*N),
  * raw B*N*4 floats, d_enc B*N*64 floats, weight packs durf_wpack_{fwd,bwd}_bytes(128), params / grads

@@ -261,3 +261,54 @@ def test_resample(cuda, N, randomized):
     # tolerance: 1e-4 * far; fp32 cumsum order shifts the CDF by a few ulp
     torch.testing.assert_close(out.cpu(), ref, rtol=0, atol=4e-3)
     assert (out.cpu() - ref).abs().median() < 1e-5
+
+
+@pytest.mark.parametrize('N,K,randomized,blm', [(128, 2, True, 0.0), (64, 0, False, 0.0), (32, 1, True, 2.0), (256, 0, True, 0.0)])
+def test_composite_resample_fused_is_bit_identical(cuda, N, K, randomized, blm):
+    """durf_composite_resample == durf_composite_fwd + durf_resample (+ durf_loss_prep of both levels), bit for bit;
+    durf_loss_bwd's optional rendered outputs == durf_composite_fwd's."""
+    Bn = 301                                  # not a multiple of the 4 rays per workgroup
+    g = torch.Generator().manual_seed(40 + N)
+    raw_b = (torch.randn(Bn, N, 4, generator=g) * 2).reshape(-1, 4).to(cuda)
+    t_vals = torch.sort(torch.rand(Bn, N + 1, generator=g) * 40, dim=-1).values.to(cuda)
+    dirs = torch.randn(Bn, 3, generator=g).to(cuda)
+    hit = (torch.rand(Bn, max(K, 1), generator=g) < 0.3).int()[:, :K]
+    raws = []
+    slot = torch.full((Bn, max(K, 1)), -1, dtype=torch.int32)
+    for k in range(K):
+        rows = torch.nonzero(hit[:, k]).flatten()
+        raws.append(torch.randn(Bn * N, 4, generator=g).to(cuda))
+        slot[rows, k] = torch.arange(rows.numel(), dtype=torch.int32)
+    slot = slot.to(cuda)
+    u = torch.rand(Bn, N + 1, generator=g).to(cuda) if randomized else None
+    lossmult = torch.ones(Bn, device=cuda)
+    depth = torch.where(torch.rand(Bn, generator=g) < 0.4, torch.rand(Bn, generator=g) * 30 + 0.5, torch.zeros(Bn)).to(cuda)
+    sky = torch.where(torch.rand(Bn, generator=g) < 0.2, torch.full((Bn,), 0.975), torch.zeros(Bn)).to(cuda)
+    dyn = (torch.rand(Bn, generator=g) < 0.2).int().to(cuda)
+    zo = (torch.rand(Bn, generator=g) * 20).to(cuda) * dyn
+    eps = 0.7
+    # separate launches
+    c = ops.composite_fwd(raw_b, raws, slot, t_vals, dirs, -1.0, ops.BKGD_GREY)
+    t1 = ops.resample(t_vals, c[3], 0.01, u)
+    n0 = ops.loss_prep(t_vals, lossmult, depth, sky, dyn, zo, eps, blm, 0)
+    n1 = ops.loss_prep(t1, lossmult, depth, sky, dyn, zo, eps, blm, 1)
+    # fused
+    norms = torch.full((2, ops.PREP_ROWS), -7.0, device=cuda)
+    f = ops.composite_resample(raw_b, raws, slot, t_vals, dirs, -1.0, ops.BKGD_GREY, 0.01, u,
+                               prep=dict(lossmult=lossmult, gt_depth=depth, sky=sky, dyn=dyn, zo=zo, eps=eps,
+                                         box_loss_mult=blm, level=0, disable_multiscale=False, norms=norms))
+    for a, b_, nm in zip(c, f[:6], ['rgb', 'depth', 'acc', 'weights', 't_mids', 't_dists']):
+        assert torch.equal(a, b_), nm
+    assert torch.equal(t1, f[6]), 't_vals of the next level'
+    assert torch.equal(norms[0], n0) and torch.equal(norms[1], n1), (norms, n0, n1)
+    # without the loss prep
+    f2 = ops.composite_resample(raw_b, raws, slot, t_vals, dirs, -1.0, ops.BKGD_GREY, 0.01, u)
+    assert torch.equal(t1, f2[6]) and torch.equal(c[3], f2[3])
+    # rendered outputs out of the loss kernel
+    out = (torch.empty(Bn, 3, device=cuda), torch.empty(Bn, device=cuda), torch.empty(Bn, device=cuda),
+           torch.empty(Bn, N, device=cuda), torch.empty(Bn, N, device=cuda), torch.empty(Bn, N, device=cuda))
+    pixels = torch.rand(Bn, 3, generator=g).to(cuda)
+    ops.loss_bwd(raw_b, raws, slot, t_vals, dirs, pixels, lossmult, depth, sky, dyn, zo, n0, eps,
+                 [1.0, 1.0, 1e-4, 1e-2, 1.0, 1e-6], blm, 0, 0.5, render_out=out)
+    for a, b_, nm in zip(c, out, ['rgb', 'depth', 'acc', 'weights', 't_mids', 't_dists']):
+        assert torch.equal(a, b_), 'loss_bwd ' + nm

@@ -99,6 +99,32 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert L.durf_mlp_layer_offset(256, 60, layer, 1) - L.durf_mlp_layer_offset(256, 60, layer, 0) == fi * fo
 
 
+def test_integration_stub_is_generated_from_the_header():
+    """INTEGRATION.md's ctypes stub and include/durf_ctypes_stub.py are generated from include/durf_hip.h, and the
+    product's own binding table (durf_amd/_lib.py) declares the same argument types for every symbol."""
+    import ctypes as C
+    import subprocess
+    import sys
+    gen = os.path.join(ROOT, 'tools', 'gen_integration_stub.py')
+    p = subprocess.run([sys.executable, gen, '--check'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    assert p.returncode == 0, p.stdout.decode()
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import gen_integration_stub as G
+    env = dict(C=C, vp=C.c_void_p, i32=C.c_int, f32=C.c_float, u64=C.c_size_t)
+    fns = G.parse_header()
+    assert sorted(n for n, _, _ in fns) == _lib.symbols()
+    for name, ret, params in fns:
+        want_ret, want_args = _lib._SIGS[name]
+        assert eval(ret, env) is want_ret, name
+        got = [eval(t, env) for t, _ in params]
+        assert got == list(want_args), (name, [n for _, n in params])
+    # the stub module itself binds against the built library
+    sys.path.insert(0, os.path.join(ROOT, 'include'))
+    import durf_ctypes_stub
+    L = durf_ctypes_stub.bind(_lib.LIB_PATH)
+    assert L.durf_version() == _lib.lib().durf_version()
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, '_lib', None)
     monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/libdurf_hip.so')
