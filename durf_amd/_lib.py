@@ -38,6 +38,13 @@ _SIGS = {
                                       vp, vp, vp, vp, vp, vp, f32, vp, vp,
                                       vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp, vp, vp]),
     'durf_resample': (i32, [vp, i32, i32, vp, vp, f32, vp, vp]),
+    'durf_sorted_piecewise_constant_pdf': (i32, [vp, i32, i32, vp, vp, vp, vp]),
+    'durf_mlp_f32_act_floats': (u64, [i32, i32]),
+    'durf_mlp_f32_dz_floats': (u64, [i32, i32]),
+    'durf_mlp_f32_dw_scratch_floats': (u64, [i32, i32, i32]),
+    'durf_mlp_fwd_f32': (i32, [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_mlp_bwd_f32': (i32, [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_mlp_dw_f32': (i32, [vp, i32, i32, u64, i32, vp, vp, vp, i32, vp, vp, vp]),
     'durf_obj_enc_stride': (u64, [i32, i32]),
     'durf_obj_view_stride': (u64, [i32, i32]),
     'durf_obj_dzout_stride': (u64, [i32, i32]),

@@ -108,7 +108,7 @@ def from_state_dict(state, sd):
         cpu = torch.zeros(buf.shape, dtype=torch.float32)
         _fill(state.variables.like(cpu), tree, what)
         buf.copy_(cpu.to(dev))
-    state.step = int(opt['state']['step'])
+    state.step = int(np.asarray(opt['state']['step']).reshape(-1)[0])
     return state
 
 

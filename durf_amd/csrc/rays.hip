@@ -297,8 +297,11 @@ __device__ __forceinline__ float wrap_100pi(float y) {
     return y;
 }
 
+#ifndef ENC_BLOCK
+#define ENC_BLOCK 256
+#endif
 template <bool OBJ>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(ENC_BLOCK)
 k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
               const float* __restrict__ t_vals, const float* __restrict__ origins_s,
               const float* __restrict__ dirs_s, const float* __restrict__ radii,
@@ -359,7 +362,11 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
                 bf16x8 o8;
 #pragma unroll
                 for (int e = 0; e < 8; e++) o8[e] = (__bf16)feat[q * 8 + e];
+#if defined(ENC_NT)
+                __builtin_nontemporal_store(o8, (bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16));
+#else
                 *(bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16) = o8;
+#endif
             }
         }
     };
@@ -495,7 +502,7 @@ int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const floa
                            (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
                            hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
     else
-        hipLaunchKernelGGL((k_encode_lane<false>), dim3(durf_cdiv((size_t)B * N, 256)), dim3(256), 0,
+        hipLaunchKernelGGL((k_encode_lane<false>), dim3(durf_cdiv((size_t)B * N, ENC_BLOCK)), dim3(ENC_BLOCK), 0,
                            (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
                            hit, K, contraction, BarfW{}, (char*)out_tile, (size_t)0, (size_t)0);
     DURF_CHECK_LAUNCH("durf_encode_bkgd");
@@ -525,7 +532,7 @@ int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* i
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
                            nullptr, 0, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), bw, (bf16x8*)out_tile, out_f32);
     else
-        hipLaunchKernelGGL((k_encode_lane<true>), dim3(durf_cdiv((size_t)max_rays * N, 256), K), dim3(256), 0,
+        hipLaunchKernelGGL((k_encode_lane<true>), dim3(durf_cdiv((size_t)max_rays * N, ENC_BLOCK), K), dim3(ENC_BLOCK), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
                            nullptr, 0, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), bw, (char*)out_tile, (size_t)max_rays, out_stride);
     DURF_CHECK_LAUNCH("durf_encode_obj");

@@ -130,7 +130,7 @@ k_composite_fwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrs
 template <int P>
 __device__ __forceinline__ float resample_ray(bool active, int b, int lane, int N, const float* sw, float* cdf,
                                               const float* bins, float padding, const float* __restrict__ u_rand,
-                                              float* __restrict__ t_out, const float* gt_eps_dm) {
+                                              float* __restrict__ t_out, const float* gt_eps_dm, bool blur = true) {
     float pw[P];
     float tot = 0.0f;
 #pragma unroll
@@ -139,7 +139,9 @@ __device__ __forceinline__ float resample_ray(bool active, int b, int lane, int 
         pw[p] = 0.0f;
         if (active && n < N) {
             const float wl = sw[n > 0 ? n - 1 : 0], wc = sw[n], wr = sw[n < N - 1 ? n + 1 : N - 1];
-            pw[p] = 0.5f * (fmaxf(wl, wc) + fmaxf(wc, wr)) + padding;
+            // blur-pool + padding of mip.resample_along_rays (mip.py:393-404); without it this is
+            // math.sorted_piecewise_constant_pdf on the given weights
+            pw[p] = blur ? 0.5f * (fmaxf(wl, wc) + fmaxf(wc, wr)) + padding : wc;
             tot += pw[p];
         }
     }
@@ -197,7 +199,7 @@ __device__ __forceinline__ float resample_ray(bool active, int b, int lane, int 
 template <int P>
 __global__ void __launch_bounds__(256)
 k_resample(int B, int N, const float* __restrict__ t_vals, const float* __restrict__ w_in,
-           float padding, const float* __restrict__ u_rand, float* __restrict__ t_out) {
+           float padding, const float* __restrict__ u_rand, float* __restrict__ t_out, int blur) {
     __shared__ float s_w[4][RS_MAXN + 2];
     __shared__ float s_cdf[4][RS_MAXN + 2];
     __shared__ float s_bins[4][RS_MAXN + 2];
@@ -211,7 +213,7 @@ k_resample(int B, int N, const float* __restrict__ t_vals, const float* __restri
         for (int n = lane; n <= N; n += 64) bins[n] = t_vals[(size_t)b * (N + 1) + n];
     }
     __syncthreads();
-    resample_ray<P>(active, b, lane, N, sw, s_cdf[wv], bins, padding, u_rand, t_out, nullptr);
+    resample_ray<P>(active, b, lane, N, sw, s_cdf[wv], bins, padding, u_rand, t_out, nullptr, blur != 0);
 }
 
 // ---------------------------------------------------------------------------
@@ -353,10 +355,23 @@ int durf_resample(void* stream, int B, int N, const float* t_vals, const float* 
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_R(P)                                                                              \
     hipLaunchKernelGGL(k_resample<P>, grid, block, 0, s, B, N, t_vals, weights, resample_padding, \
-                       u_rand, t_vals_out)
+                       u_rand, t_vals_out, 1)
     if (N <= 64) LAUNCH_R(1); else if (N <= 128) LAUNCH_R(2); else LAUNCH_R(4);
 #undef LAUNCH_R
     DURF_CHECK_LAUNCH("durf_resample");
+    return 0;
+}
+
+int durf_sorted_piecewise_constant_pdf(void* stream, int B, int N, const float* bins, const float* weights,
+                                       const float* u_rand, float* samples) {
+    DURF_REQUIRE(N >= 2 && N <= RS_MAXN, "2 <= N <= 256");
+    if (B <= 0) return 0;
+    dim3 grid(durf_cdiv(B, 4)), block(256);
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_R(P) hipLaunchKernelGGL(k_resample<P>, grid, block, 0, s, B, N, bins, weights, 0.0f, u_rand, samples, 0)
+    if (N <= 64) LAUNCH_R(1); else if (N <= 128) LAUNCH_R(2); else LAUNCH_R(4);
+#undef LAUNCH_R
+    DURF_CHECK_LAUNCH("durf_sorted_piecewise_constant_pdf");
     return 0;
 }
 

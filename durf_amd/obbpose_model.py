@@ -150,9 +150,14 @@ class MipNerfModel:
     timesteps: int = 5
     no_pose_opt: bool = False
     no_yaw_opt: bool = False
+    # not a reference knob: 'bf16' = the fused MFMA kernels (production); 'f32' = the exact-fp32 parity instrument
+    # (csrc/mlp_f32.hip: fp32 encodings, v_mfma_f32_32x32x2_f32 Dense layers, ~16x slower), which evaluates the
+    # model in the reference's own arithmetic type (obbpose_model.py:326-327, internal/math.py:22-24)
+    mlp_precision: str = 'bf16'
 
     def _check(self):
         bad = []
+        if self.mlp_precision not in ('bf16', 'f32'): bad.append('mlp_precision')
         if self.ray_shape not in ('cone', 'cylinder'): bad.append('ray_shape')
         if not self.use_viewdirs: bad.append('use_viewdirs=False')
         if (self.min_deg_point, self.max_deg_point, self.deg_view) != (0, 10, 4): bad.append('degrees')
@@ -186,9 +191,13 @@ class MipNerfModel:
         view = ops.view_enc(rays.viewdirs)
         radii = rays.radii.reshape(-1).contiguous()
         near, far = rays.near.reshape(-1).contiguous(), rays.far.reshape(-1).contiguous()
-        pk = ops.pack_weights(W_BKGD, IN_BKGD, variables.mlp_flat('MLP_0'), want_bwd=train)
-        packs = {'MLP_0': pk if train else (pk, None)}
-        if Kd:                                       # the K object MLPs sit back to back in the flat buffer
+        f32 = self.mlp_precision == 'f32'
+        view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1] if f32 else None
+        packs = {}
+        if not f32:
+            pk = ops.pack_weights(W_BKGD, IN_BKGD, variables.mlp_flat('MLP_0'), want_bwd=train)
+            packs = {'MLP_0': pk if train else (pk, None)}
+        if Kd and not f32:                           # the K object MLPs sit back to back in the flat buffer
             o0 = lay.mlp_off['BoxMLP_0']
             packs['obj'] = ops.pack_weights_batch(Kd, variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]],
                                                   lay.mlp_size[W_OBJ], want_bwd=train)
@@ -199,7 +208,7 @@ class MipNerfModel:
             noise = dict(t_rand=u[0], u_rand=u[1])
         rows = B * N
         cyl = self.ray_shape == 'cylinder'
-        view_tiles_obj = ops.obj_view_tiles(Kd, B, N, dev) if (train and Kd) else None
+        view_tiles_obj = ops.obj_view_tiles(Kd, B, N, dev) if (train and Kd and not f32) else None
         ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,
                    packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk, view_tiles_obj=view_tiles_obj)
         ret = []
@@ -229,18 +238,26 @@ class MipNerfModel:
             else:
                 t_vals = ops.resample(t_vals, weights, self.resample_padding,
                                       noise['u_rand'] if randomized else None)
-            enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
-                                       disable_integration=self.disable_integration, cylinder=cyl)
-            stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
-            mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
-            raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
-            slabs = None
-            if Kd:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
-                slabs = ops.ObjSlabs(Kd, B, N, dev, train)
-                ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
-                                  view_tile=view_tiles_obj if lvl == 0 else None,
-                                  disable_integration=self.disable_integration, cylinder=cyl)
-            raws = slabs.raws() if Kd else []
+            if f32:
+                lvd = self._level_f32(variables, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count, alpha,
+                                      B, N)
+                raw_b, slabs = lvd['raw_b'], None
+                enc_b = stash_b = mask_b = None
+                raws = lvd['raws']
+            else:
+                lvd = None
+                enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
+                                           disable_integration=self.disable_integration, cylinder=cyl)
+                stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
+                mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
+                raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
+                slabs = None
+                if Kd:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
+                    slabs = ops.ObjSlabs(Kd, B, N, dev, train)
+                    ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
+                                      view_tile=view_tiles_obj if lvl == 0 else None,
+                                      disable_integration=self.disable_integration, cylinder=cyl)
+                raws = slabs.raws() if Kd else []
             if randomized and self.density_noise > 0:    # :236-240 (added once to the merged raw density)
                 dn = noise['density'][lvl] if 'density' in noise else torch.randn(B, N, device=dev, generator=g)
                 raw_b[:, 3] += self.density_noise * dn.reshape(-1)
@@ -263,8 +280,26 @@ class MipNerfModel:
             if train:
                 ctx['levels'].append(dict(t_vals=t_vals, enc_b=enc_b, raw_b=raw_b, stash_b=stash_b,
                                           raws=raws, slabs=slabs, mask_b=mask_b, rgb=rgb, depth=depth,
-                                          acc=acc, weights=weights, t_mids=t_mids, t_dists=t_dists, deferred=deferred))
+                                          acc=acc, weights=weights, t_mids=t_mids, t_dists=t_dists, deferred=deferred,
+                                          f32=lvd))
         return ret, ctx
+
+    def _level_f32(self, variables, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count, alpha, B, N):
+        """encodings + MLPs of one level in exact fp32 (mlp_precision='f32'): accurate-libm encodings emitted as
+        fp32, Dense layers on v_mfma_f32_32x32x2_f32 straight from the fp32 parameters; object MLPs one by one."""
+        rows = B * N
+        _, enc = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction, tile=False, f32=True,
+                                 disable_integration=self.disable_integration, cylinder=cyl)
+        out = ops.mlp_fwd_f32(W_BKGD, IN_BKGD, rows, N, enc, view27, variables.mlp_flat('MLP_0'), want_act=train)
+        d = dict(raw_b=out[0] if train else out, act_b=out[1] if train else None, raws=[], act_o=[])
+        for k in range(Kd):
+            _, enc_k = ops.encode_obj(B, idx[k], count[k:k + 1], t_vals, o_s, d_s, radii, alpha, tile=False, f32=True,
+                                      disable_integration=self.disable_integration, cylinder=cyl)
+            o = ops.mlp_fwd_f32(W_OBJ, IN_OBJ, rows, N, enc_k, view27, variables.mlp_flat('BoxMLP_%d' % k),
+                                ray_idx=idx[k], count=count[k:k + 1], want_act=train)
+            d['raws'].append(o[0] if train else o)
+            d['act_o'].append(o[1] if train else None)
+        return d
 
     def apply(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
               noise=None):
@@ -310,15 +345,38 @@ def render_image(render_fn, rays, init, ext, ts, rng, alpha, chunk=8192):
     """Render all the pixels of an image in test mode (obbpose_model.py:421-479).
 
     render_fn(rng, batch) -> list of per-level tuples (as the pmapped render_eval_fn,
-    train_boxpose.py:377-390); batch keys: rays, init, ext, ts, alpha."""
+    train_boxpose.py:377-390); batch keys: rays, init, ext, ts, alpha.
+
+    Multi-rank (torch.distributed initialised, world > 1): like the reference, every chunk is edge-padded to a
+    multiple of the device count (:454-458), each rank renders its contiguous slice of the chunk, and the slices
+    are all-gathered (the `jax.lax.all_gather` of train_boxpose.py:379) and un-padded, so every rank returns the
+    full image."""
+    import torch.distributed as dist
+    world, rank = 1, 0
+    if dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(), dist.get_rank()
     height, width = rays[0].shape[:2]
     num_rays = height * width
     rays = utils.namedtuple_map(lambda r: r.reshape(num_rays, -1), rays)
     results = []
     for i in range(0, num_rays, chunk):
-        chunk_rays = utils.namedtuple_map(lambda r: r[i:i + chunk].contiguous(), rays)
-        batch = dict(rays=chunk_rays, init=init, ext=ext, ts=ts, alpha=alpha)
-        last = render_fn(rng, batch)[-1]
-        results.append(last[:3])
+        chunk_rays = utils.namedtuple_map(lambda r: r[i:i + chunk], rays)
+        n = chunk_rays[0].shape[0]
+        pad = (-n) % world
+        if pad:                                      # jnp.pad(..., mode='edge'): repeat the last ray
+            chunk_rays = utils.namedtuple_map(lambda r: torch.cat([r, r[-1:].expand(pad, -1)], 0), chunk_rays)
+        per = (n + pad) // world
+        mine = utils.namedtuple_map(lambda r: r[rank * per:(rank + 1) * per].contiguous(), chunk_rays)
+        batch = dict(rays=mine, init=init, ext=ext, ts=ts, alpha=alpha)
+        last = render_fn(rng, batch)[-1][:3]
+        if world > 1:
+            gathered = []
+            for x in last:
+                x = x.contiguous()
+                parts = [torch.empty_like(x) for _ in range(world)]
+                dist.all_gather(parts, x)
+                gathered.append(torch.cat(parts, 0)[:n])         # utils.unshard(x, padding)
+            last = gathered
+        results.append(last)
     rgb, distance, acc = [torch.cat(r, dim=0) for r in zip(*results)]
     return (rgb.reshape(height, width, -1), distance.reshape(height, width), acc.reshape(height, width))

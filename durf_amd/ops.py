@@ -257,6 +257,16 @@ def resample(t_vals, weights, padding=0.01, u_rand=None):
     return out
 
 
+def sorted_piecewise_constant_pdf(bins, weights, u_rand=None):
+    """math.sorted_piecewise_constant_pdf(key, bins, weights, num_samples=N+1, randomized=u_rand is not None)"""
+    B, N = weights.shape
+    out = torch.empty(B, N + 1, device=bins.device)
+    _lib.check(_lib.lib().durf_sorted_piecewise_constant_pdf(_stream(), B, N, _p(_f32(bins)), _p(_f32(weights)),
+                                                             _p(None if u_rand is None else _f32(u_rand)), _p(out)),
+               'durf_sorted_piecewise_constant_pdf')
+    return out
+
+
 # ---------------------------------------------------------------------------
 # training ops
 # ---------------------------------------------------------------------------
@@ -483,3 +493,42 @@ def pose_finish(pose, sums, want_pos, want_rot, grad6):
     K = pose.shape[0]
     _lib.check(_lib.lib().durf_pose_finish(_stream(), K, _p(_f32(pose)), _p(_f32(sums)), int(want_pos),
                                            int(want_rot), _p(_f32(grad6))), 'durf_pose_finish')
+
+
+# ---------------------------------------------------------------------------
+# exact-fp32 MLP (csrc/mlp_f32.hip): the parity instrument behind MipNerfModel(mlp_precision='f32')
+# ---------------------------------------------------------------------------
+def mlp_fwd_f32(width, in_dim, rows, N, enc_f32, view27, mlp_params, ray_idx=None, count=None, want_act=False):
+    """-> raw [rows,4][, act [rows, ACT]] (row-major fp32; enc_f32 [rows,in_dim], view27 [B,27])"""
+    dev = enc_f32.device
+    L = _lib.lib()
+    raw = torch.zeros(rows, 4, device=dev)
+    act = torch.zeros(rows, int(L.durf_mlp_f32_act_floats(width, in_dim)), device=dev) if want_act else None
+    with _Timed('mlp_fwd_f32_%d' % width):
+        _lib.check(L.durf_mlp_fwd_f32(_stream(), width, in_dim, rows, N, _p(_f32(enc_f32)), _p(_f32(view27)),
+                                      _p(ray_idx), _p(count), _p(_f32(mlp_params)), _p(raw), _p(act)),
+                   'durf_mlp_fwd_f32')
+    return (raw, act) if want_act else raw
+
+
+def mlp_bwd_f32(width, in_dim, rows, N, draw, mlp_params, act, ray_idx=None, count=None, want_d_enc=False):
+    """-> dz [rows, DZ][, d_enc [rows,64]]"""
+    dev = draw.device
+    L = _lib.lib()
+    dz = torch.zeros(rows, int(L.durf_mlp_f32_dz_floats(width, in_dim)), device=dev)
+    d_enc = torch.zeros(rows, ENC_DIM, device=dev) if want_d_enc else None
+    _lib.check(L.durf_mlp_bwd_f32(_stream(), width, in_dim, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
+                                  _p(_f32(mlp_params)), _p(_f32(act)), _p(dz), _p(d_enc)), 'durf_mlp_bwd_f32')
+    return (dz, d_enc) if want_d_enc else dz
+
+
+def mlp_dw_f32(width, in_dim, rows, N, act, dz, grad_mlp, count=None, nsplit=32):
+    """weight gradients of one MLP over `rows` samples, ADDED to grad_mlp (flax layout)"""
+    dev = act.device
+    L = _lib.lib()
+    scratch = torch.empty(int(L.durf_mlp_f32_dw_scratch_floats(width, in_dim, nsplit)), device=dev)
+    tiles = torch.empty(3072, dtype=torch.int32, device=dev)
+    g = torch.empty_like(grad_mlp)
+    _lib.check(L.durf_mlp_dw_f32(_stream(), width, in_dim, rows, N, _p(count), _p(_f32(act)), _p(_f32(dz)), nsplit,
+                                 _p(scratch), _p(tiles), _p(g)), 'durf_mlp_dw_f32')
+    grad_mlp += g

@@ -77,9 +77,10 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     dyn = ret[0][8].reshape(-1).to(torch.int32).contiguous()
     bg = 0.0 if config.rand_bkgd else (1.0 if config.white_bkgd else 0.5)
     grad = torch.zeros_like(variables.flat)
-    bufs = ops.dw_buffers(om.W_BKGD, dev)
+    f32 = model.mlp_precision == 'f32'
+    bufs = None if f32 else ops.dw_buffers(om.W_BKGD, dev)
     dzs = [None] * L                            # per-level (dz, dz_out) of the bkgd MLP, consumed by ONE dW launch
-    view_tile = ops.expand_view(rows, N, ctx['view'])
+    view_tile = None if f32 else ops.expand_view(rows, N, ctx['view'])
     sums = torch.empty(L, ops.TERM_ROWS, device=dev)
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
@@ -96,6 +97,22 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                gt_depth, sky, dyn, ctx['zo'], norm, float(eps),
                                level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
                                model.density_bias, config.disable_multiscale_loss, sums=sums[lvl], render_out=out)
+        if f32:                               # exact-fp32 parity instrument: per-MLP fp32 backward + weight gradients
+            fl = lv['f32']
+            off = lay.mlp_off['MLP_0']
+            dz = ops.mlp_bwd_f32(om.W_BKGD, om.IN_BKGD, rows, N, draw, variables.mlp_flat('MLP_0'), fl['act_b'])
+            ops.mlp_dw_f32(om.W_BKGD, om.IN_BKGD, rows, N, fl['act_b'], dz, grad[off:off + lay.mlp_size[om.W_BKGD]])
+            for k in range(K):
+                ck = ctx['count'][k:k + 1]
+                o = ops.mlp_bwd_f32(om.W_OBJ, om.IN_OBJ, rows, N, draw, variables.mlp_flat('BoxMLP_%d' % k),
+                                    fl['act_o'][k], ray_idx=ctx['idx'][k], count=ck, want_d_enc=pose_opt)
+                ok = lay.mlp_off['BoxMLP_%d' % k]
+                ops.mlp_dw_f32(om.W_OBJ, om.IN_OBJ, rows, N, fl['act_o'][k], o[0] if pose_opt else o,
+                               grad[ok:ok + lay.mlp_size[om.W_OBJ]], count=ck)
+                if pose_opt:
+                    ops.encode_obj_bwd(k, ctx['idx'][k], ck, o[1], lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
+                                       rays.origins, rays.directions, pose_ts, alpha, pose_sums)
+            continue
         dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
         if K:                                 # all K object MLPs: one call (csrc/objects.hip)
             ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
@@ -104,13 +121,14 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                    ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
                                    pose_sums)
     levels = ctx['levels']
-    ops.mlp_dw(om.W_BKGD, rows, N, [lv['enc_b'] for lv in levels], [view_tile] * L, [lv['stash_b'] for lv in levels],
-               [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
-    off = lay.mlp_off['MLP_0']
-    ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, rows, N, L, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
-    if K:
-        o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
-        ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)
+    if not f32:
+        ops.mlp_dw(om.W_BKGD, rows, N, [lv['enc_b'] for lv in levels], [view_tile] * L, [lv['stash_b'] for lv in levels],
+                   [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
+        off = lay.mlp_off['MLP_0']
+        ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, rows, N, L, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
+        if K:
+            o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
+            ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)
     flat = variables.flat
     weight_l2 = None
     if config.weight_decay_mult != 0:                                          # :73-75
@@ -227,3 +245,219 @@ def shard_batch(batch, rank, world):
     for k in ('pixels', 'depth', 'sky'):
         out[k] = batch[k][sl].contiguous()
     return out
+
+
+# ---------------------------------------------------------------------------
+# thin training driver (train_boxpose.py:324-437,529-580): schedules -> train_step -> pose feedback ->
+# logging / checkpoints / test-set render.  Everything device-side stays on the device between steps.
+# ---------------------------------------------------------------------------
+def make_schedules(config):
+    """learning_rate_fn, eps_rate_fn, alpha_rate_fn (train_boxpose.py:347-368)."""
+    import functools
+    lr_fn = functools.partial(dmath.learning_rate_decay, lr_init=config.lr_init, lr_final=config.lr_final,
+                              max_steps=config.max_steps, lr_delay_steps=config.lr_delay_steps,
+                              lr_delay_mult=config.lr_delay_mult)
+    eps_fn = functools.partial(dmath.learning_rate_decay, lr_init=config.eps_init, lr_final=config.eps_final,
+                               max_steps=config.eps_max_steps, lr_delay_steps=config.eps_delay_steps,
+                               lr_delay_mult=config.lr_delay_mult)
+    alpha_fn = functools.partial(dmath.freq_alpha_rate, alpha_init=config.alpha_init, alpha_final=config.alpha_final,
+                                 alpha_delay_steps=config.alpha_delay_steps, alpha_max_steps=config.alpha_max_steps)
+    return lr_fn, eps_fn, alpha_fn
+
+
+def make_render_fn(model, config, variables):
+    """render_eval_fn (train_boxpose.py:377-390): test-mode model.apply; the all-gather lives in render_image."""
+    def render_fn(rng, batch):
+        return model.apply(variables, rng, batch['rays'], batch['init'], batch['ext'], batch['ts'],
+                           randomized=False, rand_bkgd=False, white_bkgd=config.white_bkgd, alpha=batch['alpha'])
+    return render_fn
+
+
+def evaluate(model, config, variables, test_case, alpha, chunk=8192, rng=0):
+    """One test image (train_boxpose.py:535-563): render, PSNR, SSIM.  -> dict(psnr, ssim, rgb, distance, acc, rays)"""
+    from . import metrics
+    rgb, dist_, acc = om.render_image(make_render_fn(model, config, variables), test_case['rays'], test_case['init'],
+                                      test_case['ext'], test_case['ts'], rng, alpha, chunk=chunk)
+    gt = test_case['pixels'][..., :3]
+    psnr = dmath.mse_to_psnr(((rgb - gt) ** 2).mean())                                   # :562
+    ssim = metrics.compute_ssim(rgb, gt, 1.0) if rgb.is_cuda else None                   # :563
+    return dict(psnr=psnr, ssim=ssim, rgb=rgb, distance=dist_, acc=acc, rays=rgb.shape[0] * rgb.shape[1])
+
+
+def train_loop(model, config, state, dataset, test_dataset=None, train_dir=None, render_every=0, chunk=8192,
+               rng=20200823, step_fn=None, log=print, world=1, rank=0, keep=100):
+    """The body of the reference's main() (train_boxpose.py:416-580) around `train_step`.
+
+    dataset: iterator of this rank's batches (dicts as train_step takes them, 'ts' a host int) with .peek();
+    test_dataset: iterator of test cases (full-image rays [H,W,.], pixels [H,W,3], init, ext, ts) or None.
+    Box poses estimated at one timestep seed the TV prior of its neighbours (`prevs`, :414,426-437): the table
+    stays on the device and is updated in place from the step's returned pose -- no host round trip.
+    Returns (state, history) with history = list of (step, dict of logged scalars)."""
+    import time
+    from . import checkpoints
+    step_fn = step_fn or train_step
+    lr_fn, eps_fn, alpha_fn = make_schedules(config)
+    if train_dir is not None:
+        state = checkpoints.restore_checkpoint(train_dir, state)                         # :404
+    init_step = state.step + 1                                                           # :406
+    prevs = dataset.peek()['init'].clone()                                               # :414  [T,K,6] on the device
+    T = prevs.shape[0]
+    history, trace = [], []
+    t_loop, reset_timer = time.time(), True
+    alpha = alpha_fn(init_step)
+    for step, batch in zip(range(init_step, config.max_steps + 1), dataset):            # :420
+        if reset_timer:
+            t_loop, reset_timer = time.time(), False
+        lr, eps, alpha = lr_fn(step), eps_fn(step), alpha_fn(step)                       # :425-427
+        ts = int(batch['ts'])
+        nb = (ts + 1 if ts == 0 else ts - 1) % max(T, 1)                                 # :429-432
+        prev = prevs[nb:nb + 1]
+        logging = step % config.print_every == 0
+        state, stats, rng, pose = step_fn(model, config, rng, state, batch, lr, eps, alpha, prev, reduce_stats=logging)
+        if prevs.shape[1] > 0:
+            prevs[ts, :, :3] = pose                                                      # :437 (device to device)
+        trace.append((stats.loss, stats.psnr, stats.grad_norm))
+        if logging:                                                                      # :448-527 (rank 0 writes)
+            losses = torch.stack([torch.as_tensor(t[0]).float().reshape(()) for t in trace])
+            psnrs = torch.stack([torch.as_tensor(t[1]).float().reshape(()) for t in trace])
+            gn = torch.stack([torch.as_tensor(t[2]).float().reshape(()) for t in trace])
+            steps_per_sec = len(trace) / max(time.time() - t_loop, 1e-9)
+            rec = dict(loss=float(stats.loss), avg_loss=float(losses.mean()), avg_psnr=float(psnrs.mean()),
+                       max_grad_norm=float(gn.max()), lr=lr, eps=eps, alpha=alpha,
+                       rays_per_sec=config.batch_size * steps_per_sec)
+            history.append((step, rec))
+            trace, reset_timer = [], True
+            if rank == 0:
+                log('%*d/%d: i_loss=%0.4f, avg_loss=%0.4f, avg_psnr=%0.2f, lr=%0.2e, %0.0f rays/sec' % (
+                    len(str(config.max_steps)) + 1, step, config.max_steps, rec['loss'], rec['avg_loss'],
+                    rec['avg_psnr'], lr, rec['rays_per_sec']))
+        if train_dir is not None and rank == 0 and step % config.save_every == 0:        # :528-532
+            checkpoints.save_checkpoint(train_dir, state, int(step), keep=keep)
+        if test_dataset is not None and render_every > 0 and step % render_every == 0:   # :535-575 (all ranks render)
+            t0 = time.time()
+            ev = evaluate(model, config, state.variables, next(test_dataset), alpha, chunk=chunk, rng=rng)
+            dt = time.time() - t0
+            history.append((step, dict(test_psnr=float(ev['psnr']), test_ssim=None if ev['ssim'] is None else float(ev['ssim']),
+                                       test_rays_per_sec=ev['rays'] / dt)))
+            if rank == 0:
+                log('Eval %d: %0.3fs., %0.0f rays/sec, psnr %0.3f' % (step, dt, ev['rays'] / dt, float(ev['psnr'])))
+    if train_dir is not None and rank == 0 and config.max_steps % config.save_every != 0 and state.step > 0:   # :577-580
+        checkpoints.save_checkpoint(train_dir, state, int(config.max_steps), keep=keep)
+    return state, history
+
+
+class SyntheticTimestepDataset:
+    """Stand-in for obbpose_dataset.Waymo with batching == 'timestep' (obbpose_dataset.py:1551-1587): T timesteps of
+    procedural images resident in HBM (raygen.TimestepData), each step samples one timestep and `batch_size` pixel
+    indices of it and generates the rays on the device.  No dataset exists in this environment; this drives main()."""
+
+    def __init__(self, config, K=3, T=5, hw=(64, 96), n_cams=2, seed=0, device='cuda', rank=0, world=1, split='train'):
+        import numpy as np
+        from . import raygen, synthetic
+        self.config, self.device, self.rank, self.world, self.split = config, torch.device(device), rank, world, split
+        self.rs = np.random.default_rng(seed + (0 if split == 'train' else 1))
+        H, W = hw
+        b = synthetic.make_batch(64, K, T=T, far=config.far, seed=seed)
+        self.init = torch.tensor(b['init'], device=self.device)
+        if config.random_box and split == 'train':                                        # configs/waymo.gin:6,8
+            noise = self.rs.uniform(-config.box_noise, config.box_noise, self.init[..., :3].shape)
+            self.init[..., :3] += torch.tensor(noise, dtype=torch.float32, device=self.device)
+        self.target_all = torch.tensor(b['init'], device=self.device)
+        self.ext = torch.tensor(b['ext'], device=self.device)
+        self.T, self.H, self.W, self.n_cams = T, H, W, n_cams
+        self.ts_data = []
+        uu, vv = np.meshgrid(np.linspace(0, 1, W), np.linspace(0, 1, H))
+        for t in range(T):
+            c2w, imgs, deps, skys = [], [], [], []
+            for c in range(n_cams):
+                yaw = 0.2 * (c - 0.5 * (n_cams - 1)) + 0.02 * t
+                R_ = np.array([[np.cos(yaw), 0, np.sin(yaw)], [0, 1, 0], [-np.sin(yaw), 0, np.cos(yaw)]])
+                c2w.append(np.concatenate([R_, np.array([[0.05 * t], [0.0], [0.0]])], 1))
+                img = np.stack([0.5 + 0.4 * np.sin(6 * uu + c + 0.3 * t), 0.5 + 0.4 * np.cos(5 * vv + 0.2 * t),
+                                0.5 + 0.3 * np.sin(4 * (uu + vv))], -1)
+                imgs.append(img.astype(np.float32))
+                deps.append(np.where(self.rs.uniform(0, 1, (H, W)) < 0.3, 2.0 + 4.0 * vv, 0.0).astype(np.float32))
+                skys.append(np.where(vv < 0.1, 0.975, 0.0).astype(np.float32))
+            foc = [0.8 * W] * n_cams
+            pp = [(W / 2.0, H / 2.0)] * n_cams
+            self.ts_data.append(raygen.TimestepData(c2w, foc, pp, [H] * n_cams, [W] * n_cams, imgs, deps, skys,
+                                                    device=self.device))
+        self._peek = None
+
+    def _train_batch(self):
+        from . import raygen
+        ts = int(self.rs.integers(0, self.T))
+        td = self.ts_data[ts]
+        per = self.config.batch_size // self.world
+        idx_all = self.rs.integers(0, td.n_rays, self.config.batch_size)                  # same draw on every rank
+        idx = torch.tensor(idx_all[self.rank * per:(self.rank + 1) * per], dtype=torch.int32, device=self.device)
+        rays, px, dp, sk = raygen.generate_batch(td, idx, self.config.near, self.config.far)
+        return dict(rays=rays, pixels=px, depth=dp, sky=sk, init=self.init, ext=self.ext, ts=ts, target=self.target_all[ts])
+
+    def _test_case(self):
+        from . import raygen
+        ts = int(self.rs.integers(0, self.T))
+        td = self.ts_data[ts]
+        rays, px, dp, sk = raygen.generate_batch(td, None, self.config.near, self.config.far)
+        n = self.H * self.W                                                               # first camera of the timestep
+        img = lambda x: x[:n].reshape(self.H, self.W, -1)
+        return dict(rays=utils.namedtuple_map(img, rays), pixels=img(px), depth=img(dp), sky=img(sk), init=self.init,
+                    ext=self.ext, ts=ts)
+
+    def peek(self):
+        if self._peek is None:
+            self._peek = self._train_batch() if self.split == 'train' else self._test_case()
+        return self._peek
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        if self._peek is not None:
+            b, self._peek = self._peek, None
+            return b
+        return self._train_batch() if self.split == 'train' else self._test_case()
+
+
+def main(argv=None):
+    """python -m durf_amd.train_boxpose --gin_file configs/waymo.gin --train_dir /tmp/run [--gin_param ...]
+    One process per GPU (launch N with torchrun / the bench's own spawner): the reference's main() :324-580."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gin_file', action='append', default=[])
+    ap.add_argument('--gin_param', action='append', default=[])
+    ap.add_argument('--train_dir', default=None)
+    ap.add_argument('--data_dir', default=None, help='dataset directory (loaders: durf_amd.datasets); synthetic when omitted')
+    ap.add_argument('--render_every', type=int, default=0)
+    ap.add_argument('--chunk', type=int, default=8192)
+    ap.add_argument('--objects', type=int, default=3, help='dynamic boxes of the synthetic scene')
+    args = ap.parse_args(argv)
+    rank, world, local = init_distributed()
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    utils.clear_gin()
+    config = utils.load_config(args.gin_file, args.gin_param)
+    if config.batch_size % world != 0:
+        raise ValueError('Batch size must be divisible by the number of devices.')      # :332-333
+    if args.data_dir:
+        from . import datasets
+        dataset = datasets.get_dataset('train', args.data_dir, config, device=dev, rank=rank, world=world)
+        test_dataset = datasets.get_dataset('test', args.data_dir, config, device=dev, rank=rank, world=world)
+    else:
+        dataset = SyntheticTimestepDataset(config, K=args.objects, device=dev, rank=rank, world=world, split='train')
+        test_dataset = SyntheticTimestepDataset(config, K=args.objects, device=dev, rank=rank, world=world, split='test')
+    model, variables = om.construct_mipnerf(20200823, dataset.peek(), device=dev)       # :325,339
+    if rank == 0:
+        print('Number of parameters being optimized: %d' % variables.flat.numel())       # :340-342
+    state = create_train_state(variables)
+    state, history = train_loop(model, config, state, dataset, test_dataset, args.train_dir, args.render_every,
+                                args.chunk, world=world, rank=rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+    return history
+
+
+if __name__ == '__main__':
+    main()

@@ -64,6 +64,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_resample.restype = i32
     L.durf_resample.argtypes = [vp, i32, i32, vp, vp, f32, vp, vp]
     #   (stream, B, N, t_vals, weights, resample_padding, u_rand, t_vals_out)
+    L.durf_sorted_piecewise_constant_pdf.restype = i32
+    L.durf_sorted_piecewise_constant_pdf.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    #   (stream, B, N, bins, weights, u_rand, samples)
     L.durf_loss_prep.restype = i32
     L.durf_loss_prep.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]
     #   (stream, B, N, t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level, disable_multiscale, prep, norm)
@@ -91,6 +94,24 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_dw_finalize.restype = i32
     L.durf_mlp_dw_finalize.argtypes = [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp]
     #   (stream, width, in_dim, rows, N, count, nlevels, part, bpart, grad_mlp)
+    L.durf_mlp_f32_act_floats.restype = u64
+    L.durf_mlp_f32_act_floats.argtypes = [i32, i32]
+    #   (width, in_dim)
+    L.durf_mlp_f32_dz_floats.restype = u64
+    L.durf_mlp_f32_dz_floats.argtypes = [i32, i32]
+    #   (width, in_dim)
+    L.durf_mlp_f32_dw_scratch_floats.restype = u64
+    L.durf_mlp_f32_dw_scratch_floats.argtypes = [i32, i32, i32]
+    #   (width, in_dim, nsplit)
+    L.durf_mlp_fwd_f32.restype = i32
+    L.durf_mlp_fwd_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, width, in_dim, rows, N, enc, view27, ray_idx, count, mlp_params, raw, act)
+    L.durf_mlp_bwd_f32.restype = i32
+    L.durf_mlp_bwd_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, width, in_dim, rows, N, draw, ray_idx, count, mlp_params, act, dz, d_enc)
+    L.durf_mlp_dw_f32.restype = i32
+    L.durf_mlp_dw_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, i32, vp, vp, vp]
+    #   (stream, width, in_dim, rows, N, count, act, dz, nsplit, scratch, tiles_dev, grad_mlp)
     L.durf_obj_enc_stride.restype = u64
     L.durf_obj_enc_stride.argtypes = [i32, i32]
     #   (B, N)

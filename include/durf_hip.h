@@ -139,6 +139,13 @@ int durf_composite_resample(void* stream, int B, int N, int K, const float* raw_
 int durf_resample(void* stream, int B, int N, const float* t_vals, const float* weights,
                   float resample_padding, const float* u_rand, float* t_vals_out);
 
+/* math.sorted_piecewise_constant_pdf(key, bins, weights, num_samples = N + 1, randomized) (math.py:222-284) on its
+ * own -- the routine inside durf_resample without the blur-pool / padding that mip.resample_along_rays applies first
+ * (mip.py:393-404).  bins [B,N+1], weights [B,N], u_rand [B,N+1] nullable (randomized=False), samples [B,N+1].
+ * The reference's own properties for it (internal/math_test.py:183-346) run against this entry point. */
+int durf_sorted_piecewise_constant_pdf(void* stream, int B, int N, const float* bins, const float* weights,
+                                       const float* u_rand, float* samples);
+
 /* ---- training: losses, backward, optimizer ----------------------------------- */
 
 /* per-level normalisers of loss_fn (train_boxpose.py:94-102,138-140,164): writes
@@ -200,6 +207,28 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
 int durf_mlp_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count,
                          int nlevels /* the same rows, N, count, nlevels as the durf_mlp_dw call */,
                          const float* part, const float* bpart, float* grad_mlp);
+
+/* ---- exact-fp32 MLP: the parity instrument (csrc/mlp_f32.hip) ---------------------------------
+ * The reference's Dense layers are fp32 (obbpose_model.py:326-327; HIGHEST-precision matmul, internal/math.py:22-24).
+ * These entry points evaluate the same stack with v_mfma_f32_32x32x2_f32 (exact fp32, 1/16 of the bf16 rate), reading
+ * the fp32 flax-layout parameters directly and exchanging ROW-MAJOR fp32 tensors: enc [rows,in_dim] (durf_encode_*'s
+ * out_f32), view27 [B,27] (durf_view_enc's out_f32), raw [rows,4], act [rows, durf_mlp_f32_act_floats] (the input of
+ * every Dense, recorded by the forward for the backward), dz [rows, durf_mlp_f32_dz_floats] (d loss / d pre-activation
+ * of every Dense), d_enc [rows,64] (nullable; caller-zeroed).  ray_idx / count as in durf_mlp_fwd.  The weight
+ * gradients are split over `nsplit` sample ranges and summed in a fixed order (deterministic); scratch:
+ * durf_mlp_f32_dw_scratch_floats floats, tiles_dev: 3072 device ints.  grad_mlp: flax layout of one MLP, overwritten.
+ * MipNerfModel(mlp_precision='f32') routes through these; bench.py never does. */
+size_t durf_mlp_f32_act_floats(int width, int in_dim);
+size_t durf_mlp_f32_dz_floats(int width, int in_dim);
+size_t durf_mlp_f32_dw_scratch_floats(int width, int in_dim, int nsplit);
+int durf_mlp_fwd_f32(void* stream, int width, int in_dim, size_t rows, int N, const float* enc, const float* view27,
+                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, float* raw,
+                     float* act /* nullable: inference */);
+int durf_mlp_bwd_f32(void* stream, int width, int in_dim, size_t rows, int N, const float* draw,
+                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* act,
+                     float* dz, float* d_enc);
+int durf_mlp_dw_f32(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count, const float* act,
+                    const float* dz, int nsplit, float* scratch, int32_t* tiles_dev, float* grad_mlp);
 
 /* The K per-object BoxMLPs of one level as one call each (obbpose_model.py:174-201): every kernel of the
  * per-object path runs ONCE with the object index in blockIdx.y (csrc/objects.hip), on `stream`.
