@@ -106,7 +106,8 @@ def setup_workload(name, dev, rank=0, world=1, rays=0, objects=-1):
     # Weak scaling over distinct shards: every rank builds the same seeded GLOBAL batch of B*world rays (one
     # 'timestep' batch of the reference: same boxes / poses / timestep for all rays) and keeps its contiguous
     # shard, exactly what utils.shard + pmap do (internal/utils.py:193-196, train_boxpose.py:370-374).
-    batch_np = synthetic.make_batch(B * world, K_OBJ, far=far, seed=synthetic.SEED, noise_boxes=noise)
+    batch_np = synthetic.make_batch(B * world, K_OBJ, far=far, seed=synthetic.SEED, noise_boxes=noise,
+                                    redraw_noisy_multi_hit=True)
     full = synthetic.device_batch(batch_np, dev)
     batch = train_boxpose.shard_batch(full, rank, world)
     model, variables = obbpose_model.construct_mipnerf(0, full, device=dev)

@@ -27,11 +27,11 @@ _SIGS = {
     'durf_compact_hits': (i32, [vp, i32, i32, vp, vp, vp, vp]),
     'durf_sample_t': (i32, [vp, i32, i32, vp, vp, vp, i32, vp]),
     'durf_view_enc': (i32, [vp, i32, vp, vp, vp]),
-    'durf_encode_bkgd': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]),
+    'durf_encode_bkgd': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),
     'durf_encode_obj': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp, vp]),
     'durf_mlp_stash_bytes': (u64, [i32, u64]),
     'durf_mlp_mask_bytes': (u64, [u64]),
-    'durf_mlp_fwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_mlp_fwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_composite_fwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32,
                                  vp, vp, vp, vp, vp, vp]),
     'durf_composite_resample': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32,
@@ -58,13 +58,16 @@ _SIGS = {
     'durf_train_stats': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(f32), i32, vp]),
     'durf_loss_prep': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
     'durf_loss_bwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
-                            f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
-    'durf_mlp_bwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
-    'durf_expand_view': (i32, [vp, u64, i32, vp, vp, vp, vp]),
+                            f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_mlp_bwd': (i32, [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_expand_view': (i32, [vp, u64, i32, vp, vp, vp, vp, vp, vp]),
     'durf_dw_part_floats': (u64, [i32]),
     'durf_dw_bpart_floats': (u64, [i32]),
     'durf_mlp_dw': (i32, [vp, i32, u64, i32, vp, i32] + [C.POINTER(vp)] * 5 + [vp, vp]),
     'durf_mlp_dw_finalize': (i32, [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp]),
+    'durf_mlp_dw_levels': (i32, [vp, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp)] + [C.POINTER(vp)] * 5 + [vp, vp]),
+    'durf_mlp_dw_finalize_levels': (i32, [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp]),
+    'durf_expand_raw': (i32, [vp, i32, i32, vp, vp, vp, vp]),
     'durf_encode_obj_bwd': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
     'durf_pose_finish': (i32, [vp, i32, vp, vp, i32, i32, vp]),
     'durf_optim_scratch_floats': (u64, [u64]),

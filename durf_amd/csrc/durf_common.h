@@ -165,17 +165,30 @@ int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* i
                       const float* barf_w, int flags, void* out_tile, size_t out_stride, float* out_f32);
 int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile, const void* view_bf16,
                    const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
-                   void* relu_mask, int K, const FwdStrides& st);
+                   void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx = nullptr,
+                   const int32_t* tail_count = nullptr);
 int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
                    const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
-                   float* d_enc, int K, const BwdStrides& st);
+                   float* d_enc, int K, const BwdStrides& st, const int32_t* tail_idx = nullptr,
+                   const int32_t* tail_count = nullptr, const float* draw_ray_sum = nullptr);
 int launch_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
-                       const int32_t* count, void* out_tile, int K, size_t idx_stride, size_t out_stride);
-int launch_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
+                       const int32_t* count, void* out_tile, int K, size_t idx_stride, size_t out_stride,
+                       const int32_t* tail_idx = nullptr, const int32_t* tail_count = nullptr);
+// Sample axis of the weight-gradient GEMMs: `nlevels` segments, each with its own row capacity (a multiple of 32,
+// the layout stride of that level's buffers), rows per ray and (nullable) device-side ray count -- the sampling levels
+// of a step plus, for a de-duplicated batch, the one-sample-per-ray evaluations of the box-hit rays.
+struct DwLevels {
+    size_t rows[DURF_MAX_LEVELS];
+    int n[DURF_MAX_LEVELS];
+    const int32_t* count[DURF_MAX_LEVELS];
+    int nlevels;
+};
+int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
                   const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
                   const void* const* dz, const void* const* dz_out, float* part, float* bpart, int K,
                   const DwStrides& st);
-int launch_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count, int nlevels,
+int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
                        const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
                        size_t bpart_stride, size_t grad_stride);
+DwLevels uniform_levels(size_t rows, int N, const int32_t* count, int nlevels);
 }  // namespace durf

@@ -66,7 +66,7 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
            const float* __restrict__ zo, const float* __restrict__ norm, LossCfg c,
            float* __restrict__ draw, float* __restrict__ terms, float* __restrict__ rgb_out,
            float* __restrict__ depth_out, float* __restrict__ acc_out, float* __restrict__ weights_out,
-           float* __restrict__ t_mids_out, float* __restrict__ t_dists_out) {
+           float* __restrict__ t_mids_out, float* __restrict__ t_dists_out, float* __restrict__ draw_ray_sum) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -219,6 +219,7 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
 #pragma unroll
         for (int p = P - 1; p >= 0; p--) { loc[p] = acc_loc; acc_loc += gw[p] * w[p]; }
     }
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};       // sum over the ray's samples of d(loss)/d(raw): see draw_ray_sum
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const int n = lane * P + p;
@@ -232,6 +233,17 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
             o[2] = g_rgb[2] * w[p] * col[p][2] * (1.0f - col[p][2]);
             o[3] = ddens * sigmoidf_(rawd[p]);                 // softplus' = sigmoid
             *(f32x4*)(draw + ((size_t)b * N + n) * 4) = o;
+            rs[0] += o[0]; rs[1] += o[1]; rs[2] += o[2]; rs[3] += o[3];
+        }
+    }
+    // A ray whose background samples all feed the MLP the same input (a box-hit ray: obbpose_model.py:205-210 masks
+    // their Gaussians to zero) contributes to the background MLP's gradients only through this per-ray sum.
+    if (draw_ray_sum) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) rs[i] = wave_sum(rs[i]);
+        if (lane == 0) {
+            const f32x4 o = {rs[0], rs[1], rs[2], rs[3]};
+            *(f32x4*)(draw_ray_sum + (size_t)b * 4) = o;
         }
     }
     t_near = wave_sum(t_near);
@@ -337,7 +349,7 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                   const float* zo, const float* norm, float eps, const float* mults /*6: rgb,sky,depth,near,empty,dist*/,
                   float box_loss_mult, int level, int disable_multiscale, float bg, float density_bias,
                   float* draw, float* terms, float* term_sums, float* rgb_out, float* depth_out, float* acc_out,
-                  float* weights_out, float* t_mids_out, float* t_dists_out) {
+                  float* weights_out, float* t_mids_out, float* t_dists_out, float* draw_ray_sum) {
     DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
     if (B <= 0) return 0;
     LossCfg c;
@@ -351,7 +363,7 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
 #define LAUNCH_L(P)                                                                                   \
     hipLaunchKernelGGL(k_loss_bwd<P>, grid, block, 0, s, B, N, K, raw_bkgd, op, slot, t_vals, dirs_s,  \
                        pixels, lossmult, gt_depth, sky, dyn, zo, norm, c, draw, terms, rgb_out, depth_out, acc_out, \
-                       weights_out, t_mids_out, t_dists_out)
+                       weights_out, t_mids_out, t_dists_out, draw_ray_sum)
     if (N <= 64) LAUNCH_L(1); else if (N <= 128) LAUNCH_L(2); else LAUNCH_L(4);
 #undef LAUNCH_L
     hipLaunchKernelGGL(k_reduce_rows, dim3(LT_ROWS), dim3(1024), 0, s, B, -1, terms, term_sums);

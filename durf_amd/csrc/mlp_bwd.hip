@@ -251,7 +251,8 @@ __global__ void __launch_bounds__(512, 2)
 k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
           const int32_t* __restrict__ count, const char* __restrict__ wpack,
           const uint4* __restrict__ relu_mask, bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out,
-          float* __restrict__ d_enc, BwdStrides bs) {
+          float* __restrict__ d_enc, BwdStrides bs, const int32_t* __restrict__ tail_idx,
+          const int32_t* __restrict__ tail_count, const float* __restrict__ draw_ray_sum) {
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gridDim.y > 1) {                             // batched object MLPs: this workgroup's object slab
@@ -268,6 +269,11 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     if (count) {
         const size_t c = (size_t)(*count) * (size_t)N;
         nrows = c < rows ? c : rows;
+    }
+    const size_t nrows_c = nrows;                     // tail rows: one per box-hit ray (see k_mlp_fwd)
+    if (tail_count) {
+        const size_t t = nrows_c + (size_t)(*tail_count);
+        nrows = t < rows ? t : rows;
     }
     if ((size_t)blockIdx.x * 256 >= nrows) return;
     const int lane = threadIdx.x & 63;
@@ -296,9 +302,13 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     // head gradients (fp32 [*,4]: d raw_rgb[3], d raw_density); object MLPs gather by ray
     f32x4 dr = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
-        size_t src = row;
-        if (ray_idx) src = (size_t)ray_idx[row / (size_t)N] * (size_t)N + row % (size_t)N;
-        dr = *(const f32x4*)(draw + src * 4);
+        if (tail_count && row >= nrows_c) {           // the single evaluation of a box-hit ray: the ray's summed head gradient
+            dr = *(const f32x4*)(draw_ray_sum + (size_t)tail_idx[row - nrows_c] * 4);
+        } else {
+            size_t src = row;
+            if (ray_idx) src = (size_t)ray_idx[row / (size_t)N] * (size_t)N + row % (size_t)N;
+            dr = *(const f32x4*)(draw + src * 4);
+        }
     }
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool lo = lane < 32;
@@ -367,7 +377,8 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
 // view-direction features expanded per sample into tile layout [rows, 32] (dW of Dense_10)
 __global__ void __launch_bounds__(256)
 k_expand_view(size_t rows, int N, const bf16x8* __restrict__ view, const int32_t* __restrict__ ray_idx,
-              const int32_t* __restrict__ count, bf16x8* __restrict__ out, size_t idx_stride, size_t out_stride) {
+              const int32_t* __restrict__ count, bf16x8* __restrict__ out, size_t idx_stride, size_t out_stride,
+              const int32_t* __restrict__ tail_idx, const int32_t* __restrict__ tail_count) {
     if (gridDim.y > 1) {
         ray_idx += blockIdx.y * idx_stride;
         count += blockIdx.y;
@@ -378,9 +389,20 @@ k_expand_view(size_t rows, int N, const bf16x8* __restrict__ view, const int32_t
     const int q = (int)(gid & 3);
     size_t nrows = rows;
     if (count) { const size_t c = (size_t)(*count) * N; nrows = c < rows ? c : rows; }
+    const size_t nrows_c = nrows;                     // tail rows: one per box-hit ray (see k_mlp_fwd)
+    if (tail_count) {
+        const size_t t = nrows_c + (size_t)(*tail_count);
+        nrows = t < rows ? t : rows;
+        // rows of the partial last tile beyond the tail: zeros (dW reads whole 32-row tiles; their dz is zero)
+        if (row >= nrows && row < ((nrows + 31) & ~(size_t)31)) {
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            *(bf16x8*)((char*)out + tile_vec_offset(row, q, 2)) = z;
+        }
+    }
     if (row >= nrows) return;
     size_t ray = row / (size_t)N;
-    if (ray_idx) ray = (size_t)ray_idx[ray];
+    if (tail_count && row >= nrows_c) ray = (size_t)tail_idx[row - nrows_c];
+    else if (ray_idx) ray = (size_t)ray_idx[ray];
     *(bf16x8*)((char*)out + tile_vec_offset(row, q, 2)) = view[ray * 4 + q];
 }
 
@@ -463,8 +485,18 @@ __host__ __device__ inline size_t dw_tiles_per_split(size_t nt_all, int nsplit) 
     return even > DW_MIN_TPS ? even : DW_MIN_TPS;
 }
 
+// valid 32-sample tiles of level l (object `obj` of a batched launch): the last tile of a level whose row count is
+// not a multiple of 32 (one sample per ray) is partial -- its rows beyond the count carry zero dz
+__host__ __device__ inline size_t dw_level_tiles(const durf::DwLevels& lv, int l, size_t obj) {
+    size_t nrows = lv.rows[l];
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (lv.count[l]) { const size_t c = (size_t)lv.count[l][obj] * (size_t)lv.n[l]; nrows = c < nrows ? c : nrows; }
+#endif
+    return (nrows + 31) >> 5;
+}
+
 template <int NKO, int NKA, int NKB>
-__device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __restrict__ count, const DwArgs& a, int job,
+__device__ __forceinline__ void dw_job(const durf::DwLevels& lv, const DwArgs& a, int job,
                                        int nsplit, int split_idx, float* __restrict__ part,
                                        float* __restrict__ bpart, char* smem) {
     constexpr int NKI = NKA + NKB;
@@ -478,11 +510,9 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const size_t obj = blockIdx.y;                            // batched object MLPs (0 for a single MLP)
-    if (gridDim.y > 1) { count += obj; part += obj * a.ks_part; bpart += obj * a.ks_bpart; }
-    size_t nrows = rows;
-    if (count) { const size_t c = (size_t)(*count) * (size_t)N; nrows = c < rows ? c : rows; }
-    const size_t nt_valid = nrows >> 5;                       // valid 32-sample tiles per level
-    const size_t nt_all = nt_valid * (size_t)a.nlevels;       // the K axis: every level's samples
+    if (gridDim.y > 1) { part += obj * a.ks_part; bpart += obj * a.ks_bpart; }
+    size_t nt_all = 0;                                        // the K axis: every level's valid 32-sample tiles
+    for (int l = 0; l < a.nlevels; l++) nt_all += dw_level_tiles(lv, l, obj);
     const size_t tps = dw_tiles_per_split(nt_all, nsplit);    // even share of the VALID tiles
     const size_t g0 = (size_t)split_idx * tps;
     if (g0 >= nt_all) return;                                 // unused split: k_dw_finalize skips it too
@@ -539,8 +569,10 @@ __device__ __forceinline__ void dw_job(size_t rows, int N, const int32_t* __rest
 
     // The samples of every level form one K axis; a split that straddles a level boundary runs one
     // segment per level (the ring drains and refills at the boundary, the accumulators carry on).
+    size_t lo = 0, hi_t = 0;
     for (int lvl = 0; lvl < a.nlevels; lvl++) {
-        const size_t lo = (size_t)lvl * nt_valid, hi_t = lo + nt_valid;
+        lo = hi_t;
+        hi_t = lo + dw_level_tiles(lv, lvl, obj);
         const size_t b0 = g0 > lo ? g0 : lo, b1 = g1 < hi_t ? g1 : hi_t;
         if (b1 <= b0) continue;
         const size_t t0 = b0 - lo;                    // first tile of the segment within its level
@@ -636,7 +668,7 @@ extern "C" int durf_debug_dw_trace(void* dst) {
 
 template <int W>
 __global__ void __launch_bounds__(512, 2)
-k_dw_all(size_t rows, int N, const int32_t* __restrict__ count, DwArgs a) {
+k_dw_all(durf::DwLevels lv, DwArgs a) {
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // 1-D grid with no idle workgroups: the dispatcher deals workgroup ids round-robin to the 8
@@ -665,7 +697,7 @@ k_dw_all(size_t rows, int N, const int32_t* __restrict__ count, DwArgs a) {
         }
     } trace_end{t_start, job, sp};
 #endif
-#define DW_CALL(NKO, NKA, NKB) dw_job<NKO, NKA, NKB>(rows, N, count, a, job, ns, sp, a.part[job], a.bpart[job], smem)
+#define DW_CALL(NKO, NKA, NKB) dw_job<NKO, NKA, NKB>(lv, a, job, ns, sp, a.part[job], a.bpart[job], smem)
     switch (job) {
         case 0: DW_CALL(S::KW, S::KE, 0); break;
         case 5: DW_CALL(S::KW, S::KW, S::KE); break;
@@ -706,15 +738,13 @@ struct DwJobs { DwJob j[12]; size_t part_off[12], bpart_off[12]; int nparts[12];
 __global__ void __launch_bounds__(256)
 k_dw_finalize(int W, int in_dim, DwJobs jobs, const float* __restrict__ part_all,
               const float* __restrict__ bpart_all, float* __restrict__ grad_mlp, size_t part_stride,
-              size_t bpart_stride, size_t grad_stride, size_t rows, int N, int nlevels,
-              const int32_t* __restrict__ count) {
+              size_t bpart_stride, size_t grad_stride, durf::DwLevels lv) {
     __shared__ float red[4][64];
     part_all += blockIdx.z * part_stride;            // batched object MLPs: blockIdx.z = object
     bpart_all += blockIdx.z * bpart_stride;
     grad_mlp += blockIdx.z * grad_stride;
-    size_t nrows = rows;                             // the splits k_dw_all actually wrote (see dw_tiles_per_split)
-    if (count) { const size_t c = (size_t)count[blockIdx.z] * (size_t)N; nrows = c < rows ? c : rows; }
-    const size_t nt_all = (nrows >> 5) * (size_t)nlevels;
+    size_t nt_all = 0;                               // the splits k_dw_all actually wrote (see dw_tiles_per_split)
+    for (int l = 0; l < lv.nlevels; l++) nt_all += dw_level_tiles(lv, l, blockIdx.z);
     const DwJob job = jobs.j[blockIdx.y];
     const size_t tps_ = dw_tiles_per_split(nt_all, jobs.nparts[blockIdx.y]);
     const int nparts = (int)((nt_all + tps_ - 1) / tps_);
@@ -832,14 +862,18 @@ int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_
 
 int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
                  const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
-                 float* d_enc) {
+                 float* d_enc, const int32_t* tail_idx, const int32_t* tail_count, const float* draw_ray_sum) {
+    DURF_REQUIRE((tail_idx == nullptr) == (tail_count == nullptr) && (tail_idx == nullptr) == (draw_ray_sum == nullptr),
+                 "tail_idx, tail_count and draw_ray_sum go together");
+    DURF_REQUIRE(tail_idx == nullptr || (count != nullptr && N % 32 == 0), "tail rows follow a compacted ray list");
     return durf::launch_mlp_bwd(stream, width, rows, N, draw, ray_idx, count, wpack_bwd, relu_mask, dz, dz_out, d_enc,
-                                1, BwdStrides{});
+                                1, BwdStrides{}, tail_idx, tail_count, draw_ray_sum);
 }
 
 int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
-                     const int32_t* count, void* out_tile) {
-    return durf::launch_expand_view(stream, rows, N, view_bf16, ray_idx, count, out_tile, 1, 0, 0);
+                     const int32_t* count, void* out_tile, const int32_t* tail_idx, const int32_t* tail_count) {
+    DURF_REQUIRE((tail_idx == nullptr) == (tail_count == nullptr), "tail_idx and tail_count go together");
+    return durf::launch_expand_view(stream, rows, N, view_bf16, ray_idx, count, out_tile, 1, 0, 0, tail_idx, tail_count);
 }
 
 size_t durf_dw_part_floats(int width) { return dw_plan(width).part_total; }
@@ -848,13 +882,45 @@ size_t durf_dw_bpart_floats(int width) { return dw_plan(width).bpart_total; }
 int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
                 const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
                 const void* const* dz, const void* const* dz_out, float* part, float* bpart) {
-    return durf::launch_mlp_dw(stream, width, rows, N, count, nlevels, enc_tile, view_tile, stash, dz, dz_out, part,
+    DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
+    DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
+    return durf::launch_mlp_dw(stream, width, durf::uniform_levels(rows, N, count, nlevels), enc_tile, view_tile, stash, dz, dz_out, part,
                                bpart, 1, DwStrides{});
+}
+
+static int make_levels(int nlevels, const size_t* rows, const int* rows_per_ray, const int32_t* const* count,
+                       durf::DwLevels* lv) {
+    DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
+    lv->nlevels = nlevels;
+    for (int l = 0; l < DURF_MAX_LEVELS; l++) {
+        const int ll = l < nlevels ? l : 0;
+        DURF_REQUIRE(rows_per_ray[ll] >= 1, "rows_per_ray >= 1");
+        lv->rows[l] = rows[ll]; lv->n[l] = rows_per_ray[ll]; lv->count[l] = count ? count[ll] : nullptr;
+    }
+    return 0;
+}
+
+int durf_mlp_dw_levels(void* stream, int width, int nlevels, const size_t* rows, const int* rows_per_ray,
+                       const int32_t* const* count, const void* const* enc_tile, const void* const* view_tile,
+                       const void* const* stash, const void* const* dz, const void* const* dz_out, float* part,
+                       float* bpart) {
+    durf::DwLevels lv;
+    if (int rc = make_levels(nlevels, rows, rows_per_ray, count, &lv)) return rc;
+    return durf::launch_mlp_dw(stream, width, lv, enc_tile, view_tile, stash, dz, dz_out, part, bpart, 1, DwStrides{});
+}
+
+int durf_mlp_dw_finalize_levels(void* stream, int width, int in_dim, int nlevels, const size_t* rows,
+                                const int* rows_per_ray, const int32_t* const* count, const float* part,
+                                const float* bpart, float* grad_mlp) {
+    durf::DwLevels lv;
+    if (int rc = make_levels(nlevels, rows, rows_per_ray, count, &lv)) return rc;
+    return durf::launch_dw_finalize(stream, width, in_dim, lv, part, bpart, grad_mlp, 1, 0, 0, 0);
 }
 
 int durf_mlp_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count,
                          int nlevels, const float* part, const float* bpart, float* grad_mlp) {
-    return durf::launch_dw_finalize(stream, width, in_dim, rows, N, count, nlevels, part, bpart, grad_mlp, 1, 0, 0, 0);
+    DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
+    return durf::launch_dw_finalize(stream, width, in_dim, durf::uniform_levels(rows, N, count, nlevels), part, bpart, grad_mlp, 1, 0, 0, 0);
 }
 
 }  // extern "C"
@@ -876,7 +942,8 @@ int pack_bwd_launch(void* stream, int width, int in_dim, int K, const float* par
 
 int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
                    const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
-                   float* d_enc, int K, const BwdStrides& st) {
+                   float* d_enc, int K, const BwdStrides& st, const int32_t* tail_idx, const int32_t* tail_count,
+                   const float* draw_ray_sum) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
@@ -890,7 +957,7 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
         (void)hipFuncSetAttribute((const void*)k_mlp_bwd<WW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((k_mlp_bwd<WW, PP>), grid, block, lds, s, rows, N, draw, ray_idx, count,         \
                            (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out,  \
-                           d_enc, st);                                                                     \
+                           d_enc, st, tail_idx, tail_count, draw_ray_sum);                                 \
     }
     if (width == 256) { if (d_enc) LAUNCH_B(256, true) else LAUNCH_B(256, false) }
     else { if (d_enc) LAUNCH_B(128, true) else LAUNCH_B(128, false) }
@@ -900,30 +967,43 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
 }
 
 int launch_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
-                       const int32_t* count, void* out_tile, int K, size_t idx_stride, size_t out_stride) {
+                       const int32_t* count, void* out_tile, int K, size_t idx_stride, size_t out_stride,
+                       const int32_t* tail_idx, const int32_t* tail_count) {
     if (rows == 0 || K <= 0) return 0;
     hipLaunchKernelGGL(k_expand_view, dim3(durf_cdiv(rows * 4, 256), K), dim3(256), 0, (hipStream_t)stream, rows, N,
-                       (const bf16x8*)view_bf16, ray_idx, count, (bf16x8*)out_tile, idx_stride, out_stride);
+                       (const bf16x8*)view_bf16, ray_idx, count, (bf16x8*)out_tile, idx_stride, out_stride, tail_idx,
+                       tail_count);
     DURF_CHECK_LAUNCH("durf_expand_view");
     return 0;
 }
 
 // All weight gradients of one MLP: ONE grouped launch of the 12 split-K GEMMs whose K axis runs over
 // the samples of every level (per-level operand buffers, one set of fp32 partials).
-int launch_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* count, int nlevels,
+DwLevels uniform_levels(size_t rows, int N, const int32_t* count, int nlevels) {
+    DwLevels lv;
+    lv.nlevels = nlevels;
+    for (int l = 0; l < DURF_MAX_LEVELS; l++) { lv.rows[l] = rows; lv.n[l] = N; lv.count[l] = count; }
+    return lv;
+}
+
+int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
                   const void* const* enc_tile, const void* const* view_tile, const void* const* stash,
                   const void* const* dz, const void* const* dz_out, float* part, float* bpart, int K,
                   const DwStrides& st) {
-    DURF_REQUIRE(K == 1 || count, "batched launches are for compacted object rays");
+    const int nlevels = lv.nlevels;
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
-    DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
-    if (rows == 0 || K <= 0) return 0;
+    size_t total_rows = 0;
+    for (int l = 0; l < nlevels; l++) {
+        DURF_REQUIRE(lv.rows[l] % 32 == 0, "rows must be a multiple of 32");
+        DURF_REQUIRE(K == 1 || lv.count[l], "batched launches are for compacted object rays");
+        total_rows += lv.rows[l];
+    }
+    if (total_rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const DwPlan P = dw_plan(width);
-    const size_t nt = rows >> 5;
     const int KW = width / 16;
-    auto region = [&](const void* base, int j) { return (const char*)base + ((size_t)j * KW * nt) * 1024; };
+    auto region = [&](const void* base, int j, int l) { return (const char*)base + ((size_t)j * KW * (lv.rows[l] >> 5)) * 1024; };
     DwArgs a;
     a.nlevels = nlevels;
     a.ks_part = st.part; a.ks_bpart = st.bpart;
@@ -942,15 +1022,15 @@ int launch_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* co
         for (int j = 0; j < 12; j++) {
             a.inB[l][j] = nullptr;
             if (j <= 7) {
-                a.dz[l][j] = region(dz[ll], j);
-                a.inA[l][j] = j == 0 ? (const char*)enc_tile[ll] : region(stash[ll], j - 1);
+                a.dz[l][j] = region(dz[ll], j, ll);
+                a.inA[l][j] = j == 0 ? (const char*)enc_tile[ll] : region(stash[ll], j - 1, ll);
             }
         }
         a.inB[l][5] = (const char*)enc_tile[ll];
-        a.dz[l][8] = (const char*)dz_out[ll]; a.inA[l][8] = region(stash[ll], 7);          // density head
-        a.dz[l][9] = region(dz[ll], 8); a.inA[l][9] = region(stash[ll], 7);                // bottleneck
-        a.dz[l][10] = region(dz[ll], 9); a.inA[l][10] = region(stash[ll], 8); a.inB[l][10] = (const char*)view_tile[ll];
-        a.dz[l][11] = (const char*)dz_out[ll]; a.inA[l][11] = region(stash[ll], 9);        // rgb head
+        a.dz[l][8] = (const char*)dz_out[ll]; a.inA[l][8] = region(stash[ll], 7, ll);          // density head
+        a.dz[l][9] = region(dz[ll], 8, ll); a.inA[l][9] = region(stash[ll], 7, ll);            // bottleneck
+        a.dz[l][10] = region(dz[ll], 9, ll); a.inA[l][10] = region(stash[ll], 8, ll); a.inB[l][10] = (const char*)view_tile[ll];
+        a.dz[l][11] = (const char*)dz_out[ll]; a.inA[l][11] = region(stash[ll], 9, ll);        // rgb head
     }
     // narrow jobs first: their workgroups run longest (less data in flight per stage)
     static const int order[12] = {11, 8, 0, 10, 5, 1, 2, 3, 4, 6, 7, 9};
@@ -965,19 +1045,19 @@ int launch_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* co
     if (width == 256) {
         constexpr int lds = DW_LDS_BYTES;
         (void)hipFuncSetAttribute((const void*)k_dw_all<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(k_dw_all<256>, grid, block, lds, s, rows, N, count, a);
+        hipLaunchKernelGGL(k_dw_all<256>, grid, block, lds, s, lv, a);
     } else {
         // widest W=128 job: 20 KB per stage x 4 stages = 80 KB, so two workgroups share a CU (80 VGPRs per lane):
         // the object GEMMs are per-tile-latency-bound with one resident workgroup
         constexpr int lds = dw_stages(20) * 20 * 1024;
         (void)hipFuncSetAttribute((const void*)k_dw_all<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(k_dw_all<128>, grid, block, lds, s, rows, N, count, a);
+        hipLaunchKernelGGL(k_dw_all<128>, grid, block, lds, s, lv, a);
     }
     DURF_CHECK_LAUNCH("durf_mlp_dw");
     return 0;
 }
 
-int launch_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count, int nlevels,
+int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
                        const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
                        size_t bpart_stride, size_t grad_stride) {
     if (K <= 0) return 0;
@@ -1003,7 +1083,7 @@ int launch_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, 
         if (el > max_el) max_el = el;
     }
     hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12, K), dim3(256), 0, s, W, in_dim, jobs, part, bpart,
-                       grad_mlp, part_stride, bpart_stride, grad_stride, rows, N, nlevels, count);
+                       grad_mlp, part_stride, bpart_stride, grad_stride, lv);
     DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
     return 0;
 }

@@ -276,7 +276,8 @@ __global__ void __launch_bounds__(512, 2)
 k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
           const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
           const char* __restrict__ wpack, float* __restrict__ raw, bf16x8* __restrict__ stash,
-          uint4* __restrict__ relu_mask, FwdStrides bs) {
+          uint4* __restrict__ relu_mask, FwdStrides bs, const int32_t* __restrict__ tail_idx,
+          const int32_t* __restrict__ tail_count) {
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gridDim.y > 1) {                             // batched object MLPs: this workgroup's object slab
@@ -295,6 +296,14 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     if (count) {
         const size_t c = (size_t)(*count) * (size_t)N;
         nrows = c < rows ? c : rows;
+    }
+    // Tail rows (de-duplicated background evaluation, include/durf_hip.h durf_expand_raw): after the count*N rows of
+    // the rays evaluated sample by sample come *tail_count rows, ONE per box-hit ray tail_idx[i], whose trunk input is
+    // the constant encoding of a zero-masked Gaussian ([0 x 30, 1 x 30]) and whose view direction is that ray's.
+    const size_t nrows_c = nrows;                             // a multiple of 32 whenever a tail is given (N % 32 == 0)
+    if (tail_count) {
+        const size_t t = nrows_c + (size_t)(*tail_count);
+        nrows = t < rows ? t : rows;
     }
     if ((size_t)blockIdx.x * 256 >= nrows) return;           // whole workgroup idle
     const int lane = threadIdx.x & 63;
@@ -333,10 +342,27 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     const bool tile_valid = tile32 * 32 < nrows;
 
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool tail = tail_count != nullptr && tile32 * 32 >= nrows_c;   // wave-uniform
+    // natural-order fragment of the constant encoding: feature 16 k + 8 hi + e is 1 for the 30 cosine features
+    auto const_enc = [&](int k) -> bf16x8 {
+        bf16x8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int f = 16 * k + 8 * (lane >> 5) + e;
+            v[e] = (f >= 30 && f < 60) ? (__bf16)1.0f : (__bf16)0.0f;
+        }
+        return v;
+    };
     bf16x8 encf[S::KE];
     const char* enc_u = (const char*)enc + tile32 * (S::KE * 1024);      // wave-uniform
 #pragma unroll
-    for (int k = 0; k < S::KE; k++) encf[k] = tile_valid ? *(const bf16x8*)(enc_u + k * 1024 + lane * 16) : zero8;
+    for (int k = 0; k < S::KE; k++)
+        encf[k] = tile_valid ? (tail ? const_enc(k) : *(const bf16x8*)(enc_u + k * 1024 + lane * 16)) : zero8;
+    if (TRAIN && tail && tile_valid) {       // the weight-gradient GEMMs of Dense_0 / Dense_5 read the encoding tile
+#pragma unroll
+        for (int k = 0; k < S::KE; k++) *(bf16x8*)(const_cast<char*>(enc_u) + k * 1024 + lane * 16) = encf[k];
+        p.since += S::KE;
+    }
     // jnp.maximum propagates NaN through every ReLU, v_max_f32 does not.  The only source of
     // non-finite values is the encoding of a garbage (multi-hit) ray, and one non-finite
     // feature makes the reference's MLP output NaN: detect it once here and poison the output.
@@ -376,7 +402,8 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     // held in 16 VGPRs across stages 1-4, where the kernel sits at the 256-register cap.
     bf16x8 encs[S::KE];
 #pragma unroll
-    for (int k = 0; k < S::KE; k++) encs[k] = tile_valid ? *(const bf16x8*)(enc_u + k * 1024 + lane * 16) : zero8;
+    for (int k = 0; k < S::KE; k++)
+        encs[k] = tile_valid ? (tail ? const_enc(k) : *(const bf16x8*)(enc_u + k * 1024 + lane * 16)) : zero8;
     run_stage<SLOT, S::KW, S::KE, S::WT, true, TRAIN, S::WT>(p, a, encs, b, GW, ST(5), tile_valid, a, ST(4), MK(4), mcarry);
     // stages 6, 7
     run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, b, nullptr, a, GW, ST(6), tile_valid, b, ST(5), MK(5), mcarry);
@@ -393,7 +420,8 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     bf16x8 vf[S::KV];
     {
         size_t ray = row / (size_t)N;
-        if (ray_idx && valid) ray = (size_t)ray_idx[ray];
+        if (tail) ray = valid ? (size_t)tail_idx[row - nrows_c] : 0;
+        else if (ray_idx && valid) ray = (size_t)ray_idx[ray];
 #pragma unroll
         for (int k = 0; k < S::KV; k++)
             vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + (lane >> 5)] : zero8;
@@ -454,9 +482,12 @@ int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_para
 
 int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
                  const void* view_bf16, const int32_t* ray_idx, const int32_t* count,
-                 const void* wpack_fwd, float* raw, void* stash, void* relu_mask) {
+                 const void* wpack_fwd, float* raw, void* stash, void* relu_mask,
+                 const int32_t* tail_idx, const int32_t* tail_count) {
+    DURF_REQUIRE((tail_idx == nullptr) == (tail_count == nullptr), "tail_idx and tail_count go together");
+    DURF_REQUIRE(tail_idx == nullptr || (count != nullptr && N % 32 == 0), "tail rows follow a compacted ray list");
     return durf::launch_mlp_fwd(stream, width, rows, N, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash,
-                                relu_mask, 1, FwdStrides{});
+                                relu_mask, 1, FwdStrides{}, tail_idx, tail_count);
 }
 
 }  // extern "C"
@@ -488,7 +519,7 @@ int launch_pack(void* stream, int width, int in_dim, int K, const float* params,
 
 int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile, const void* view_bf16,
                    const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
-                   void* relu_mask, int K, const FwdStrides& st) {
+                   void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx, const int32_t* tail_count) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
@@ -502,7 +533,7 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
         (void)hipFuncSetAttribute((const void*)k_mlp_fwd<WW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((k_mlp_fwd<WW, TR>), grid, block, lds, s, rows, N, (const bf16x8*)enc_tile, \
                            (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw,  \
-                           (bf16x8*)stash, (uint4*)relu_mask, st);                                 \
+                           (bf16x8*)stash, (uint4*)relu_mask, st, tail_idx, tail_count);           \
     }
     if (width == 256) { if (stash) LAUNCH_F(256, true) else LAUNCH_F(256, false) }
     else { if (stash) LAUNCH_F(128, true) else LAUNCH_F(128, false) }

@@ -62,11 +62,11 @@ int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, i
     st.enc = durf_obj_enc_stride(B, N); st.view = durf_obj_view_stride(B, N);
     st.stash = durf_mlp_stash_bytes(DURF_W_OBJ, rows); st.dz_out = durf_obj_dzout_stride(B, N);
     st.part = durf_dw_part_floats(DURF_W_OBJ); st.bpart = durf_dw_bpart_floats(DURF_W_OBJ);
-    int rc = durf::launch_mlp_dw(stream, DURF_W_OBJ, rows, N, count, nlevels, enc, view_tile, stash, dz, dz_out, part,
-                                 bpart, K, st);
+    DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
+    const durf::DwLevels lv = durf::uniform_levels(rows, N, count, nlevels);
+    int rc = durf::launch_mlp_dw(stream, DURF_W_OBJ, lv, enc, view_tile, stash, dz, dz_out, part, bpart, K, st);
     if (rc) return rc;
-    return durf::launch_dw_finalize(stream, DURF_W_OBJ, in_dim, rows, N, count, nlevels, part, bpart, grad_mlp, K, st.part,
-                                    st.bpart, grad_stride);
+    return durf::launch_dw_finalize(stream, DURF_W_OBJ, in_dim, lv, part, bpart, grad_mlp, K, st.part, st.bpart, grad_stride);
 }
 
 }  // extern "C"

@@ -316,7 +316,7 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
     const int j = (int)(row / N), n = (int)(row % N);
     if (j >= rays) return;
     int b = j;
-    if (OBJ) {
+    if (OBJ || idx) {                        // compacted ray list (object rays; background rays of a de-duplicated batch)
         if (j >= *count) return;
         b = idx[j];
     }
@@ -362,10 +362,13 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
                 bf16x8 o8;
 #pragma unroll
                 for (int e = 0; e < 8; e++) o8[e] = (__bf16)feat[q * 8 + e];
-#if defined(ENC_NT)
-                __builtin_nontemporal_store(o8, (bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16));
-#else
+                // non-temporal: the tile is written once and read once by the fused MLP (measured 18.7 -> 17.9 us at
+                // 4096 rays, 125 -> 113 us at 32 768; the kernel is bound by its store path: with the arithmetic
+                // compiled out the same stores take 14.8 / 105 us)
+#if defined(ENC_NO_NT)
                 *(bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16) = o8;
+#else
+                __builtin_nontemporal_store(o8, (bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16));
 #endif
             }
         }
@@ -382,14 +385,14 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
     // one op when the arguments are moderate.  Differences from the exact wrap: it ignores that the reference's 100 pi
     // is rounded to fp32 (5.9e-6 rad per wrap) and it rounds y / 2 pi in fp32 (<= 2e-4 rad at |y| = 2048); both are far
     // below the bf16 quantum 4e-3 this path writes (measured: max / mean abs error vs the oracle unchanged to three
-    // digits, tests/encode_error.py).  A wave in which ANY sample has max|x| * 512 + pi/2 >= 2048 takes the exact
-    // wrap, unchanged -- that covers uncontracted coordinates (|y| up to 1e5, where the fp32 rounding of y / 2 pi
+    // digits, tests/encode_error.py).  A sample with max|x| * 512 + pi/2 >= 2048 takes the exact wrap, unchanged (a
+    // wave with both kinds runs both paths under their lane masks) -- that covers uncontracted coordinates (|y| up to 1e5, where the fp32 rounding of y / 2 pi
     // would reach the quantum), object-frame rays, and also contracted points: the reference's contraction switches
-    // at norm 0.1, so norms just above 0.1 map to |2 - 1/n| up to 8, not <= 2.  How many waves that is depends on
-    // the scene (level 0 of the bench.py batch: none of 8192).
+    // at norm 0.1, so norms just above 0.1 map to |2 - 1/n| up to 8, not <= 2.  How many samples that is depends on
+    // the scene (level 0 of the bench.py batch: none).
     const float amax = fmaxf(fmaxf(fabsf(g.x[0]), fabsf(g.x[1])), fabsf(g.x[2]));
     const bool big = !(amax * 512.0f + 1.5707963705062866f < 2048.0f);         // also true for NaN
-    if (__builtin_amdgcn_ballot_w64(big) != 0) {
+    if (big) {        // per lane: a sample's features never depend on which samples share its wave
 #pragma unroll
         for (int deg = 0; deg < 10; deg++) {
             const float sc = (float)(1 << deg);
@@ -494,16 +497,18 @@ int durf_view_enc(void* stream, int B, const float* viewdirs, void* out_bf16, fl
 
 int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const float* origins_s,
                      const float* dirs_s, const float* radii, const int32_t* hit, int K,
-                     int contraction, void* out_tile, float* out_f32) {
+                     int contraction, void* out_tile, float* out_f32, const int32_t* idx, const int32_t* count) {
     if (B <= 0) return 0;
     DURF_REQUIRE(((size_t)B * N) % 32 == 0 || out_tile == nullptr, "B*N must be a multiple of 32");
+    DURF_REQUIRE((idx == nullptr) == (count == nullptr), "idx and count go together");
+    DURF_REQUIRE(idx == nullptr || out_f32 == nullptr, "the compacted ray list is for the bf16 tile output");
     if (out_f32)
         hipLaunchKernelGGL((k_encode<false>), dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
                            (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
                            hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
     else
         hipLaunchKernelGGL((k_encode_lane<false>), dim3(durf_cdiv((size_t)B * N, ENC_BLOCK)), dim3(ENC_BLOCK), 0,
-                           (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
+                           (hipStream_t)stream, B, N, idx, count, t_vals, origins_s, dirs_s, radii,
                            hit, K, contraction, BarfW{}, (char*)out_tile, (size_t)0, (size_t)0);
     DURF_CHECK_LAUNCH("durf_encode_bkgd");
     return 0;

@@ -289,7 +289,29 @@ k_composite_resample(int B, int N, int K, const float* __restrict__ raw_bkgd, Ob
     }
 }
 
+// De-duplicated background evaluation (see durf_expand_raw in include/durf_hip.h): raw of the full [B*N,4] layout
+// from the compacted rows of the rays evaluated sample by sample and, after them, the ONE row of each box-hit ray.
+__global__ void __launch_bounds__(256)
+k_expand_raw(int B, int N, const float* __restrict__ raw_c, const int32_t* __restrict__ count,
+             const int32_t* __restrict__ slot, float* __restrict__ raw_full) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * N) return;
+    const int b = (int)(i / N), n = (int)(i % N);
+    const int s0 = slot[b * 2], s1 = slot[b * 2 + 1];
+    const size_t src = s0 >= 0 ? (size_t)s0 * N + n : (size_t)count[0] * N + (size_t)s1;
+    *(f32x4*)(raw_full + i * 4) = *(const f32x4*)(raw_c + src * 4);
+}
+
 extern "C" {
+
+int durf_expand_raw(void* stream, int B, int N, const float* raw_c, const int32_t* count, const int32_t* slot,
+                    float* raw_full) {
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_expand_raw, dim3(durf_cdiv((size_t)B * N, 256)), dim3(256), 0, (hipStream_t)stream, B, N, raw_c,
+                       count, slot, raw_full);
+    DURF_CHECK_LAUNCH("durf_expand_raw");
+    return 0;
+}
 
 int durf_composite_fwd(void* stream, int B, int N, int K, const float* raw_bkgd,
                        const float* const* raw_obj, const int32_t* slot, const float* t_vals,

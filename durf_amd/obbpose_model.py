@@ -228,6 +228,17 @@ class MipNerfModel:
         # (durf_composite_resample); the last level launches no composite at all -- durf_loss_bwd recomputes it
         # anyway and fills this level's rgb / depth / acc / weights (`deferred`).  Inference keeps the plain calls.
         fused = train and loss_prep is not None
+        # De-duplicated background evaluation (include/durf_hip.h, durf_expand_raw): a ray that hits exactly ONE box
+        # feeds the background MLP the same trunk input at all its samples, so it is evaluated once (a "tail row" of
+        # the same launch) and the other rays sample by sample on a compacted list.  Same results, ~hit-fraction less
+        # background MLP work.  Rays that hit no box or several (the reference's garbage-in case) take the full path.
+        dd = None
+        if Kd and not f32 and ops.DEDUP_HIT_RAYS:
+            nh = dyn_mask.reshape(-1)
+            cls = torch.stack([nh != 1, nh == 1], -1).to(torch.int32).contiguous()
+            idx2, count2, slot2 = ops.compact_hits(cls)
+            dd = dict(idx=idx2, count=count2, slot=slot2)
+            ctx['dedup'] = dd
         t_next = None
         for lvl in range(self.num_levels):
             last = lvl == self.num_levels - 1
@@ -246,11 +257,20 @@ class MipNerfModel:
                 raws = lvd['raws']
             else:
                 lvd = None
-                enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
-                                           disable_integration=self.disable_integration, cylinder=cyl)
                 stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
                 mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
-                raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
+                if dd is not None:
+                    enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,
+                                               disable_integration=self.disable_integration, cylinder=cyl,
+                                               idx=dd['idx'][0], count=dd['count'][0:1])
+                    raw_c = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], ray_idx=dd['idx'][0],
+                                        count=dd['count'][0:1], stash=stash_b, relu_mask=mask_b,
+                                        tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
+                    raw_b = ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'])
+                else:
+                    enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
+                                               disable_integration=self.disable_integration, cylinder=cyl)
+                    raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
                 slabs = None
                 if Kd:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
                     slabs = ops.ObjSlabs(Kd, B, N, dev, train)

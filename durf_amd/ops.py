@@ -110,8 +110,9 @@ ENC_CONTRACT, ENC_NO_INTEGRATION, ENC_CYLINDER = 1, 2, 4
 
 
 def encode_bkgd(t_vals, origins_s, dirs_s, radii, hit, contraction=True, tile=True, f32=False,
-                disable_integration=False, cylinder=False):
-    """hit=None: no object masking of the samples (MipNerfModel.dynamics=False)"""
+                disable_integration=False, cylinder=False, idx=None, count=None):
+    """hit=None: no object masking of the samples (MipNerfModel.dynamics=False);
+    idx / count: encode only rays idx[:count] into compacted rows (bf16 tiles)"""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     K = 0 if hit is None else hit.shape[1]
     dev = t_vals.device
@@ -122,7 +123,7 @@ def encode_bkgd(t_vals, origins_s, dirs_s, radii, hit, contraction=True, tile=Tr
                                                _p(_f32(dirs_s)), _p(_f32(radii)), _p(hit), K,
                                                (ENC_CONTRACT if contraction else 0) | (ENC_NO_INTEGRATION if disable_integration else 0) |
                                                (ENC_CYLINDER if cylinder else 0),
-                                               _p(ot), _p(of)), 'durf_encode_bkgd')
+                                               _p(ot), _p(of), _p(idx), _p(count)), 'durf_encode_bkgd')
     return ot, of
 
 
@@ -179,16 +180,32 @@ def mlp_mask_bytes(rows):
 
 
 def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=None, stash=None,
-            raw=None, relu_mask=None):
+            raw=None, relu_mask=None, tail_idx=None, tail_count=None):
+    """tail_idx / tail_count: once-per-ray rows of a de-duplicated batch after the count*N compacted rows"""
     dev = enc_tile.device
     if raw is None:
         raw = torch.empty(rows, 4, device=dev)
     with _Timed('mlp_fwd_%d%s' % (width, '_train' if stash is not None else '')):
         _lib.check(_lib.lib().durf_mlp_fwd(_stream(), width, rows, N, _p(enc_tile), _p(view_bf16),
                                            _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash),
-                                           _p(relu_mask)),
+                                           _p(relu_mask), _p(tail_idx), _p(tail_count)),
                    'durf_mlp_fwd')
     return raw
+
+
+# Evaluate the background MLP once per box-hit ray instead of once per sample (exact: see durf_expand_raw in
+# include/durf_hip.h).  Module switch for A/B measurements and tests.
+DEDUP_HIT_RAYS = True
+
+
+def expand_raw(B, N, raw_c, slot2, count2):
+    """compacted raw (count2[0]*N rows of the sample-by-sample rays, then one row per box-hit ray) -> [B*N,4]"""
+    raw_full = torch.empty(B * N, 4, device=raw_c.device)
+    # the tail starts at row count2[0]*N: hand the kernel a pointer to that row (device-side count -> device-side offset
+    # is not available on the host, so the kernel takes the base and the slot of the tail separately)
+    _lib.check(_lib.lib().durf_expand_raw(_stream(), B, N, _p(_f32(raw_c)), _p(count2), _p(slot2), _p(raw_full)),
+               'durf_expand_raw')
+    return raw_full
 
 
 BKGD_GREY, BKGD_WHITE, BKGD_RAND = 0, 1, 2
@@ -290,7 +307,8 @@ def loss_prep(t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, leve
 
 
 def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, eps,
-             mults, box_loss_mult, level, bg, density_bias=-1.0, disable_multiscale=False, sums=None, render_out=None):
+             mults, box_loss_mult, level, bg, density_bias=-1.0, disable_multiscale=False, sums=None, render_out=None,
+             draw_ray_sum=None):
     """-> draw [B*N,4], term_sums[7] (rgb, obj, depth, near, empty, sky, dist numerators).
     render_out = (rgb [B,3], depth [B], acc [B], weights [B,N], t_mids [B,N], t_dists [B,N]) tensors to fill with the level's rendered
     outputs (what composite_fwd returns; a training step then skips that launch for the last level)."""
@@ -308,7 +326,7 @@ def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth
                                         _p(_f32(lossmult)), _p(_f32(gt_depth)), _p(_f32(sky)), _p(dyn),
                                         _p(_f32(zo)), _p(norm), eps, m, box_loss_mult, level,
                                         int(disable_multiscale), bg, density_bias, _p(draw), _p(terms),
-                                        _p(sums), *[_p(t) for t in (render_out or (None,) * 6)]), 'durf_loss_bwd')
+                                        _p(sums), *[_p(t) for t in (render_out or (None,) * 6)], _p(draw_ray_sum)), 'durf_loss_bwd')
     return draw, sums
 
 
@@ -340,7 +358,8 @@ def stats_views(out, L):
     return d
 
 
-def mlp_bwd(width, rows, N, draw, wpack_bwd, relu_mask, ray_idx=None, count=None, want_d_enc=False):
+def mlp_bwd(width, rows, N, draw, wpack_bwd, relu_mask, ray_idx=None, count=None, want_d_enc=False,
+            tail_idx=None, tail_count=None, draw_ray_sum=None):
     """-> dz (same layout as the stash), dz_out tile [rows,16][, d_enc [rows,64] fp32]"""
     dev = draw.device
     dz = torch.empty(mlp_stash_bytes(width, rows), dtype=torch.uint8, device=dev)
@@ -348,15 +367,16 @@ def mlp_bwd(width, rows, N, draw, wpack_bwd, relu_mask, ray_idx=None, count=None
     d_enc = torch.zeros(rows, ENC_DIM, device=dev) if want_d_enc else None
     with _Timed('mlp_bwd_%d' % width):
         _lib.check(_lib.lib().durf_mlp_bwd(_stream(), width, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
-                                           _p(wpack_bwd), _p(relu_mask), _p(dz), _p(dz_out), _p(d_enc)),
+                                           _p(wpack_bwd), _p(relu_mask), _p(dz), _p(dz_out), _p(d_enc),
+                                           _p(tail_idx), _p(tail_count), _p(draw_ray_sum)),
                    'durf_mlp_bwd')
     return (dz, dz_out, d_enc) if want_d_enc else (dz, dz_out)
 
 
-def expand_view(rows, N, view_bf16, ray_idx=None, count=None):
+def expand_view(rows, N, view_bf16, ray_idx=None, count=None, tail_idx=None, tail_count=None):
     out = torch.empty(tile_rows(rows), VIEW_DIM, dtype=torch.bfloat16, device=view_bf16.device)
     _lib.check(_lib.lib().durf_expand_view(_stream(), rows, N, _p(view_bf16), _p(ray_idx), _p(count),
-                                           _p(out)), 'durf_expand_view')
+                                           _p(out), _p(tail_idx), _p(tail_count)), 'durf_expand_view')
     return out
 
 
@@ -373,6 +393,29 @@ def mlp_dw(width, rows, N, enc_tiles, view_tiles, stashes, dzs, dz_outs, part, b
     with _Timed('mlp_dw_%d' % width):
         _lib.check(_lib.lib().durf_mlp_dw(_stream(), width, rows, N, _p(count), L, arr(enc_tiles), arr(view_tiles),
                                           arr(stashes), arr(dzs), arr(dz_outs), _p(part), _p(bpart)), 'durf_mlp_dw')
+
+
+def _levels_args(rows_l, n_l, count_l):
+    L = len(rows_l)
+    return (L, (C.c_size_t * L)(*[int(r) for r in rows_l]), (C.c_int * L)(*[int(n) for n in n_l]),
+            (C.c_void_p * L)(*[None if c is None else c.data_ptr() for c in count_l]))
+
+
+def mlp_dw_levels(width, rows_l, n_l, count_l, enc_tiles, view_tiles, stashes, dzs, dz_outs, part, bpart):
+    """mlp_dw with per-segment geometry: row capacity, rows per ray and device ray count of every segment"""
+    L, rows_a, n_a, cnt_a = _levels_args(rows_l, n_l, count_l)
+    arr = lambda ts: (C.c_void_p * L)(*[t.data_ptr() for t in ts])
+    with _Timed('mlp_dw_%d' % width):
+        _lib.check(_lib.lib().durf_mlp_dw_levels(_stream(), width, L, rows_a, n_a, cnt_a, arr(enc_tiles), arr(view_tiles),
+                                                 arr(stashes), arr(dzs), arr(dz_outs), _p(part), _p(bpart)),
+                   'durf_mlp_dw_levels')
+
+
+def mlp_dw_finalize_levels(width, in_dim, rows_l, n_l, count_l, part, bpart, grad_mlp):
+    L, rows_a, n_a, cnt_a = _levels_args(rows_l, n_l, count_l)
+    with _Timed('mlp_dw_finalize_%d' % width):
+        _lib.check(_lib.lib().durf_mlp_dw_finalize_levels(_stream(), width, in_dim, L, rows_a, n_a, cnt_a, _p(part),
+                                                          _p(bpart), _p(grad_mlp)), 'durf_mlp_dw_finalize_levels')
 
 
 def mlp_dw_finalize(width, in_dim, rows, N, nlevels, part, bpart, grad_mlp, count=None):

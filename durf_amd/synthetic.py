@@ -37,7 +37,7 @@ def _hits(o, d, centers, rots, ext):
 
 
 def make_batch(B, K, T=5, far=40.0, seed=SEED, hit_range=(0.05, 0.15), noise_boxes=0.0,
-               img_hw=(320, 480), focal=515.0, allow_multi_hit=False):
+               img_hw=(320, 480), focal=515.0, allow_multi_hit=False, redraw_noisy_multi_hit=False):
     """One training batch.  `noise_boxes` > 0 emulates Config.random_box (init = target
     + U(-noise, noise) on the centres, configs/waymo.gin:6,8).  Rays that would hit two boxes
     at once are re-drawn unless allow_multi_hit: the reference sums their object-frame origins
@@ -112,6 +112,22 @@ def make_batch(B, K, T=5, far=40.0, seed=SEED, hit_range=(0.05, 0.15), noise_box
     if noise_boxes > 0:
         init = init.copy()
         init[:, :, :3] += rng.uniform(-noise_boxes, noise_boxes, (T, K, 3))
+        if redraw_noisy_multi_hit and K > 1:
+            # the model intersects the rays with the NOISY boxes init[ts]: re-draw rays that hit two of those
+            # (a separate generator, so batches made without this flag keep their values)
+            rng2 = np.random.default_rng(seed + 7919)
+            for _ in range(100):
+                bad = np.nonzero(_hits(o, d, init[ts, :, :3], init[ts, :, 3:], ext).sum(-1) > 1)[0]
+                if bad.size == 0:
+                    break
+                u[bad] = rng2.uniform(0, W - 1, bad.size)
+                v[bad] = rng2.uniform(0, H - 1, bad.size)
+                o[bad] = rng2.uniform(-0.5, 0.5, (bad.size, 3))
+                d = cam_dirs(u)
+                dx = np.linalg.norm(cam_dirs(u + 1.0) - d, axis=-1)
+                radii = (dx * 2 / np.sqrt(12))[:, None]
+                viewdirs = d / np.linalg.norm(d, axis=-1, keepdims=True)
+            frac = float(_hits(o, d, init[ts, :, :3], init[ts, :, 3:], ext).any(-1).mean())
 
     depth = np.where(rng.uniform(0, 1, B) < 0.3, rng.uniform(0.5, 30.0, B), 0.0)[:, None]
     sky = np.where(rng.uniform(0, 1, B) < 0.1, 0.975, 0.0)[:, None]

@@ -80,7 +80,17 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     f32 = model.mlp_precision == 'f32'
     bufs = None if f32 else ops.dw_buffers(om.W_BKGD, dev)
     dzs = [None] * L                            # per-level (dz, dz_out) of the bkgd MLP, consumed by ONE dW launch
-    view_tile = None if f32 else ops.expand_view(rows, N, ctx['view'])
+    dd = ctx.get('dedup')                        # de-duplicated background evaluation (obbpose_model._forward)
+    if f32:
+        view_tile = None
+    elif dd is not None:
+        view_tile = ops.expand_view(rows, N, ctx['view'], ray_idx=dd['idx'][0], count=dd['count'][0:1],
+                                    tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
+        # valid rows of the compacted buffers: count[0] * N sample rows + count[1] once-per-ray rows
+        dd['nrows'] = (dd['count'][0] * N + dd['count'][1]).to(torch.int32).reshape(1)
+    else:
+        view_tile = ops.expand_view(rows, N, ctx['view'])
+    ray_sums = torch.empty(L, B, 4, device=dev) if dd is not None else None
     sums = torch.empty(L, ops.TERM_ROWS, device=dev)
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
@@ -96,7 +106,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         draw, _ = ops.loss_bwd(lv['raw_b'], lv['raws'], ctx['slot'], lv['t_vals'], ctx['d_s'], pixels, lossmult,
                                gt_depth, sky, dyn, ctx['zo'], norm, float(eps),
                                level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
-                               model.density_bias, config.disable_multiscale_loss, sums=sums[lvl], render_out=out)
+                               model.density_bias, config.disable_multiscale_loss, sums=sums[lvl], render_out=out,
+                               draw_ray_sum=None if dd is None else ray_sums[lvl])
         if f32:                               # exact-fp32 parity instrument: per-MLP fp32 backward + weight gradients
             fl = lv['f32']
             off = lay.mlp_off['MLP_0']
@@ -113,7 +124,12 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                     ops.encode_obj_bwd(k, ctx['idx'][k], ck, o[1], lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
                                        rays.origins, rays.directions, pose_ts, alpha, pose_sums)
             continue
-        dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
+        if dd is not None:
+            dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'], ray_idx=dd['idx'][0],
+                                   count=dd['count'][0:1], tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
+                                   draw_ray_sum=ray_sums[lvl])
+        else:
+            dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
         if K:                                 # all K object MLPs: one call (csrc/objects.hip)
             ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
             for k in range(K if pose_opt else 0):   # d(loss)/d(box pose) through the object encoding
@@ -122,10 +138,16 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                    pose_sums)
     levels = ctx['levels']
     if not f32:
-        ops.mlp_dw(om.W_BKGD, rows, N, [lv['enc_b'] for lv in levels], [view_tile] * L, [lv['stash_b'] for lv in levels],
-                   [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
         off = lay.mlp_off['MLP_0']
-        ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, rows, N, L, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
+        if dd is not None:               # every level: one segment of `nrows` valid rows (1 row per "ray")
+            geo = ([rows] * L, [1] * L, [dd['nrows']] * L)
+            ops.mlp_dw_levels(om.W_BKGD, *geo, [lv['enc_b'] for lv in levels], [view_tile] * L,
+                              [lv['stash_b'] for lv in levels], [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
+            ops.mlp_dw_finalize_levels(om.W_BKGD, om.IN_BKGD, *geo, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
+        else:
+            ops.mlp_dw(om.W_BKGD, rows, N, [lv['enc_b'] for lv in levels], [view_tile] * L,
+                       [lv['stash_b'] for lv in levels], [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
+            ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, rows, N, L, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
         if K:
             o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
             ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)
@@ -142,7 +164,9 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
         grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)[ctx['ts']] += g6
     pose = ret[0][7][0]
-    raw = dict(norms=norms, sums=sums, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if lay.K > 0 else None)
+    multi = (dyn > 1).sum() if lay.K > 1 else torch.zeros((), dtype=torch.int64, device=dev)
+    raw = dict(norms=norms, sums=sums, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if lay.K > 0 else None,
+               multi_hit=multi)
     return grad, raw, pose
 
 
@@ -203,7 +227,7 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
         offsets=st['offsets'], offset_x=st['offset_x'], offset_y=st['offset_y'], offset_z=st['offset_z'],
         offset_yaw=st['offset_yaw'], pose=pose, weights=[r[3] for r in ret], samples=[r[4] for r in ret],
         weight_l2=st['weight_l2'], psnr=st['psnrs'][-1], psnrs=st['psnrs'], obj_psnr=st['obj_psnrs'][-1],
-        grad_norm=gs[0], grad_abs_max=gs[1], grad_norm_clipped=gs[3])
+        grad_norm=gs[0], grad_abs_max=gs[1], grad_norm_clipped=gs[3], multi_hit_rays=raw['multi_hit'])
     new_rng = (int(rng) + 1) if isinstance(rng, int) else rng
     return new_state, stats, new_rng, pose.clone()
 
@@ -325,6 +349,10 @@ def train_loop(model, config, state, dataset, test_dataset=None, train_dir=None,
             rec = dict(loss=float(stats.loss), avg_loss=float(losses.mean()), avg_psnr=float(psnrs.mean()),
                        max_grad_norm=float(gn.max()), lr=lr, eps=eps, alpha=alpha,
                        rays_per_sec=config.batch_size * steps_per_sec)
+            pose_opt = not (model.no_pose_opt and model.no_yaw_opt)
+            if pose_opt and int(getattr(stats, 'multi_hit_rays', 0)) > 0 and rank == 0:
+                log('warning: %d rays of this batch hit two or more boxes; their cross-object pose gradient is not '
+                    'propagated (see utils.Stats.multi_hit_rays)' % int(stats.multi_hit_rays))
             history.append((step, rec))
             trace, reset_timer = [], True
             if rank == 0:

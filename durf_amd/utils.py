@@ -45,6 +45,11 @@ class Stats:
     grad_norm: Any = 0.0
     grad_abs_max: Any = 0.0
     grad_norm_clipped: Any = 0.0
+    # not a reference field: rays of the batch that hit two or more boxes.  The reference sums their object-frame
+    # origins (obbpose_model.py:120-122, "assumes that objects do not occlude each other"); this build treats them
+    # as out of domain (non-finite on both sides) and, with pose optimisation on, drops the cross-object part of
+    # their pose gradient -- so a driver can see how many there were (train_loop warns when pose_opt is on).
+    multi_hit_rays: Any = 0
 
 
 @dataclasses.dataclass

@@ -41,8 +41,8 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_view_enc.argtypes = [vp, i32, vp, vp, vp]
     #   (stream, B, viewdirs, out_bf16, out_f32)
     L.durf_encode_bkgd.restype = i32
-    L.durf_encode_bkgd.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp]
-    #   (stream, B, N, t_vals, origins_s, dirs_s, radii, hit, K, contraction, out_tile, out_f32)
+    L.durf_encode_bkgd.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]
+    #   (stream, B, N, t_vals, origins_s, dirs_s, radii, hit, K, contraction, out_tile, out_f32, idx, count)
     L.durf_encode_obj.restype = i32
     L.durf_encode_obj.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp, vp]
     #   (stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags, out_tile, out_f32)
@@ -53,8 +53,8 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_mask_bytes.argtypes = [u64]
     #   (rows)
     L.durf_mlp_fwd.restype = i32
-    L.durf_mlp_fwd.argtypes = [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
-    #   (stream, width, rows, N, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash, relu_mask)
+    L.durf_mlp_fwd.argtypes = [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, width, rows, N, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash, relu_mask, tail_idx, tail_count)
     L.durf_composite_fwd.restype = i32
     L.durf_composite_fwd.argtypes = [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp]
     #   (stream, B, N, K, raw_bkgd, raw_obj, slot, t_vals, dirs_s, density_bias, bkgd_mode, rgb, depth, acc, weights, t_mids, t_dists)
@@ -71,17 +71,17 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_loss_prep.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]
     #   (stream, B, N, t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level, disable_multiscale, prep, norm)
     L.durf_loss_bwd.restype = i32
-    L.durf_loss_bwd.argtypes = [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    #   (stream, B, N, K, raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, eps, mults, box_loss_mult, level, disable_multiscale, bg, density_bias, draw, terms, term_sums, rgb_out, depth_out, acc_out, weights_out, t_mids_out, t_dists_out)
+    L.durf_loss_bwd.argtypes = [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, B, N, K, raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, eps, mults, box_loss_mult, level, disable_multiscale, bg, density_bias, draw, terms, term_sums, rgb_out, depth_out, acc_out, weights_out, t_mids_out, t_dists_out, draw_ray_sum)
     L.durf_train_stats.restype = i32
     L.durf_train_stats.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(f32), i32, vp]
     #   (stream, L, K, N, norms, sums, weight_l2, pose6, prev6, target6, t_vals, mults, mode, out)
     L.durf_mlp_bwd.restype = i32
-    L.durf_mlp_bwd.argtypes = [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
-    #   (stream, width, rows, N, draw, ray_idx, count, wpack_bwd, relu_mask, dz, dz_out, d_enc)
+    L.durf_mlp_bwd.argtypes = [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, width, rows, N, draw, ray_idx, count, wpack_bwd, relu_mask, dz, dz_out, d_enc, tail_idx, tail_count, draw_ray_sum)
     L.durf_expand_view.restype = i32
-    L.durf_expand_view.argtypes = [vp, u64, i32, vp, vp, vp, vp]
-    #   (stream, rows, N, view_bf16, ray_idx, count, out_tile)
+    L.durf_expand_view.argtypes = [vp, u64, i32, vp, vp, vp, vp, vp, vp]
+    #   (stream, rows, N, view_bf16, ray_idx, count, out_tile, tail_idx, tail_count)
     L.durf_dw_part_floats.restype = u64
     L.durf_dw_part_floats.argtypes = [i32]
     #   (width)
@@ -94,6 +94,15 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_dw_finalize.restype = i32
     L.durf_mlp_dw_finalize.argtypes = [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp]
     #   (stream, width, in_dim, rows, N, count, nlevels, part, bpart, grad_mlp)
+    L.durf_mlp_dw_levels.restype = i32
+    L.durf_mlp_dw_levels.argtypes = [vp, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp]
+    #   (stream, width, nlevels, rows, rows_per_ray, count, enc_tile, view_tile, stash, dz, dz_out, part, bpart)
+    L.durf_mlp_dw_finalize_levels.restype = i32
+    L.durf_mlp_dw_finalize_levels.argtypes = [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp]
+    #   (stream, width, in_dim, nlevels, rows, rows_per_ray, count, part, bpart, grad_mlp)
+    L.durf_expand_raw.restype = i32
+    L.durf_expand_raw.argtypes = [vp, i32, i32, vp, vp, vp, vp]
+    #   (stream, B, N, raw_c, count, slot, raw_full)
     L.durf_mlp_f32_act_floats.restype = u64
     L.durf_mlp_f32_act_floats.argtypes = [i32, i32]
     #   (width, in_dim)

@@ -86,7 +86,9 @@ int durf_view_enc(void* stream, int B, const float* viewdirs, void* out_bf16, fl
  * out_f32: [B*N, 60] row-major (either may be null). */
 int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const float* origins_s,
                      const float* dirs_s, const float* radii, const int32_t* hit, int K,
-                     int contraction /* DURF_ENC_* flags */, void* out_tile, float* out_f32);
+                     int contraction /* DURF_ENC_* flags */, void* out_tile, float* out_f32,
+                     const int32_t* idx /* nullable */, const int32_t* count /* nullable: with idx, encode only the
+                     rays idx[0..*count) into compacted rows (row r <-> ray idx[r/N]); bf16 tile output only */);
 
 /* K4 object encoding for compacted hit rays of object k: weighted_ipe (mip.py:182-223),
  * no contraction, xyz prepended -> 63 features.  idx/count from durf_compact_hits
@@ -108,7 +110,12 @@ size_t durf_mlp_stash_bytes(int width, size_t rows);
 size_t durf_mlp_mask_bytes(size_t rows);
 int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
                  const void* view_bf16, const int32_t* ray_idx, const int32_t* count,
-                 const void* wpack_fwd, float* raw, void* stash, void* relu_mask);
+                 const void* wpack_fwd, float* raw, void* stash, void* relu_mask,
+                 const int32_t* tail_idx /* nullable */, const int32_t* tail_count /* nullable: "tail rows", the
+                 once-per-ray evaluations of a de-duplicated batch (durf_expand_raw): rows [count*N, count*N +
+                 *tail_count) hold ONE sample of ray tail_idx[i] each, evaluated on the constant encoding of a
+                 zero-masked Gaussian ([0 x 30, 1 x 30]; enc_tile is not read for them) with that ray's view
+                 direction; raw / stash / relu_mask rows follow the same numbering */);
 
 /* K8 merge + activations + volumetric_rendering (obbpose_model.py:232-254, mip.py:285-327).
  * raw_bkgd [B*N,4]; raw_obj[k] [count_k*N,4] compacted, slot from durf_compact_hits.
@@ -170,7 +177,9 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                   float* rgb_out /* nullable [B,3] */, float* depth_out /* nullable [B] */,
                   float* acc_out /* nullable [B] */, float* weights_out /* nullable [B,N] */,
                   float* t_mids_out, float* t_dists_out /* nullable [B,N], written with weights_out: the level's
-                  rendered outputs, bit-identical to durf_composite_fwd's, for a level nothing is resampled from */);
+                  rendered outputs, bit-identical to durf_composite_fwd's, for a level nothing is resampled from */,
+                  float* draw_ray_sum /* nullable [B,4]: sum over each ray's samples of draw (the head gradient of the
+                  ONE background sample a box-hit ray is evaluated with, see durf_expand_raw) */);
 
 /* Scalars of utils.Stats from the per-level sums (train_boxpose.py:123-249,291-292) in one launch.
  * norms [L,5] (durf_loss_prep), sums [L,7] (durf_loss_bwd), weight_l2 nullable device scalar,
@@ -189,9 +198,12 @@ int durf_train_stats(void* stream, int L, int K, int N, const float* norms, cons
  * 3 d density). */
 int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
                  const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
-                 float* d_enc /* nullable: [rows,64] fp32 d(loss)/d(encoding), for box-pose gradients */);
+                 float* d_enc /* nullable: [rows,64] fp32 d(loss)/d(encoding), for box-pose gradients */,
+                 const int32_t* tail_idx, const int32_t* tail_count, const float* draw_ray_sum /* all nullable, together:
+                 the tail rows of durf_mlp_fwd take their head gradient from draw_ray_sum[tail_idx[i]] (durf_loss_bwd) */);
 int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
-                     const int32_t* count, void* out_tile /* tile layout [rows,32] */);
+                     const int32_t* count, void* out_tile /* tile layout [rows,32] */,
+                     const int32_t* tail_idx, const int32_t* tail_count /* nullable: tail rows as in durf_mlp_fwd */);
 
 /* K11 weight gradients of one MLP: ONE grouped launch of the 12 split-K GEMMs (one per Dense)
  * whose K axis runs over the `rows` samples of EVERY level; enc_tile/view_tile/stash/dz/dz_out
@@ -207,6 +219,32 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
 int durf_mlp_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count,
                          int nlevels /* the same rows, N, count, nlevels as the durf_mlp_dw call */,
                          const float* part, const float* bpart, float* grad_mlp);
+/* The same with per-segment geometry: segment l of the sample axis has row capacity rows[l] (a multiple of 32: the
+ * layout stride of its buffers), rows_per_ray[l] rows per ray and a nullable device ray count count[l] (valid rows =
+ * count * rows_per_ray; a partial last tile is fine when the rows beyond the count carry zero dz and finite
+ * operands).  Used for a de-duplicated batch: two sampling levels of the compacted rays + two one-row-per-ray
+ * segments of the box-hit rays (durf_expand_raw).  Host arrays of nlevels entries. */
+int durf_mlp_dw_levels(void* stream, int width, int nlevels, const size_t* rows, const int* rows_per_ray,
+                       const int32_t* const* count, const void* const* enc_tile, const void* const* view_tile,
+                       const void* const* stash, const void* const* dz, const void* const* dz_out, float* part,
+                       float* bpart);
+int durf_mlp_dw_finalize_levels(void* stream, int width, int in_dim, int nlevels, const size_t* rows,
+                                const int* rows_per_ray, const int32_t* const* count, const float* part,
+                                const float* bpart, float* grad_mlp);
+
+/* Background MLP without redundant work.  A ray that hits exactly one box feeds the background MLP the SAME trunk
+ * input at every sample (obbpose_model.py:205-210 masks its Gaussians to zero -> encoding [0 x 30, 1 x 30]); only the
+ * view direction differs, per ray.  So the background MLP is evaluated sample by sample on the other rays only
+ * (compacted: durf_encode_bkgd / durf_mlp_fwd with idx, count) and ONCE per box-hit ray (durf_mlp_fwd with N = 1 on a
+ * constant encoding: the "tail rows" of the same durf_mlp_fwd launch); this call rebuilds the reference's [B*N,4]
+ * raw layout from the two: slot [B,2] from
+ * durf_compact_hits on the two ray classes (column 0: position among the sample-by-sample rays or -1, column 1:
+ * position among the once-per-ray rays).  Backward: durf_loss_bwd's draw_ray_sum is the head gradient of the single
+ * evaluation (the MLP is the same function at every sample of such a ray, so the sum of the per-sample output
+ * gradients is exactly what reaches its weights), and durf_mlp_dw_levels takes both kinds of segment. */
+int durf_expand_raw(void* stream, int B, int N, const float* raw_c /* compacted rows, then the tail rows */,
+                    const int32_t* count /* device int[2] of durf_compact_hits on the two classes */,
+                    const int32_t* slot /* [B,2] */, float* raw_full /* [B*N,4] */);
 
 /* ---- exact-fp32 MLP: the parity instrument (csrc/mlp_f32.hip) ---------------------------------
  * The reference's Dense layers are fp32 (obbpose_model.py:326-327; HIGHEST-precision matmul, internal/math.py:22-24).

@@ -73,3 +73,43 @@ def test_two_rank_train_step_matches_shard_average(cuda, tmp_path):
     torch.cuda.synchronize()
     torch.testing.assert_close(got['flat'], variables.flat.cpu(), rtol=0, atol=0)     # deterministic kernels
     torch.testing.assert_close(got['loss'], ((losses[0] + losses[1]) / 2).cpu(), rtol=1e-6, atol=0)
+
+
+def _bench_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DURF_DIST_BACKEND='gloo')
+    sys.path.insert(0, ROOT)
+    import bench
+    from durf_amd import train_boxpose
+    r, w, local = train_boxpose.init_distributed()
+    dev = torch.device('cuda', local)
+    wl = bench.setup_workload('cfg3', dev, r, w, rays=256)           # bench.py's own path: global batch -> this rank's shard
+    state, stats_seen = wl['state'], []
+    rng = 1000 * r
+    for i in range(3):
+        state, stats, rng, _ = train_boxpose.train_step(wl['model'], wl['config'], rng, state, wl['batch'], 5e-4, 3.0,
+                                                        wl['alpha'], wl['prev'], reduce_stats=(i == 2))
+        stats_seen.append(float(stats.loss))
+    torch.cuda.synchronize()
+    torch.save(dict(flat=state.variables.flat.cpu(), losses=stats_seen, first_pixel=wl['batch']['pixels'][0].cpu()),
+               os.path.join(out_dir, 'bench_r%d.pt' % r))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_through_bench_workload_with_distinct_shards(cuda, tmp_path):
+    """bench.py's sharding (every rank builds the seeded global batch and keeps its contiguous shard) + the stats
+    all-reduce cadence: both ranks end with identical parameters; the rank-local losses of the unreduced steps differ
+    (distinct shards), the reduced one is identical on both ranks."""
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_bench_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'bench_r0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'bench_r1.pt'))
+    assert torch.equal(a['flat'], b['flat']), 'replicas must stay bit-identical after the gradient all-reduce'
+    assert not torch.equal(a['first_pixel'], b['first_pixel']), 'the ranks train on distinct shards'
+    assert a['losses'][0] != b['losses'][0] and a['losses'][1] != b['losses'][1]      # shard-local scalars
+    assert a['losses'][2] == b['losses'][2]                                            # all-reduced when logged

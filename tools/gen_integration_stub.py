@@ -28,6 +28,10 @@ def ctype_of(param):
         return SCALARS[base], name
     if stars == 1 and base == 'float' and name in ('barf_w', 'mults', 'cams_host'):
         return 'C.POINTER(f32)', name          # HOST float arrays (documented as such in the header)
+    if stars == 1 and base == 'size_t':
+        return 'C.POINTER(u64)', name          # HOST array (per-segment row capacities)
+    if stars == 1 and base == 'int':
+        return 'C.POINTER(i32)', name          # HOST array (per-segment rows per ray)
     if stars == 2:
         return 'C.POINTER(vp)', name           # host array of device pointers
     return 'vp', name                          # device pointer / stream
