@@ -154,6 +154,13 @@ def test_train_step_fp32_exact(cuda, K, N, B):
             r = _rel(grad.cpu()[sl], og[sl])
             assert r < 1e-3, '%s grad rel err %g' % (name, r)
     torch.testing.assert_close(stats.grad_norm.cpu(), ostats['grad_norm'], rtol=1e-3, atol=0)
+    # post-Adam parameters: the first step moves every weight by lr * sign(g) (bias-corrected Adam), so the update
+    # only differs where a gradient is so close to zero that fp32 summation order decides its sign: <= 5e-2 here
+    # (the bf16 path, whose gradients carry 1e-2 noise, is held to 0.15 in tests/test_gpu_train.py)
+    newflat = torch.cat([x.reshape(-1) for x in R.params_leaves(p2)])
+    step_ref = newflat - flat0.cpu()
+    step_got = new_state.variables.flat.cpu() - flat0.cpu()
+    assert _rel(step_got, step_ref) < 5e-2, _rel(step_got, step_ref)
 
 
 def test_box_pose_gradients_fp32_exact(cuda):
