@@ -259,10 +259,12 @@ class MipNerfModel:
                 lvd = None
                 stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
                 mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
+                side = ops.on_side(dev, bool(Kd))          # the object MLPs run in the shadow of the background MLP
                 if dd is not None:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl,
                                                idx=dd['idx'][0], count=dd['count'][0:1])
+                    side.fork()
                     raw_c = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], ray_idx=dd['idx'][0],
                                         count=dd['count'][0:1], stash=stash_b, relu_mask=mask_b,
                                         tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
@@ -270,13 +272,16 @@ class MipNerfModel:
                 else:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl)
+                    side.fork()
                     raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
                 slabs = None
                 if Kd:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
-                    slabs = ops.ObjSlabs(Kd, B, N, dev, train)
-                    ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
-                                      view_tile=view_tiles_obj if lvl == 0 else None,
-                                      disable_integration=self.disable_integration, cylinder=cyl)
+                    slabs = ops.ObjSlabs(Kd, B, N, dev, train)      # allocated on the main stream, filled on the side one
+                    with side:
+                        ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
+                                          view_tile=view_tiles_obj if lvl == 0 else None,
+                                          disable_integration=self.disable_integration, cylinder=cyl)
+                    side.join()
                 raws = slabs.raws() if Kd else []
             if randomized and self.density_noise > 0:    # :236-240 (added once to the merged raw density)
                 dn = noise['density'][lvl] if 'density' in noise else torch.randn(B, N, device=dev, generator=g)

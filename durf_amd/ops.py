@@ -3,6 +3,7 @@ C ABI of libdurf_hip.so on the current HIP stream.  PyTorch is used for device m
 streams only.  Reference lines each op replaces are cited in include/durf_hip.h."""
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -193,9 +194,52 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
     return raw
 
 
+# The K object MLPs touch ~10 % of the rays: their launches are small and latency-bound, and the persistent background
+# kernels leave CUs idle in their last round of blocks.  With this switch the object work of a stage is issued on a
+# side HIP stream, forked after the background encode / the loss kernel and joined before its results are consumed, so
+# it runs in the shadow of the background kernel of the same stage.
+OVERLAP_OBJECTS = os.environ.get('DURF_OVERLAP_OBJECTS', '1') != '0'     # env switch: A/B measurements
+_SIDE = {}
+
+
+def side_stream(device):
+    key = (device.type, device.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=device)
+    return _SIDE[key]
+
+
+class on_side:
+    """with on_side(device, enabled): ... -- launches inside go to the side stream (no-op when disabled).  fork():
+    the side stream waits for everything issued so far on the current stream; join(): the reverse."""
+
+    def __init__(self, device, enabled=True):
+        self.enabled = enabled and OVERLAP_OBJECTS and device.type == 'cuda'
+        self.side = side_stream(device) if self.enabled else None
+        self.ctx = None
+
+    def fork(self):
+        if self.enabled:
+            self.side.wait_stream(torch.cuda.current_stream())
+
+    def join(self):
+        if self.enabled:
+            torch.cuda.current_stream().wait_stream(self.side)
+
+    def __enter__(self):
+        if self.enabled:
+            self.ctx = torch.cuda.stream(self.side)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        if self.enabled:
+            self.ctx.__exit__(*a)
+
+
 # Evaluate the background MLP once per box-hit ray instead of once per sample (exact: see durf_expand_raw in
 # include/durf_hip.h).  Module switch for A/B measurements and tests.
-DEDUP_HIT_RAYS = True
+DEDUP_HIT_RAYS = os.environ.get('DURF_DEDUP_HIT_RAYS', '1') != '0'
 
 
 def expand_raw(B, N, raw_c, slot2, count2):

@@ -95,6 +95,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
+    side = ops.on_side(dev, bool(K) and not f32)
     # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
     for lvl in reversed(range(L)):
         lv = ctx['levels'][lvl]
@@ -124,6 +125,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                     ops.encode_obj_bwd(k, ctx['idx'][k], ck, o[1], lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
                                        rays.origins, rays.directions, pose_ts, alpha, pose_sums)
             continue
+        side.fork()                          # the object backward runs in the shadow of the background backward
         if dd is not None:
             dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'], ray_idx=dd['idx'][0],
                                    count=dd['count'][0:1], tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
@@ -131,11 +133,12 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         else:
             dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
         if K:                                 # all K object MLPs: one call (csrc/objects.hip)
-            ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
-            for k in range(K if pose_opt else 0):   # d(loss)/d(box pose) through the object encoding
-                ops.encode_obj_bwd(k, ctx['idx'][k], ctx['count'][k:k + 1], lv['slabs'].d_enc[k], lv['t_vals'],
-                                   ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
-                                   pose_sums)
+            with side:
+                ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
+                for k in range(K if pose_opt else 0):   # d(loss)/d(box pose) through the object encoding
+                    ops.encode_obj_bwd(k, ctx['idx'][k], ctx['count'][k:k + 1], lv['slabs'].d_enc[k], lv['t_vals'],
+                                       ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
+                                       pose_sums)
     levels = ctx['levels']
     if not f32:
         off = lay.mlp_off['MLP_0']
@@ -150,7 +153,9 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, rows, N, L, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
         if K:
             o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
-            ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)
+            with side:
+                ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)
+    side.join()
     flat = variables.flat
     weight_l2 = None
     if config.weight_decay_mult != 0:                                          # :73-75
