@@ -386,17 +386,29 @@ class SyntheticTimestepDataset:
 
     def __init__(self, config, K=3, T=5, hw=(64, 96), n_cams=2, seed=0, device='cuda', rank=0, world=1, split='train'):
         import numpy as np
-        from . import raygen, synthetic
+        from . import raygen
         self.config, self.device, self.rank, self.world, self.split = config, torch.device(device), rank, world, split
         self.rs = np.random.default_rng(seed + (0 if split == 'train' else 1))
         H, W = hw
-        b = synthetic.make_batch(64, K, T=T, far=config.far, seed=seed)
-        self.init = torch.tensor(b['init'], device=self.device)
-        if config.random_box and split == 'train':                                        # configs/waymo.gin:6,8
-            noise = self.rs.uniform(-config.box_noise, config.box_noise, self.init[..., :3].shape)
+        # K boxes fanned out in azimuth at distance 6 in front of the rig, so that no ray can hit two of them (the
+        # reference's model is undefined there: obbpose_model.py:120-122), even after the random_box noise
+        dist_, half = 6.0, np.array([0.2, 0.17, 0.45])
+        az = np.deg2rad(np.linspace(-35.0, 35.0, K)) if K > 1 else np.zeros(K)
+        centers = np.stack([dist_ * np.sin(az), np.zeros(K), -dist_ * np.cos(az)], -1)
+        rots = np.zeros((K, 3))
+        rots[:, 1] = self.rs.uniform(-0.5, 0.5, K)
+        base = np.concatenate([centers, rots], -1)
+        init = np.tile(base[None], (T, 1, 1))
+        init[:, :, :3] += np.random.default_rng(seed).normal(0, 0.03, (T, K, 3))       # the boxes drift between timesteps
+        self.target_all = torch.tensor(init, dtype=torch.float32, device=self.device)
+        self.init = self.target_all.clone()
+        self.ext = torch.tensor(np.tile(half, (K, 1)), dtype=torch.float32, device=self.device)
+        if config.random_box and split == 'train' and K > 0:                          # configs/waymo.gin:6,8
+            gap = np.deg2rad(70.0 / (K - 1)) if K > 1 else np.pi
+            cap = max(0.0, dist_ * (gap / 2 - 0.12) / 2)                              # keeps the noisy boxes apart in azimuth
+            amp = min(config.box_noise, cap)
+            noise = self.rs.uniform(-amp, amp, (T, K, 3))
             self.init[..., :3] += torch.tensor(noise, dtype=torch.float32, device=self.device)
-        self.target_all = torch.tensor(b['init'], device=self.device)
-        self.ext = torch.tensor(b['ext'], device=self.device)
         self.T, self.H, self.W, self.n_cams = T, H, W, n_cams
         self.ts_data = []
         uu, vv = np.meshgrid(np.linspace(0, 1, W), np.linspace(0, 1, H))

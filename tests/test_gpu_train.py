@@ -1,5 +1,7 @@
 """Training-path parity: losses + composite backward (fp32, tight), fused MLP backward and
 weight-gradient GEMMs (bf16, norm-wise), clip+Adam, and one full train_step against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -7,6 +9,8 @@ import torch
 from durf_amd import obbpose_model, ops, synthetic, train_boxpose, utils
 from oracle import durf_ref as R
 from tests import helpers as H
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -326,3 +330,21 @@ def test_train_stats_kernel(cuda, K, L):
     ref['weight_l2'] = wl2
     for k, v in ref.items():
         torch.testing.assert_close(st[k], v.float(), rtol=2e-6, atol=1e-7, msg=lambda m: k + ': ' + m)
+
+
+def test_main_driver_trains_on_the_synthetic_timestep_dataset(cuda, tmp_path):
+    """durf_amd.train_boxpose.main (the reference's main(), train_boxpose.py:324-580): schedules, device-side pose
+    feedback, logging, checkpoint, test-image render + PSNR / SSIM -- end to end on the GPU with the device ray generator."""
+    from durf_amd import checkpoints
+    hist = train_boxpose.main(['--gin_file', os.path.join(ROOT, 'configs', 'waymo.gin'),
+                               '--gin_param', 'Config.max_steps = 40', '--gin_param', 'Config.print_every = 10',
+                               '--gin_param', 'Config.save_every = 25', '--gin_param', 'Config.batch_size = 512',
+                               '--gin_param', 'Config.lr_delay_steps = 0', '--gin_param', 'MipNerfModel.num_samples = 32',
+                               '--train_dir', str(tmp_path), '--render_every', '20', '--objects', '3'])
+    logs = [r for _, r in hist if 'loss' in r]
+    evals = [r for _, r in hist if 'test_psnr' in r]
+    assert [s for s, r in hist if 'loss' in r] == [10, 20, 30, 40] and len(evals) == 2
+    assert all(np.isfinite(r['loss']) and np.isfinite(r['avg_psnr']) for r in logs)
+    assert logs[-1]['avg_loss'] < logs[0]['avg_loss'], 'the loss must go down'
+    assert all(np.isfinite(e['test_psnr']) and 0.0 < e['test_ssim'] <= 1.0 for e in evals)
+    assert checkpoints._steps(str(tmp_path)) == [25, 40]
