@@ -80,3 +80,35 @@ def test_ssim_converted_inputs(cuda):
     gotbf = metrics.compute_ssim(ta[..., :3].bfloat16(), tb[..., :3].bfloat16(), 1.0)
     wantbf = D.compute_ssim(ta[..., :3].bfloat16().float().cpu().numpy(), tb[..., :3].bfloat16().float().cpu().numpy(), 1.0)
     assert abs(float(gotbf) - wantbf) < 2e-5
+
+
+def test_c2f_levels_on_the_device(cuda):
+    """C2F multi-resolution schedule (c2f_obb_dataset.py:306-313,843-891) on top of the device ray generator: the
+    factor follows the training iteration, the principal point sits at the image centre, and the rays of every level
+    match the reference's ray generation at that resolution."""
+    rs = np.random.default_rng(3)
+    n, H0, W0, f0 = 2, 64, 96, 200.0
+    c2w = np.zeros((n, 3, 4), np.float32)
+    for i in range(n):
+        q, _ = np.linalg.qr(rs.normal(size=(3, 3)))
+        c2w[i, :, :3] = q
+        c2w[i, :, 3] = rs.uniform(-1, 1, 3)
+    levels = {}
+    for fac in raygen.C2F_FACTORS:
+        h, w = H0 // fac, W0 // fac
+        levels[fac] = dict(h=[h] * n, w=[w] * n, focal=[f0 / fac] * n,
+                           images=[rs.uniform(0, 1, (h, w, 3)).astype(np.float32) for _ in range(n)])
+    data = raygen.C2FTimestepData(c2w, levels, device=cuda)
+    steps = (100, 200, 300)
+    for it, fac in ((1, 16), (100, 16), (101, 12), (250, 8), (301, 4)):
+        td = data.at(it, steps)
+        assert td is data.data[fac]
+        h, w = H0 // fac, W0 // fac
+        pp = np.tile(np.array([[w * 0.5, h * 0.5]], np.float32), (n, 1))
+        want = D.generate_rays_multi(np.array([h] * n), np.array([w] * n), np.array([f0 / fac] * n, np.float32), pp, c2w, 0.0, 40.0)
+        got, px, _, _ = raygen.generate_batch(td, None, 0.0, 40.0)
+        for name in ('origins', 'directions', 'viewdirs', 'radii'):
+            flat = np.concatenate([r.reshape(-1, r.shape[-1]) for r in want[name]], 0)
+            torch.testing.assert_close(getattr(got, name).cpu(), torch.tensor(flat), rtol=3e-5 if name == 'radii' else 2e-6,
+                                       atol=1e-7, msg=lambda m: '%s at factor %d: %s' % (name, fac, m))
+        assert torch.equal(px.cpu(), torch.tensor(np.concatenate([im.reshape(-1, 3) for im in levels[fac]['images']], 0)))
