@@ -36,6 +36,7 @@ MAC_BKGD, MAC_OBJ = 591872, 167552
 PEAK_BF16 = 2.5e15     # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12      # HBM3E spec peak (6.29e12 measured-achievable), MI355X_MICROARCH.md
 ENC_BYTES, COMPOSITE_BYTES = 15928, 3108    # algorithmic bytes per ray-level, SURVEY.md 8(d) (bf16 features)
+FUSED_RAY_BYTES = COMPOSITE_BYTES + 516     # composite + resample in one launch: + the next level's t_vals, no weights re-read
 
 # name -> (gin file, K objects, far, rays per GPU, extra gin bindings, box noise, alpha)
 WORKLOADS = {
@@ -246,7 +247,7 @@ def main():
     sync()
     # live HIP-event timers over the timed region (recorded on the launch stream): the kernels the roofline
     # reports, or every wrapped op with --profile-ops (every timed op costs two event records)
-    timed = {'mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256', 'encode_bkgd', 'composite_fwd'}
+    timed = {'mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256', 'encode_bkgd', 'composite_resample'}
     ops.TIMED_NAMES = None if args.profile_ops else timed
     ops.TIMERS = {}
     t0 = time.perf_counter()
@@ -269,7 +270,8 @@ def main():
         # 2.5 PFLOP/s.  Encode / composite: HBM-bound -- algorithmic bytes per ray-level / time / 8 TB/s.
         mfma = {'mlp_fwd_256_train': 2.0 * MAC_BKGD * rows, 'mlp_bwd_256': 2.0 * MAC_BKGD * rows,
                 'mlp_dw_256': N_LEVELS * 2.0 * MAC_BKGD * rows}
-        hbm = {'encode_bkgd': float(ENC_BYTES) * B, 'composite_fwd': float(COMPOSITE_BYTES) * B}
+        # (the fused per-ray launch is latency-bound at 4096 rays, DESIGN.md 4: reported, not a tuning target)
+        hbm = {'encode_bkgd': float(ENC_BYTES) * B, 'composite_resample': float(FUSED_RAY_BYTES) * B}
         info = {}
         for k, (n, s) in totals.items():
             t = s / n

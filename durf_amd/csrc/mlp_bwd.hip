@@ -479,7 +479,9 @@ struct DwArgs {
 // Tiles per split: an even share, but at least DW_MIN_TPS, so that a sparsely hit object (a few hundred
 // valid tiles) uses a few dozen splits instead of ~100 per GEMM -- the unused workgroups exit at once and
 // neither write nor get summed (k_dw_finalize derives the same count from the device-side ray count).
+#ifndef DW_MIN_TPS
 #define DW_MIN_TPS 48
+#endif
 __host__ __device__ inline size_t dw_tiles_per_split(size_t nt_all, int nsplit) {
     const size_t even = (nt_all + nsplit - 1) / nsplit;
     return even > DW_MIN_TPS ? even : DW_MIN_TPS;
