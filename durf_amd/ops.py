@@ -194,11 +194,18 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
     return raw
 
 
-# The K object MLPs touch ~10 % of the rays: their launches are small and latency-bound, and the persistent background
-# kernels leave CUs idle in their last round of blocks.  With this switch the object work of a stage is issued on a
-# side HIP stream, forked after the background encode / the loss kernel and joined before its results are consumed, so
-# it runs in the shadow of the background kernel of the same stage.
-OVERLAP_OBJECTS = os.environ.get('DURF_OVERLAP_OBJECTS', '1') != '0'     # env switch: A/B measurements
+# The K object MLPs touch ~10 % of the rays: their launches are small and latency-bound.  DURF_OVERLAP_OBJECTS issues the
+# object work of a stage on a side HIP stream, forked after the background encode / the loss kernel and joined before its
+# results are consumed, so that it can run beside the background kernel of the same stage:
+#   0 (default) everything on one stream;   1 the object forward;   3 forward + backward;   2 forward + backward + dW.
+# Measured at cfg3, five interleaved runs per mode on one box (ms/step): 0: 4.889 / 4.982, 1: 4.924, 3: 5.004, 2: 4.835 /
+# 4.929 -- only the weight-gradient overlap pays (-1.1 %), and it costs the background weight-gradient launch +64 us (its
+# workgroups share CUs and HBM with the object ones), i.e. it trades the dominant kernel's own time for step time.  The
+# default keeps the kernels' timings clean; the switch stays for measurements.
+_MODE = os.environ.get('DURF_OVERLAP_OBJECTS', '0')
+OVERLAP_OBJECTS = _MODE != '0'
+OVERLAP_BACKWARD = _MODE in ('2', '3')
+OVERLAP_DW = _MODE == '2'
 _SIDE = {}
 
 

@@ -95,7 +95,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
-    side = ops.on_side(dev, bool(K) and not f32)
+    # optional side stream for the object backward / weight gradients (ops.OVERLAP_*: off by default, see ops.py)
+    side = ops.on_side(dev, bool(K) and not f32 and ops.OVERLAP_BACKWARD)
     # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
     for lvl in reversed(range(L)):
         lv = ctx['levels'][lvl]
@@ -153,8 +154,12 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, rows, N, L, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]])
         if K:
             o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
-            with side:
+            if not ops.OVERLAP_DW:
+                side.join()
                 ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)
+            else:
+                with side:
+                    ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz)
     side.join()
     flat = variables.flat
     weight_l2 = None
