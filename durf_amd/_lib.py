@@ -25,6 +25,7 @@ _SIGS = {
     'durf_pack_weights': (i32, [vp, i32, i32, vp, vp, vp]),
     'durf_ray_setup': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_compact_hits': (i32, [vp, i32, i32, vp, vp, vp, vp]),
+    'durf_compact_classes': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
     'durf_sample_t': (i32, [vp, i32, i32, vp, vp, vp, i32, vp]),
     'durf_view_enc': (i32, [vp, i32, vp, vp, vp]),
     'durf_encode_bkgd': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),

@@ -98,18 +98,36 @@ k_ray_setup(int B, int K, const float* __restrict__ origins, const float* __rest
 // ---------------------------------------------------------------------------
 // ordered stream compaction of hit[:,k]; one block per object, wave-ballot scan.
 // ---------------------------------------------------------------------------
+// CLASSES = false: block k compacts the rays with hit[:,k] != 0.
+// CLASSES = true (2 blocks): the two ray classes of the de-duplicated background evaluation (durf_expand_raw):
+//   class 0 = rays that hit no box or several (evaluated sample by sample), class 1 = rays that hit exactly one.
+//   Block 0 also writes dyn[b] = number of boxes ray b hits, count[2] = count0 * N + count1 (the valid rows of the
+//   compacted buffers) and count[3] = number of rays that hit several boxes.
+template <bool CLASSES>
 __global__ void __launch_bounds__(1024)
-k_compact_hits(int B, int K, const int32_t* __restrict__ hit, int32_t* __restrict__ idx,
-               int32_t* __restrict__ count, int32_t* __restrict__ slot) {
+k_compact_hits(int B, int K, int N, const int32_t* __restrict__ hit, int32_t* __restrict__ idx,
+               int32_t* __restrict__ count, int32_t* __restrict__ slot, int32_t* __restrict__ dyn) {
     const int k = blockIdx.x;
+    const int KS = CLASSES ? 2 : K;                  // columns of slot
     __shared__ int wave_tot[16];
-    __shared__ int base_s;
+    __shared__ int base_s, multi_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) base_s = 0;
+    if (threadIdx.x == 0) { base_s = 0; multi_s = 0; }
     __syncthreads();
+    int multi = 0;
     for (int b0 = 0; b0 < B; b0 += 1024) {
         const int b = b0 + threadIdx.x;
-        const int h = (b < B) ? (hit[b * K + k] != 0) : 0;
+        int h = 0;
+        if (b < B) {
+            if (CLASSES) {
+                int nh = 0;
+                for (int j = 0; j < K; j++) nh += hit[b * K + j] != 0;
+                h = k == 0 ? (nh != 1) : (nh == 1);
+                if (k == 0) { dyn[b] = nh; multi += nh > 1; }
+            } else {
+                h = hit[b * K + k] != 0;
+            }
+        }
         const unsigned long long m = __ballot(h);
         const int before = __popcll(m & ((1ull << lane) - 1ull));
         if (lane == 0) wave_tot[wave] = __popcll(m);
@@ -119,14 +137,24 @@ k_compact_hits(int B, int K, const int32_t* __restrict__ hit, int32_t* __restric
         const int base = base_s;
         if (b < B) {
             const int pos = base + woff + before;
-            slot[b * K + k] = h ? pos : -1;
+            slot[b * KS + k] = h ? pos : -1;
             if (h) idx[(size_t)k * B + pos] = b;
         }
         __syncthreads();
         if (threadIdx.x == 0) base_s = base + tot;
         __syncthreads();
     }
-    if (threadIdx.x == 0) count[k] = base_s;
+    if (CLASSES && k == 0) {
+        if (multi) atomicAdd(&multi_s, multi);       // integer: order-independent
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        count[k] = base_s;
+        if (CLASSES && k == 0) {
+            count[2] = base_s * N + (B - base_s);
+            count[3] = multi_s;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -472,9 +500,19 @@ int durf_ray_setup(void* stream, int B, int K, const float* origins, const float
 int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* idx,
                       int32_t* count, int32_t* slot) {
     if (K <= 0 || B <= 0) return 0;
-    hipLaunchKernelGGL(k_compact_hits, dim3(K), dim3(1024), 0, (hipStream_t)stream, B, K, hit, idx,
-                       count, slot);
+    hipLaunchKernelGGL(k_compact_hits<false>, dim3(K), dim3(1024), 0, (hipStream_t)stream, B, K, 0, hit, idx,
+                       count, slot, (int32_t*)nullptr);
     DURF_CHECK_LAUNCH("durf_compact_hits");
+    return 0;
+}
+
+int durf_compact_classes(void* stream, int B, int K, int N, const int32_t* hit, int32_t* idx, int32_t* count,
+                         int32_t* slot, int32_t* dyn) {
+    DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ, "1 <= K <= DURF_MAX_OBJ");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_compact_hits<true>, dim3(2), dim3(1024), 0, (hipStream_t)stream, B, K, N, hit, idx, count,
+                       slot, dyn);
+    DURF_CHECK_LAUNCH("durf_compact_classes");
     return 0;
 }
 

@@ -214,7 +214,11 @@ class MipNerfModel:
         ret = []
         t_vals = weights = None
         box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
-        if K > 1:
+        use_dd = bool(Kd) and not f32 and ops.DEDUP_HIT_RAYS
+        cls = ops.compact_classes(hit, N) if use_dd else None     # also counts the boxes each ray hits
+        if cls is not None:
+            dyn_mask = cls[3].reshape(B, 1)
+        elif K > 1:
             dyn_mask = hit.sum(dim=-1, keepdim=True, dtype=torch.int32)
         else:
             dyn_mask = hit if K == 1 else torch.zeros(B, 1, dtype=torch.int32, device=dev)
@@ -233,11 +237,8 @@ class MipNerfModel:
         # the same launch) and the other rays sample by sample on a compacted list.  Same results, ~hit-fraction less
         # background MLP work.  Rays that hit no box or several (the reference's garbage-in case) take the full path.
         dd = None
-        if Kd and not f32 and ops.DEDUP_HIT_RAYS:
-            nh = dyn_mask.reshape(-1)
-            cls = torch.stack([nh != 1, nh == 1], -1).to(torch.int32).contiguous()
-            idx2, count2, slot2 = ops.compact_hits(cls)
-            dd = dict(idx=idx2, count=count2, slot=slot2)
+        if cls is not None:
+            dd = dict(idx=cls[0], count=cls[1], slot=cls[2], nrows=cls[1][2:3], multi_hit=cls[1][3])
             ctx['dedup'] = dd
         t_next = None
         for lvl in range(self.num_levels):

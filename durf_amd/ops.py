@@ -85,6 +85,20 @@ def compact_hits(hit):
     return idx, count, slot
 
 
+def compact_classes(hit, N):
+    """-> idx[2,B], count[4] (class-0 rays, class-1 rays, valid compacted rows, multi-hit rays), slot[B,2], dyn[B]:
+    the ray classes of the de-duplicated background evaluation (class 1 = rays that hit exactly one box)"""
+    B, K = hit.shape
+    dev = hit.device
+    idx = torch.empty(2, B, dtype=torch.int32, device=dev)
+    count = torch.empty(4, dtype=torch.int32, device=dev)
+    slot = torch.empty(B, 2, dtype=torch.int32, device=dev)
+    dyn = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(_lib.lib().durf_compact_classes(_stream(), B, K, N, _p(hit), _p(idx), _p(count), _p(slot), _p(dyn)),
+               'durf_compact_classes')
+    return idx, count, slot, dyn
+
+
 def sample_t(near, far, N, t_rand=None, lindisp=False):
     B = near.shape[0]
     t = torch.empty(B, N + 1, device=near.device)

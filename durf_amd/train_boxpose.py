@@ -86,8 +86,6 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     elif dd is not None:
         view_tile = ops.expand_view(rows, N, ctx['view'], ray_idx=dd['idx'][0], count=dd['count'][0:1],
                                     tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
-        # valid rows of the compacted buffers: count[0] * N sample rows + count[1] once-per-ray rows
-        dd['nrows'] = (dd['count'][0] * N + dd['count'][1]).to(torch.int32).reshape(1)
     else:
         view_tile = ops.expand_view(rows, N, ctx['view'])
     ray_sums = torch.empty(L, B, 4, device=dev) if dd is not None else None
@@ -174,7 +172,10 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
         grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)[ctx['ts']] += g6
     pose = ret[0][7][0]
-    multi = (dyn > 1).sum() if lay.K > 1 else torch.zeros((), dtype=torch.int64, device=dev)
+    if dd is not None:
+        multi = dd['multi_hit']
+    else:
+        multi = (dyn > 1).sum() if lay.K > 1 else torch.zeros((), dtype=torch.int64, device=dev)
     raw = dict(norms=norms, sums=sums, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if lay.K > 0 else None,
                multi_hit=multi)
     return grad, raw, pose

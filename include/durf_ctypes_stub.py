@@ -34,6 +34,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_compact_hits.restype = i32
     L.durf_compact_hits.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     #   (stream, B, K, hit, idx, count, slot)
+    L.durf_compact_classes.restype = i32
+    L.durf_compact_classes.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
+    #   (stream, B, K, N, hit, idx, count, slot, dyn)
     L.durf_sample_t.restype = i32
     L.durf_sample_t.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
     #   (stream, B, N, near, far, t_rand, lindisp, t_vals)

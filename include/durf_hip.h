@@ -71,6 +71,12 @@ int durf_ray_setup(void* stream, int B, int K, const float* origins, const float
  * count[k] = number of such rays, slot[b*K+k] = position of ray b in list k or -1. */
 int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* idx,
                       int32_t* count, int32_t* slot);
+/* The two ray classes of the de-duplicated background evaluation (durf_expand_raw) from hit [B,K] in one launch:
+ * class 0 = rays that hit no box or several, class 1 = rays that hit exactly one.  idx [2,B], slot [B,2] as above;
+ * count [4] = {class-0 rays, class-1 rays, class0 * N + class1 (valid rows of the compacted buffers), rays that hit
+ * several boxes}; dyn [B] = boxes hit per ray (obbpose_model.py:257 `jnp.array(ret_masks).sum(axis=0)`). */
+int durf_compact_classes(void* stream, int B, int K, int N, const int32_t* hit, int32_t* idx, int32_t* count,
+                         int32_t* slot, int32_t* dyn);
 
 /* mip.sample_along_rays t_vals (mip.py:353-368). t_rand nullable (randomized=False). */
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
