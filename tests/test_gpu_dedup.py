@@ -100,3 +100,36 @@ def test_gradients_match_the_sample_by_sample_path_and_the_oracle(cuda, B, K, N)
                                         ob['init'][0:1], noise=noise_c, mlp_hook=R.mlp_apply_bf16)
     og = torch.cat([x.reshape(-1) for x in ograds])
     assert _rel(grads[True].cpu()[sl], og[sl]) < 5e-2
+
+
+@pytest.mark.parametrize('case', ['all_rays_hit', 'no_ray_hits'])
+def test_extreme_hit_fractions(cuda, case):
+    """every ray in the once-per-ray class (no compacted rows at all) and none in it (an empty tail): forward
+    bit-identical to the sample-by-sample path, a training step stays finite and matches it"""
+    B, K, N = 200, 1, 32
+    config, b, db, model, variables, noise = _setup(cuda, B, K, N, 5)
+    if case == 'all_rays_hit':
+        db['ext'] = db['ext'] * 0 + 1.0e3                        # a box that contains every camera
+    else:
+        db['init'] = db['init'].clone()
+        db['init'][:, :, 2] = 1.0e4                              # far behind every camera
+        model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
+    outs, grads = {}, {}
+    for on in (True, False):
+        ops.DEDUP_HIT_RAYS = on
+        try:
+            outs[on] = model.apply(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], randomized=True,
+                                   rand_bkgd=False, white_bkgd=False, alpha=10.0, noise=noise)
+            grads[on], _, _ = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, 10.0, db['init'][0:1],
+                                                          noise=noise)
+        finally:
+            ops.DEDUP_HIT_RAYS = True
+    nh = outs[True][0][8].reshape(-1)
+    assert bool((nh == (1 if case == 'all_rays_hit' else 0)).all())
+    for lvl in range(2):
+        for i in range(5):
+            assert torch.equal(outs[True][lvl][i], outs[False][lvl][i]), (lvl, i)
+    assert torch.isfinite(grads[True]).all()
+    lay = variables.layout
+    sl = slice(lay.mlp_off['MLP_0'], lay.mlp_off['MLP_0'] + lay.mlp_size[256])
+    assert _rel(grads[True][sl], grads[False][sl]) < 2e-3
