@@ -52,7 +52,7 @@ _SIGS = {
     'durf_pack_weights_batch': (i32, [vp, i32, i32, i32, vp, u64, vp, vp]),
     'durf_obj_fwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp, vp, vp, vp, vp, vp, vp]),
     'durf_obj_bwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
-    'durf_obj_dw_batch': (i32, [vp, i32, i32, i32, vp, i32] + [C.POINTER(vp)] * 5 + [i32, vp, vp, vp, u64]),
+    'durf_obj_dw_batch': (i32, [vp, i32, i32, i32, vp, i32] + [C.POINTER(vp)] * 5 + [i32, vp, vp, vp, u64, vp]),
     'durf_gen_batch': (i32, [vp, i32, i32, C.POINTER(f32), vp, f32, f32, vp, vp, vp, i32] + [vp] * 10),
     'durf_ssim_scratch_floats': (u64, [i32, i32, i32, i32]),
     'durf_ssim': (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, f32, f32, vp, vp, vp]),
@@ -65,9 +65,9 @@ _SIGS = {
     'durf_dw_part_floats': (u64, [i32]),
     'durf_dw_bpart_floats': (u64, [i32]),
     'durf_mlp_dw': (i32, [vp, i32, u64, i32, vp, i32] + [C.POINTER(vp)] * 5 + [vp, vp]),
-    'durf_mlp_dw_finalize': (i32, [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp]),
+    'durf_mlp_dw_finalize': (i32, [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp, vp]),
     'durf_mlp_dw_levels': (i32, [vp, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp)] + [C.POINTER(vp)] * 5 + [vp, vp]),
-    'durf_mlp_dw_finalize_levels': (i32, [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp]),
+    'durf_mlp_dw_finalize_levels': (i32, [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp, vp]),
     'durf_expand_raw': (i32, [vp, i32, i32, vp, vp, vp, vp]),
     'durf_encode_obj_bwd': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
     'durf_pose_finish': (i32, [vp, i32, vp, vp, i32, i32, vp]),

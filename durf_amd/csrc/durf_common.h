@@ -189,6 +189,6 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
                   const DwStrides& st);
 int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
                        const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
-                       size_t bpart_stride, size_t grad_stride);
+                       size_t bpart_stride, size_t grad_stride, const float* mlp_params, size_t param_stride);
 DwLevels uniform_levels(size_t rows, int N, const int32_t* count, int nlevels);
 }  // namespace durf

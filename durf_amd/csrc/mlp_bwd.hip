@@ -190,7 +190,7 @@ __host__ __device__ constexpr int bgroup_tiles(int nmt, int ch, int slot) {
 
 // one backward stage: NMT tiles over the fwd stage's input features, buffered in tile groups
 // (one barrier + one prefetch burst per group, see mlp_fwd.hip)
-template <int SLOT, int NA, int NB, int NMT, bool MASK, int PREV_NMT>
+template <int SLOT, int NA, int NB, int NMT, bool MASK, int PREV_NMT, bool STORE_OUT = true>
 __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf16x8* inB, bf16x8* out,
                                            int next_stage_chunks, const char* mask_src,
                                            char* dz_dst, bool valid, const bf16x8* prev_out, char* prev_dst,
@@ -213,10 +213,12 @@ __device__ __forceinline__ void run_bstage(BPipe& p, const bf16x8* inA, const bf
         }
         if (valid) {          // stores trail the compute by one pair, also across stages (mlp_fwd.hip)
             if (mo > 0) {
+                if (STORE_OUT) {      // false: the linear bottleneck's gradient, which no weight-gradient GEMM reads
 #pragma unroll
-                for (int q = 4; q >= 1; q--) STREAM_STORE(dz_dst + (2 * mo - q) * 1024 + p.lane * 16, out[2 * mo - q]);
-                p.since += 4;
-            } else if (PREV_NMT > 0) {
+                    for (int q = 4; q >= 1; q--) STREAM_STORE(dz_dst + (2 * mo - q) * 1024 + p.lane * 16, out[2 * mo - q]);
+                    p.since += 4;
+                }
+            } else if (PREV_NMT > 0 && prev_dst != nullptr) {
 #pragma unroll
                 for (int q = 4; q >= 1; q--)
                     STREAM_STORE(prev_dst + (2 * PREV_NMT - q) * 1024 + p.lane * 16, prev_out[2 * PREV_NMT - q]);
@@ -335,9 +337,9 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     constexpr int GE = 2 * S::KW;                                             // d(enc) stage: 2 tiles, one group
     run_bstage<SLOT, 1, 0, S::CT, true, 0>(p, g10, nullptr, c, GC, stash_at(9), dz_at(9), tile_valid, nullptr, nullptr);
     // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear)
-    run_bstage<SLOT, S::KC, 0, S::WT, false, S::CT>(p, c, nullptr, a, G8, nullptr, dz_at(8), tile_valid, c, dz_at(9));
+    run_bstage<SLOT, S::KC, 0, S::WT, false, S::CT, false>(p, c, nullptr, a, G8, nullptr, nullptr, tile_valid, c, dz_at(9));
     // bwd of stage 8 (bottleneck + density head): -> d A7
-    run_bstage<SLOT, S::KW, 1, S::WT, true, S::WT>(p, a, gd, b, GW, stash_at(7), dz_at(7), tile_valid, a, dz_at(8));
+    run_bstage<SLOT, S::KW, 1, S::WT, true, S::WT>(p, a, gd, b, GW, stash_at(7), dz_at(7), tile_valid, a, nullptr);
     // bwd of stages 7, 6 -> d Z6, d Z5
     run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, b, nullptr, a, GW, stash_at(6), dz_at(6), tile_valid, b, dz_at(7));
     run_bstage<SLOT, S::KW, 0, S::WT, true, S::WT>(p, a, nullptr, b, GW, stash_at(5), dz_at(5), tile_valid, a, dz_at(6));
@@ -742,6 +744,7 @@ k_dw_finalize(int W, int in_dim, DwJobs jobs, const float* __restrict__ part_all
               const float* __restrict__ bpart_all, float* __restrict__ grad_mlp, size_t part_stride,
               size_t bpart_stride, size_t grad_stride, durf::DwLevels lv) {
     __shared__ float red[4][64];
+    if (jobs.nparts[blockIdx.y] == 0) return;        // the bottleneck layer: no job of its own
     part_all += blockIdx.z * part_stride;            // batched object MLPs: blockIdx.z = object
     bpart_all += blockIdx.z * bpart_stride;
     grad_mlp += blockIdx.z * grad_stride;
@@ -787,12 +790,69 @@ k_dw_finalize(int W, int in_dim, DwJobs jobs, const float* __restrict__ part_all
         int row;
         if (i_slot < job.in_nat_base) row = cperm_feat(i_slot) < job.in_perm_rows ? cperm_feat(i_slot) : -1;
         else row = job.in_perm_rows + (i_slot - job.in_nat_base);
-        if (col >= 0 && col < fo && row >= 0 && row < fi)
+        if (job.layer == 10 && i_slot < job.in_nat_base) {
+            // view layer, rows fed by the bottleneck: this job multiplied dz10 with h7, not with the bottleneck output.
+            // Keep the sum P[h7 feature, dz10 feature] in split 0's slot (only this thread group reads this element)
+            // for k_bottleneck_grads, which turns it into the gradients of Dense_9 and of these rows of Dense_10.
+            const_cast<float*>(part)[idx] = s;
+        } else if (col >= 0 && col < fo && row >= 0 && row < fi)
             grad_mlp[durf_layer_offset(W, in_dim, job.layer, 0) + (size_t)row * fo + col] = s;
     } else {
         const int o_slot = idx - nfrag;
         const int col = job.out_nat_off >= 0 ? o_slot - job.out_nat_off : cperm_feat(o_slot);
         if (col >= 0 && col < fo) grad_mlp[durf_layer_offset(W, in_dim, job.layer, 1) + col] = s;
+        if (job.layer == 10) const_cast<float*>(bpart)[idx - nfrag] = s;     // db10, kept for k_bottleneck_grads
+    }
+}
+
+// The bottleneck Dense_9 is LINEAR (obbpose_model.py:339: no activation between it and the view layer), so neither its
+// output nor its gradient has to be exchanged through HBM:
+//     bott = h7 K9 + b9,   z10 = [bott, view] K10 + b10,   d bott = dz10 K10_top^T      (K10_top: rows of K10 fed by bott)
+//     dK9      = h7^T d bott  = (h7^T dz10) K10_top^T                  = P K10_top^T
+//     db9      = sum_s d bott = (sum_s dz10) K10_top^T                 = db10 K10_top^T
+//     dK10_top = bott^T dz10  = K9^T (h7^T dz10) + b9 (x) sum_s dz10   = K9^T P + b9 (x) db10
+// with ONE sample-axis GEMM P = h7^T dz10 [W x 128] (job 10 of k_dw_all, which multiplies dz10 with [h7 | view]).  The
+// forward stores no bottleneck activations (512 B/sample), the backward no bottleneck gradients (512 B/sample), and the
+// weight-gradient launch reads neither (-768 B/sample together with the dropped job).  K9 / K10 enter bf16-rounded, as
+// the MFMA kernels saw them; b9 in fp32, as the forward added it.  P and db10 are read from split 0 of job 10's
+// partial buffers (fragment order), where k_dw_finalize left their sums.  blockIdx.y = object of a batched launch.
+__device__ __forceinline__ float bf16r(float x) { return (float)(__bf16)x; }
+__device__ __forceinline__ size_t frag_index(int W, int i, int j, int NI) {
+    // P[h7 feature i, dz10 feature j] in job 10's fragment space [mo][ni][lane][16]
+    const int i_slot = cperm_slot(i), o_slot = cperm_slot(j);
+    const int ni = i_slot >> 5, jn = i_slot & 31, mo = o_slot >> 5, ol = o_slot & 31;
+    const int hi = (ol >> 2) & 1, r = (ol & 3) + 4 * (ol >> 3);
+    return (((size_t)mo * NI + ni) * 64 + hi * 32 + jn) * 16 + r;
+}
+__global__ void __launch_bounds__(256)
+k_bottleneck_grads(int W, int in_dim, int NI, const float* __restrict__ part10, const float* __restrict__ bpart10,
+                   const float* __restrict__ params, float* __restrict__ grad, size_t part_stride, size_t bpart_stride,
+                   size_t param_stride, size_t grad_stride) {
+    part10 += blockIdx.y * part_stride;
+    bpart10 += blockIdx.y * bpart_stride;
+    params += blockIdx.y * param_stride;
+    grad += blockIdx.y * grad_stride;
+    const size_t off9 = durf_layer_offset(W, in_dim, 9, 0), off10 = durf_layer_offset(W, in_dim, 10, 0);
+    const float* K9 = params + off9;                 // [W, W]
+    const float* b9 = K9 + (size_t)W * W;
+    const float* K10 = params + off10;               // [W + 27, 128]; rows < W are fed by the bottleneck
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int nA = W * W, nB = W, nC = W * 128;
+    if (t < nA) {                                    // dK9[i, o] = sum_j P[i, j] K10[o, j]
+        const int i = t / W, o = t % W;
+        float s = 0.0f;
+        for (int j = 0; j < 128; j++) s += part10[frag_index(W, i, j, NI)] * bf16r(K10[(size_t)o * 128 + j]);
+        grad[off9 + (size_t)i * W + o] = s;
+    } else if (t < nA + nB) {                        // db9[o] = sum_j db10[j] K10[o, j]
+        const int o = t - nA;
+        float s = 0.0f;
+        for (int j = 0; j < 128; j++) s += bpart10[cperm_slot(j)] * bf16r(K10[(size_t)o * 128 + j]);
+        grad[off9 + (size_t)W * W + o] = s;
+    } else if (t < nA + nB + nC) {                   // dK10[o, j] = sum_i K9[i, o] P[i, j] + b9[o] db10[j]     (o < W)
+        const int u = t - nA - nB, o = u / 128, j = u % 128;
+        float s = b9[o] * bpart10[cperm_slot(j)];
+        for (int i = 0; i < W; i++) s += bf16r(K9[(size_t)i * W + o]) * part10[frag_index(W, i, j, NI)];
+        grad[off10 + (size_t)o * 128 + j] = s;
     }
 }
 
@@ -816,6 +876,7 @@ static DwPlan dw_plan(int width) {
         P.nko[j] = nko; P.nki[j] = nki;
         P.MO[j] = (nko + 1) / 2; P.NI[j] = nki / 2;
         wcost[j] = nko + nki + (nko + nki < 12 ? 3 : 0);     // the 9 KB/stage job is latency-bound: +30 % time per byte (traced)
+        if (j == 9) wcost[j] = 0;                            // the bottleneck layer has no GEMM of its own (see k_bottleneck_grads)
         cost += wcost[j];
     }
     // splits per job in proportion to its bytes per sample, summing EXACTLY to total_wgs (largest
@@ -825,7 +886,7 @@ static DwPlan dw_plan(int width) {
     int base[12], given = 0;
     for (int j = 0; j < 12; j++) {
         base[j] = total_wgs * wcost[j] / cost;
-        if (base[j] < 2) base[j] = 2;
+        if (base[j] < 2) base[j] = wcost[j] ? 2 : 0;
         given += base[j];
     }
     for (int left = total_wgs - given; left > 0; left--) {
@@ -833,7 +894,7 @@ static DwPlan dw_plan(int width) {
         long best_rem = -1;
         for (int j = 0; j < 12; j++) {
             const long rem = (long)total_wgs * wcost[j] - (long)base[j] * cost;
-            if (rem > best_rem) { best_rem = rem; best = j; }
+            if (wcost[j] && rem > best_rem) { best_rem = rem; best = j; }
         }
         base[best]++;
     }
@@ -913,16 +974,18 @@ int durf_mlp_dw_levels(void* stream, int width, int nlevels, const size_t* rows,
 
 int durf_mlp_dw_finalize_levels(void* stream, int width, int in_dim, int nlevels, const size_t* rows,
                                 const int* rows_per_ray, const int32_t* const* count, const float* part,
-                                const float* bpart, float* grad_mlp) {
+                                const float* bpart, float* grad_mlp, const float* mlp_params) {
     durf::DwLevels lv;
     if (int rc = make_levels(nlevels, rows, rows_per_ray, count, &lv)) return rc;
-    return durf::launch_dw_finalize(stream, width, in_dim, lv, part, bpart, grad_mlp, 1, 0, 0, 0);
+    return durf::launch_dw_finalize(stream, width, in_dim, lv, part, bpart, grad_mlp, 1, 0, 0, 0, mlp_params, 0);
 }
 
 int durf_mlp_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count,
-                         int nlevels, const float* part, const float* bpart, float* grad_mlp) {
+                         int nlevels, const float* part, const float* bpart, float* grad_mlp,
+                         const float* mlp_params) {
     DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
-    return durf::launch_dw_finalize(stream, width, in_dim, durf::uniform_levels(rows, N, count, nlevels), part, bpart, grad_mlp, 1, 0, 0, 0);
+    return durf::launch_dw_finalize(stream, width, in_dim, durf::uniform_levels(rows, N, count, nlevels), part, bpart, grad_mlp, 1, 0, 0, 0,
+                                    mlp_params, 0);
 }
 
 }  // extern "C"
@@ -1030,8 +1093,9 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
         }
         a.inB[l][5] = (const char*)enc_tile[ll];
         a.dz[l][8] = (const char*)dz_out[ll]; a.inA[l][8] = region(stash[ll], 7, ll);          // density head
-        a.dz[l][9] = region(dz[ll], 8, ll); a.inA[l][9] = region(stash[ll], 7, ll);            // bottleneck
-        a.dz[l][10] = region(dz[ll], 9, ll); a.inA[l][10] = region(stash[ll], 8, ll); a.inB[l][10] = (const char*)view_tile[ll];
+        a.dz[l][9] = nullptr; a.inA[l][9] = nullptr;            // bottleneck (linear): no job, see k_bottleneck_grads
+        // view layer: dz10 x [h7 | view] -- P = h7^T dz10 stands in for the bottleneck's activations and gradients
+        a.dz[l][10] = region(dz[ll], 9, ll); a.inA[l][10] = region(stash[ll], 7, ll); a.inB[l][10] = (const char*)view_tile[ll];
         a.dz[l][11] = (const char*)dz_out[ll]; a.inA[l][11] = region(stash[ll], 9, ll);        // rgb head
     }
     // narrow jobs first: their workgroups run longest (less data in flight per stage)
@@ -1061,7 +1125,8 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
 
 int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
                        const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
-                       size_t bpart_stride, size_t grad_stride) {
+                       size_t bpart_stride, size_t grad_stride, const float* mlp_params, size_t param_stride) {
+    DURF_REQUIRE(mlp_params != nullptr, "the bottleneck gradients need the MLP's parameters");
     if (K <= 0) return 0;
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     hipStream_t s = (hipStream_t)stream;
@@ -1086,6 +1151,10 @@ int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
     }
     hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12, K), dim3(256), 0, s, W, in_dim, jobs, part, bpart,
                        grad_mlp, part_stride, bpart_stride, grad_stride, lv);
+    const int nthr = W * W + W + W * 128;
+    hipLaunchKernelGGL(k_bottleneck_grads, dim3(durf_cdiv(nthr, 256), K), dim3(256), 0, s, W, in_dim, P.NI[10],
+                       part + P.part_off[10], bpart + P.bpart_off[10], mlp_params, grad_mlp, part_stride, bpart_stride,
+                       param_stride, grad_stride);
     DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
     return 0;
 }

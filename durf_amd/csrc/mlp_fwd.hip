@@ -215,7 +215,7 @@ __host__ __device__ constexpr int group_tiles(int nmt, int ch, int slot) {
 // also across stage boundaries (the previous stage's last pair is written after THIS stage's
 // first barrier): a store issued right before a barrier would expose its full HBM latency,
 // because the barrier's release waits for every outstanding memory operation of the wave.
-template <int SLOT, int NA, int NB, int NMT, bool RELU, bool TRAIN, int PREV_NMT>
+template <int SLOT, int NA, int NB, int NMT, bool RELU, bool TRAIN, int PREV_NMT, bool STORE_OUT = true>
 __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf16x8* inB,
                                           bf16x8* out, int next_stage_chunks, char* stash_dst,
                                           bool valid, const bf16x8* prev_out, char* prev_dst,
@@ -239,17 +239,18 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
         const char* s0 = slot + (mo % G) * CH * 1024;
         const char* s1 = slot + (mo % G + 1) * CH * 1024;
         if (TRAIN) {          // the previous pair's stores (this stage's, or the previous stage's last pair) ride inside the k-loop
-            if (mo > 0) {
+            if (mo > 0 && STORE_OUT) {
                 mma_tile2<NA, NB, true>(s0, s1, p.lane, inA, inB, acc0, acc1, out + 2 * mo - 4,
                                         stash_dst + (2 * mo - 4) * 1024 + p.lane * 16, valid);
                 if (valid) p.since += 4;
-            } else if (PREV_NMT > 0) {
+            } else if (mo == 0 && PREV_NMT > 0) {
+                // prev_dst == nullptr: the previous stage's output is not stashed (the linear bottleneck, whose
+                // activations no weight-gradient GEMM reads: k_bottleneck_grads in mlp_bwd.hip)
+                const bool st = valid && prev_dst != nullptr;
                 mma_tile2<NA, NB, true>(s0, s1, p.lane, inA, inB, acc0, acc1, prev_out + 2 * PREV_NMT - 4,
-                                        prev_dst + (2 * PREV_NMT - 4) * 1024 + p.lane * 16, valid);
-                if (valid) {
-                    p.since += 4;
-                    if (prev_mask_dst) *(uint4*)(prev_mask_dst + p.lane * 16) = mask_carry;
-                }
+                                        prev_dst + (2 * PREV_NMT - 4) * 1024 + p.lane * 16, st);
+                if (st) p.since += 4;
+                if (valid && prev_mask_dst) *(uint4*)(prev_mask_dst + p.lane * 16) = mask_carry;
             } else {
                 mma_tile2<NA, NB>(s0, s1, p.lane, inA, inB, acc0, acc1);
             }
@@ -409,7 +410,7 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, b, nullptr, a, GW, ST(6), tile_valid, b, ST(5), MK(5), mcarry);
     run_stage<SLOT, S::KW, 0, S::WT, true, TRAIN, S::WT>(p, a, nullptr, b, GW, ST(7), tile_valid, a, ST(6), MK(6), mcarry);
     // stage 8: b -> bottleneck (a, linear) + density
-    run_stage<SLOT, S::KW, 0, S::WT, false, TRAIN, S::WT>(p, b, nullptr, a, CHW, ST(8), tile_valid, b, ST(7), MK(7), mcarry);
+    run_stage<SLOT, S::KW, 0, S::WT, false, TRAIN, S::WT, false>(p, b, nullptr, a, CHW, nullptr, tile_valid, b, ST(7), MK(7), mcarry);
     float dens;
     {
         const char* slot = p.begin(G9);
@@ -427,7 +428,7 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
             vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + (lane >> 5)] : zero8;
     }
     bf16x8 c[S::KC];
-    run_stage<SLOT, S::KW, S::KV, S::CT, true, TRAIN, S::WT>(p, a, vf, c, S::KC + 1, ST(9), tile_valid, a, ST(8), nullptr, mcarry);
+    run_stage<SLOT, S::KW, S::KV, S::CT, true, TRAIN, S::WT>(p, a, vf, c, S::KC + 1, ST(9), tile_valid, a, nullptr, nullptr, mcarry);
     // stage 10: c -> rgb; meanwhile the next block's first weight group streams in
     {
         p.gnext = 0;

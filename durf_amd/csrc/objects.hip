@@ -56,7 +56,7 @@ int durf_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, co
 int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
                       const void* const* enc, const void* const* view_tile, const void* const* stash,
                       const void* const* dz, const void* const* dz_out, int in_dim, float* part, float* bpart,
-                      float* grad_mlp, size_t grad_stride) {
+                      float* grad_mlp, size_t grad_stride, const float* mlp_params) {
     const size_t rows = (size_t)B * N;
     DwStrides st;
     st.enc = durf_obj_enc_stride(B, N); st.view = durf_obj_view_stride(B, N);
@@ -66,7 +66,8 @@ int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, i
     const durf::DwLevels lv = durf::uniform_levels(rows, N, count, nlevels);
     int rc = durf::launch_mlp_dw(stream, DURF_W_OBJ, lv, enc, view_tile, stash, dz, dz_out, part, bpart, K, st);
     if (rc) return rc;
-    return durf::launch_dw_finalize(stream, DURF_W_OBJ, in_dim, lv, part, bpart, grad_mlp, K, st.part, st.bpart, grad_stride);
+    return durf::launch_dw_finalize(stream, DURF_W_OBJ, in_dim, lv, part, bpart, grad_mlp, K, st.part, st.bpart, grad_stride,
+                                    mlp_params, grad_stride);
 }
 
 }  // extern "C"

@@ -476,18 +476,20 @@ def mlp_dw_levels(width, rows_l, n_l, count_l, enc_tiles, view_tiles, stashes, d
                    'durf_mlp_dw_levels')
 
 
-def mlp_dw_finalize_levels(width, in_dim, rows_l, n_l, count_l, part, bpart, grad_mlp):
+def mlp_dw_finalize_levels(width, in_dim, rows_l, n_l, count_l, part, bpart, grad_mlp, mlp_params):
     L, rows_a, n_a, cnt_a = _levels_args(rows_l, n_l, count_l)
     with _Timed('mlp_dw_finalize_%d' % width):
         _lib.check(_lib.lib().durf_mlp_dw_finalize_levels(_stream(), width, in_dim, L, rows_a, n_a, cnt_a, _p(part),
-                                                          _p(bpart), _p(grad_mlp)), 'durf_mlp_dw_finalize_levels')
+                                                          _p(bpart), _p(grad_mlp), _p(_f32(mlp_params))),
+                   'durf_mlp_dw_finalize_levels')
 
 
-def mlp_dw_finalize(width, in_dim, rows, N, nlevels, part, bpart, grad_mlp, count=None):
-    """rows, N, nlevels, count: as in the mlp_dw call that wrote the partials"""
+def mlp_dw_finalize(width, in_dim, rows, N, nlevels, part, bpart, grad_mlp, mlp_params, count=None):
+    """rows, N, nlevels, count: as in the mlp_dw call that wrote the partials; mlp_params: the MLP's fp32 parameters
+    (the linear bottleneck layer's gradients are derived from them, see durf_mlp_dw_finalize)"""
     with _Timed('mlp_dw_finalize_%d' % width):
         _lib.check(_lib.lib().durf_mlp_dw_finalize(_stream(), width, in_dim, rows, N, _p(count), nlevels, _p(part),
-                                                   _p(bpart), _p(grad_mlp)), 'durf_mlp_dw_finalize')
+                                                   _p(bpart), _p(grad_mlp), _p(_f32(mlp_params))), 'durf_mlp_dw_finalize')
 
 
 # ---------------------------------------------------------------------------
@@ -553,8 +555,9 @@ def obj_bwd_batch(slabs, idx, count, draw, wb, want_d_enc=False):
                                         _p(slabs.dz), _p(slabs.dz_out), _p(slabs.d_enc)), 'durf_obj_bwd_batch')
 
 
-def obj_dw_batch(slabs_levels, view_tile, count, grad_obj, grad_stride):
-    """weight gradients of all K object MLPs over every level -> grad_obj (flat, K x grad_stride floats)"""
+def obj_dw_batch(slabs_levels, view_tile, count, grad_obj, grad_stride, obj_params):
+    """weight gradients of all K object MLPs over every level -> grad_obj (flat, K x grad_stride floats);
+    obj_params: their fp32 parameters with the same stride"""
     L = _lib.lib()
     s0 = slabs_levels[0]
     K, B, N = s0.K, s0.B, s0.N
@@ -567,7 +570,8 @@ def obj_dw_batch(slabs_levels, view_tile, count, grad_obj, grad_stride):
         _lib.check(L.durf_obj_dw_batch(_stream(), K, B, N, _p(count), nl, arr([s.enc for s in slabs_levels]),
                                        arr([view_tile] * nl), arr([s.stash for s in slabs_levels]),
                                        arr([s.dz for s in slabs_levels]), arr([s.dz_out for s in slabs_levels]),
-                                       IN_OBJ_, _p(part), _p(bpart), _p(grad_obj), grad_stride), 'durf_obj_dw_batch')
+                                       IN_OBJ_, _p(part), _p(bpart), _p(grad_obj), grad_stride, _p(_f32(obj_params))),
+                   'durf_obj_dw_batch')
 
 
 def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):

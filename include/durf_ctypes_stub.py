@@ -95,14 +95,14 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_dw.argtypes = [vp, i32, u64, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp]
     #   (stream, width, rows, N, count, nlevels, enc_tile, view_tile, stash, dz, dz_out, part, bpart)
     L.durf_mlp_dw_finalize.restype = i32
-    L.durf_mlp_dw_finalize.argtypes = [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp]
-    #   (stream, width, in_dim, rows, N, count, nlevels, part, bpart, grad_mlp)
+    L.durf_mlp_dw_finalize.argtypes = [vp, i32, i32, u64, i32, vp, i32, vp, vp, vp, vp]
+    #   (stream, width, in_dim, rows, N, count, nlevels, part, bpart, grad_mlp, mlp_params)
     L.durf_mlp_dw_levels.restype = i32
     L.durf_mlp_dw_levels.argtypes = [vp, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp]
     #   (stream, width, nlevels, rows, rows_per_ray, count, enc_tile, view_tile, stash, dz, dz_out, part, bpart)
     L.durf_mlp_dw_finalize_levels.restype = i32
-    L.durf_mlp_dw_finalize_levels.argtypes = [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp]
-    #   (stream, width, in_dim, nlevels, rows, rows_per_ray, count, part, bpart, grad_mlp)
+    L.durf_mlp_dw_finalize_levels.argtypes = [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp, vp]
+    #   (stream, width, in_dim, nlevels, rows, rows_per_ray, count, part, bpart, grad_mlp, mlp_params)
     L.durf_expand_raw.restype = i32
     L.durf_expand_raw.argtypes = [vp, i32, i32, vp, vp, vp, vp]
     #   (stream, B, N, raw_c, count, slot, raw_full)
@@ -143,8 +143,8 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_obj_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, K, B, N, idx, count, draw, wpack_bwd, relu_mask, dz, dz_out, d_enc)
     L.durf_obj_dw_batch.restype = i32
-    L.durf_obj_dw_batch.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, vp, u64]
-    #   (stream, K, B, N, count, nlevels, enc, view_tile, stash, dz, dz_out, in_dim, part, bpart, grad_mlp, grad_stride)
+    L.durf_obj_dw_batch.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, vp, u64, vp]
+    #   (stream, K, B, N, count, nlevels, enc, view_tile, stash, dz, dz_out, in_dim, part, bpart, grad_mlp, grad_stride, mlp_params)
     L.durf_encode_obj_bwd.restype = i32
     L.durf_encode_obj_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]
     #   (stream, B, N, k_obj, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums)

@@ -224,7 +224,11 @@ int durf_mlp_dw(void* stream, int width, size_t rows, int N, const int32_t* coun
                 const void* const* dz, const void* const* dz_out, float* part, float* bpart);
 int durf_mlp_dw_finalize(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count,
                          int nlevels /* the same rows, N, count, nlevels as the durf_mlp_dw call */,
-                         const float* part, const float* bpart, float* grad_mlp);
+                         const float* part, const float* bpart, float* grad_mlp,
+                         const float* mlp_params /* fp32 flax-layout parameters of this MLP: the bottleneck Dense_9 is
+                         linear, so its gradients (and the bottleneck-fed rows of Dense_10's) are derived from ONE
+                         sample-axis product h7^T dz10 and the weights, see k_bottleneck_grads in csrc/mlp_bwd.hip --
+                         neither the bottleneck activations nor their gradients are exchanged through memory */);
 /* The same with per-segment geometry: segment l of the sample axis has row capacity rows[l] (a multiple of 32: the
  * layout stride of its buffers), rows_per_ray[l] rows per ray and a nullable device ray count count[l] (valid rows =
  * count * rows_per_ray; a partial last tile is fine when the rows beyond the count carry zero dz and finite
@@ -236,7 +240,7 @@ int durf_mlp_dw_levels(void* stream, int width, int nlevels, const size_t* rows,
                        float* bpart);
 int durf_mlp_dw_finalize_levels(void* stream, int width, int in_dim, int nlevels, const size_t* rows,
                                 const int* rows_per_ray, const int32_t* const* count, const float* part,
-                                const float* bpart, float* grad_mlp);
+                                const float* bpart, float* grad_mlp, const float* mlp_params);
 
 /* Background MLP without redundant work.  A ray that hits exactly one box feeds the background MLP the SAME trunk
  * input at every sample (obbpose_model.py:205-210 masks its Gaussians to zero -> encoding [0 x 30, 1 x 30]); only the
@@ -297,7 +301,7 @@ int durf_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, co
 int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
                       const void* const* enc, const void* const* view_tile, const void* const* stash,
                       const void* const* dz, const void* const* dz_out, int in_dim, float* part, float* bpart,
-                      float* grad_mlp, size_t grad_stride);
+                      float* grad_mlp, size_t grad_stride, const float* mlp_params /* K MLPs, grad_stride floats apart */);
 
 /* Box-pose gradients (cfg4): reverse of weighted_ipe / cast_rays / world2object_rpy / aa2matrix
  * (mip.py:182-223,155-179; box_helpers.py:286-341,148-167).  Per level and object:

@@ -37,7 +37,7 @@ part, bpart = ops.dw_buffers(width, cuda)
 view_tile = ops.expand_view(rows, N, view)
 ops.mlp_dw(width, rows, N, [enc_tile], [view_tile], [stash], [dz], [dz_out], part, bpart)
 grad = torch.zeros_like(flat)
-ops.mlp_dw_finalize(width, in_dim, rows, N, 1, part, bpart, grad)
+ops.mlp_dw_finalize(width, in_dim, rows, N, 1, part, bpart, grad, flat)
 grad = grad.cpu()
 rgb, dens = R.mlp_apply_bf16(params, x, cond, cfg)
 out = torch.cat([rgb.reshape(rows, 3), dens.reshape(rows, 1)], -1)

@@ -101,7 +101,7 @@ def test_weight_gradient_checksum_full_size(cuda):
     part, bpart = ops.dw_buffers(W, cuda)
     ops.mlp_dw(W, rows, N, [enc] * 2, [view_tile] * 2, [stash] * 2, [d[0] for d in dzs], [d[1] for d in dzs], part, bpart)
     grad = torch.zeros_like(flat)
-    ops.mlp_dw_finalize(W, IN, rows, N, 2, part, bpart, grad)
+    ops.mlp_dw_finalize(W, IN, rows, N, 2, part, bpart, grad, flat)
     off_b11 = ops.mlp_layer_offset(W, IN, 11, True)
     off_b8 = ops.mlp_layer_offset(W, IN, 8, True)
     want = sum(d.to(torch.bfloat16).double().sum(0) for d in draws)

@@ -105,7 +105,7 @@ def test_mlp_backward_and_weight_grads(cuda, width, in_dim):
     ops.mlp_dw(width, rows, N, [enc_tile] * 2, [view_tile] * 2, [stash, stash.clone()], [dz, dz.clone()],
                [dz_out] * 2, part, bpart)
     grad = torch.zeros_like(flat)
-    ops.mlp_dw_finalize(width, in_dim, rows, N, 2, part, bpart, grad)
+    ops.mlp_dw_finalize(width, in_dim, rows, N, 2, part, bpart, grad, flat)
     grad = grad.cpu() / 2
     # oracle
     rgb, dens = R.mlp_apply_bf16(params, x, cond, cfg)

@@ -54,7 +54,7 @@ by = (stash.numel() + dz.numel() * dz.element_size() + dz_out.numel() * dz_out.e
       + enc.numel() * 2 + view_tile.numel() * view_tile.element_size())
 print('dW              %8.1f us  %6.1f TFLOP/s  %.2f GB -> %.2f TB/s' % (t * 1e6, flops / t / 1e12, by / 1e9, by / t / 1e12))
 grad = torch.empty(ops.mlp_param_count(W, IN), device=dev)
-t = timeit(lambda: ops.mlp_dw_finalize(W, IN, rows, N, 1, part, bpart, grad))
+t = timeit(lambda: ops.mlp_dw_finalize(W, IN, rows, N, 1, part, bpart, grad, flat))
 print('dW finalize     %8.1f us' % (t * 1e6))
 stash2, dz2 = stash.clone(), dz.clone()
 t = timeit(lambda: ops.mlp_dw(W, rows, N, [enc, enc], [view_tile] * 2, [stash, stash2], [dz, dz2], [dz_out] * 2, part, bpart))
