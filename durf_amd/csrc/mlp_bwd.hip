@@ -469,6 +469,8 @@ struct DwArgs {
     const char* inA[DURF_MAX_LEVELS][12];
     const char* inB[DURF_MAX_LEVELS][12];
     int nlevels;
+    const char* dz2[DURF_MAX_LEVELS];          // job 10 only: the [rows,16] head-gradient tile, one more dz k-step (density head)
+    size_t ks_dz2;
     size_t ks_dz[12], ks_a[12], ks_b[12];      // per-object strides of the three operand streams (batched object MLPs)
     size_t ks_part, ks_bpart;                  // ... and of the partial buffers (floats)
     float* part[12];
@@ -499,7 +501,8 @@ __host__ __device__ inline size_t dw_level_tiles(const durf::DwLevels& lv, int l
     return (nrows + 31) >> 5;
 }
 
-template <int NKO, int NKA, int NKB>
+// NKO2 of the NKO dz k-steps come from a second buffer (a.dz2: the head-gradient tile) after the NKO - NKO2 of a.dz
+template <int NKO, int NKA, int NKB, int NKO2 = 0>
 __device__ __forceinline__ void dw_job(const durf::DwLevels& lv, const DwArgs& a, int job,
                                        int nsplit, int split_idx, float* __restrict__ part,
                                        float* __restrict__ bpart, char* smem) {
@@ -533,7 +536,8 @@ __device__ __forceinline__ void dw_job(const durf::DwLevels& lv, const DwArgs& a
         const int n = (g_p & 16) | ((g_p - 4 * c) & 15);
         voff[par] = (unsigned)((g_hif * 32 + n) * 16);
     }
-    i32x4 r_dz, r_a, r_b;                             // descriptors based at the current segment's first tile
+    constexpr int NKO1 = NKO - NKO2;
+    i32x4 r_dz, r_a, r_b, r_dz2;                      // descriptors based at the current segment's first tile
     auto stage_load = [&](int ti, int slot) {        // ti = tile index relative to t0
         ti = __builtin_amdgcn_readfirstlane(ti);
         const unsigned dst = lds0 + (unsigned)(slot * STAGE);
@@ -541,8 +545,10 @@ __device__ __forceinline__ void dw_job(const durf::DwLevels& lv, const DwArgs& a
         for (int i = 0; i < CPW; i++) {
             int ci = wave + 8 * i;
             if (ci >= NC) ci -= NC;                    // pad: re-load an early chunk (same bytes, same place)
-            if (ci < NKO) {
-                lds_dma16(r_dz, (unsigned)((ti * NKO + ci) * 1024), voff[ci & 1], dst + ci * 1024);
+            if (ci < NKO1) {
+                lds_dma16(r_dz, (unsigned)((ti * NKO1 + ci) * 1024), voff[ci & 1], dst + ci * 1024);
+            } else if (NKO2 > 0 && ci < NKO) {
+                lds_dma16(r_dz2, (unsigned)((ti * NKO2 + ci - NKO1) * 1024), voff[ci & 1], dst + ci * 1024);
             } else if (ci < NKO + NKA) {
                 const int ks = ci - NKO;
                 lds_dma16(r_a, (unsigned)((ti * NKA + ks) * 1024), voff[ks & 1], dst + ci * 1024);
@@ -581,7 +587,8 @@ __device__ __forceinline__ void dw_job(const durf::DwLevels& lv, const DwArgs& a
         if (b1 <= b0) continue;
         const size_t t0 = b0 - lo;                    // first tile of the segment within its level
         const int nt = (int)(b1 - b0);
-        r_dz = make_rsrc(a.dz[lvl][job] + obj * a.ks_dz[job] + t0 * NKO * 1024);
+        r_dz = make_rsrc(a.dz[lvl][job] + obj * a.ks_dz[job] + t0 * NKO1 * 1024);
+        r_dz2 = make_rsrc(NKO2 ? a.dz2[lvl] + obj * a.ks_dz2 + t0 * (NKO2 ? NKO2 : 1) * 1024 : a.dz[lvl][job]);
         r_a = make_rsrc(a.inA[lvl][job] + obj * a.ks_a[job] + t0 * NKA * 1024);
         r_b = make_rsrc(NKB ? a.inB[lvl][job] + obj * a.ks_b[job] + t0 * (NKB ? NKB : 1) * 1024 : a.inA[lvl][job]);
         __builtin_amdgcn_s_barrier();                 // everyone is done reading the previous segment's slots
@@ -701,12 +708,18 @@ k_dw_all(durf::DwLevels lv, DwArgs a) {
         }
     } trace_end{t_start, job, sp};
 #endif
-#define DW_CALL(NKO, NKA, NKB) dw_job<NKO, NKA, NKB>(lv, a, job, ns, sp, a.part[job], a.bpart[job], smem)
+#define DW_CALL(...) dw_job<__VA_ARGS__>(lv, a, job, ns, sp, a.part[job], a.bpart[job], smem)
     switch (job) {
         case 0: DW_CALL(S::KW, S::KE, 0); break;
         case 5: DW_CALL(S::KW, S::KW, S::KE); break;
-        case 8: DW_CALL(1, S::KW, 0); break;
-        case 10: DW_CALL(S::KC, S::KW, S::KV); break;
+        // W = 256: the density head (d raw x h7) rides in job 10 as one more dz k-step -- both read h7 (512 B/sample).
+        // W = 128 keeps it as its own job: the merged variant needs 147 instead of 81 VGPRs and would cost the
+        // latency-bound object launches their second workgroup per CU.
+        case 8: if (W != 256) DW_CALL(1, S::KW, 0); break;
+        case 10:
+            if (W == 256) DW_CALL(S::KC + 1, S::KW, S::KV, 1);     // [dz10 | d raw] x [h7 | view]
+            else DW_CALL(S::KC, S::KW, S::KV);
+            break;
         case 11: DW_CALL(1, S::KC, 0); break;
         default: DW_CALL(S::KW, S::KW, 0); break;      // Dense 1-4, 6, 7, 9
     }
@@ -790,7 +803,12 @@ k_dw_finalize(int W, int in_dim, DwJobs jobs, const float* __restrict__ part_all
         int row;
         if (i_slot < job.in_nat_base) row = cperm_feat(i_slot) < job.in_perm_rows ? cperm_feat(i_slot) : -1;
         else row = job.in_perm_rows + (i_slot - job.in_nat_base);
-        if (job.layer == 10 && i_slot < job.in_nat_base) {
+        if (job.layer == 10 && o_slot >= 128) {
+            // the head-gradient k-step of job 10 (dz_out: slots 0-2 d rgb, 3 d density) x h7 = the density head's
+            // weight gradient (Dense_8, kernel [W,1]); its products with the rgb slots and with the view features mean nothing
+            if (o_slot == 128 + 3 && i_slot < job.in_nat_base)
+                grad_mlp[durf_layer_offset(W, in_dim, 8, 0) + cperm_feat(i_slot)] = s;
+        } else if (job.layer == 10 && i_slot < job.in_nat_base) {
             // view layer, rows fed by the bottleneck: this job multiplied dz10 with h7, not with the bottleneck output.
             // Keep the sum P[h7 feature, dz10 feature] in split 0's slot (only this thread group reads this element)
             // for k_bottleneck_grads, which turns it into the gradients of Dense_9 and of these rows of Dense_10.
@@ -799,9 +817,13 @@ k_dw_finalize(int W, int in_dim, DwJobs jobs, const float* __restrict__ part_all
             grad_mlp[durf_layer_offset(W, in_dim, job.layer, 0) + (size_t)row * fo + col] = s;
     } else {
         const int o_slot = idx - nfrag;
-        const int col = job.out_nat_off >= 0 ? o_slot - job.out_nat_off : cperm_feat(o_slot);
-        if (col >= 0 && col < fo) grad_mlp[durf_layer_offset(W, in_dim, job.layer, 1) + col] = s;
-        if (job.layer == 10) const_cast<float*>(bpart)[idx - nfrag] = s;     // db10, kept for k_bottleneck_grads
+        if (job.layer == 10 && o_slot >= 128) {
+            if (o_slot == 128 + 3) grad_mlp[durf_layer_offset(W, in_dim, 8, 1)] = s;        // density head bias
+        } else {
+            const int col = job.out_nat_off >= 0 ? o_slot - job.out_nat_off : cperm_feat(o_slot);
+            if (col >= 0 && col < fo) grad_mlp[durf_layer_offset(W, in_dim, job.layer, 1) + col] = s;
+            if (job.layer == 10) const_cast<float*>(bpart)[idx - nfrag] = s;     // db10, kept for k_bottleneck_grads
+        }
     }
 }
 
@@ -871,12 +893,13 @@ static DwPlan dw_plan(int width) {
         if (j == 0) nki = 4;
         else if (j == 5) nki = KW + 4;
         else if (j == 8) nko = 1;
-        else if (j == 10) { nko = 8; nki = KW + 2; }
+        else if (j == 10) { nko = width == 256 ? 9 : 8; nki = KW + 2; }        // W = 256: + the head-gradient k-step (density head)
         else if (j == 11) { nko = 1; nki = 8; }
         P.nko[j] = nko; P.nki[j] = nki;
         P.MO[j] = (nko + 1) / 2; P.NI[j] = nki / 2;
         wcost[j] = nko + nki + (nko + nki < 12 ? 3 : 0);     // the 9 KB/stage job is latency-bound: +30 % time per byte (traced)
-        if (j == 9) wcost[j] = 0;                            // the bottleneck layer has no GEMM of its own (see k_bottleneck_grads)
+        if (j == 9 || (j == 8 && width == 256)) wcost[j] = 0;   // no GEMM of their own: the bottleneck (k_bottleneck_grads)
+                                                                // and, at W = 256, the density head (rides in job 10)
         cost += wcost[j];
     }
     // splits per job in proportion to its bytes per sample, summing EXACTLY to total_wgs (largest
@@ -1072,6 +1095,7 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
     DwArgs a;
     a.nlevels = nlevels;
     a.ks_part = st.part; a.ks_bpart = st.bpart;
+    a.ks_dz2 = st.dz_out;
     for (int j = 0; j < 12; j++) {
         a.ks_dz[j] = (j == 8 || j == 11) ? st.dz_out : st.stash;
         a.ks_a[j] = j == 0 ? st.enc : st.stash;
@@ -1092,7 +1116,8 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
             }
         }
         a.inB[l][5] = (const char*)enc_tile[ll];
-        a.dz[l][8] = (const char*)dz_out[ll]; a.inA[l][8] = region(stash[ll], 7, ll);          // density head
+        a.dz[l][8] = (const char*)dz_out[ll]; a.inA[l][8] = region(stash[ll], 7, ll);      // density head (its own job at W = 128)
+        a.dz2[l] = (const char*)dz_out[ll];                                                  // ... the last dz k-step of job 10 at W = 256
         a.dz[l][9] = nullptr; a.inA[l][9] = nullptr;            // bottleneck (linear): no job, see k_bottleneck_grads
         // view layer: dz10 x [h7 | view] -- P = h7^T dz10 stands in for the bottleneck's activations and gradients
         a.dz[l][10] = region(dz[ll], 9, ll); a.inA[l][10] = region(stash[ll], 7, ll); a.inB[l][10] = (const char*)view_tile[ll];
