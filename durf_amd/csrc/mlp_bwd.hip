@@ -846,10 +846,16 @@ __device__ __forceinline__ size_t frag_index(int W, int i, int j, int NI) {
     const int hi = (ol >> 2) & 1, r = (ol & 3) + 4 * (ol >> 3);
     return (((size_t)mo * NI + ni) * 64 + hi * 32 + jn) * 16 + r;
 }
+// One workgroup per 32 x 32 output tile (LDS-staged operands: P is gathered from fragment order once per tile):
+//   tiles [0, nA):        dK9[i, o]  = sum_j P[i, j] K10[o, j]                    (W/32 x W/32 tiles, K = 128)
+//   tiles [nA, nA + nC):  dK10[o, j] = sum_i K9[i, o] P[i, j] + b9[o] db10[j]     (W/32 x 4 tiles,    K = W)
+//   tile nA + nC:         db9[o]     = sum_j db10[j] K10[o, j]
 __global__ void __launch_bounds__(256)
 k_bottleneck_grads(int W, int in_dim, int NI, const float* __restrict__ part10, const float* __restrict__ bpart10,
                    const float* __restrict__ params, float* __restrict__ grad, size_t part_stride, size_t bpart_stride,
                    size_t param_stride, size_t grad_stride) {
+    __shared__ float sa[32][257];        // rows of the first operand, K (<= 256) values each
+    __shared__ float sb[32][257];        // rows of the second operand
     part10 += blockIdx.y * part_stride;
     bpart10 += blockIdx.y * bpart_stride;
     params += blockIdx.y * param_stride;
@@ -858,23 +864,45 @@ k_bottleneck_grads(int W, int in_dim, int NI, const float* __restrict__ part10, 
     const float* K9 = params + off9;                 // [W, W]
     const float* b9 = K9 + (size_t)W * W;
     const float* K10 = params + off10;               // [W + 27, 128]; rows < W are fed by the bottleneck
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    const int nA = W * W, nB = W, nC = W * 128;
-    if (t < nA) {                                    // dK9[i, o] = sum_j P[i, j] K10[o, j]
-        const int i = t / W, o = t % W;
-        float s = 0.0f;
-        for (int j = 0; j < 128; j++) s += part10[frag_index(W, i, j, NI)] * bf16r(K10[(size_t)o * 128 + j]);
-        grad[off9 + (size_t)i * W + o] = s;
-    } else if (t < nA + nB) {                        // db9[o] = sum_j db10[j] K10[o, j]
-        const int o = t - nA;
-        float s = 0.0f;
-        for (int j = 0; j < 128; j++) s += bpart10[cperm_slot(j)] * bf16r(K10[(size_t)o * 128 + j]);
-        grad[off9 + (size_t)W * W + o] = s;
-    } else if (t < nA + nB + nC) {                   // dK10[o, j] = sum_i K9[i, o] P[i, j] + b9[o] db10[j]     (o < W)
-        const int u = t - nA - nB, o = u / 128, j = u % 128;
-        float s = b9[o] * bpart10[cperm_slot(j)];
-        for (int i = 0; i < W; i++) s += bf16r(K9[(size_t)i * W + o]) * part10[frag_index(W, i, j, NI)];
-        grad[off10 + (size_t)o * 128 + j] = s;
+    const int wt = W / 32, nA = wt * wt, nC = wt * 4;
+    const int t = blockIdx.x, tid = threadIdx.x;
+    const int tx = tid & 31, ty = tid >> 5;          // output (row = ty + 8 q, col = tx), q = 0..3
+    if (t < nA) {
+        const int i0 = (t / wt) * 32, o0 = (t % wt) * 32;
+        for (int e = tid; e < 32 * 128; e += 256) {
+            const int r = e >> 7, j = e & 127;
+            sa[r][j] = part10[frag_index(W, i0 + r, j, NI)];
+            sb[r][j] = bf16r(K10[(size_t)(o0 + r) * 128 + j]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = ty + 8 * q;
+            float s = 0.0f;
+            for (int j = 0; j < 128; j++) s += sa[r][j] * sb[tx][j];
+            grad[off9 + (size_t)(i0 + r) * W + o0 + tx] = s;
+        }
+    } else if (t < nA + nC) {
+        const int u = t - nA, o0 = (u / 4) * 32, j0 = (u % 4) * 32;
+        for (int e = tid; e < 32 * W; e += 256) {
+            const int r = e / W, i = e % W;
+            sa[r][i] = bf16r(K9[(size_t)i * W + o0 + r]);              // K9^T rows: output feature o0 + r
+            sb[r][i] = part10[frag_index(W, i, j0 + r, NI)];          // P^T rows: dz10 feature j0 + r
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int r = ty + 8 * q;
+            float s = b9[o0 + r] * bpart10[cperm_slot(j0 + tx)];
+            for (int i = 0; i < W; i++) s += sa[r][i] * sb[tx][i];
+            grad[off10 + (size_t)(o0 + r) * 128 + j0 + tx] = s;
+        }
+    } else {
+        for (int o = tid; o < W; o += 256) {
+            float s = 0.0f;
+            for (int j = 0; j < 128; j++) s += bpart10[cperm_slot(j)] * bf16r(K10[(size_t)o * 128 + j]);
+            grad[off9 + (size_t)W * W + o] = s;
+        }
     }
 }
 
@@ -1176,8 +1204,8 @@ int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
     }
     hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12, K), dim3(256), 0, s, W, in_dim, jobs, part, bpart,
                        grad_mlp, part_stride, bpart_stride, grad_stride, lv);
-    const int nthr = W * W + W + W * 128;
-    hipLaunchKernelGGL(k_bottleneck_grads, dim3(durf_cdiv(nthr, 256), K), dim3(256), 0, s, W, in_dim, P.NI[10],
+    const int ntiles = (W / 32) * (W / 32) + (W / 32) * 4 + 1;
+    hipLaunchKernelGGL(k_bottleneck_grads, dim3(ntiles, K), dim3(256), 0, s, W, in_dim, P.NI[10],
                        part + P.part_off[10], bpart + P.bpart_off[10], mlp_params, grad_mlp, part_stride, bpart_stride,
                        param_stride, grad_stride);
     DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
