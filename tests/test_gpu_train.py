@@ -348,3 +348,40 @@ def test_main_driver_trains_on_the_synthetic_timestep_dataset(cuda, tmp_path):
     assert logs[-1]['avg_loss'] < logs[0]['avg_loss'], 'the loss must go down'
     assert all(np.isfinite(e['test_psnr']) and 0.0 < e['test_ssim'] <= 1.0 for e in evals)
     assert checkpoints._steps(str(tmp_path)) == [25, 40]
+
+
+@pytest.mark.parametrize('L,K', [(1, 1), (3, 2)])
+def test_train_step_with_other_level_counts(cuda, L, K):
+    """MipNerfModel.num_levels is a knob (obbpose_model.py:46): 1 level (no resampling, the unfused per-ray launches) and
+    3 levels (two fused composite + resample launches, the last level deferred to the loss kernel) against the oracle."""
+    N, B = 32, 192
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.num_levels = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
+                    'Config.randomized = True\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
+                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.0\n' % (N, L))
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(B, K, seed=47 + L)
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(1, db, device=cuda)
+    assert model.num_levels == L
+    g = torch.Generator().manual_seed(4)
+    noise_c = dict(t_rand=torch.rand(B, N + 1, generator=g), u_rand=torch.rand(B, N + 1, generator=g))
+    noise_d = {k: v.to(cuda) for k, v in noise_c.items()}
+    params = H.oracle_params_from_variables(variables)
+    grad, raw, pose = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, 10.0, db['init'][0:1], noise=noise_d)
+    stats = ops.stats_views(train_boxpose._assemble_stats(config, db, raw, db['init'][0:1], ops.STATS_ASSEMBLE | ops.STATS_PSNR), L)
+    ocfg = dict(R.CONFIG_DEFAULTS, randomized=True, tv_loss_mult=0.0)
+    _, _, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, dict(num_samples=N, num_levels=L), 5e-4,
+                                        3.0, 10.0, ob['init'][0:1], noise=noise_c, mlp_hook=R.mlp_apply_bf16)
+    assert len(raw['ret']) == L and ostats['losses'].shape[0] == L
+    for k in ('losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses'):
+        torch.testing.assert_close(stats[k].cpu(), ostats[k], rtol=2e-3, atol=1e-6, msg=lambda m: k + ': ' + m)
+    torch.testing.assert_close(stats['loss'].cpu(), ostats['loss'], rtol=2e-3, atol=1e-6)
+    og = torch.cat([x.reshape(-1) for x in ograds])
+    lay = variables.layout
+    for name in lay.mlp_names():
+        w, _ = lay.mlp_dims(name)
+        sl = slice(lay.mlp_off[name], lay.mlp_off[name] + lay.mlp_size[w])
+        if float(og[sl].norm()) > 0:
+            assert _rel(grad.cpu()[sl], og[sl]) < 5e-2, '%s grad rel err %g' % (name, _rel(grad.cpu()[sl], og[sl]))
