@@ -134,28 +134,13 @@ __device__ __forceinline__ f32x16 bmma_tile(const char* slot, int lane, const bf
     return acc;
 }
 
-// two tiles with interleaved, independent accumulators (see mma_tile2 in mlp_fwd.hip)
+// two tiles with interleaved, independent accumulators, fragments through the register ring (mma_pair_ring, mlp_spec.h)
 template <int NA, int NB>
 __device__ __forceinline__ void bmma_tile2(const char* slot0, const char* slot1, int lane, const bf16x8* inA,
                                            const bf16x8* inB, f32x16& acc0, f32x16& acc1) {
 #pragma unroll
     for (int r = 0; r < 16; r++) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
-    const char* ap0 = slot0 + lane * 16;
-    const char* ap1 = slot1 + lane * 16;
-#pragma unroll
-    for (int ks = 0; ks < NA; ks++) {
-        const bf16x8 a0 = *(const bf16x8*)(ap0 + ks * 1024);
-        const bf16x8 a1 = *(const bf16x8*)(ap1 + ks * 1024);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, inA[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, inA[ks], acc1, 0, 0, 0);
-    }
-#pragma unroll
-    for (int ks = 0; ks < NB; ks++) {
-        const bf16x8 a0 = *(const bf16x8*)(ap0 + (NA + ks) * 1024);
-        const bf16x8 a1 = *(const bf16x8*)(ap1 + (NA + ks) * 1024);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, inB[ks], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, inB[ks], acc1, 0, 0, 0);
-    }
+    mma_pair_ring<NA, NB, BWD_LDS_RING>(slot0, slot1, lane, inA, inB, acc0, acc1, [](auto) {});
 }
 
 // gradient wrt the pre-activation: pass where the stashed post-ReLU activation is non-zero

@@ -129,9 +129,7 @@ __device__ __forceinline__ f32x16 mma_tile(const char* slot, int lane, const bf1
     return acc;
 }
 
-// Two output tiles at once: their MFMAs alternate, so consecutive MFMAs never share an
-// accumulator (a dependent same-accumulator chain with LDS reads / waits between its links
-// pays ~43 extra cycles per link on gfx950) and each B fragment is used twice back-to-back.
+// Two output tiles at once through the fragment ring (mma_pair_ring, mlp_spec.h); the bias rows are the initial accumulators.
 template <int NA, int NB, bool SPREAD = false>
 __device__ __forceinline__ void mma_tile2(const char* slot0, const char* slot1, int lane, const bf16x8* inA,
                                           const bf16x8* inB, f32x16& acc0, f32x16& acc1,
@@ -147,25 +145,19 @@ __device__ __forceinline__ void mma_tile2(const char* slot0, const char* slot1, 
         acc0[4 * g + 0] = b0[0]; acc0[4 * g + 1] = b0[1]; acc0[4 * g + 2] = b0[2]; acc0[4 * g + 3] = b0[3];
         acc1[4 * g + 0] = b1[0]; acc1[4 * g + 1] = b1[1]; acc1[4 * g + 2] = b1[2]; acc1[4 * g + 3] = b1[3];
     }
-    const char* ap0 = slot0 + lane * 16;
-    const char* ap1 = slot1 + lane * 16;
-#pragma unroll
-    for (int ks = 0; ks < T; ks++) {
-        const bf16x8 a0 = *(const bf16x8*)(ap0 + ks * 1024);
-        const bf16x8 a1 = *(const bf16x8*)(ap1 + ks * 1024);
-        const bf16x8 b = ks < NA ? inA[ks < NA ? ks : 0] : inB[ks < NA ? 0 : ks - NA];
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b, acc1, 0, 0, 0);
-        if (SPREAD) {
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                if (ks == (q + 1) * T / 4 - 1) {
+    mma_pair_ring<NA, NB, FWD_LDS_RING>(slot0, slot1, lane, inA, inB, acc0, acc1, [&](auto ks_) {
+        constexpr int ks = decltype(ks_)::value;
+        if constexpr (SPREAD) {
+            static_for<0, 4>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if constexpr (ks == (q + 1) * T / 4 - 1) {
                     __builtin_amdgcn_sched_barrier(0);
                     if (do_store) STREAM_STORE(sp + q * 1024, sv[q]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+            });
         }
-    }
+    });
 }
 
 // packs one output tile to bf16 (ReLU optional) and returns its 16 "activation != 0" flags

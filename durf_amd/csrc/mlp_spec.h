@@ -14,6 +14,7 @@
 //   inputs that come from memory (encoding, view dirs) use the natural order
 //      feature(ks, hi, e) = 16*ks + 8*hi + e                              ("natural")
 #pragma once
+#include <type_traits>
 #include "durf_common.h"
 
 template <int W_>
@@ -102,4 +103,68 @@ __host__ __device__ inline int durf_fwd_in_row(int s, int ks, int hi, int e, int
     if (s == 5) return f < in_dim ? W + f : -1;
     if (s == 9) return f < 27 ? W + f : -1;
     return -1;
+}
+
+// ---------------------------------------------------------------------------
+// Weight fragments LDS -> registers: a REGISTER RING of 2-4 ds_read_b128 in flight, issued from inline asm with
+// counted s_waitcnt lgkmcnt(n).  Left to itself hipcc (at the 256-register cap of these kernels) sinks every fragment
+// read to just before the MFMA that consumes it -- "ds_read_b128 v[40:43]; s_waitcnt lgkmcnt(0); v_mfma", 1184 times per
+// 256-sample block -- so each MFMA waited for a full LDS round trip.  LDS reads return in order, so fragment i is valid
+// once at most min(ring - 1, reads after it) younger reads are outstanding; reads hipcc issues by itself in between
+// (bias rows, masks) and scalar loads only make that wait conservative (at least one more LDS read has completed than
+// the count requires, and the oldest completes first).
+// Two output tiles at once (read i: tile i & 1, k-step i >> 1): their MFMAs alternate, so consecutive MFMAs never share
+// an accumulator and each B fragment is used twice back to back.  `hook(ks)` runs after the second MFMA of k-step ks.
+// ---------------------------------------------------------------------------
+// ring depth, measured on MI355X (same-box A/B, 4096 rays x 128 samples; tools/time_fwd.py): forward 2 (690 -> 669 us
+// with the training stores, 2-4 alike; 6-8 slower), backward 4 (605 -> 597 us at 2, 582 at 4)
+#ifndef FWD_LDS_RING
+#define FWD_LDS_RING 2
+#endif
+#ifndef BWD_LDS_RING
+#define BWD_LDS_RING 4
+#endif
+typedef int v4i_ __attribute__((ext_vector_type(4)));
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+template <int OFF>
+__device__ __forceinline__ v4i_ lds_read16(unsigned addr) {
+    v4i_ r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(v4i_& frag) {     // frag is valid once at most N younger LDS reads are outstanding
+    asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(frag) : "n"(N));
+}
+__device__ __forceinline__ unsigned lds_addr_of(const char* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+template <int NA, int NB, int RING, class H>
+__device__ __forceinline__ void mma_pair_ring(const char* slot0, const char* slot1, int lane, const bf16x8* inA,
+                                              const bf16x8* inB, f32x16& acc0, f32x16& acc1, H&& hook) {
+    constexpr int T = NA + NB, NR = 2 * T;
+    constexpr int D = RING < NR ? RING : NR;
+    const unsigned l0 = lds_addr_of(slot0) + lane * 16, l1 = lds_addr_of(slot1) + lane * 16;
+    v4i_ ring[D];
+    static_for<0, D>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        ring[i] = lds_read16<(i >> 1) * 1024>((i & 1) ? l1 : l0);
+    });
+    static_for<0, NR>([&](auto i_) {
+        constexpr int i = decltype(i_)::value, ks = i >> 1;
+        constexpr int later = (NR - 1 - i) < (D - 1) ? (NR - 1 - i) : (D - 1);
+        lds_wait<later>(ring[i % D]);
+        const bf16x8 a = __builtin_bit_cast(bf16x8, ring[i % D]);
+        const bf16x8 b = ks < NA ? inA[ks < NA ? ks : 0] : inB[ks < NA ? 0 : ks - NA];
+        if constexpr (i & 1) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
+        else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+        if constexpr (i + D < NR) ring[i % D] = lds_read16<((i + D) >> 1) * 1024>(((i + D) & 1) ? l1 : l0);
+        if constexpr (i & 1) hook(std::integral_constant<int, ks>{});
+    });
 }
