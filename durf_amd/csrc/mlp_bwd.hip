@@ -916,9 +916,13 @@ static DwPlan dw_plan(int width) {
         cost += wcost[j];
     }
     // splits per job in proportion to its bytes per sample, summing EXACTLY to total_wgs (largest
-    // remainder): with one resident workgroup per CU, 4 x 256 workgroups are four full rounds; two
-    // stragglers from plain rounding (1026) cost a fifth round = +25 % (measured).
-    static const int total_wgs = getenv("DURF_DW_WGS") ? atoi(getenv("DURF_DW_WGS")) : 1024;
+    // remainder): with one resident workgroup per CU, n x 256 workgroups are n full rounds; two
+    // stragglers from plain rounding (1026) cost another round (measured).  W = 256: two rounds -- round 2's
+    // sweep at cfg3 (tools/sweep_dw_wgs.sh): 256 1507 us, 384 1617, 512 1445-1460, 640 1600, 768 1451-1459,
+    // 1024 1464-1495, 1280 1490, 1536 1508; fewer workgroups also mean fewer fp32 partials to write and re-read
+    // (268 -> 134 MB).  W = 128 (objects, two workgroups per CU, most splits empty): four rounds as before.
+    static const int env_wgs = getenv("DURF_DW_WGS") ? atoi(getenv("DURF_DW_WGS")) : 0;
+    const int total_wgs = env_wgs > 0 ? env_wgs : (width == 256 ? 512 : 1024);
     int base[12], given = 0;
     for (int j = 0; j < 12; j++) {
         base[j] = total_wgs * wcost[j] / cost;
