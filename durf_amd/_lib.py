@@ -23,6 +23,7 @@ _SIGS = {
     'durf_wpack_fwd_bytes': (u64, [i32]),
     'durf_wpack_bwd_bytes': (u64, [i32]),
     'durf_pack_weights': (i32, [vp, i32, i32, vp, vp, vp]),
+    'durf_pack_weights_all': (i32, [vp, vp, i32, vp, vp, i32, vp, u64, i32, vp, vp]),
     'durf_ray_setup': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_compact_hits': (i32, [vp, i32, i32, vp, vp, vp, vp]),
     'durf_compact_classes': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
@@ -53,6 +54,9 @@ _SIGS = {
     'durf_obj_fwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp, vp, vp, vp, vp, vp, vp]),
     'durf_obj_bwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_obj_dw_batch': (i32, [vp, i32, i32, i32, vp, i32] + [C.POINTER(vp)] * 5 + [i32, vp, vp, vp, u64, vp]),
+    'durf_obj_dw_partials': (i32, [vp, i32, i32, i32, vp, i32] + [C.POINTER(vp)] * 5 + [vp, vp]),
+    'durf_dw_finalize_all': (i32, [vp, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp, vp,
+                                   i32, i32, i32, vp, i32, i32, vp, vp, vp, u64, vp]),
     'durf_gen_batch': (i32, [vp, i32, i32, C.POINTER(f32), vp, f32, f32, vp, vp, vp, i32] + [vp] * 10),
     'durf_ssim_scratch_floats': (u64, [i32, i32, i32, i32]),
     'durf_ssim': (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, f32, f32, vp, vp, vp]),

@@ -191,4 +191,11 @@ int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
                        const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
                        size_t bpart_stride, size_t grad_stride, const float* mlp_params, size_t param_stride);
 DwLevels uniform_levels(size_t rows, int N, const int32_t* count, int nlevels);
+struct DwFinSpec {           // one class of MLPs of a finalize launch (launch_dw_finalize2)
+    int width, in_dim, K;
+    DwLevels lv;
+    const float* part; const float* bpart; float* grad; const float* params;
+    size_t part_stride, bpart_stride, grad_stride, param_stride;
+};
+int launch_dw_finalize2(void* stream, const DwFinSpec& a, const DwFinSpec& b);
 }  // namespace durf

@@ -12,78 +12,16 @@
 //      workgroups with fp32 partials, summed in a fixed order by k_dw_finalize
 //      (deterministic; no atomics).  HBM-bound: 1 KB read per sample per 256x256 layer.
 #include <stdlib.h>
-#include "mlp_spec.h"
+#include "mlp_pack.h"
 
 
-// ---------------------------------------------------------------------------
-// backward weight stream: for fwd stage s = 10..1, tiles over INPUT features
-// ---------------------------------------------------------------------------
-// Backward stages in execution order.  b: 0..5 = fwd stages 10,9,8,7,6,5 (trunk rows),
-// 6 = input-encoding rows of Dense_5 (skip connection; only needed for box-pose gradients),
-// 7..10 = fwd stages 4,3,2,1, 11 = Dense_0 -> d encoding (box-pose gradients only).
-template <int W>
-struct BwdSpec {
-    using S = MlpSpec<W>;
-    static constexpr int NB = 12;
-    __host__ __device__ static constexpr int fwd_stage(int b) { return b <= 5 ? 10 - b : (b == 6 ? 5 : (b <= 10 ? 11 - b : 0)); }
-    __host__ __device__ static constexpr bool is_enc(int b) { return b == 6 || b == 11; }
-    __host__ __device__ static constexpr int n_mt(int b) { return is_enc(b) ? S::KE / 2 : (b == 0 ? S::CT : S::WT); }
-    __host__ __device__ static constexpr int n_ks(int b) {
-        return b == 0 ? 1 : (b == 1 ? S::KC : (b == 2 ? S::KW + 1 : S::KW));
-    }
-    __host__ __device__ static constexpr int chunk_base(int b) {
-        int c = 0;
-        for (int i = 0; i < b; i++) c += n_mt(i) * n_ks(i);
-        return c;
-    }
-    static constexpr int TOTAL_CHUNKS = chunk_base(NB);
-    static constexpr int MAX_TILE_CHUNKS = S::KW + 1;
-};
-
+// (BwdSpec and the packer bodies: mlp_pack.h)
 template <int W>
 __global__ void __launch_bounds__(256)
 k_pack_bwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out, size_t p_stride, size_t out_stride) {
-    using S = MlpSpec<W>;
-    using Bs = BwdSpec<W>;
     P += blockIdx.y * p_stride;                                  // object index (0 for a single MLP)
     out = (bf16x8*)((char*)out + blockIdx.y * out_stride);
-    const int vec = blockIdx.x * blockDim.x + threadIdx.x;
-    if (vec >= Bs::TOTAL_CHUNKS * 64) return;
-    const int chunk = vec >> 6, lane = vec & 63;
-    int b = 0, base = 0;
-    for (; b < Bs::NB; b++) {
-        const int cnt = Bs::n_mt(b) * Bs::n_ks(b);
-        if (chunk < base + cnt) break;
-        base += cnt;
-    }
-    const int s = Bs::fwd_stage(b);
-    const bool enc_rows = Bs::is_enc(b);
-    const int rel = chunk - base;
-    const int mo = rel / Bs::n_ks(b), ks = rel % Bs::n_ks(b);
-    const int i = lane & 31, hi = lane >> 5;
-    // input feature (kernel row) of fwd stage s this A-fragment row stands for
-    const int row = enc_rows ? (s == 5 ? W : 0) + 32 * mo + i : 32 * mo + i;
-    bf16x8 v;
-#pragma unroll
-    for (int e = 0; e < 8; e++) {
-        const int perm = 16 * ks + (e & 3) + 8 * (e >> 2) + 4 * hi;
-        const int nat = 8 * hi + e;
-        int L = -1, col = 0;
-        if (s == 10) { if (nat < 3) { L = 11; col = nat; } }
-        else if (s == 9) { L = 10; col = perm; }
-        else if (s == 8) { if (ks < S::KW) { L = 9; col = perm; } else if (nat == 0) { L = 8; col = 0; } }
-        else { L = s; col = perm; }
-        float val = 0.0f;
-        if (L >= 0) {
-            int fi, fo;
-            durf_layer_shape(W, in_dim, L, &fi, &fo);
-            const int row_lim = enc_rows ? fi : ((s == 10) ? 128 : W);   // trunk/bottleneck rows, or the encoding rows
-            if (row < row_lim && row < fi && col < fo)
-                val = P[durf_layer_offset(W, in_dim, L, 0) + (size_t)row * fo + col];
-        }
-        v[e] = (__bf16)val;
-    }
-    out[vec] = v;
+    pack_bwd_vec<W>(in_dim, P, out, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------
@@ -737,17 +675,33 @@ __host__ __device__ inline int cperm_feat(int s) {
 // One launch covers all 12 Dense layers of an MLP (blockIdx.y = job).
 struct DwJobs { DwJob j[12]; size_t part_off[12], bpart_off[12]; int nparts[12]; };
 
+// One launch finalizes up to TWO classes of MLPs (blockIdx.z: first the `count` MLPs of class 0, then those of class 1):
+// a training step has the background MLP (W = 256, its own segment geometry) and the K object MLPs (W = 128, per-object
+// ray counts), and finalizing them together saves two dependent launches per step.
+struct FinMlp {
+    int W, in_dim, count, NI10;
+    DwJobs jobs;
+    const float* part; const float* bpart; float* grad; const float* params;
+    size_t part_stride, bpart_stride, grad_stride, param_stride;
+    durf::DwLevels lv;
+};
+struct FinArgs { FinMlp m[2]; };
+
 __global__ void __launch_bounds__(256)
-k_dw_finalize(int W, int in_dim, DwJobs jobs, const float* __restrict__ part_all,
-              const float* __restrict__ bpart_all, float* __restrict__ grad_mlp, size_t part_stride,
-              size_t bpart_stride, size_t grad_stride, durf::DwLevels lv) {
+k_dw_finalize(FinArgs A) {
     __shared__ float red[4][64];
+    const int cls = (int)blockIdx.z < A.m[0].count ? 0 : 1;
+    const FinMlp& M = A.m[cls];
+    const size_t obj = blockIdx.z - (cls ? A.m[0].count : 0);      // batched object MLPs: the object
+    const int W = M.W, in_dim = M.in_dim;
+    const DwJobs& jobs = M.jobs;
+    const durf::DwLevels& lv = M.lv;
     if (jobs.nparts[blockIdx.y] == 0) return;        // the bottleneck layer: no job of its own
-    part_all += blockIdx.z * part_stride;            // batched object MLPs: blockIdx.z = object
-    bpart_all += blockIdx.z * bpart_stride;
-    grad_mlp += blockIdx.z * grad_stride;
+    const float* part_all = M.part + obj * M.part_stride;
+    const float* bpart_all = M.bpart + obj * M.bpart_stride;
+    float* grad_mlp = M.grad + obj * M.grad_stride;
     size_t nt_all = 0;                               // the splits k_dw_all actually wrote (see dw_tiles_per_split)
-    for (int l = 0; l < lv.nlevels; l++) nt_all += dw_level_tiles(lv, l, blockIdx.z);
+    for (int l = 0; l < lv.nlevels; l++) nt_all += dw_level_tiles(lv, l, obj);
     const DwJob job = jobs.j[blockIdx.y];
     const size_t tps_ = dw_tiles_per_split(nt_all, jobs.nparts[blockIdx.y]);
     const int nparts = (int)((nt_all + tps_ - 1) / tps_);
@@ -836,15 +790,18 @@ __device__ __forceinline__ size_t frag_index(int W, int i, int j, int NI) {
 //   tiles [nA, nA + nC):  dK10[o, j] = sum_i K9[i, o] P[i, j] + b9[o] db10[j]     (W/32 x 4 tiles,    K = W)
 //   tile nA + nC:         db9[o]     = sum_j db10[j] K10[o, j]
 __global__ void __launch_bounds__(256)
-k_bottleneck_grads(int W, int in_dim, int NI, const float* __restrict__ part10, const float* __restrict__ bpart10,
-                   const float* __restrict__ params, float* __restrict__ grad, size_t part_stride, size_t bpart_stride,
-                   size_t param_stride, size_t grad_stride) {
+k_bottleneck_grads(FinArgs A) {
     __shared__ float sa[32][257];        // rows of the first operand, K (<= 256) values each
     __shared__ float sb[32][257];        // rows of the second operand
-    part10 += blockIdx.y * part_stride;
-    bpart10 += blockIdx.y * bpart_stride;
-    params += blockIdx.y * param_stride;
-    grad += blockIdx.y * grad_stride;
+    const int cls = (int)blockIdx.y < A.m[0].count ? 0 : 1;       // blockIdx.y: MLP, classes as in k_dw_finalize
+    const FinMlp& M = A.m[cls];
+    const size_t obj = blockIdx.y - (cls ? A.m[0].count : 0);
+    const int W = M.W, in_dim = M.in_dim, NI = M.NI10;
+    if ((int)blockIdx.x >= (W / 32) * (W / 32) + (W / 32) * 4 + 1) return;      // the grid is sized for the wider class
+    const float* part10 = M.part + M.jobs.part_off[10] + obj * M.part_stride;
+    const float* bpart10 = M.bpart + M.jobs.bpart_off[10] + obj * M.bpart_stride;
+    const float* params = M.params + obj * M.param_stride;
+    float* grad = M.grad + obj * M.grad_stride;
     const size_t off9 = durf_layer_offset(W, in_dim, 9, 0), off10 = durf_layer_offset(W, in_dim, 10, 0);
     const float* K9 = params + off9;                 // [W, W]
     const float* b9 = K9 + (size_t)W * W;
@@ -1165,19 +1122,20 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
     return 0;
 }
 
-int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
-                       const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
-                       size_t bpart_stride, size_t grad_stride, const float* mlp_params, size_t param_stride) {
+// fills one class of a finalize launch
+static int fin_class(FinMlp& M, int width, int in_dim, const DwLevels& lv, const float* part, const float* bpart,
+                     float* grad_mlp, int K, size_t part_stride, size_t bpart_stride, size_t grad_stride,
+                     const float* mlp_params, size_t param_stride, int* max_el, int* max_tiles) {
     DURF_REQUIRE(mlp_params != nullptr, "the bottleneck gradients need the MLP's parameters");
-    if (K <= 0) return 0;
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
-    hipStream_t s = (hipStream_t)stream;
     const int W = width, KW = W / 16;
     const DwPlan P = dw_plan(width);
-    DwJobs jobs;
-    int max_el = 0;
+    M.W = W; M.in_dim = in_dim; M.count = K; M.NI10 = P.NI[10];
+    M.part = part; M.bpart = bpart; M.grad = grad_mlp; M.params = mlp_params;
+    M.part_stride = part_stride; M.bpart_stride = bpart_stride; M.grad_stride = grad_stride; M.param_stride = param_stride;
+    M.lv = lv;
     for (int job = 0; job < 12; job++) {
-        DwJob& J = jobs.j[job];
+        DwJob& J = M.jobs.j[job];
         J.layer = job;
         J.out_nat_off = -1;
         J.in_perm_rows = W; J.in_nat_base = KW * 16;
@@ -1185,20 +1143,51 @@ int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
         else if (job == 8) { J.out_nat_off = 3; }                 // density head: dz_out slot 3
         else if (job == 11) { J.out_nat_off = 0; J.in_perm_rows = 128; J.in_nat_base = 128; }
         J.MO = P.MO[job]; J.NI = P.NI[job];
-        jobs.part_off[job] = P.part_off[job];
-        jobs.bpart_off[job] = P.bpart_off[job];
-        jobs.nparts[job] = P.nsplit[job];
+        M.jobs.part_off[job] = P.part_off[job];
+        M.jobs.bpart_off[job] = P.bpart_off[job];
+        M.jobs.nparts[job] = P.nsplit[job];
         const int el = J.MO * J.NI * 1024 + J.MO * 32;
-        if (el > max_el) max_el = el;
+        if (el > *max_el) *max_el = el;
     }
-    hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12, K), dim3(256), 0, s, W, in_dim, jobs, part, bpart,
-                       grad_mlp, part_stride, bpart_stride, grad_stride, lv);
     const int ntiles = (W / 32) * (W / 32) + (W / 32) * 4 + 1;
-    hipLaunchKernelGGL(k_bottleneck_grads, dim3(ntiles, K), dim3(256), 0, s, W, in_dim, P.NI[10],
-                       part + P.part_off[10], bpart + P.bpart_off[10], mlp_params, grad_mlp, part_stride, bpart_stride,
-                       param_stride, grad_stride);
+    if (ntiles > *max_tiles) *max_tiles = ntiles;
+    return 0;
+}
+
+static int launch_fin(void* stream, const FinArgs& A, int max_el, int max_tiles) {
+    const int n = A.m[0].count + A.m[1].count;
+    if (n <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12, n), dim3(256), 0, s, A);
+    hipLaunchKernelGGL(k_bottleneck_grads, dim3(max_tiles, n), dim3(256), 0, s, A);
     DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
     return 0;
+}
+
+int launch_dw_finalize(void* stream, int width, int in_dim, const DwLevels& lv,
+                       const float* part, const float* bpart, float* grad_mlp, int K, size_t part_stride,
+                       size_t bpart_stride, size_t grad_stride, const float* mlp_params, size_t param_stride) {
+    if (K <= 0) return 0;
+    FinArgs A;
+    A.m[1].count = 0;
+    int max_el = 0, max_tiles = 0;
+    if (int rc = fin_class(A.m[0], width, in_dim, lv, part, bpart, grad_mlp, K, part_stride, bpart_stride, grad_stride,
+                           mlp_params, param_stride, &max_el, &max_tiles)) return rc;
+    return launch_fin(stream, A, max_el, max_tiles);
+}
+
+// the background MLP (class 0) and the K object MLPs (class 1) in one finalize launch
+int launch_dw_finalize2(void* stream, const DwFinSpec& a, const DwFinSpec& b) {
+    FinArgs A;
+    A.m[0].count = 0; A.m[1].count = 0;
+    int max_el = 0, max_tiles = 0, c = 0;
+    for (const DwFinSpec* sp : {&a, &b}) {
+        if (sp->K <= 0) continue;
+        if (int rc = fin_class(A.m[c], sp->width, sp->in_dim, sp->lv, sp->part, sp->bpart, sp->grad, sp->K, sp->part_stride,
+                               sp->bpart_stride, sp->grad_stride, sp->params, sp->param_stride, &max_el, &max_tiles)) return rc;
+        c++;
+    }
+    return launch_fin(stream, A, max_el, max_tiles);
 }
 
 

@@ -6,7 +6,7 @@
 // global_load_lds (one 1 KB chunk per wave-instruction, lane-linear = fragment order, so
 // ds_read_b128 is conflict-free), double buffered per output M-tile, one barrier per tile.
 // MFMA-bound: 2*606 208 padded MAC per sample (591 872 algorithmic) for W=256.
-#include "mlp_spec.h"
+#include "mlp_pack.h"
 
 // 16 bytes per lane, global -> LDS (lane-linear destination), as a BUFFER load: descriptor in
 // SGPRs, one constant per-lane VGPR offset (lane*16), the chunk offset in an SGPR.  The
@@ -20,55 +20,32 @@
 template <int W>
 __global__ void __launch_bounds__(256)
 k_pack_fwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out, size_t p_stride, size_t out_stride) {
-    using S = MlpSpec<W>;
     P += blockIdx.y * p_stride;                                  // object index (0 for a single MLP)
     out = (bf16x8*)((char*)out + blockIdx.y * out_stride);
+    pack_fwd_vec<W>(in_dim, P, out, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// Every weight stream of the model in one launch: blockIdx.y = 0 the background MLP (W = 256), 1..K the object MLPs
+// (W = 128); blockIdx.x runs over the forward vectors, then the backward ones (bwd streams nullable: inference).
+struct PackAll {
+    const float* p_bkgd; bf16x8* f_bkgd; bf16x8* b_bkgd; int in_bkgd;
+    const float* p_obj; bf16x8* f_obj; bf16x8* b_obj; int in_obj;
+    size_t p_stride, f_stride, b_stride;
+};
+__global__ void __launch_bounds__(256)
+k_pack_all(PackAll a) {
     const int vec = blockIdx.x * blockDim.x + threadIdx.x;
-    if (vec >= S::TOTAL_CHUNKS * 64) return;
-    const int chunk = vec >> 6, lane = vec & 63;
-    int s = 0, base = 0;
-    for (; s < S::NSTAGE; s++) {
-        const int cnt = S::n_mt(s) * S::tile_chunks(s);
-        if (chunk < base + cnt) break;
-        base += cnt;
-    }
-    const int rel = chunk - base;
-    const int mo = rel / S::tile_chunks(s), ck = rel % S::tile_chunks(s);
-    bf16x8 v;
-    if (ck < S::n_ks(s)) {
-        const int i = lane & 31, hi = lane >> 5;
-        int L, col;
-        durf_fwd_out_col<W>(s, mo, i, &L, &col);
-        int fi = 0, fo = 0;
-        if (L >= 0) durf_layer_shape(W, in_dim, L, &fi, &fo);
-        const size_t koff = (L >= 0) ? durf_layer_offset(W, in_dim, L, 0) : 0;
-#pragma unroll
-        for (int e = 0; e < 8; e++) {
-            const int row = durf_fwd_in_row<W>(s, ck, hi, e, in_dim);
-            float val = 0.0f;
-            if (L >= 0 && col < fo && row >= 0 && row < fi) val = P[koff + (size_t)row * fo + col];
-            v[e] = (__bf16)val;
-        }
-        out[vec] = v;
+    if (blockIdx.y == 0) {
+        constexpr int NF = MlpSpec<256>::TOTAL_CHUNKS * 64;
+        if (a.p_bkgd == nullptr) return;
+        if (vec < NF) pack_fwd_vec<256>(a.in_bkgd, a.p_bkgd, a.f_bkgd, vec);
+        else if (a.b_bkgd) pack_bwd_vec<256>(a.in_bkgd, a.p_bkgd, a.b_bkgd, vec - NF);
     } else {
-        // bias chunk: floats [hi][r] = bias[out feature 32*mo + (r&3) + 8*(r>>2) + 4*hi]
-        float f[4] = {0.f, 0.f, 0.f, 0.f};
-        if (lane < 8) {
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const int idx = lane * 4 + j, hi = idx >> 4, r = idx & 15;
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * hi;
-                int L, col;
-                durf_fwd_out_col<W>(s, mo, i, &L, &col);
-                if (L >= 0) {
-                    int fi, fo;
-                    durf_layer_shape(W, in_dim, L, &fi, &fo);
-                    if (col < fo) f[j] = P[durf_layer_offset(W, in_dim, L, 1) + col];
-                }
-            }
-        }
-        f32x4 fv = {f[0], f[1], f[2], f[3]};
-        *(f32x4*)&out[vec] = fv;
+        constexpr int NF = MlpSpec<128>::TOTAL_CHUNKS * 64;
+        const size_t k = blockIdx.y - 1;
+        const float* P = a.p_obj + k * a.p_stride;
+        if (vec < NF) pack_fwd_vec<128>(a.in_obj, P, (bf16x8*)((char*)a.f_obj + k * a.f_stride), vec);
+        else if (a.b_obj) pack_bwd_vec<128>(a.in_obj, P, (bf16x8*)((char*)a.b_obj + k * a.b_stride), vec - NF);
     }
 }
 
@@ -463,9 +440,28 @@ size_t durf_mlp_stash_bytes(int width, size_t rows) {
 }
 
 int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_bwd);
+size_t durf_wpack_bwd_bytes(int width);
 
 int durf_pack_weights_fwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_fwd) {
     return durf::launch_pack(stream, width, in_dim, 1, mlp_params, 0, wpack_fwd, nullptr);
+}
+
+int durf_pack_weights_all(void* stream, const float* bkgd_params, int in_bkgd, void* bkgd_fwd, void* bkgd_bwd, int K,
+                          const float* obj_params, size_t obj_param_stride, int in_obj, void* obj_fwd, void* obj_bwd) {
+    DURF_REQUIRE(bkgd_params == nullptr || (bkgd_fwd != nullptr && in_bkgd > 0 && in_bkgd <= DURF_ENC_DIM),
+                 "background MLP: forward stream and 1 <= in_dim <= 64");
+    DURF_REQUIRE(K == 0 || (obj_params != nullptr && obj_fwd != nullptr && in_obj > 0 && in_obj <= DURF_ENC_DIM),
+                 "object MLPs: parameters, forward streams and 1 <= in_dim <= 64");
+    if (K < 0 || (bkgd_params == nullptr && K == 0)) return 0;
+    PackAll a;
+    a.p_bkgd = bkgd_params; a.f_bkgd = (bf16x8*)bkgd_fwd; a.b_bkgd = (bf16x8*)bkgd_bwd; a.in_bkgd = in_bkgd;
+    a.p_obj = obj_params; a.f_obj = (bf16x8*)obj_fwd; a.b_obj = (bf16x8*)obj_bwd; a.in_obj = in_obj;
+    a.p_stride = obj_param_stride; a.f_stride = durf_wpack_fwd_bytes(128); a.b_stride = durf_wpack_bwd_bytes(128);
+    size_t nv = durf_wpack_fwd_bytes(256) / 16 + durf_wpack_bwd_bytes(256) / 16;        // the wider MLP bounds the grid
+    if (bkgd_params == nullptr) nv = durf_wpack_fwd_bytes(128) / 16 + durf_wpack_bwd_bytes(128) / 16;
+    hipLaunchKernelGGL(k_pack_all, dim3(durf_cdiv(nv, 256), 1 + K), dim3(256), 0, (hipStream_t)stream, a);
+    DURF_CHECK_LAUNCH("durf_pack_weights_all");
+    return 0;
 }
 
 int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_fwd,

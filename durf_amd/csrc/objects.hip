@@ -53,21 +53,59 @@ int durf_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, co
                                 K, st);
 }
 
-int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
-                      const void* const* enc, const void* const* view_tile, const void* const* stash,
-                      const void* const* dz, const void* const* dz_out, int in_dim, float* part, float* bpart,
-                      float* grad_mlp, size_t grad_stride, const float* mlp_params) {
+static DwStrides obj_dw_strides(int B, int N) {
     const size_t rows = (size_t)B * N;
     DwStrides st;
     st.enc = durf_obj_enc_stride(B, N); st.view = durf_obj_view_stride(B, N);
     st.stash = durf_mlp_stash_bytes(DURF_W_OBJ, rows); st.dz_out = durf_obj_dzout_stride(B, N);
     st.part = durf_dw_part_floats(DURF_W_OBJ); st.bpart = durf_dw_bpart_floats(DURF_W_OBJ);
+    return st;
+}
+
+int durf_obj_dw_partials(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
+                         const void* const* enc, const void* const* view_tile, const void* const* stash,
+                         const void* const* dz, const void* const* dz_out, float* part, float* bpart) {
     DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
-    const durf::DwLevels lv = durf::uniform_levels(rows, N, count, nlevels);
-    int rc = durf::launch_mlp_dw(stream, DURF_W_OBJ, lv, enc, view_tile, stash, dz, dz_out, part, bpart, K, st);
+    const durf::DwLevels lv = durf::uniform_levels((size_t)B * N, N, count, nlevels);
+    return durf::launch_mlp_dw(stream, DURF_W_OBJ, lv, enc, view_tile, stash, dz, dz_out, part, bpart, K, obj_dw_strides(B, N));
+}
+
+int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
+                      const void* const* enc, const void* const* view_tile, const void* const* stash,
+                      const void* const* dz, const void* const* dz_out, int in_dim, float* part, float* bpart,
+                      float* grad_mlp, size_t grad_stride, const float* mlp_params) {
+    int rc = durf_obj_dw_partials(stream, K, B, N, count, nlevels, enc, view_tile, stash, dz, dz_out, part, bpart);
     if (rc) return rc;
-    return durf::launch_dw_finalize(stream, DURF_W_OBJ, in_dim, lv, part, bpart, grad_mlp, K, st.part, st.bpart, grad_stride,
-                                    mlp_params, grad_stride);
+    const DwStrides st = obj_dw_strides(B, N);
+    return durf::launch_dw_finalize(stream, DURF_W_OBJ, in_dim, durf::uniform_levels((size_t)B * N, N, count, nlevels), part, bpart,
+                                    grad_mlp, K, st.part, st.bpart, grad_stride, mlp_params, grad_stride);
+}
+
+int durf_dw_finalize_all(void* stream, int in_bkgd, int nseg, const size_t* rows, const int* rows_per_ray,
+                         const int32_t* const* seg_count, const float* part_bkgd, const float* bpart_bkgd,
+                         float* grad_bkgd, const float* bkgd_params, int K, int B, int N, const int32_t* obj_count,
+                         int nlevels, int in_obj, const float* part_obj, const float* bpart_obj, float* grad_obj,
+                         size_t obj_grad_stride, const float* obj_params) {
+    durf::DwFinSpec a, b;
+    a.width = 256; a.in_dim = in_bkgd; a.K = 1;
+    DURF_REQUIRE(nseg >= 1 && nseg <= DURF_MAX_LEVELS, "1 <= segments <= DURF_MAX_LEVELS");
+    a.lv.nlevels = nseg;
+    for (int l = 0; l < DURF_MAX_LEVELS; l++) {
+        const int ll = l < nseg ? l : 0;
+        DURF_REQUIRE(rows_per_ray[ll] >= 1, "rows_per_ray >= 1");
+        a.lv.rows[l] = rows[ll]; a.lv.n[l] = rows_per_ray[ll]; a.lv.count[l] = seg_count ? seg_count[ll] : nullptr;
+    }
+    a.part = part_bkgd; a.bpart = bpart_bkgd; a.grad = grad_bkgd; a.params = bkgd_params;
+    a.part_stride = a.bpart_stride = a.grad_stride = a.param_stride = 0;
+    b.width = DURF_W_OBJ; b.in_dim = in_obj; b.K = K;
+    if (K > 0) {
+        DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
+        b.lv = durf::uniform_levels((size_t)B * N, N, obj_count, nlevels);
+        b.part = part_obj; b.bpart = bpart_obj; b.grad = grad_obj; b.params = obj_params;
+        b.part_stride = durf_dw_part_floats(DURF_W_OBJ); b.bpart_stride = durf_dw_bpart_floats(DURF_W_OBJ);
+        b.grad_stride = b.param_stride = obj_grad_stride;
+    }
+    return durf::launch_dw_finalize2(stream, a, b);
 }
 
 }  // extern "C"

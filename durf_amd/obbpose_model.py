@@ -194,13 +194,14 @@ class MipNerfModel:
         f32 = self.mlp_precision == 'f32'
         view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1] if f32 else None
         packs = {}
-        if not f32:
-            pk = ops.pack_weights(W_BKGD, IN_BKGD, variables.mlp_flat('MLP_0'), want_bwd=train)
-            packs = {'MLP_0': pk if train else (pk, None)}
-        if Kd and not f32:                           # the K object MLPs sit back to back in the flat buffer
-            o0 = lay.mlp_off['BoxMLP_0']
-            packs['obj'] = ops.pack_weights_batch(Kd, variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]],
-                                                  lay.mlp_size[W_OBJ], want_bwd=train)
+        if not f32:                                  # every weight stream in one launch; the K object MLPs sit back
+            o0 = lay.mlp_off['BoxMLP_0'] if Kd else 0    # to back in the flat buffer
+            pk_b, pk_o = ops.pack_weights_all(variables.mlp_flat('MLP_0'), Kd,
+                                              variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]] if Kd else None,
+                                              lay.mlp_size[W_OBJ], want_bwd=train)
+            packs = {'MLP_0': pk_b}
+            if Kd:
+                packs['obj'] = pk_o
         bk = ops.BKGD_RAND if rand_bkgd else (ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY)
         g = _make_generator(rng, dev) if randomized else None
         if randomized and noise is None:

@@ -186,6 +186,25 @@ def pack_weights(width, in_dim, mlp_params, want_bwd=False):
     return (wf, wb) if want_bwd else wf
 
 
+def pack_weights_all(bkgd_params, K, obj_params, obj_param_stride, want_bwd=False):
+    """Every weight stream of the model in one launch (durf_pack_weights_all): the background MLP and the K object MLPs
+    (obj_params: BoxMLP_0 .. BoxMLP_{K-1} back to back, obj_param_stride floats apart).  Returns
+    ((bkgd_fwd, bkgd_bwd), (obj_fwd, obj_bwd)); the bwd streams are None without want_bwd, the obj pair is None at K = 0."""
+    L = _lib.lib()
+    dev = bkgd_params.device
+    u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+    bf = u8(L.durf_wpack_fwd_bytes(W_BKGD_))
+    bb = u8(L.durf_wpack_bwd_bytes(W_BKGD_)) if want_bwd else None
+    of = ob = None
+    if K:
+        of = u8(K * int(L.durf_wpack_fwd_bytes(W_OBJ_)))
+        ob = u8(K * int(L.durf_wpack_bwd_bytes(W_OBJ_))) if want_bwd else None
+    _lib.check(L.durf_pack_weights_all(_stream(), _p(_f32(bkgd_params)), IN_BKGD, _p(bf), _p(bb), int(K),
+                                       _p(obj_params) if K else None, int(obj_param_stride), IN_OBJ_, _p(of), _p(ob)),
+               'durf_pack_weights_all')
+    return (bf, bb), ((of, ob) if K else None)
+
+
 def mlp_stash_bytes(width, rows):
     return int(_lib.lib().durf_mlp_stash_bytes(width, rows))
 
@@ -496,6 +515,7 @@ def mlp_dw_finalize(width, in_dim, rows, N, nlevels, part, bpart, grad_mlp, mlp_
 # the K object MLPs of one level as one call each (csrc/objects.hip)
 # ---------------------------------------------------------------------------
 W_OBJ_, IN_OBJ_ = 128, 63
+W_BKGD_, IN_BKGD = 256, 60
 
 
 class ObjSlabs:
@@ -572,6 +592,39 @@ def obj_dw_batch(slabs_levels, view_tile, count, grad_obj, grad_stride, obj_para
                                        arr([s.dz for s in slabs_levels]), arr([s.dz_out for s in slabs_levels]),
                                        IN_OBJ_, _p(part), _p(bpart), _p(grad_obj), grad_stride, _p(_f32(obj_params))),
                    'durf_obj_dw_batch')
+
+
+def obj_dw_partials(slabs_levels, view_tile, count):
+    """the split-K half of obj_dw_batch: returns (part, bpart) for dw_finalize_all"""
+    L = _lib.lib()
+    s0 = slabs_levels[0]
+    K, B, N = s0.K, s0.B, s0.N
+    nl = len(slabs_levels)
+    dev = s0.enc.device
+    part = torch.empty(K * int(L.durf_dw_part_floats(W_OBJ_)), device=dev)
+    bpart = torch.empty(K * int(L.durf_dw_bpart_floats(W_OBJ_)), device=dev)
+    arr = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    with _Timed('obj_dw_batch'):
+        _lib.check(L.durf_obj_dw_partials(_stream(), K, B, N, _p(count), nl, arr([s.enc for s in slabs_levels]),
+                                          arr([view_tile] * nl), arr([s.stash for s in slabs_levels]),
+                                          arr([s.dz for s in slabs_levels]), arr([s.dz_out for s in slabs_levels]),
+                                          _p(part), _p(bpart)), 'durf_obj_dw_partials')
+    return part, bpart
+
+
+def dw_finalize_all(rows_l, n_l, count_l, part, bpart, grad_bkgd, bkgd_params, obj=None):
+    """Finalize the background MLP's weight gradients (segments as in mlp_dw_levels) and, with
+    obj = (K, B, N, count, nlevels, part, bpart, grad_obj, grad_stride, obj_params), those of the K object MLPs in the
+    same pair of launches (durf_dw_finalize_all)."""
+    L, rows_a, n_a, cnt_a = _levels_args(rows_l, n_l, count_l)
+    if obj is None:
+        oa = (0, 0, 0, None, 1, IN_OBJ_, None, None, None, 0, None)
+    else:
+        K, B, N, cnt, nl, po, bo, go, gs, pr = obj
+        oa = (int(K), int(B), int(N), _p(cnt), int(nl), IN_OBJ_, _p(po), _p(bo), _p(go), int(gs), _p(_f32(pr)))
+    with _Timed('mlp_dw_finalize_256'):
+        _lib.check(_lib.lib().durf_dw_finalize_all(_stream(), IN_BKGD, L, rows_a, n_a, cnt_a, _p(part), _p(bpart),
+                                                   _p(grad_bkgd), _p(_f32(bkgd_params)), *oa), 'durf_dw_finalize_all')
 
 
 def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):

@@ -141,27 +141,25 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     levels = ctx['levels']
     if not f32:
         off = lay.mlp_off['MLP_0']
+        g_b, p_b = grad[off:off + lay.mlp_size[om.W_BKGD]], variables.mlp_flat('MLP_0')
+        enc_l, stash_l = [lv['enc_b'] for lv in levels], [lv['stash_b'] for lv in levels]
         if dd is not None:               # every level: one segment of `nrows` valid rows (1 row per "ray")
             geo = ([rows] * L, [1] * L, [dd['nrows']] * L)
-            ops.mlp_dw_levels(om.W_BKGD, *geo, [lv['enc_b'] for lv in levels], [view_tile] * L,
-                              [lv['stash_b'] for lv in levels], [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
-            ops.mlp_dw_finalize_levels(om.W_BKGD, om.IN_BKGD, *geo, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]],
-                                       variables.mlp_flat('MLP_0'))
         else:
-            ops.mlp_dw(om.W_BKGD, rows, N, [lv['enc_b'] for lv in levels], [view_tile] * L,
-                       [lv['stash_b'] for lv in levels], [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
-            ops.mlp_dw_finalize(om.W_BKGD, om.IN_BKGD, rows, N, L, *bufs, grad[off:off + lay.mlp_size[om.W_BKGD]],
-                                variables.mlp_flat('MLP_0'))
-        if K:
-            o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
-            if not ops.OVERLAP_DW:
-                side.join()
-                ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz,
-                                 variables.flat[o0:o0 + K * sz])
-            else:
+            geo = ([rows] * L, [N] * L, [None] * L)
+        ops.mlp_dw_levels(om.W_BKGD, *geo, enc_l, [view_tile] * L, stash_l, [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
+        o0, sz = (lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]) if K else (0, 0)
+        if K and not ops.OVERLAP_DW:     # every MLP of the model is finalized by ONE pair of launches
+            side.join()
+            po, bo = ops.obj_dw_partials([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'])
+            ops.dw_finalize_all(*geo, *bufs, g_b, p_b,
+                                obj=(K, B, N, ctx['count'], L, po, bo, grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz]))
+        else:
+            ops.dw_finalize_all(*geo, *bufs, g_b, p_b)
+            if K:
                 with side:
-                    ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'], grad[o0:o0 + K * sz], sz,
-                                 variables.flat[o0:o0 + K * sz])
+                    ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
+                                     grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
     side.join()
     flat = variables.flat
     weight_l2 = None

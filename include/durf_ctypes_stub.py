@@ -28,6 +28,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_pack_weights.restype = i32
     L.durf_pack_weights.argtypes = [vp, i32, i32, vp, vp, vp]
     #   (stream, width, in_dim, mlp_params, wpack_fwd, wpack_bwd)
+    L.durf_pack_weights_all.restype = i32
+    L.durf_pack_weights_all.argtypes = [vp, vp, i32, vp, vp, i32, vp, u64, i32, vp, vp]
+    #   (stream, bkgd_params, in_bkgd, bkgd_fwd, bkgd_bwd, K, obj_params, obj_param_stride, in_obj, obj_fwd, obj_bwd)
     L.durf_ray_setup.restype = i32
     L.durf_ray_setup.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, B, K, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo)
@@ -145,6 +148,12 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_obj_dw_batch.restype = i32
     L.durf_obj_dw_batch.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, vp, u64, vp]
     #   (stream, K, B, N, count, nlevels, enc, view_tile, stash, dz, dz_out, in_dim, part, bpart, grad_mlp, grad_stride, mlp_params)
+    L.durf_obj_dw_partials.restype = i32
+    L.durf_obj_dw_partials.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), vp, vp]
+    #   (stream, K, B, N, count, nlevels, enc, view_tile, stash, dz, dz_out, part, bpart)
+    L.durf_dw_finalize_all.restype = i32
+    L.durf_dw_finalize_all.argtypes = [vp, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, u64, vp]
+    #   (stream, in_bkgd, nseg, rows, rows_per_ray, seg_count, part_bkgd, bpart_bkgd, grad_bkgd, bkgd_params, K, B, N, obj_count, nlevels, in_obj, part_obj, bpart_obj, grad_obj, obj_grad_stride, obj_params)
     L.durf_encode_obj_bwd.restype = i32
     L.durf_encode_obj_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]
     #   (stream, B, N, k_obj, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums)

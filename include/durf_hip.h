@@ -57,6 +57,12 @@ size_t durf_wpack_fwd_bytes(int width);
 size_t durf_wpack_bwd_bytes(int width);
 int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_params,
                       void* wpack_fwd, void* wpack_bwd /* nullable */);
+/* Every weight stream of the model in ONE launch (a training step re-packs after each optimizer update): the
+ * background MLP (width 256; bkgd_params nullable = skip) and K object MLPs (width 128, parameters obj_param_stride
+ * floats apart, streams durf_wpack_{fwd,bwd}_bytes(128) apart).  The backward streams are nullable (inference). */
+int durf_pack_weights_all(void* stream, const float* bkgd_params, int in_bkgd, void* bkgd_fwd, void* bkgd_bwd,
+                          int K, const float* obj_params, size_t obj_param_stride, int in_obj, void* obj_fwd,
+                          void* obj_bwd);
 
 /* ---- stage-level entry points (each one kernel; used by parity + roofline tests) */
 
@@ -302,6 +308,18 @@ int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, i
                       const void* const* enc, const void* const* view_tile, const void* const* stash,
                       const void* const* dz, const void* const* dz_out, int in_dim, float* part, float* bpart,
                       float* grad_mlp, size_t grad_stride, const float* mlp_params /* K MLPs, grad_stride floats apart */);
+/* The same in two halves, so that a training step finalizes ALL its MLPs with one pair of launches: durf_obj_dw_partials
+ * = the grouped split-K launch of durf_obj_dw_batch only; durf_dw_finalize_all = durf_mlp_dw_finalize_levels of the
+ * background MLP (segments as in durf_mlp_dw_levels) and the finalize half of durf_obj_dw_batch (K may be 0) as ONE
+ * k_dw_finalize + ONE k_bottleneck_grads launch (blockIdx.z / .y: the background MLP, then the K object MLPs). */
+int durf_obj_dw_partials(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
+                         const void* const* enc, const void* const* view_tile, const void* const* stash,
+                         const void* const* dz, const void* const* dz_out, float* part, float* bpart);
+int durf_dw_finalize_all(void* stream, int in_bkgd, int nseg, const size_t* rows, const int* rows_per_ray,
+                         const int32_t* const* seg_count, const float* part_bkgd, const float* bpart_bkgd,
+                         float* grad_bkgd, const float* bkgd_params, int K, int B, int N, const int32_t* obj_count,
+                         int nlevels, int in_obj, const float* part_obj, const float* bpart_obj, float* grad_obj,
+                         size_t obj_grad_stride, const float* obj_params);
 
 /* Box-pose gradients (cfg4): reverse of weighted_ipe / cast_rays / world2object_rpy / aa2matrix
  * (mip.py:182-223,155-179; box_helpers.py:286-341,148-167).  Per level and object:

@@ -312,3 +312,24 @@ def test_composite_resample_fused_is_bit_identical(cuda, N, K, randomized, blm):
                  [1.0, 1.0, 1e-4, 1e-2, 1.0, 1e-6], blm, 0, 0.5, render_out=out)
     for a, b_, nm in zip(c, out, ['rgb', 'depth', 'acc', 'weights', 't_mids', 't_dists']):
         assert torch.equal(a, b_), 'loss_bwd ' + nm
+
+
+@pytest.mark.gpu
+def test_pack_weights_all_matches_the_per_mlp_packers(cuda):
+    """durf_pack_weights_all (one launch per step) writes the same streams as durf_pack_weights / _batch"""
+    K = 3
+    g = torch.Generator().manual_seed(5)
+    nb, no = ops.mlp_param_count(256, 60), ops.mlp_param_count(128, 63)
+    pb = (torch.rand(nb, generator=g) - 0.5).to(cuda)
+    po = (torch.rand(K * no, generator=g) - 0.5).to(cuda)
+    for want_bwd in (False, True):
+        (bf, bb), (of, ob) = ops.pack_weights_all(pb, K, po, no, want_bwd=want_bwd)
+        ref_b = ops.pack_weights(256, 60, pb, want_bwd=want_bwd)
+        ref_o = ops.pack_weights_batch(K, po, no, want_bwd=want_bwd)
+        assert torch.equal(bf, ref_b[0] if want_bwd else ref_b) and torch.equal(of, ref_o[0])
+        if want_bwd:
+            assert torch.equal(bb, ref_b[1]) and torch.equal(ob, ref_o[1])
+        else:
+            assert bb is None and ob is None
+    (bf, _), none = ops.pack_weights_all(pb, 0, None, no)
+    assert none is None and torch.equal(bf, ops.pack_weights(256, 60, pb))
