@@ -685,48 +685,58 @@ struct FinMlp {
     size_t part_stride, bpart_stride, grad_stride, param_stride;
     durf::DwLevels lv;
 };
-struct FinArgs { FinMlp m[2]; };
+// 1-D grid of exactly the blocks that have work (an early-exit block is not free: the 3 x 12 x 768 padding blocks of a
+// (widest job) x 12 x (1 + K) grid cost the merged launch ~80 us): MLP-major, then job, then 64-element block;
+// job_blk[c][j] = first block of job j within one MLP of class c, job_blk[c][12] = blocks per MLP.
+struct FinArgs { FinMlp m[2]; int job_blk[2][13]; };
 
 __global__ void __launch_bounds__(256)
 k_dw_finalize(FinArgs A) {
     __shared__ float red[4][64];
-    const int cls = (int)blockIdx.z < A.m[0].count ? 0 : 1;
+    const int n0 = A.m[0].count * A.job_blk[0][12];
+    const int cls = (int)blockIdx.x < n0 ? 0 : 1;
     const FinMlp& M = A.m[cls];
-    const size_t obj = blockIdx.z - (cls ? A.m[0].count : 0);      // batched object MLPs: the object
+    const int rel = (int)blockIdx.x - (cls ? n0 : 0);
+    const size_t obj = rel / A.job_blk[cls][12];                   // batched object MLPs: the object
+    const int rb = rel % A.job_blk[cls][12];
+    int jb = 0;
+#pragma unroll
+    for (int j = 1; j < 12; j++) jb += (rb >= A.job_blk[cls][j]) ? 1 : 0;
+    const int xblk = rb - A.job_blk[cls][jb];
     const int W = M.W, in_dim = M.in_dim;
     const DwJobs& jobs = M.jobs;
     const durf::DwLevels& lv = M.lv;
-    if (jobs.nparts[blockIdx.y] == 0) return;        // the bottleneck layer: no job of its own
     const float* part_all = M.part + obj * M.part_stride;
     const float* bpart_all = M.bpart + obj * M.bpart_stride;
     float* grad_mlp = M.grad + obj * M.grad_stride;
     size_t nt_all = 0;                               // the splits k_dw_all actually wrote (see dw_tiles_per_split)
     for (int l = 0; l < lv.nlevels; l++) nt_all += dw_level_tiles(lv, l, obj);
-    const DwJob job = jobs.j[blockIdx.y];
-    const size_t tps_ = dw_tiles_per_split(nt_all, jobs.nparts[blockIdx.y]);
+    const DwJob job = jobs.j[jb];
+    const size_t tps_ = dw_tiles_per_split(nt_all, jobs.nparts[jb]);
     const int nparts = (int)((nt_all + tps_ - 1) / tps_);
-    const float* part = part_all + jobs.part_off[blockIdx.y];
-    const float* bpart = bpart_all + jobs.bpart_off[blockIdx.y];
+    const float* part = part_all + jobs.part_off[jb];
+    const float* bpart = bpart_all + jobs.bpart_off[jb];
     int fi, fo;
     durf_layer_shape(W, in_dim, job.layer, &fi, &fo);
     const int nfrag = job.MO * job.NI * 1024;
     const int nb = job.MO * 32;
     const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int idx = blockIdx.x * 64 + el;
-    if (blockIdx.x * 64 >= nfrag + nb) return;
+    const int idx = xblk * 64 + el;
+    if (xblk * 64 >= nfrag + nb) return;
     float s = 0.0f;
     if (idx < nfrag + nb) {
         const float* p0 = idx < nfrag ? part + idx : bpart + (idx - nfrag);
         const size_t stride = idx < nfrag ? (size_t)nfrag : (size_t)nb;
-        int p = grp;
-        for (; p + 28 < nparts; p += 32) {
+        // 8 independent loads in flight per wave, also in the last (partial) batch: a scalar remainder loop is a chain of
+        // dependent HBM round trips (with ~57 partials per job it made this kernel 130 us); same order of additions
+        for (int p = grp; p < nparts; p += 32) {
             float v[8];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = p0[(size_t)(p + 4 * u) * stride];
+            for (int u = 0; u < 8; u++) v[u] = (p + 4 * u < nparts) ? p0[(size_t)(p + 4 * u) * stride] : 0.0f;
 #pragma unroll
-            for (int u = 0; u < 8; u++) s += v[u];
+            for (int u = 0; u < 8; u++)
+                if (p + 4 * u < nparts) s += v[u];
         }
-        for (; p < nparts; p += 4) s += p0[(size_t)p * stride];
     }
     red[grp][el] = s;
     __syncthreads();
@@ -1154,11 +1164,23 @@ static int fin_class(FinMlp& M, int width, int in_dim, const DwLevels& lv, const
     return 0;
 }
 
-static int launch_fin(void* stream, const FinArgs& A, int max_el, int max_tiles) {
+static int launch_fin(void* stream, FinArgs& A, int max_el, int max_tiles) {
     const int n = A.m[0].count + A.m[1].count;
     if (n <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_dw_finalize, dim3(durf_cdiv(max_el, 64), 12, n), dim3(256), 0, s, A);
+    int total = 0;
+    for (int c = 0; c < 2; c++) {
+        int b = 0;
+        for (int j = 0; j < 12; j++) {
+            A.job_blk[c][j] = b;
+            if (A.m[c].count > 0 && A.m[c].jobs.nparts[j] > 0)          // (the bottleneck layer has no job of its own)
+                b += durf_cdiv(A.m[c].jobs.j[j].MO * A.m[c].jobs.j[j].NI * 1024 + A.m[c].jobs.j[j].MO * 32, 64);
+        }
+        A.job_blk[c][12] = b > 0 ? b : 1;
+        total += A.m[c].count * b;
+    }
+    (void)max_el;
+    hipLaunchKernelGGL(k_dw_finalize, dim3(total), dim3(256), 0, s, A);
     hipLaunchKernelGGL(k_bottleneck_grads, dim3(max_tiles, n), dim3(256), 0, s, A);
     DURF_CHECK_LAUNCH("durf_mlp_dw_finalize");
     return 0;

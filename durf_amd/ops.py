@@ -239,6 +239,7 @@ _MODE = os.environ.get('DURF_OVERLAP_OBJECTS', '0')
 OVERLAP_OBJECTS = _MODE != '0'
 OVERLAP_BACKWARD = _MODE in ('2', '3')
 OVERLAP_DW = _MODE == '2'
+MERGE_FINALIZE = os.environ.get('DURF_MERGE_FINALIZE', '1') != '0'    # A/B switch: one finalize launch pair for all MLPs
 _SIDE = {}
 
 

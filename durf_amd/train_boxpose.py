@@ -147,11 +147,16 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             geo = ([rows] * L, [1] * L, [dd['nrows']] * L)
         else:
             geo = ([rows] * L, [N] * L, [None] * L)
-        ops.mlp_dw_levels(om.W_BKGD, *geo, enc_l, [view_tile] * L, stash_l, [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
         o0, sz = (lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]) if K else (0, 0)
-        if K and not ops.OVERLAP_DW:     # every MLP of the model is finalized by ONE pair of launches
+        merged = K and not ops.OVERLAP_DW and ops.MERGE_FINALIZE
+        if merged:
+            # The objects' split-K launch goes FIRST: the finalize launch then finds the background MLP's partials
+            # (134 MB, the bulk) still in the 256 MB Infinity Cache -- behind the objects' 0.7 GB operand stream it
+            # read them from HBM (k_dw_finalize 117 us instead of 2 x 37, rocprofv3)
             side.join()
             po, bo = ops.obj_dw_partials([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'])
+        ops.mlp_dw_levels(om.W_BKGD, *geo, enc_l, [view_tile] * L, stash_l, [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
+        if merged:                       # every MLP of the model is finalized by ONE pair of launches
             ops.dw_finalize_all(*geo, *bufs, g_b, p_b,
                                 obj=(K, B, N, ctx['count'], L, po, bo, grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz]))
         else:
