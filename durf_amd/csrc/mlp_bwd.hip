@@ -887,9 +887,13 @@ static DwPlan dw_plan(int width) {
     // stragglers from plain rounding (1026) cost another round (measured).  W = 256: two rounds -- round 2's
     // sweep at cfg3 (tools/sweep_dw_wgs.sh): 256 1507 us, 384 1617, 512 1445-1460, 640 1600, 768 1451-1459,
     // 1024 1464-1495, 1280 1490, 1536 1508; fewer workgroups also mean fewer fp32 partials to write and re-read
-    // (268 -> 134 MB).  W = 128 (objects, two workgroups per CU, most splits empty): four rounds as before.
+    // (268 -> 134 MB).  W = 128 (objects; the grid is total_wgs x K and a sparsely hit object leaves most of its
+    // workgroups without tiles -- an early-exit workgroup still costs its dispatch): 256 per object (1024 -> 256: the
+    // launch takes 137 -> 127 us at cfg3, K = 3, and 139 -> 73 us at cfg5, K = 8; rocprofv3).
     static const int env_wgs = getenv("DURF_DW_WGS") ? atoi(getenv("DURF_DW_WGS")) : 0;
-    const int total_wgs = env_wgs > 0 ? env_wgs : (width == 256 ? 512 : 1024);
+    static const int env_wgs_obj = getenv("DURF_DW_WGS_OBJ") ? atoi(getenv("DURF_DW_WGS_OBJ")) : 0;
+    const int env_w = width == 256 ? env_wgs : env_wgs_obj;
+    const int total_wgs = env_w > 0 ? env_w : (width == 256 ? 512 : 256);
     int base[12], given = 0;
     for (int j = 0; j < 12; j++) {
         base[j] = total_wgs * wcost[j] / cost;
