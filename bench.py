@@ -55,10 +55,11 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=20)
     ap.add_argument('--config', default='cfg3', choices=sorted(WORKLOADS))
     ap.add_argument('--rays', type=int, default=0, help='rays per GPU (default: the workload\'s)')
     ap.add_argument('--objects', type=int, default=-1, help='override the number of dynamic boxes K')
+    ap.add_argument('--max-ahead', type=int, default=0, help='bound the number of steps the host may enqueue ahead of the GPU (0 = unbounded)')
     ap.add_argument('--no-calibration', action='store_true', help='skip the vendor-GEMM board calibration line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-op time table to stderr')
@@ -266,19 +267,33 @@ def main():
                                         reduce_stats=(i % config.print_every == 0))
 
     rng = 1000 * rank                                  # stratified-sampling noise differs per rank
+    # The warm-up runs exactly what the timed region runs, the live HIP-event timers included.  One of the first ~7 steps of
+    # a process takes ~40 ms instead of 4.3 (a one-off of the HIP runtime around the first timing events / its growing
+    # signal pool -- not a kernel: the step before and after it are normal); with 5 warm-up steps it landed in the timed
+    # region and cost every earlier figure of this repo 4-5 %.  Default warm-up: 20 steps; `step_ms` in the JSON line
+    # (p50 / p90 / max / slow_steps) shows any such outlier.
+    ops.TIMED_NAMES = None if args.profile_ops else {'mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256', 'encode_bkgd',
+                                                     'composite_resample'}
+    ops.TIMERS = {}
+    torch.cuda.Event(enable_timing=True).record()
     for i in range(args.warmup):
         state, stats, rng, _ = step(state, rng, i)
     sync()
     # live HIP-event timers over the timed region (recorded on the launch stream): the kernels the roofline
     # reports, or every wrapped op with --profile-ops (every timed op costs two event records)
-    timed = {'mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256', 'encode_bkgd', 'composite_resample'}
-    ops.TIMED_NAMES = None if args.profile_ops else timed
-    ops.TIMERS = {}
+    ops.TIMERS = {}                                    # drop the warm-up's records
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step GPU timestamps (diagnostic)
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         state, stats, rng, _ = step(state, rng, i + 1)
+        marks[i + 1].record()
+        if args.max_ahead > 0 and i + 1 > args.max_ahead:
+            marks[i + 1 - args.max_ahead].synchronize()      # the host never runs more than max_ahead steps ahead
     sync()
     dt = time.perf_counter() - t0
+    step_raw = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_times = sorted(step_raw)
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -336,7 +351,12 @@ def main():
                                name=args.config, rays_per_gpu=B, global_batch=B * world, num_samples=N_SAMPLES,
                                num_levels=N_LEVELS, objects=K_OBJ, far=far, hit_fraction=hit, randomized=True,
                                pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world),
-                   loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb)
+                   loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,
+                   # distribution of the individual steps' GPU time: ms_per_step is the mean over the timed region and
+                   # includes any stall (a step far above the median is the host or the runtime, not the kernels)
+                   step_ms=dict(p50=step_times[len(step_times) // 2], p90=step_times[(9 * len(step_times)) // 10],
+                                max=step_times[-1],
+                                slow_steps=[i for i, t in enumerate(step_raw) if t > 1.5 * step_times[len(step_times) // 2]]))
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

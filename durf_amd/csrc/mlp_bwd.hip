@@ -669,9 +669,8 @@ __host__ __device__ inline int cperm_feat(int s) {
     return 16 * (s >> 4) + (e & 3) + 8 * (e >> 2) + 4 * ((s >> 3) & 1);
 }
 
-// Sum the split-K partials in fragment space (each wave reads 64 consecutive floats of a
-// partial: coalesced; 4 waves take interleaved partials with 8 loads in flight each, combined
-// in a fixed order -> deterministic), then scatter each sum to its flax [in,out] position.
+// Sum the split-K partials in fragment space (consecutive threads read consecutive floats of a partial: coalesced;
+// one thread per element, partials in split order -> deterministic), then scatter each sum to its flax [in,out] position.
 // One launch covers all 12 Dense layers of an MLP (blockIdx.y = job).
 struct DwJobs { DwJob j[12]; size_t part_off[12], bpart_off[12]; int nparts[12]; };
 
@@ -686,13 +685,12 @@ struct FinMlp {
     durf::DwLevels lv;
 };
 // 1-D grid of exactly the blocks that have work (an early-exit block is not free: the 3 x 12 x 768 padding blocks of a
-// (widest job) x 12 x (1 + K) grid cost the merged launch ~80 us): MLP-major, then job, then 64-element block;
+// (widest job) x 12 x (1 + K) grid cost the merged launch ~80 us): MLP-major, then job, then 256-element block;
 // job_blk[c][j] = first block of job j within one MLP of class c, job_blk[c][12] = blocks per MLP.
 struct FinArgs { FinMlp m[2]; int job_blk[2][13]; };
 
 __global__ void __launch_bounds__(256)
 k_dw_finalize(FinArgs A) {
-    __shared__ float red[4][64];
     const int n0 = A.m[0].count * A.job_blk[0][12];
     const int cls = (int)blockIdx.x < n0 ? 0 : 1;
     const FinMlp& M = A.m[cls];
@@ -720,28 +718,24 @@ k_dw_finalize(FinArgs A) {
     durf_layer_shape(W, in_dim, job.layer, &fi, &fo);
     const int nfrag = job.MO * job.NI * 1024;
     const int nb = job.MO * 32;
-    const int el = threadIdx.x & 63, grp = threadIdx.x >> 6;
-    const int idx = xblk * 64 + el;
-    if (xblk * 64 >= nfrag + nb) return;
+    // One thread per element, all of its partials with 16 independent loads in flight, summed in split order
+    // (deterministic).  A block covers 256 consecutive elements: with 64 per block and the partials dealt to 4 waves the
+    // launch was bound by the dispatch of its ~30 000 tiny blocks whenever a job has few partials (small batches, objects).
+    const int idx = xblk * 256 + (int)threadIdx.x;
+    if (idx >= nfrag + nb) return;
     float s = 0.0f;
-    if (idx < nfrag + nb) {
+    {
         const float* p0 = idx < nfrag ? part + idx : bpart + (idx - nfrag);
         const size_t stride = idx < nfrag ? (size_t)nfrag : (size_t)nb;
-        // 8 independent loads in flight per wave, also in the last (partial) batch: a scalar remainder loop is a chain of
-        // dependent HBM round trips (with ~57 partials per job it made this kernel 130 us); same order of additions
-        for (int p = grp; p < nparts; p += 32) {
-            float v[8];
+        for (int p = 0; p < nparts; p += 16) {
+            float v[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = (p + 4 * u < nparts) ? p0[(size_t)(p + 4 * u) * stride] : 0.0f;
+            for (int u = 0; u < 16; u++) v[u] = (p + u < nparts) ? p0[(size_t)(p + u) * stride] : 0.0f;
 #pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (p + 4 * u < nparts) s += v[u];
+            for (int u = 0; u < 16; u++)
+                if (p + u < nparts) s += v[u];
         }
     }
-    red[grp][el] = s;
-    __syncthreads();
-    if (grp != 0 || idx >= nfrag + nb) return;
-    s = ((red[0][el] + red[1][el]) + red[2][el]) + red[3][el];
     if (idx < nfrag) {
         const int r = idx & 15, lane = (idx >> 4) & 63, t = idx >> 10;
         const int ni = t % job.NI, mo = t / job.NI;
@@ -821,38 +815,76 @@ k_bottleneck_grads(FinArgs A) {
     const int tx = tid & 31, ty = tid >> 5;          // output (row = ty + 8 q, col = tx), q = 0..3
     if (t < nA) {
         const int i0 = (t / wt) * 32, o0 = (t % wt) * 32;
-        for (int e = tid; e < 32 * 128; e += 256) {
-            const int r = e >> 7, j = e & 127;
-            sa[r][j] = part10[frag_index(W, i0 + r, j, NI)];
-            sb[r][j] = bf16r(K10[(size_t)(o0 + r) * 128 + j]);
+        // (operand gathers: 8 independent loads per thread in flight -- one at a time the tile was a chain of L2 round trips)
+#pragma unroll 1
+        for (int e0 = tid; e0 < 32 * 128; e0 += 8 * 256) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + 256 * u, r = e >> 7, j = e & 127;
+                va[u] = part10[frag_index(W, i0 + r, j, NI)];
+                vb[u] = K10[(size_t)(o0 + r) * 128 + j];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + 256 * u, r = e >> 7, j = e & 127;
+                sa[r][j] = va[u];
+                sb[r][j] = bf16r(vb[u]);
+            }
         }
         __syncthreads();
+        float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};        // four independent chains, LDS reads batched 8 k-values at a time
+#pragma unroll 8
+        for (int j = 0; j < 128; j++) {
+            const float b = sb[tx][j];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r = ty + 8 * q;
-            float s = 0.0f;
-            for (int j = 0; j < 128; j++) s += sa[r][j] * sb[tx][j];
-            grad[off9 + (size_t)(i0 + r) * W + o0 + tx] = s;
+            for (int q = 0; q < 4; q++) s4[q] += sa[ty + 8 * q][j] * b;
         }
+#pragma unroll
+        for (int q = 0; q < 4; q++) grad[off9 + (size_t)(i0 + ty + 8 * q) * W + o0 + tx] = s4[q];
     } else if (t < nA + nC) {
         const int u = t - nA, o0 = (u / 4) * 32, j0 = (u % 4) * 32;
-        for (int e = tid; e < 32 * W; e += 256) {
-            const int r = e / W, i = e % W;
-            sa[r][i] = bf16r(K9[(size_t)i * W + o0 + r]);              // K9^T rows: output feature o0 + r
-            sb[r][i] = part10[frag_index(W, i, j0 + r, NI)];          // P^T rows: dz10 feature j0 + r
+#pragma unroll 1
+        for (int e0 = tid; e0 < 32 * W; e0 += 8 * 256) {           // 32 W is a multiple of 2048 for W = 128, 256
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + 256 * u, r = e / W, i = e % W;
+                va[u] = K9[(size_t)i * W + o0 + r];                    // K9^T rows: output feature o0 + r
+                vb[u] = part10[frag_index(W, i, j0 + r, NI)];          // P^T rows: dz10 feature j0 + r
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int e = e0 + 256 * u, r = e / W, i = e % W;
+                sa[r][i] = bf16r(va[u]);
+                sb[r][i] = vb[u];
+            }
         }
         __syncthreads();
+        float s4[4];
+        const float db = bpart10[cperm_slot(j0 + tx)];
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int r = ty + 8 * q;
-            float s = b9[o0 + r] * bpart10[cperm_slot(j0 + tx)];
-            for (int i = 0; i < W; i++) s += sa[r][i] * sb[tx][i];
-            grad[off10 + (size_t)(o0 + r) * 128 + j0 + tx] = s;
+        for (int q = 0; q < 4; q++) s4[q] = b9[o0 + ty + 8 * q] * db;
+#pragma unroll 8
+        for (int i = 0; i < W; i++) {
+            const float b = sb[tx][i];
+#pragma unroll
+            for (int q = 0; q < 4; q++) s4[q] += sa[ty + 8 * q][i] * b;
         }
+#pragma unroll
+        for (int q = 0; q < 4; q++) grad[off10 + (size_t)(o0 + ty + 8 * q) * 128 + j0 + tx] = s4[q];
     } else {
+        if (tid < 128) sa[0][tid] = bpart10[cperm_slot(tid)];
+        __syncthreads();
         for (int o = tid; o < W; o += 256) {
             float s = 0.0f;
-            for (int j = 0; j < 128; j++) s += bpart10[cperm_slot(j)] * bf16r(K10[(size_t)o * 128 + j]);
+            for (int j0 = 0; j0 < 128; j0 += 16) {
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = K10[(size_t)o * 128 + j0 + u];
+#pragma unroll
+                for (int u = 0; u < 16; u++) s += sa[0][j0 + u] * bf16r(v[u]);
+            }
             grad[off9 + (size_t)W * W + o] = s;
         }
     }
@@ -1178,7 +1210,7 @@ static int launch_fin(void* stream, FinArgs& A, int max_el, int max_tiles) {
         for (int j = 0; j < 12; j++) {
             A.job_blk[c][j] = b;
             if (A.m[c].count > 0 && A.m[c].jobs.nparts[j] > 0)          // (the bottleneck layer has no job of its own)
-                b += durf_cdiv(A.m[c].jobs.j[j].MO * A.m[c].jobs.j[j].NI * 1024 + A.m[c].jobs.j[j].MO * 32, 64);
+                b += durf_cdiv(A.m[c].jobs.j[j].MO * A.m[c].jobs.j[j].NI * 1024 + A.m[c].jobs.j[j].MO * 32, 256);
         }
         A.job_blk[c][12] = b > 0 ? b : 1;
         total += A.m[c].count * b;

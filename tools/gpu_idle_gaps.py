@@ -18,10 +18,16 @@ last = adam[warm + steps - 1]
 seg = ev[first:last + 1]
 span = seg[-1][1] - seg[0][0]
 busy, gaps, cur_end = 0, [], seg[0][0]
+where = []                      # (gap, step within the segment, kernel before, kernel after)
+step_i, prev_n = 0, ''
 for s, e, n in seg:
     if s > cur_end:
         gaps.append((s - cur_end, n))
+        where.append((s - cur_end, step_i, prev_n[:36], n[:36]))
         cur_end = s
+    if n.startswith('k_adam'):
+        step_i += 1
+    prev_n = n
     if e > cur_end:
         busy += e - cur_end
         cur_end = e
@@ -34,3 +40,7 @@ c = collections.Counter()
 for g, n in gaps:
     c[n[:40]] += g
 print('idle by following kernel (us/step):', [(k, round(v / steps / 1e3, 1)) for k, v in c.most_common(8)])
+where.sort(reverse=True)
+print('largest gaps (us, step, after kernel -> before kernel):')
+for g, st, a, b in where[:6]:
+    print('   %10.1f  step %3d  %s -> %s' % (g / 1e3, st, a, b))
