@@ -59,6 +59,8 @@ def parse_args():
     ap.add_argument('--config', default='cfg3', choices=sorted(WORKLOADS))
     ap.add_argument('--rays', type=int, default=0, help='rays per GPU (default: the workload\'s)')
     ap.add_argument('--objects', type=int, default=-1, help='override the number of dynamic boxes K')
+    ap.add_argument('--prewarm-events', type=int, default=512,
+                    help='timing events recorded (and kept alive) before the warm-up: grows the HIP runtime\'s event pool there')
     ap.add_argument('--max-ahead', type=int, default=0, help='bound the number of steps the host may enqueue ahead of the GPU (0 = unbounded)')
     ap.add_argument('--no-calibration', action='store_true', help='skip the vendor-GEMM board calibration line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
@@ -267,15 +269,18 @@ def main():
                                         reduce_stats=(i % config.print_every == 0))
 
     rng = 1000 * rank                                  # stratified-sampling noise differs per rank
-    # The warm-up runs exactly what the timed region runs, the live HIP-event timers included.  One of the first ~7 steps of
-    # a process takes ~40 ms instead of 4.3 (a one-off of the HIP runtime around the first timing events / its growing
-    # signal pool -- not a kernel: the step before and after it are normal); with 5 warm-up steps it landed in the timed
-    # region and cost every earlier figure of this repo 4-5 %.  Default warm-up: 20 steps; `step_ms` in the JSON line
-    # (p50 / p90 / max / slow_steps) shows any such outlier.
+    # The warm-up runs exactly what the timed region runs, the live HIP-event timers included, after --prewarm-events
+    # timing events have been recorded and parked: when the number of live timing events of a process first passes
+    # ~100, the HIP runtime stalls the stream ONCE for ~40 ms (it grows a pool; tools/stall_probe.py: no stall without
+    # timing events, none after this pre-warm even with --warmup 2).  With the timers switched on at the first timed step
+    # and 5 warm-up steps, that stall used to sit in the timed region and cost every earlier figure of this repo 4-5 %.
+    # `step_ms` in the JSON line (p50 / p90 / max / slow_steps) shows any such outlier.
     ops.TIMED_NAMES = None if args.profile_ops else {'mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256', 'encode_bkgd',
                                                      'composite_resample'}
     ops.TIMERS = {}
-    torch.cuda.Event(enable_timing=True).record()
+    prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]    # kept alive to the end
+    for e in prewarm:
+        e.record()
     for i in range(args.warmup):
         state, stats, rng, _ = step(state, rng, i)
     sync()
