@@ -165,3 +165,34 @@ def test_render_image(cuda):
                          cfg=dict(num_samples=32), mlp_hook=R.mlp_apply_bf16)
     torch.testing.assert_close(rgb.cpu(), ref[0], rtol=0, atol=2e-3)
     torch.testing.assert_close(acc.cpu(), ref[2], rtol=0, atol=2e-3)
+
+
+@pytest.mark.parametrize('seed', list(range(100, 112)))
+def test_forward_random_configurations(cuda, seed):
+    """Seeded sweep over combinations the hand-picked cases above do not pair up: ragged ray counts (partial 256-sample
+    blocks and compaction rounds), K in 0..8, N in {32, 64, 96, 128}, randomized sampling, and the gin knobs two at a
+    time.  Same tolerances as test_forward_parity / test_forward_knobs, single-hit rays only."""
+    import random
+    r = random.Random(seed)
+    K = r.choice([0, 1, 2, 3, 5, 8])
+    N = r.choice([32, 64, 96, 128])
+    B = r.choice([37, 64, 141, 256, 300])
+    randomized = r.random() < 0.5
+    far = r.choice([20.0, 40.0, 200.0])
+    alpha = r.choice([10.0, 3.3, 0.0])
+    knobs = {}
+    for name, val in (('disable_integration', True), ('contraction', False), ('ray_shape', 'cylinder'),
+                      ('dynamics', False), ('resample_padding', 0.05)):
+        if r.random() < 0.3:
+            knobs[name] = val
+    b, ret, ref_bf, ref_32 = _run(cuda, B, K, N, randomized, seed=seed, alpha=alpha, far=far, knobs=knobs)
+    single = torch.tensor(b['_multi'] == 0)
+    assert single.any()
+    for lvl in range(2):
+        got, rb = ret[lvl], ref_bf[lvl]
+        for i, tol in ((0, 3e-3), (1, 3e-3 * far), (2, 3e-3), (3, 3e-3), (4, 2e-3 * far)):
+            torch.testing.assert_close(got[i].cpu()[single], rb[i][single], rtol=0, atol=tol,
+                                       msg=lambda m: 'seed %d K=%d N=%d B=%d %s: output %d l%d: %s' % (
+                                           seed, K, N, B, knobs, i, lvl, m))
+        assert (got[0].cpu() - ref_32[lvl][0]).abs()[single].max() < 2e-2, 'rgb vs fp32 oracle'
+        assert torch.equal(got[8].cpu().long().reshape(-1), rb[8].reshape(-1)), 'dyn_mask'

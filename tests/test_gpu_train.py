@@ -385,3 +385,55 @@ def test_train_step_with_other_level_counts(cuda, L, K):
         sl = slice(lay.mlp_off[name], lay.mlp_off[name] + lay.mlp_size[w])
         if float(og[sl].norm()) > 0:
             assert _rel(grad.cpu()[sl], og[sl]) < 5e-2, '%s grad rel err %g' % (name, _rel(grad.cpu()[sl], og[sl]))
+
+
+@pytest.mark.parametrize('seed', [200, 201, 202, 203, 204, 205])
+def test_train_step_random_configurations(cuda, seed):
+    """Seeded sweep over loss-knob / shape combinations of one full step (same gates as test_train_step): loss
+    multipliers off their shipped values, box loss, weight decay, multiscale loss off, ragged B, K in 0..5."""
+    import random
+    r = random.Random(seed)
+    K = r.choice([0, 1, 2, 3, 5])
+    N = r.choice([32, 64])
+    B = r.choice([96, 141, 256])
+    knobs = dict(depth_loss_mult=r.choice([1e-4, 1e-2, 0.0]), near_loss_mult=r.choice([1e-2, 0.0, 0.1]),
+                 empty_loss_mult=r.choice([1.0, 0.1]), sky_loss_mult=r.choice([1.0, 0.0]),
+                 coarse_loss_mult=r.choice([0.1, 1.0]), box_loss_mult=r.choice([0, 0.5]),
+                 weight_decay_mult=r.choice([0.0, 1e-4]), disable_multiscale_loss=r.random() < 0.3,
+                 grad_max_norm=r.choice([1.0, 0.0, 10.0]), grad_max_val=r.choice([0.1, 0.0]))
+    eps, alpha, lr = r.choice([3.0, 0.5]), r.choice([10.0, 2.5]), 5e-4
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
+                    'Config.randomized = True\nConfig.rand_bkgd = False\nConfig.tv_loss_mult = 0.0\n' % N +
+                    ''.join('Config.%s = %r\n' % kv for kv in knobs.items()))
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(B, K, seed=seed)
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(seed, db, device=cuda)
+    g = torch.Generator().manual_seed(seed)
+    noise_c = dict(t_rand=torch.rand(B, N + 1, generator=g), u_rand=torch.rand(B, N + 1, generator=g))
+    noise_d = {k: v.to(cuda) for k, v in noise_c.items()}
+    params = H.oracle_params_from_variables(variables)
+    prev_c, prev_d = ob['init'][0:1], db['init'][0:1]
+    grad, raw, pose = train_boxpose.loss_and_grad(model, config, 0, variables, db, eps, alpha, prev_d, noise=noise_d)
+    torch.cuda.synchronize()
+    ocfg = dict(R.CONFIG_DEFAULTS, randomized=True, tv_loss_mult=0.0, **knobs)
+    p2, st2, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, dict(num_samples=N), lr, eps,
+                                           alpha, prev_c, noise=noise_c, mlp_hook=R.mlp_apply_bf16)
+    if (ostats['losses'] != ostats['losses']).any():
+        pytest.skip('seed %d drew a multi-hit ray (NaN in the reference too)' % seed)
+    og = torch.cat([x.reshape(-1) for x in ograds])
+    lay = variables.layout
+    for name in lay.mlp_names():
+        w, _ = lay.mlp_dims(name)
+        sl = slice(lay.mlp_off[name], lay.mlp_off[name] + lay.mlp_size[w])
+        if float(og[sl].norm()) > 0:
+            assert _rel(grad.cpu()[sl], og[sl]) < 5e-2, 'seed %d %s %s grad rel err %g' % (
+                seed, knobs, name, _rel(grad.cpu()[sl], og[sl]))
+    state = train_boxpose.create_train_state(variables)
+    new_state, stats, rng, pose = train_boxpose.train_step(model, config, 0, state, db, lr, eps, alpha, prev_d, noise=noise_d)
+    for k in ('losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses'):
+        torch.testing.assert_close(getattr(stats, k).cpu(), ostats[k], rtol=2e-3, atol=1e-6,
+                                   msg=lambda m: 'seed %d %s: %s: %s' % (seed, knobs, k, m))
+    torch.testing.assert_close(stats.loss.cpu(), ostats['loss'], rtol=2e-3, atol=1e-6)
