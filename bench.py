@@ -347,7 +347,7 @@ def main():
             for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
                 print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / args.steps),
                       file=sys.stderr)
-        cb = None if args.no_cpu_baseline else cpu_baseline(batch_np, K_OBJ)
+        cb = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(batch_np, K_OBJ)     # rank 0 at N = 1 only
         out = dict(metric='train_rays_per_sec', value=B * world * args.steps / dt, unit='rays/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
