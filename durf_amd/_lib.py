@@ -74,6 +74,7 @@ _SIGS = {
     'durf_mlp_dw_finalize_levels': (i32, [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp, vp]),
     'durf_expand_raw': (i32, [vp, i32, i32, vp, vp, vp, vp]),
     'durf_encode_obj_bwd': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
+    'durf_encode_obj_bwd_batch': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]),
     'durf_pose_finish': (i32, [vp, i32, vp, vp, i32, i32, vp]),
     'durf_optim_scratch_floats': (u64, [u64]),
     'durf_clip_adam': (i32, [vp, u64, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp]),

@@ -12,6 +12,10 @@
 
 enum { POSE_ROWS = 21 };   // [0..2] sum g_o ; [3..11] sum g_o (x) o ; [12..20] sum g_u (x) d
 
+// One WORKGROUP per hit ray and object (blockIdx.x = compact ray, blockIdx.y = object of a batched call): the four waves
+// split the 60 encoding features (15 each: the per-sample chain of 60 sin / cos / exp is what a launch waits for -- with
+// one wave per ray it was 50 us per object and level, K host-driven launches per level), lanes take the samples, and the
+// per-wave partial d(o'), d(d') meet in LDS in a fixed order.
 template <int P>
 __global__ void __launch_bounds__(256)
 k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
@@ -19,10 +23,15 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
                  const float* __restrict__ origins_s, const float* __restrict__ dirs_s,
                  const float* __restrict__ radii, const float* __restrict__ origins,
                  const float* __restrict__ dirs, const float* __restrict__ pose, BarfW bw,
-                 float* __restrict__ rows_out /* [21][B], column j = compact ray index */) {
-    const int lane = threadIdx.x & 63;
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= *count) return;
+                 float* __restrict__ rows_out /* [21][B] per object, column j = compact ray index */,
+                 size_t idx_stride, size_t denc_stride, size_t rows_stride) {
+    __shared__ float part[4][6];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int kb = blockIdx.y;                      // object within this call
+    k_obj += kb;
+    idx += kb * idx_stride; count += kb; d_enc += kb * denc_stride; rows_out += kb * rows_stride;
+    const int j = blockIdx.x;
+    if (j >= *count) return;                        // whole workgroup
     const int b = idx[j];
     const float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
     const float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
@@ -48,8 +57,9 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
             var[i] = t_var * (d[i] * d[i]) + r_var * (1.0f - d[i] * (d[i] / m));
         }
         const float* ge = d_enc + ((size_t)j * N + n) * DURF_ENC_DIM;
-        float gx[3] = {ge[0], ge[1], ge[2]}, gv[3] = {0.f, 0.f, 0.f};     // identity features (mip.py:222)
-        for (int f = 0; f < 60; f++) {
+        float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};
+        if (wv == 0) { gx[0] = ge[0]; gx[1] = ge[1]; gx[2] = ge[2]; }     // identity features (mip.py:222)
+        for (int f = 15 * wv; f < 15 * wv + 15; f++) {
             const int c = f / 30, r = f - c * 30, deg = r / 3, i = r - deg * 3;
             const float sc = (float)(1 << deg);
             float z = x[i] * sc;
@@ -58,10 +68,12 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
             if (!(fabsf(z) < t)) { float q = fmodf(z, t); if (q != 0.0f && q < 0.0f) q += t; z = q; }
             const float e = expf(-0.5f * (var[i] * sc * sc));
             const float g = ge[3 + f] * bw.w[f / 6];
-            gx[i] += g * e * sc * cosf(z);
-            gv[i] += g * (-0.5f * sc * sc) * e * sinf(z);
+            const float gxf = g * e * sc * cosf(z), gvf = g * (-0.5f * sc * sc) * e * sinf(z);
+            if (i == 0) { gx[0] += gxf; gv[0] += gvf; }
+            else if (i == 1) { gx[1] += gxf; gv[1] += gvf; }
+            else { gx[2] += gxf; gv[2] += gvf; }
         }
-        // x_i = o_i + d_i t_mean ; var_i = t_var d_i^2 + r_var (1 - d_i^2 / m)
+        // x_i = o_i + d_i t_mean ; var_i = t_var d_i^2 + r_var (1 - d_i^2 / m)     (linear in gx, gv: per-wave partials add up)
         float s_gv = 0.0f;
 #pragma unroll
         for (int i = 0; i < 3; i++) s_gv += gv[i] * r_var * (d[i] * d[i]) / (m * m);
@@ -75,7 +87,17 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
     }
 #pragma unroll
     for (int i = 0; i < 3; i++) { go[i] = wave_sum(go[i]); gd[i] = wave_sum(gd[i]); }
-    if (lane != 0) return;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++) { part[wv][i] = go[i]; part[wv][3 + i] = gd[i]; }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        go[i] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
+        gd[i] = ((part[0][3 + i] + part[1][3 + i]) + part[2][3 + i]) + part[3][3 + i];
+    }
     // o' = R (o_w - c), u = R d_w, d' = u / |u|  (box_helpers.py:323-340)
     const float* pk = pose + k_obj * 6;
     const float rx = pk[3], ry = pk[4], rz = pk[5];
@@ -118,6 +140,9 @@ __global__ void __launch_bounds__(1024)
 k_pose_reduce(int n, const int32_t* __restrict__ count, const float* __restrict__ in, float* __restrict__ out) {
     __shared__ float sh[16];
     const int r = blockIdx.x;
+    count += blockIdx.y;                               // batched call: blockIdx.y = object
+    in += (size_t)blockIdx.y * POSE_ROWS * n;
+    out += blockIdx.y * POSE_ROWS;
     const int c = *count < n ? *count : n;
     const float* p = in + (size_t)r * n;
     float v = 0.0f;
@@ -183,26 +208,43 @@ __global__ void k_pose_finish(int K, const float* __restrict__ pose, const float
 
 extern "C" {
 
-// One level, one object: d_enc [count*N, 64] -> accumulates sums[k*21 .. +21) (caller zeroes).
-// scratch: 21*B floats.
+// One level: d_enc [K][count*N, 64] -> accumulates sums[(k0 + k)*21 .. +21) for the K objects of the call (caller
+// zeroes sums once per step).  scratch: K*21*B floats.  idx [K,B] / count [K] / d_enc slabs denc_stride floats apart.
+static int encode_obj_bwd_launch(void* stream, int K, int B, int N, int k0, const int32_t* idx, const int32_t* count,
+                                 const float* d_enc, size_t denc_stride, const float* t_vals, const float* origins_s,
+                                 const float* dirs_s, const float* radii, const float* origins, const float* dirs,
+                                 const float* pose, const float* barf_w, float* scratch, float* sums) {
+    DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
+    if (B <= 0 || K <= 0) return 0;
+    BarfW bw;
+    for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
+    hipStream_t s = (hipStream_t)stream;
+    dim3 grid(B, K), block(256);
+#define LAUNCH_E(P)                                                                                       \
+    hipLaunchKernelGGL(k_encode_obj_bwd<P>, grid, block, 0, s, B, N, k0, idx, count, d_enc, t_vals,       \
+                       origins_s, dirs_s, radii, origins, dirs, pose, bw, scratch, (size_t)B, denc_stride, \
+                       (size_t)POSE_ROWS * B)
+    if (N <= 64) LAUNCH_E(1); else if (N <= 128) LAUNCH_E(2); else LAUNCH_E(4);
+#undef LAUNCH_E
+    hipLaunchKernelGGL(k_pose_reduce, dim3(POSE_ROWS, K), dim3(1024), 0, s, B, count, scratch, sums + k0 * POSE_ROWS);
+    DURF_CHECK_LAUNCH("durf_encode_obj_bwd");
+    return 0;
+}
+
 int durf_encode_obj_bwd(void* stream, int B, int N, int k_obj, const int32_t* idx, const int32_t* count,
                         const float* d_enc, const float* t_vals, const float* origins_s,
                         const float* dirs_s, const float* radii, const float* origins, const float* dirs,
                         const float* pose, const float* barf_w, float* scratch, float* sums) {
-    DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
-    if (B <= 0) return 0;
-    BarfW bw;
-    for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
-    hipStream_t s = (hipStream_t)stream;
-    dim3 grid(durf_cdiv(B, 4)), block(256);
-#define LAUNCH_E(P)                                                                                       \
-    hipLaunchKernelGGL(k_encode_obj_bwd<P>, grid, block, 0, s, B, N, k_obj, idx, count, d_enc, t_vals,    \
-                       origins_s, dirs_s, radii, origins, dirs, pose, bw, scratch)
-    if (N <= 64) LAUNCH_E(1); else if (N <= 128) LAUNCH_E(2); else LAUNCH_E(4);
-#undef LAUNCH_E
-    hipLaunchKernelGGL(k_pose_reduce, dim3(POSE_ROWS), dim3(1024), 0, s, B, count, scratch, sums + k_obj * POSE_ROWS);
-    DURF_CHECK_LAUNCH("durf_encode_obj_bwd");
-    return 0;
+    return encode_obj_bwd_launch(stream, 1, B, N, k_obj, idx, count, d_enc, 0, t_vals, origins_s, dirs_s, radii, origins,
+                                 dirs, pose, barf_w, scratch, sums);
+}
+
+int durf_encode_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
+                              const float* d_enc, const float* t_vals, const float* origins_s,
+                              const float* dirs_s, const float* radii, const float* origins, const float* dirs,
+                              const float* pose, const float* barf_w, float* scratch, float* sums) {
+    return encode_obj_bwd_launch(stream, K, B, N, 0, idx, count, d_enc, (size_t)B * N * DURF_ENC_DIM, t_vals, origins_s,
+                                 dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums);
 }
 
 // sums [K,21] (all levels accumulated) -> adds d(loss)/d(box_centers[ts]) into grad6 [K,6]

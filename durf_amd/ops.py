@@ -570,7 +570,7 @@ def obj_bwd_batch(slabs, idx, count, draw, wb, want_d_enc=False):
     K, B, N = slabs.K, slabs.B, slabs.N
     slabs.dz = torch.empty(K * mlp_stash_bytes(W_OBJ_, B * N), dtype=torch.uint8, device=dev)
     slabs.dz_out = torch.empty(K * int(L.durf_obj_dzout_stride(B, N)), dtype=torch.uint8, device=dev)
-    slabs.d_enc = torch.zeros(K, B * N, ENC_DIM, device=dev) if want_d_enc else None
+    slabs.d_enc = torch.empty(K, B * N, ENC_DIM, device=dev) if want_d_enc else None     # every valid row is written
     with _Timed('obj_bwd_batch'):
         _lib.check(L.durf_obj_bwd_batch(_stream(), K, B, N, _p(idx), _p(count), _p(_f32(draw)), _p(wb), _p(slabs.mask),
                                         _p(slabs.dz), _p(slabs.dz_out), _p(slabs.d_enc)), 'durf_obj_bwd_batch')
@@ -653,6 +653,18 @@ def encode_obj_bwd(k_obj, idx_k, count_k, d_enc, t_vals, origins_s, dirs_s, radi
                                               _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
                                               _p(_f32(radii)), _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
                                               wa, _p(scratch), _p(_f32(sums))), 'durf_encode_obj_bwd')
+
+
+def encode_obj_bwd_batch(K, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, alpha, sums):
+    """all K objects of one level in one launch pair: idx [K,B], count [K], d_enc [K, B*N, 64] (obj_bwd_batch's slab)"""
+    B, N = t_vals.shape[0], t_vals.shape[1] - 1
+    scratch = torch.empty(K * 21 * B, device=t_vals.device)
+    w = barf_weights(alpha)
+    wa = (C.c_float * 10)(*[float(x) for x in w])
+    _lib.check(_lib.lib().durf_encode_obj_bwd_batch(_stream(), int(K), B, N, _p(idx), _p(count), _p(_f32(d_enc)),
+                                                    _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
+                                                    _p(_f32(radii)), _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
+                                                    wa, _p(scratch), _p(_f32(sums))), 'durf_encode_obj_bwd_batch')
 
 
 def pose_finish(pose, sums, want_pos, want_rot, grad6):

@@ -134,10 +134,10 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         if K:                                 # all K object MLPs: one call (csrc/objects.hip)
             with side:
                 ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
-                for k in range(K if pose_opt else 0):   # d(loss)/d(box pose) through the object encoding
-                    ops.encode_obj_bwd(k, ctx['idx'][k], ctx['count'][k:k + 1], lv['slabs'].d_enc[k], lv['t_vals'],
-                                       ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
-                                       pose_sums)
+                if pose_opt:                            # d(loss)/d(box pose) through the object encoding, all K at once
+                    ops.encode_obj_bwd_batch(K, ctx['idx'], ctx['count'], lv['slabs'].d_enc, lv['t_vals'],
+                                             ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
+                                             pose_sums)
     levels = ctx['levels']
     if not f32:
         off = lay.mlp_off['MLP_0']

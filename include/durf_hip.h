@@ -331,6 +331,12 @@ int durf_encode_obj_bwd(void* stream, int B, int N, int k_obj, const int32_t* id
                         const float* d_enc, const float* t_vals, const float* origins_s,
                         const float* dirs_s, const float* radii, const float* origins, const float* dirs,
                         const float* pose, const float* barf_w, float* scratch, float* sums);
+/* The same for all K objects of a level in one launch pair (blockIdx.y = object): idx [K,B], count [K], d_enc [K, B*N, 64]
+ * (the slab durf_obj_bwd_batch fills), pose [K,6], scratch K*21*B floats, sums [K,21] accumulated over levels. */
+int durf_encode_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
+                              const float* d_enc, const float* t_vals, const float* origins_s,
+                              const float* dirs_s, const float* radii, const float* origins, const float* dirs,
+                              const float* pose, const float* barf_w /* host float[10] */, float* scratch, float* sums);
 int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, int want_pos, int want_rot,
                      float* grad6);
 

@@ -268,6 +268,7 @@ def test_pose_chain_fp32(cuda):
     idx, count, slot = ops.compact_hits(hit)
     t_d = ops.sample_t(db['rays'].near.reshape(-1), db['rays'].far.reshape(-1), N)
     sums = torch.zeros(K, 21, device=cuda)
+    slab = torch.zeros(K, B * N, 64, device=cuda)                 # the [K, B*N, 64] slab of the batched call
     loss = 0.0
     for k in range(K):
         rows = torch.nonzero(inter[:, k]).flatten()
@@ -277,8 +278,14 @@ def test_pose_chain_fp32(cuda):
         loss = loss + (enc * d_enc[:, :63]).sum()
         buf = torch.zeros(B * N, 64, device=cuda)
         buf[: rows.numel() * N] = d_enc.float().to(cuda)
+        slab[k] = buf
         ops.encode_obj_bwd(k, idx[k], count[k:k + 1], buf, t_d, o_sd, d_sd, db['rays'].radii.reshape(-1).contiguous(),
                            db['rays'].origins, db['rays'].directions, pose_d, alpha, sums)
+    # all objects in one launch pair: the same kernels, the same sums
+    sums_b = torch.zeros(K, 21, device=cuda)
+    ops.encode_obj_bwd_batch(K, idx, count, slab, t_d, o_sd, d_sd, db['rays'].radii.reshape(-1).contiguous(),
+                             db['rays'].origins, db['rays'].directions, pose_d, alpha, sums_b)
+    assert torch.equal(sums_b, sums)
     loss.backward()
     g6 = torch.zeros(K, 6, device=cuda)
     ops.pose_finish(pose_d, sums, True, True, g6)
