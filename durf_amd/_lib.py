@@ -60,7 +60,8 @@ _SIGS = {
     'durf_gen_batch': (i32, [vp, i32, i32, C.POINTER(f32), vp, f32, f32, vp, vp, vp, i32] + [vp] * 10),
     'durf_ssim_scratch_floats': (u64, [i32, i32, i32, i32]),
     'durf_ssim': (i32, [vp, i32, i32, i32, vp, vp, f32, i32, vp, f32, f32, vp, vp, vp]),
-    'durf_train_stats': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(f32), i32, vp]),
+    'durf_train_stats': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(f32), i32, vp,
+                               C.POINTER(vp), i32]),
     'durf_loss_prep': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, i32, i32, vp, vp]),
     'durf_loss_bwd': (i32, [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                             f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

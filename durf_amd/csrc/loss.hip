@@ -271,10 +271,31 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
 struct TvalPtrs { const float* p[DURF_MAX_LEVELS]; };
 struct StatMults { float coarse, sky, depth, near, empty, tv; };
 
-__global__ void k_train_stats(int L, int K, int N, const float* __restrict__ norms, const float* __restrict__ sums,
-                              const float* __restrict__ weight_l2, const float* __restrict__ pose6,
-                              const float* __restrict__ prev6, const float* __restrict__ target6, TvalPtrs tv,
-                              StatMults m, int mode, float* __restrict__ out) {
+__global__ void __launch_bounds__(1024)
+k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __restrict__ sums,
+              const float* __restrict__ weight_l2, const float* __restrict__ pose6,
+              const float* __restrict__ prev6, const float* __restrict__ target6, TvalPtrs tv, TvalPtrs terms, int B,
+              StatMults m, int mode, float* __restrict__ out) {
+    // terms given: the per-ray loss terms [LT_ROWS, B] of every level are reduced HERE (the order of k_reduce_rows, so
+    // the sums are the ones durf_loss_bwd's own reduction launch would have produced) and left in sums [L, LT_ROWS]
+    __shared__ float s_w[16];
+    if ((mode & 1) && terms.p[0] != nullptr) {
+        for (int row = 0; row < L * LT_ROWS; row++) {
+            const float* p = terms.p[row / LT_ROWS] + (size_t)(row % LT_ROWS) * B;
+            float v = 0.0f;
+            for (int i = threadIdx.x; i < B; i += 1024) v += p[i];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+            if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                float a = s_w[0];
+                for (int w = 1; w < 16; w++) a += s_w[w];
+                sums[row] = a;
+            }
+            __syncthreads();
+        }
+    }
     if (threadIdx.x != 0) return;
     float* rows = out + 1;
     if (mode & 1) {
@@ -366,20 +387,24 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                        weights_out, t_mids_out, t_dists_out, draw_ray_sum)
     if (N <= 64) LAUNCH_L(1); else if (N <= 128) LAUNCH_L(2); else LAUNCH_L(4);
 #undef LAUNCH_L
-    hipLaunchKernelGGL(k_reduce_rows, dim3(LT_ROWS), dim3(1024), 0, s, B, -1, terms, term_sums);
+    if (term_sums) hipLaunchKernelGGL(k_reduce_rows, dim3(LT_ROWS), dim3(1024), 0, s, B, -1, terms, term_sums);
     DURF_CHECK_LAUNCH("durf_loss_bwd");
     return 0;
 }
 
-int durf_train_stats(void* stream, int L, int K, int N, const float* norms, const float* sums,
+int durf_train_stats(void* stream, int L, int K, int N, const float* norms, float* sums,
                      const float* weight_l2, const float* pose6, const float* prev6, const float* target6,
-                     const float* const* t_vals, const float* mults, int mode, float* out) {
+                     const float* const* t_vals, const float* mults, int mode, float* out,
+                     const float* const* terms, int B) {
     DURF_REQUIRE(L >= 1 && L <= DURF_MAX_LEVELS, "1 <= num_levels <= DURF_MAX_LEVELS");
-    TvalPtrs tv;
-    for (int l = 0; l < DURF_MAX_LEVELS; l++) tv.p[l] = l < L ? t_vals[l] : nullptr;
+    TvalPtrs tv, tm;
+    for (int l = 0; l < DURF_MAX_LEVELS; l++) {
+        tv.p[l] = l < L ? t_vals[l] : nullptr;
+        tm.p[l] = (terms && l < L) ? terms[l] : nullptr;
+    }
     const StatMults m = {mults[0], mults[1], mults[2], mults[3], mults[4], mults[5]};
-    hipLaunchKernelGGL(k_train_stats, dim3(1), dim3(64), 0, (hipStream_t)stream, L, K, N, norms, sums, weight_l2,
-                       pose6, prev6, target6, tv, m, mode, out);
+    hipLaunchKernelGGL(k_train_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, K, N, norms, sums, weight_l2,
+                       pose6, prev6, target6, tv, tm, B, m, mode, out);
     DURF_CHECK_LAUNCH("durf_train_stats");
     return 0;
 }

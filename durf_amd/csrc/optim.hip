@@ -1,9 +1,9 @@
 // Gradient post-processing + Adam (K12): train_boxpose.py:257-289 and flax.optim.Adam
 // (apply_param_gradient: bias-corrected moments, eps outside the sqrt, no weight decay).
-// Three passes over the flat fp32 buffers (0.6-2 M floats: latency-, not bandwidth-bound):
+// Two passes over the flat fp32 buffers (0.6-2 M floats: latency-, not bandwidth-bound):
 //   1. scrub (nan/+inf -> 0, -inf -> -FLT_MAX), value clip, per-block sum of squares / abs max
-//   2. one block: global norm, abs max, clip multiplier
-//   3. Adam update with the scaled gradient
+//   2. Adam update with the scaled gradient; every workgroup first derives the global norm, abs max and clip multiplier
+//      from the per-block partials (a separate single-workgroup launch in round 1)
 #include "durf_common.h"
 
 #define OPT_BLOCK 256
@@ -39,33 +39,40 @@ k_grad_scrub(size_t n, float* __restrict__ g, float inv_world, float max_val, fl
     }
 }
 
+// The global norm / clip multiplier from the per-block partials.  Every workgroup of the Adam launch recomputes it (537
+// pairs at 1.1 M parameters: a few L2 reads per thread) instead of a separate single-workgroup launch in between; the
+// order of additions is fixed, so every workgroup gets the same bits.
 // out[0] = grad_norm, out[1] = grad_abs_max, out[2] = clip multiplier, out[3] = grad_norm_clipped
-__global__ void __launch_bounds__(1024)
-k_grad_norm(int nblocks, const float* __restrict__ part, float max_norm, float* __restrict__ out) {
-    __shared__ float s_sq[16], s_mx[16];
+__device__ __forceinline__ float grad_clip_mult(int nblocks, const float* __restrict__ part, float max_norm,
+                                                float* __restrict__ out, bool write) {
+    __shared__ float s_sq[4], s_mx[4], s_mult;
     float sq = 0.0f, mx = 0.0f;
-    for (int i = threadIdx.x; i < nblocks; i += 1024) { sq += part[2 * i]; mx = fmaxf(mx, part[2 * i + 1]); }
+    for (int i = threadIdx.x; i < nblocks; i += 256) { sq += part[2 * i]; mx = fmaxf(mx, part[2 * i + 1]); }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
     if ((threadIdx.x & 63) == 0) { s_sq[threadIdx.x >> 6] = sq; s_mx[threadIdx.x >> 6] = mx; }
     __syncthreads();
     if (threadIdx.x == 0) {
         float a = 0.0f, m = 0.0f;
-        for (int w = 0; w < 16; w++) { a += s_sq[w]; m = fmaxf(m, s_mx[w]); }
+        for (int w = 0; w < 4; w++) { a += s_sq[w]; m = fmaxf(m, s_mx[w]); }
         const float norm = sqrtf(a);
         float mult = 1.0f;
         if (max_norm > 0.0f) mult = fminf(1.0f, max_norm / (1e-7f + norm));       // :283-285
-        out[0] = norm; out[1] = m; out[2] = mult; out[3] = norm * mult;
+        s_mult = mult;
+        if (write) { out[0] = norm; out[1] = m; out[2] = mult; out[3] = norm * mult; }
     }
+    __syncthreads();
+    return s_mult;
 }
 
 __global__ void __launch_bounds__(256)
 k_adam(size_t n, float* __restrict__ p, float* __restrict__ m, float* __restrict__ v,
-       const float* __restrict__ g, const float* __restrict__ stats, float lr, float beta1, float beta2,
-       float eps, float bc1, float bc2) {
+       const float* __restrict__ g, int nblocks, const float* __restrict__ part, float max_norm,
+       float* __restrict__ stats, float lr, float beta1, float beta2, float eps, float bc1, float bc2) {
+    const float mult = grad_clip_mult(nblocks, part, max_norm, stats, blockIdx.x == 0);
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const float gi = stats[2] * g[i];
+    const float gi = mult * g[i];
     const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
     const float vi = beta2 * v[i] + (1.0f - beta2) * (gi * gi);
     m[i] = mi;
@@ -88,11 +95,10 @@ int durf_clip_adam(void* stream, size_t n, float* params, float* m, float* v, fl
     hipStream_t s = (hipStream_t)stream;
     const int nb = (int)durf_cdiv(n, OPT_BLOCK * OPT_PER_THREAD);
     hipLaunchKernelGGL(k_grad_scrub, dim3(nb), dim3(OPT_BLOCK), 0, s, n, grad, inv_world, max_val, scratch);
-    hipLaunchKernelGGL(k_grad_norm, dim3(1), dim3(1024), 0, s, nb, scratch, max_norm, stats);
     const double b1 = 0.9, b2 = 0.999;
     const double t = (double)step + 1.0;
-    hipLaunchKernelGGL(k_adam, dim3(durf_cdiv(n, 256)), dim3(256), 0, s, n, params, m, v, grad, stats, lr,
-                       (float)b1, (float)b2, 1e-8f, (float)(1.0 - pow(b1, t)), (float)(1.0 - pow(b2, t)));
+    hipLaunchKernelGGL(k_adam, dim3(durf_cdiv(n, 256)), dim3(256), 0, s, n, params, m, v, grad, nb, scratch, max_norm,
+                       stats, lr, (float)b1, (float)b2, 1e-8f, (float)(1.0 - pow(b1, t)), (float)(1.0 - pow(b2, t)));
     DURF_CHECK_LAUNCH("durf_clip_adam");
     return 0;
 }

@@ -393,8 +393,9 @@ def loss_prep(t_vals, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, leve
 
 def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, eps,
              mults, box_loss_mult, level, bg, density_bias=-1.0, disable_multiscale=False, sums=None, render_out=None,
-             draw_ray_sum=None):
+             draw_ray_sum=None, defer_sums=False):
     """-> draw [B*N,4], term_sums[7] (rgb, obj, depth, near, empty, sky, dist numerators).
+    defer_sums: no reduction launch here; returns (draw, terms [7,B]) for train_stats(..., terms=...) to reduce.
     render_out = (rgb [B,3], depth [B], acc [B], weights [B,N], t_mids [B,N], t_dists [B,N]) tensors to fill with the level's rendered
     outputs (what composite_fwd returns; a training step then skips that launch for the last level)."""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
@@ -402,7 +403,7 @@ def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth
     dev = t_vals.device
     draw = torch.empty(B * N, 4, device=dev)
     terms = torch.empty(TERM_ROWS, B, device=dev)
-    if sums is None:
+    if sums is None and not defer_sums:
         sums = torch.empty(TERM_ROWS, device=dev)
     ptrs = (C.c_void_p * max(K, 1))(*[r.data_ptr() for r in raw_obj])
     m = (C.c_float * 6)(*[float(x) for x in mults])
@@ -411,8 +412,9 @@ def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth
                                         _p(_f32(lossmult)), _p(_f32(gt_depth)), _p(_f32(sky)), _p(dyn),
                                         _p(_f32(zo)), _p(norm), eps, m, box_loss_mult, level,
                                         int(disable_multiscale), bg, density_bias, _p(draw), _p(terms),
-                                        _p(sums), *[_p(t) for t in (render_out or (None,) * 6)], _p(draw_ray_sum)), 'durf_loss_bwd')
-    return draw, sums
+                                        None if defer_sums else _p(sums), *[_p(t) for t in (render_out or (None,) * 6)],
+                                        _p(draw_ray_sum)), 'durf_loss_bwd')
+    return draw, (terms if defer_sums else sums)
 
 
 STAT_ROWS = ('losses', 'obj_losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses', 'tv_losses',
@@ -420,8 +422,9 @@ STAT_ROWS = ('losses', 'obj_losses', 'd_losses', 'n_losses', 'e_losses', 's_loss
 STATS_ASSEMBLE, STATS_PSNR = 1, 2
 
 
-def train_stats(norms, sums, weight_l2, pose6, prev6, target6, t_vals_levels, mults, mode, out=None):
-    """Scalars of utils.Stats in one launch; see durf_train_stats.  -> out [2 + 17 L]"""
+def train_stats(norms, sums, weight_l2, pose6, prev6, target6, t_vals_levels, mults, mode, out=None, terms=None):
+    """Scalars of utils.Stats in one launch; see durf_train_stats.  -> out [2 + 17 L]
+    terms: per-level [7,B] tensors of loss_bwd(defer_sums=True); reduced into `sums` by the same launch."""
     L = norms.shape[0]
     K = 0 if pose6 is None else pose6.shape[0]
     N = t_vals_levels[0].shape[1] - 1
@@ -431,7 +434,9 @@ def train_stats(norms, sums, weight_l2, pose6, prev6, target6, t_vals_levels, mu
     m = (C.c_float * 6)(*[float(x) for x in mults])
     _lib.check(_lib.lib().durf_train_stats(_stream(), L, K, N, _p(norms), _p(sums), _p(weight_l2),
                                            _p(pose6) if K else None, _p(prev6) if K else None,
-                                           _p(target6) if K else None, ptrs, m, mode, _p(out)), 'durf_train_stats')
+                                           _p(target6) if K else None, ptrs, m, mode, _p(out),
+                                           (C.c_void_p * L)(*[t.data_ptr() for t in terms]) if terms is not None else None,
+                                           int(terms[0].shape[1]) if terms is not None else 0), 'durf_train_stats')
     return out
 
 

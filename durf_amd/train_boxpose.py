@@ -89,7 +89,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     else:
         view_tile = ops.expand_view(rows, N, ctx['view'])
     ray_sums = torch.empty(L, B, 4, device=dev) if dd is not None else None
-    sums = torch.empty(L, ops.TERM_ROWS, device=dev)
+    sums = torch.empty(L, ops.TERM_ROWS, device=dev)      # filled by the stats launch from the per-ray terms (ops.train_stats)
+    terms = [None] * L
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
@@ -103,11 +104,11 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                           float(config.box_loss_mult), lvl, config.disable_multiscale_loss, norm=norms[lvl])
         norm = norms[lvl]
         out = (lv['rgb'], lv['depth'], lv['acc'], lv['weights'], lv['t_mids'], lv['t_dists']) if lv['deferred'] else None
-        draw, _ = ops.loss_bwd(lv['raw_b'], lv['raws'], ctx['slot'], lv['t_vals'], ctx['d_s'], pixels, lossmult,
-                               gt_depth, sky, dyn, ctx['zo'], norm, float(eps),
-                               level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
-                               model.density_bias, config.disable_multiscale_loss, sums=sums[lvl], render_out=out,
-                               draw_ray_sum=None if dd is None else ray_sums[lvl])
+        draw, terms[lvl] = ops.loss_bwd(lv['raw_b'], lv['raws'], ctx['slot'], lv['t_vals'], ctx['d_s'], pixels, lossmult,
+                                        gt_depth, sky, dyn, ctx['zo'], norm, float(eps),
+                                        level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
+                                        model.density_bias, config.disable_multiscale_loss, render_out=out,
+                                        draw_ray_sum=None if dd is None else ray_sums[lvl], defer_sums=True)
         if f32:                               # exact-fp32 parity instrument: per-MLP fp32 backward + weight gradients
             fl = lv['f32']
             off = lay.mlp_off['MLP_0']
@@ -183,7 +184,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         multi = dd['multi_hit']
     else:
         multi = (dyn > 1).sum() if lay.K > 1 else torch.zeros((), dtype=torch.int64, device=dev)
-    raw = dict(norms=norms, sums=sums, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if lay.K > 0 else None,
+    raw = dict(norms=norms, sums=sums, terms=terms, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if lay.K > 0 else None,
                multi_hit=multi)
     return grad, raw, pose
 
@@ -200,7 +201,7 @@ def _assemble_stats(config, batch, raw, prev, mode):
     t_levels = [r[4] for r in raw['ret']]
     return ops.train_stats(raw['norms'], raw['sums'], raw['weight_l2'], pose6,
                            prev[0].contiguous() if K else None, batch['target'].contiguous() if K else None,
-                           t_levels, _stat_mults(config), mode)
+                           t_levels, _stat_mults(config), mode, terms=raw['terms'])
 
 
 def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, reduce_stats=True):

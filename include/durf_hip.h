@@ -185,7 +185,7 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                   const float* lossmult, const float* gt_depth, const float* sky, const int32_t* dyn,
                   const float* zo, const float* norm, float eps, const float* mults,
                   float box_loss_mult, int level, int disable_multiscale, float bg, float density_bias,
-                  float* draw, float* terms, float* term_sums,
+                  float* draw, float* terms, float* term_sums /* nullable: see durf_train_stats */,
                   float* rgb_out /* nullable [B,3] */, float* depth_out /* nullable [B] */,
                   float* acc_out /* nullable [B] */, float* weights_out /* nullable [B,N] */,
                   float* t_mids_out, float* t_dists_out /* nullable [B,N], written with weights_out: the level's
@@ -200,9 +200,13 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
  * out [2 + 17 L]: loss | 15 rows of L (losses, obj_losses, d, n, e, s, distr, tv, offsets,
  * offset_x, offset_y, offset_z, offset_yaw, psnrs, obj_psnrs) | 2L sampling stats | weight_l2.
  * mode bit 0: everything but the PSNRs; bit 1: PSNRs from out's (possibly all-reduced) losses. */
-int durf_train_stats(void* stream, int L, int K, int N, const float* norms, const float* sums,
+int durf_train_stats(void* stream, int L, int K, int N, const float* norms, float* sums,
                      const float* weight_l2, const float* pose6, const float* prev6, const float* target6,
-                     const float* const* t_vals, const float* mults, int mode, float* out);
+                     const float* const* t_vals, const float* mults, int mode, float* out,
+                     const float* const* terms /* nullable: L device pointers to durf_loss_bwd's per-ray terms [7,B];
+                     given (with mode bit 0), the launch reduces them itself into sums [L,7] -- in durf_loss_bwd's own
+                     order -- and durf_loss_bwd may be called with term_sums = NULL (two launches fewer per step) */,
+                     int B);
 
 /* K11 fused MLP backward (data path).  draw [*,4] fp32 head gradients (object MLPs gather
  * rows through ray_idx); relu_mask from durf_mlp_fwd; dz: same size/layout as the stash,
