@@ -44,3 +44,11 @@ def cperm_cols(nks):
             for e in range(8):
                 pos_of_feat[16 * ks + (e & 3) + 8 * (e >> 2) + 4 * hi] = 16 * ks + 8 * hi + e
     return torch.tensor(pos_of_feat)
+
+
+def extra_fuzz_seeds(kind):
+    """DURF_FUZZ_EXTRA=n widens the seeded random sweeps by n more seeds (one-off soak runs; default 0)"""
+    import os
+    n = int(os.environ.get('DURF_FUZZ_EXTRA', '0'))
+    base = 1000 if kind == 'FWD' else 2000
+    return list(range(base, base + n))

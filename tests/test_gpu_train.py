@@ -394,11 +394,15 @@ def test_train_step_with_other_level_counts(cuda, L, K):
             assert _rel(grad.cpu()[sl], og[sl]) < 5e-2, '%s grad rel err %g' % (name, _rel(grad.cpu()[sl], og[sl]))
 
 
-@pytest.mark.parametrize('seed', [200, 201, 202, 203, 204, 205])
-def test_train_step_random_configurations(cuda, seed):
-    """Seeded sweep over loss-knob / shape combinations of one full step (same gates as test_train_step): loss
-    multipliers off their shipped values, box loss, weight decay, multiscale loss off, ragged B, K in 0..5."""
+@pytest.mark.parametrize('precision', ['bf16', 'f32'])
+@pytest.mark.parametrize('seed', [200, 201, 202, 203, 204, 205] + H.extra_fuzz_seeds('TRAIN'))
+def test_train_step_random_configurations(cuda, seed, precision):
+    """Seeded sweep over loss-knob / shape combinations of one full step: loss multipliers off their shipped values, box
+    loss, weight decay, multiscale loss off, ragged B, K in 0..5.  bf16: the production path against the oracle with
+    bf16-rounded GEMM operands (gates of test_train_step).  f32: the exact-fp32 instrument against the fp32 oracle at
+    test_train_step_fp32_exact's gates.  DURF_FUZZ_EXTRA=n adds n seeds (soak runs)."""
     import random
+    f32 = precision == 'f32'
     r = random.Random(seed)
     K = r.choice([0, 1, 2, 3, 5])
     N = r.choice([32, 64])
@@ -413,6 +417,7 @@ def test_train_step_random_configurations(cuda, seed):
     utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
                     'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
                     'Config.randomized = True\nConfig.rand_bkgd = False\nConfig.tv_loss_mult = 0.0\n' % N +
+                    ("MipNerfModel.mlp_precision = 'f32'\n" if f32 else '') +
                     ''.join('Config.%s = %r\n' % kv for kv in knobs.items()))
     config = utils.configured(utils.Config)
     b = synthetic.make_batch(B, K, seed=seed)
@@ -427,7 +432,7 @@ def test_train_step_random_configurations(cuda, seed):
     torch.cuda.synchronize()
     ocfg = dict(R.CONFIG_DEFAULTS, randomized=True, tv_loss_mult=0.0, **knobs)
     p2, st2, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, dict(num_samples=N), lr, eps,
-                                           alpha, prev_c, noise=noise_c, mlp_hook=R.mlp_apply_bf16)
+                                           alpha, prev_c, noise=noise_c, mlp_hook=None if f32 else R.mlp_apply_bf16)
     if (ostats['losses'] != ostats['losses']).any():
         pytest.skip('seed %d drew a multi-hit ray (NaN in the reference too)' % seed)
     og = torch.cat([x.reshape(-1) for x in ograds])
@@ -436,11 +441,18 @@ def test_train_step_random_configurations(cuda, seed):
         w, _ = lay.mlp_dims(name)
         sl = slice(lay.mlp_off[name], lay.mlp_off[name] + lay.mlp_size[w])
         if float(og[sl].norm()) > 0:
-            assert _rel(grad.cpu()[sl], og[sl]) < 5e-2, 'seed %d %s %s grad rel err %g' % (
+            assert _rel(grad.cpu()[sl], og[sl]) < (1e-3 if f32 else 5e-2), 'seed %d %s %s grad rel err %g' % (
                 seed, knobs, name, _rel(grad.cpu()[sl], og[sl]))
     state = train_boxpose.create_train_state(variables)
     new_state, stats, rng, pose = train_boxpose.train_step(model, config, 0, state, db, lr, eps, alpha, prev_d, noise=noise_d)
     for k in ('losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses'):
-        torch.testing.assert_close(getattr(stats, k).cpu(), ostats[k], rtol=2e-3, atol=1e-6,
-                                   msg=lambda m: 'seed %d %s: %s: %s' % (seed, knobs, k, m))
-    torch.testing.assert_close(stats.loss.cpu(), ostats['loss'], rtol=2e-3, atol=1e-6)
+        got, want = getattr(stats, k).cpu(), ostats[k]
+        tight = 2e-5 if f32 else 2e-3
+        # the depth-shaped terms of the RESAMPLED level hinge on where its samples fall relative to the LIDAR depth:
+        # a 1e-6 difference in level-1 t_vals moves them by up to 2.4e-4 rel even in exact-fp32 mode (soak run, 46
+        # seeds), 5e-3 in bf16 mode -- conditioning of the quantity, not of the kernels
+        loose = (1e-3 if f32 else 1e-2) if k in ('n_losses', 'd_losses', 'distr_losses') else tight
+        msg = lambda m: 'seed %d %s %s: %s: %s' % (seed, precision, knobs, k, m)
+        torch.testing.assert_close(got[:1], want[:1], rtol=tight, atol=1e-7 if f32 else 1e-6, msg=msg)
+        torch.testing.assert_close(got[1:], want[1:], rtol=loose, atol=1e-7 if f32 else 1e-6, msg=msg)
+    torch.testing.assert_close(stats.loss.cpu(), ostats['loss'], rtol=1e-4 if f32 else 2e-3, atol=1e-7 if f32 else 1e-6)
