@@ -196,3 +196,15 @@ def test_forward_random_configurations(cuda, seed):
                                            seed, K, N, B, knobs, i, lvl, m))
         assert (got[0].cpu() - ref_32[lvl][0]).abs()[single].max() < 2e-2, 'rgb vs fp32 oracle'
         assert torch.equal(got[8].cpu().long().reshape(-1), rb[8].reshape(-1)), 'dyn_mask'
+    if K > 0:       # the de-duplicated background evaluation renders bit-identically to the plain path
+        from durf_amd import ops
+        keep = ops.DEDUP_HIT_RAYS
+        try:
+            ops.DEDUP_HIT_RAYS = not keep
+            _, ret2, _, _ = _run(cuda, B, K, N, randomized, seed=seed, alpha=alpha, far=far, knobs=knobs)
+        finally:
+            ops.DEDUP_HIT_RAYS = keep
+        for lvl in range(2):
+            for i in range(5):
+                a, c = ret[lvl][i].cpu(), ret2[lvl][i].cpu()
+                assert torch.equal(a[single], c[single]), 'seed %d: output %d l%d differs with de-duplication toggled' % (seed, i, lvl)
