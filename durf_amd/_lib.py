@@ -27,6 +27,8 @@ _SIGS = {
     'durf_ray_setup': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
     'durf_compact_hits': (i32, [vp, i32, i32, vp, vp, vp, vp]),
     'durf_compact_classes': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp]),
+    'durf_compact_all': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]),
+    'durf_ray_prologue': (i32, [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]),
     'durf_sample_t': (i32, [vp, i32, i32, vp, vp, vp, i32, vp]),
     'durf_view_enc': (i32, [vp, i32, vp, vp, vp]),
     'durf_encode_bkgd': (i32, [vp, i32, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp]),

@@ -9,11 +9,11 @@
 // ---------------------------------------------------------------------------
 // K1: ray_setup.  One thread per ray, K-loop; rotation matrices built once per block.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_ray_setup(int B, int K, const float* __restrict__ origins, const float* __restrict__ dirs,
-            const float* __restrict__ pose, const float* __restrict__ ext,
-            float* __restrict__ origins_s, float* __restrict__ dirs_s,
-            int32_t* __restrict__ hit, float* __restrict__ zo) {
+__device__ __forceinline__ void ray_setup_block(int blk, int B, int K, const float* __restrict__ origins,
+                                                const float* __restrict__ dirs, const float* __restrict__ pose,
+                                                const float* __restrict__ ext, float* __restrict__ origins_s,
+                                                float* __restrict__ dirs_s, int32_t* __restrict__ hit,
+                                                float* __restrict__ zo) {
     __shared__ float sR[DURF_MAX_OBJ][9];
     __shared__ float sT[DURF_MAX_OBJ][3];   // R * (-c)
     __shared__ float sE[DURF_MAX_OBJ][3];
@@ -46,7 +46,7 @@ k_ray_setup(int B, int K, const float* __restrict__ origins, const float* __rest
         }
     }
     __syncthreads();
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blk * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float ox = origins[b * 3 + 0], oy = origins[b * 3 + 1], oz = origins[b * 3 + 2];
     const float dx = dirs[b * 3 + 0], dy = dirs[b * 3 + 1], dz = dirs[b * 3 + 2];
@@ -95,6 +95,14 @@ k_ray_setup(int B, int K, const float* __restrict__ origins, const float* __rest
     zo[b] = zsum;
 }
 
+__global__ void __launch_bounds__(256)
+k_ray_setup(int B, int K, const float* __restrict__ origins, const float* __restrict__ dirs,
+            const float* __restrict__ pose, const float* __restrict__ ext,
+            float* __restrict__ origins_s, float* __restrict__ dirs_s,
+            int32_t* __restrict__ hit, float* __restrict__ zo) {
+    ray_setup_block(blockIdx.x, B, K, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo);
+}
+
 // ---------------------------------------------------------------------------
 // ordered stream compaction of hit[:,k]; one block per object, wave-ballot scan.
 // ---------------------------------------------------------------------------
@@ -104,10 +112,9 @@ k_ray_setup(int B, int K, const float* __restrict__ origins, const float* __rest
 //   Block 0 also writes dyn[b] = number of boxes ray b hits, count[2] = count0 * N + count1 (the valid rows of the
 //   compacted buffers) and count[3] = number of rays that hit several boxes.
 template <bool CLASSES>
-__global__ void __launch_bounds__(1024)
-k_compact_hits(int B, int K, int N, const int32_t* __restrict__ hit, int32_t* __restrict__ idx,
-               int32_t* __restrict__ count, int32_t* __restrict__ slot, int32_t* __restrict__ dyn) {
-    const int k = blockIdx.x;
+__device__ __forceinline__ void compact_hits_block(int k, int B, int K, int N, const int32_t* __restrict__ hit,
+                                                   int32_t* __restrict__ idx, int32_t* __restrict__ count,
+                                                   int32_t* __restrict__ slot, int32_t* __restrict__ dyn) {
     const int KS = CLASSES ? 2 : K;                  // columns of slot
     __shared__ int wave_tot[16];
     __shared__ int base_s, multi_s;
@@ -157,13 +164,29 @@ k_compact_hits(int B, int K, int N, const int32_t* __restrict__ hit, int32_t* __
     }
 }
 
+template <bool CLASSES>
+__global__ void __launch_bounds__(1024)
+k_compact_hits(int B, int K, int N, const int32_t* __restrict__ hit, int32_t* __restrict__ idx,
+               int32_t* __restrict__ count, int32_t* __restrict__ slot, int32_t* __restrict__ dyn) {
+    compact_hits_block<CLASSES>(blockIdx.x, B, K, N, hit, idx, count, slot, dyn);
+}
+
+// both compactions of a step in one launch: blocks [0, K) the per-object ray lists, blocks K, K+1 the two ray classes
+__global__ void __launch_bounds__(1024)
+k_compact_all(int B, int K, int N, const int32_t* __restrict__ hit, int32_t* __restrict__ idx_obj,
+              int32_t* __restrict__ count_obj, int32_t* __restrict__ slot_obj, int32_t* __restrict__ idx_cls,
+              int32_t* __restrict__ count_cls, int32_t* __restrict__ slot_cls, int32_t* __restrict__ dyn) {
+    if ((int)blockIdx.x < K) compact_hits_block<false>(blockIdx.x, B, K, 0, hit, idx_obj, count_obj, slot_obj, nullptr);
+    else compact_hits_block<true>(blockIdx.x - K, B, K, N, hit, idx_cls, count_cls, slot_cls, dyn);
+}
+
 // ---------------------------------------------------------------------------
 // K2: level-0 t_vals (mip.py:353-368).  linspace(0,1,N+1)[i] == i/N in fp32.
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_sample_t(int B, int N, const float* __restrict__ near, const float* __restrict__ far,
-           const float* __restrict__ t_rand, int lindisp, float* __restrict__ t_vals) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void sample_t_block(size_t blk, int B, int N, const float* __restrict__ near,
+                                               const float* __restrict__ far, const float* __restrict__ t_rand,
+                                               int lindisp, float* __restrict__ t_vals) {
+    const size_t i = blk * blockDim.x + threadIdx.x;
     const size_t tot = (size_t)B * (N + 1);
     if (i >= tot) return;
     const int b = (int)(i / (N + 1)), n = (int)(i % (N + 1));
@@ -182,13 +205,18 @@ k_sample_t(int B, int N, const float* __restrict__ near, const float* __restrict
     t_vals[i] = t;
 }
 
+__global__ void __launch_bounds__(256)
+k_sample_t(int B, int N, const float* __restrict__ near, const float* __restrict__ far,
+           const float* __restrict__ t_rand, int lindisp, float* __restrict__ t_vals) {
+    sample_t_block(blockIdx.x, B, N, near, far, t_rand, lindisp, t_vals);
+}
+
 // ---------------------------------------------------------------------------
 // K5: view-direction encoding (mip.py:36-45): [v, sin(2^i v_j), sin(2^i v_j + pi/2)]
 // ---------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_view_enc(int B, const float* __restrict__ viewdirs, __bf16* __restrict__ out_bf16,
-           float* __restrict__ out_f32) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void view_enc_block(int blk, int B, const float* __restrict__ viewdirs,
+                                               __bf16* __restrict__ out_bf16, float* __restrict__ out_f32) {
+    const int i = blk * blockDim.x + threadIdx.x;
     if (i >= B * DURF_VIEW_DIM) return;
     const int b = i / DURF_VIEW_DIM, f = i % DURF_VIEW_DIM;
     float val = 0.0f;
@@ -202,6 +230,28 @@ k_view_enc(int B, const float* __restrict__ viewdirs, __bf16* __restrict__ out_b
     }
     if (out_bf16) out_bf16[i] = (__bf16)val;
     if (out_f32 && f < 27) out_f32[b * 27 + f] = val;
+}
+
+__global__ void __launch_bounds__(256)
+k_view_enc(int B, const float* __restrict__ viewdirs, __bf16* __restrict__ out_bf16,
+           float* __restrict__ out_f32) {
+    view_enc_block(blockIdx.x, B, viewdirs, out_bf16, out_f32);
+}
+
+// The three per-ray preparations of a step that depend on nothing but the batch -- ray setup (K1), view-direction
+// encoding (K5) and the level-0 sample positions (K2) -- as ONE launch: the grid covers the largest of the three index
+// spaces (B (N+1) sample positions) and the leading blocks also do the other two.
+__global__ void __launch_bounds__(256)
+k_ray_prologue(int B, int K, int N, const float* __restrict__ origins, const float* __restrict__ dirs,
+               const float* __restrict__ pose, const float* __restrict__ ext, float* __restrict__ origins_s,
+               float* __restrict__ dirs_s, int32_t* __restrict__ hit, float* __restrict__ zo,
+               const float* __restrict__ viewdirs, __bf16* __restrict__ view_bf16,
+               const float* __restrict__ near, const float* __restrict__ far, const float* __restrict__ t_rand,
+               int lindisp, float* __restrict__ t_vals) {
+    if ((int)blockIdx.x < (B + 255) / 256)                            // block-uniform: ray_setup_block has a barrier
+        ray_setup_block(blockIdx.x, B, K, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo);
+    if ((int)blockIdx.x < (B * DURF_VIEW_DIM + 255) / 256) view_enc_block(blockIdx.x, B, viewdirs, view_bf16, nullptr);
+    sample_t_block(blockIdx.x, B, N, near, far, t_rand, lindisp, t_vals);
 }
 
 // ---------------------------------------------------------------------------
@@ -497,6 +547,19 @@ int durf_ray_setup(void* stream, int B, int K, const float* origins, const float
     return 0;
 }
 
+int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
+                      const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
+                      const float* viewdirs, void* view_bf16, const float* near, const float* far, const float* t_rand,
+                      int lindisp, float* t_vals) {
+    DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_ray_prologue, dim3(durf_cdiv((size_t)B * (N + 1), 256)), dim3(256), 0, (hipStream_t)stream, B,
+                       K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, (__bf16*)view_bf16, near,
+                       far, t_rand, lindisp, t_vals);
+    DURF_CHECK_LAUNCH("durf_ray_prologue");
+    return 0;
+}
+
 int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* idx,
                       int32_t* count, int32_t* slot) {
     if (K <= 0 || B <= 0) return 0;
@@ -513,6 +576,16 @@ int durf_compact_classes(void* stream, int B, int K, int N, const int32_t* hit, 
     hipLaunchKernelGGL(k_compact_hits<true>, dim3(2), dim3(1024), 0, (hipStream_t)stream, B, K, N, hit, idx, count,
                        slot, dyn);
     DURF_CHECK_LAUNCH("durf_compact_classes");
+    return 0;
+}
+
+int durf_compact_all(void* stream, int B, int K, int N, const int32_t* hit, int32_t* idx_obj, int32_t* count_obj,
+                     int32_t* slot_obj, int32_t* idx_cls, int32_t* count_cls, int32_t* slot_cls, int32_t* dyn) {
+    DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ, "1 <= K <= DURF_MAX_OBJ");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(k_compact_all, dim3(K + 2), dim3(1024), 0, (hipStream_t)stream, B, K, N, hit, idx_obj, count_obj,
+                       slot_obj, idx_cls, count_cls, slot_cls, dyn);
+    DURF_CHECK_LAUNCH("durf_compact_all");
     return 0;
 }
 

@@ -186,12 +186,21 @@ class MipNerfModel:
         pc = variables['params']['box_centers']
         pose = pc[ts].contiguous()
         ext = ext.reshape(-1, 3).contiguous() if K > 0 else torch.zeros(0, 3, device=dev)
-        o_s, d_s, hit, zo = ops.ray_setup(rays.origins, rays.directions, pose, ext)
-        idx, count, slot = ops.compact_hits(hit)
-        view = ops.view_enc(rays.viewdirs)
         radii = rays.radii.reshape(-1).contiguous()
         near, far = rays.near.reshape(-1).contiguous(), rays.far.reshape(-1).contiguous()
         f32 = self.mlp_precision == 'f32'
+        g = _make_generator(rng, dev) if randomized else None
+        if randomized and noise is None:
+            u = torch.rand(2, B, N + 1, device=dev, generator=g)          # one launch for both levels' noise
+            noise = dict(t_rand=u[0], u_rand=u[1])
+        use_dd = bool(Kd) and not f32 and ops.DEDUP_HIT_RAYS
+        # ray setup + view encoding + level-0 sample positions: one launch; both compactions: one launch
+        o_s, d_s, hit, zo, view, t_vals0 = ops.ray_prologue(rays.origins, rays.directions, pose, ext, rays.viewdirs, near,
+                                                            far, N, noise['t_rand'] if randomized else None, self.lindisp)
+        if use_dd:
+            (idx, count, slot), cls = ops.compact_all(hit, N)     # cls also counts the boxes each ray hits
+        else:
+            (idx, count, slot), cls = ops.compact_hits(hit), None
         view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1] if f32 else None
         packs = {}
         if not f32:                                  # every weight stream in one launch; the K object MLPs sit back
@@ -203,10 +212,6 @@ class MipNerfModel:
             if Kd:
                 packs['obj'] = pk_o
         bk = ops.BKGD_RAND if rand_bkgd else (ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY)
-        g = _make_generator(rng, dev) if randomized else None
-        if randomized and noise is None:
-            u = torch.rand(2, B, N + 1, device=dev, generator=g)          # one launch for both levels' noise
-            noise = dict(t_rand=u[0], u_rand=u[1])
         rows = B * N
         cyl = self.ray_shape == 'cylinder'
         view_tiles_obj = ops.obj_view_tiles(Kd, B, N, dev) if (train and Kd and not f32) else None
@@ -215,8 +220,6 @@ class MipNerfModel:
         ret = []
         t_vals = weights = None
         box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
-        use_dd = bool(Kd) and not f32 and ops.DEDUP_HIT_RAYS
-        cls = ops.compact_classes(hit, N) if use_dd else None     # also counts the boxes each ray hits
         if cls is not None:
             dyn_mask = cls[3].reshape(B, 1)
         elif K > 1:
@@ -245,7 +248,7 @@ class MipNerfModel:
         for lvl in range(self.num_levels):
             last = lvl == self.num_levels - 1
             if lvl == 0:
-                t_vals = ops.sample_t(near, far, N, noise['t_rand'] if randomized else None, self.lindisp)
+                t_vals = t_vals0
             elif t_next is not None:
                 t_vals = t_next
             else:

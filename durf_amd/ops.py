@@ -69,6 +69,36 @@ def ray_setup(origins, dirs, pose, ext):
     return o_s, d_s, hit, zo
 
 
+def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, lindisp=False):
+    """ray_setup + view_enc (bf16) + sample_t as ONE launch (durf_ray_prologue)
+    -> origins_s[B,3], dirs_s[B,3], hit[B,K] int32, zo[B], view[B,32] bf16, t_vals[B,N+1]"""
+    B, K = origins.shape[0], pose.shape[0]
+    dev = origins.device
+    o_s = torch.empty(B, 3, device=dev)
+    d_s = torch.empty(B, 3, device=dev)
+    hit = torch.empty(B, K, dtype=torch.int32, device=dev)
+    zo = torch.empty(B, device=dev)
+    view = torch.empty(B, VIEW_DIM, dtype=torch.bfloat16, device=dev)
+    t = torch.empty(B, N + 1, device=dev)
+    _lib.check(_lib.lib().durf_ray_prologue(_stream(), B, K, N, _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
+                                            _p(_f32(ext)), _p(o_s), _p(d_s), _p(hit), _p(zo), _p(_f32(viewdirs)), _p(view),
+                                            _p(_f32(near)), _p(_f32(far)), _p(None if t_rand is None else _f32(t_rand)),
+                                            int(lindisp), _p(t)), 'durf_ray_prologue')
+    return o_s, d_s, hit, zo, view, t
+
+
+def compact_all(hit, N):
+    """compact_hits + compact_classes as ONE launch -> (idx, count, slot), (idx2, count4, slot2, dyn)"""
+    B, K = hit.shape
+    dev = hit.device
+    i32 = lambda *sh: torch.empty(*sh, dtype=torch.int32, device=dev)
+    idx, count, slot = i32(K, B), i32(K), i32(B, K)
+    idx2, count4, slot2, dyn = i32(2, B), i32(4), i32(B, 2), i32(B)
+    _lib.check(_lib.lib().durf_compact_all(_stream(), B, K, N, _p(hit), _p(idx), _p(count), _p(slot), _p(idx2),
+                                           _p(count4), _p(slot2), _p(dyn)), 'durf_compact_all')
+    return (idx, count, slot), (idx2, count4, slot2, dyn)
+
+
 def compact_hits(hit):
     """-> idx[K,B] int32, count[K] int32, slot[B,K] int32"""
     B, K = hit.shape

@@ -40,6 +40,12 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_compact_classes.restype = i32
     L.durf_compact_classes.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp]
     #   (stream, B, K, N, hit, idx, count, slot, dyn)
+    L.durf_compact_all.restype = i32
+    L.durf_compact_all.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, B, K, N, hit, idx_obj, count_obj, slot_obj, idx_cls, count_cls, slot_cls, dyn)
+    L.durf_ray_prologue.restype = i32
+    L.durf_ray_prologue.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    #   (stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far, t_rand, lindisp, t_vals)
     L.durf_sample_t.restype = i32
     L.durf_sample_t.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
     #   (stream, B, N, near, far, t_rand, lindisp, t_vals)

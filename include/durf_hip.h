@@ -83,6 +83,16 @@ int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* i
  * several boxes}; dyn [B] = boxes hit per ray (obbpose_model.py:257 `jnp.array(ret_masks).sum(axis=0)`). */
 int durf_compact_classes(void* stream, int B, int K, int N, const int32_t* hit, int32_t* idx, int32_t* count,
                          int32_t* slot, int32_t* dyn);
+/* Both compactions in one launch (a training step needs both): the per-object lists of durf_compact_hits and the two
+ * ray classes of durf_compact_classes. */
+int durf_compact_all(void* stream, int B, int K, int N, const int32_t* hit, int32_t* idx_obj, int32_t* count_obj,
+                     int32_t* slot_obj, int32_t* idx_cls, int32_t* count_cls, int32_t* slot_cls, int32_t* dyn);
+/* The three preparations of a step that depend on the batch only, as ONE launch: durf_ray_setup, durf_view_enc (bf16
+ * output) and durf_sample_t -- same kernels' code, same results. */
+int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
+                      const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
+                      const float* viewdirs, void* view_bf16, const float* near, const float* far,
+                      const float* t_rand /* nullable */, int lindisp, float* t_vals);
 
 /* mip.sample_along_rays t_vals (mip.py:353-368). t_rand nullable (randomized=False). */
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,

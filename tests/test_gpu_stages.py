@@ -333,3 +333,35 @@ def test_pack_weights_all_matches_the_per_mlp_packers(cuda):
             assert bb is None and ob is None
     (bf, _), none = ops.pack_weights_all(pb, 0, None, no)
     assert none is None and torch.equal(bf, ops.pack_weights(256, 60, pb))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('B,K,N,rand', [(300, 3, 32, True), (1024, 1, 128, False), (77, 8, 64, True), (256, 0, 32, True)])
+def test_fused_prologue_and_compaction_match_the_separate_launches(cuda, B, K, N, rand):
+    """durf_ray_prologue == durf_ray_setup + durf_view_enc + durf_sample_t, durf_compact_all == durf_compact_hits +
+    durf_compact_classes: the same device code behind one launch each, so bit for bit"""
+    b = synthetic.make_batch(B, K, seed=40 + K, allow_multi_hit=True)
+    db = H.device_batch(b, cuda)
+    rays = db['rays']
+    pose = db['init'][b['ts']].contiguous() if K else torch.zeros(0, 6, device=cuda)
+    ext = db['ext'].reshape(-1, 3).contiguous() if K else torch.zeros(0, 3, device=cuda)
+    near, far = rays.near.reshape(-1).contiguous(), rays.far.reshape(-1).contiguous()
+    t_rand = torch.rand(B, N + 1, device=cuda) if rand else None
+    o_s, d_s, hit, zo = ops.ray_setup(rays.origins, rays.directions, pose, ext)
+    view = ops.view_enc(rays.viewdirs)
+    t = ops.sample_t(near, far, N, t_rand)
+    got = ops.ray_prologue(rays.origins, rays.directions, pose, ext, rays.viewdirs, near, far, N, t_rand)
+    for a, c, name in zip(got, (o_s, d_s, hit, zo, view, t), ('origins_s', 'dirs_s', 'hit', 'zo', 'view', 't_vals')):
+        assert torch.equal(a, c), name
+    if K:
+        idx, count, slot = ops.compact_hits(hit)
+        idx2, count4, slot2, dyn = ops.compact_classes(hit, N)
+        (i1, c1, s1), (i2, c2, s2, d2) = ops.compact_all(hit, N)
+        assert torch.equal(c1, count) and torch.equal(s1, slot) and torch.equal(c2, count4) and torch.equal(s2, slot2)
+        assert torch.equal(d2, dyn)
+        for k in range(K):
+            n = int(count[k])
+            assert torch.equal(i1[k, :n], idx[k, :n])
+        for k in range(2):
+            n = int(count4[k])
+            assert torch.equal(i2[k, :n], idx2[k, :n])
