@@ -167,7 +167,7 @@ def test_render_image(cuda):
     torch.testing.assert_close(acc.cpu(), ref[2], rtol=0, atol=2e-3)
 
 
-@pytest.mark.parametrize('seed', list(range(100, 112)) + H.extra_fuzz_seeds('FWD'))
+@pytest.mark.parametrize('seed', list(range(100, 108)) + H.extra_fuzz_seeds('FWD'))
 def test_forward_random_configurations(cuda, seed):
     """Seeded sweep over combinations the hand-picked cases above do not pair up: ragged ray counts (partial 256-sample
     blocks and compaction rounds), K in 0..8, N in {32, 64, 96, 128}, randomized sampling, and the gin knobs two at a
