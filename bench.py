@@ -333,6 +333,8 @@ def main():
             tr, src = pmc_traffic(int(_lib.lib().durf_version()), args.config, B, dom)
             roof = dict(bound='mfma', kernel=dom, achieved=d['achieved'], peak=PEAK_BF16 / 1e12, unit='TFLOP/s',
                         frac=d['frac'], traffic=tr, traffic_source=src, launch_us=d['us'], all=info)
+            if tr:      # what the counter bytes say about the launch: its HBM rate as a fraction of the 8 TB/s peak
+                roof['traffic_frac_of_hbm_peak'] = tr / (d['us'] * 1e-6) / PEAK_HBM
             # end-to-end MFMA rate of the whole step (fwd + bwd-data + dW = 3 x fwd FLOPs, both levels, incl.
             # the object MLPs on the measured fraction of hit rays) and the time outside the three MLP kernels
             step_s = dt / args.steps
