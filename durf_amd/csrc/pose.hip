@@ -66,9 +66,15 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
             if (c) z = z + 1.5707963705062866f;
             const float t = 314.15927124023438f;                          // safe_sin wrap (math.py:35-46)
             if (!(fabsf(z) < t)) { float q = fmodf(z, t); if (q != 0.0f && q < 0.0f) q += t; z = q; }
+#ifdef POSE_PRECISE_TRIG
             const float e = expf(-0.5f * (var[i] * sc * sc));
+            const float cz = cosf(z), sz = sinf(z);
+#else       // hardware exp / sin / cos (|z| < 314.16 after the wrap: abs error ~1e-6, against a 2e-3 gate vs fp64)
+            const float e = __expf(-0.5f * (var[i] * sc * sc));
+            const float cz = __cosf(z), sz = __sinf(z);
+#endif
             const float g = ge[3 + f] * bw.w[f / 6];
-            const float gxf = g * e * sc * cosf(z), gvf = g * (-0.5f * sc * sc) * e * sinf(z);
+            const float gxf = g * e * sc * cz, gvf = g * (-0.5f * sc * sc) * e * sz;
             if (i == 0) { gx[0] += gxf; gv[0] += gvf; }
             else if (i == 1) { gx[1] += gxf; gv[1] += gvf; }
             else { gx[2] += gxf; gv[2] += gvf; }
