@@ -31,15 +31,18 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_LEVELS = 2
-N_SAMPLES = 128
 MAC_BKGD, MAC_OBJ = 591872, 167552
 PEAK_BF16 = 2.5e15     # dense MFMA bf16 peak, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12      # HBM3E spec peak (6.29e12 measured-achievable), MI355X_MICROARCH.md
-ENC_BYTES, COMPOSITE_BYTES = 15928, 3108    # algorithmic bytes per ray-level, SURVEY.md 8(d) (bf16 features)
-FUSED_RAY_BYTES = COMPOSITE_BYTES + 516     # composite + resample in one launch: + the next level's t_vals, no weights re-read
+# algorithmic bytes per ray-level of the HBM-bound stages: derived from the workload's samples/ray in main()
+# (N = 128: encode 15 928 B with bf16 features; composite 3 108 B + 516 B for the next level's t_vals in the fused launch)
 
-# name -> (gin file, K objects, far, rays per GPU, extra gin bindings, box noise, alpha)
+# name -> (gin file, K objects, far, rays per GPU, extra gin bindings, box noise, alpha, label); samples/ray: WORKLOAD_SAMPLES
+WORKLOAD_SAMPLES = {'cfg1': 64}
 WORKLOADS = {
+    'cfg1': ('carla_dyn.gin', 0, 200.0, 512, ('MipNerfModel.num_samples = 64',), 0.0, 10.0,
+             'cfg1: CARLA static scene (configs/carla_dyn.gin, 0 dynamic boxes), 64 samples/ray, the gin-literal 512-ray batch '
+             '(BASELINE.json configs[0], the CPU-reference configuration)'),
     'cfg2': ('carla_dyn.gin', 1, 200.0, 4096, (), 0.0, 10.0,
              'cfg2: CARLA-like dynamic scene (configs/carla_dyn.gin), K=1 OBB, far=200'),
     'cfg3': ('waymo.gin', 3, 40.0, 4096, (), 0.0, 10.0,
@@ -118,7 +121,7 @@ def setup_workload(name, dev, rank=0, world=1, rays=0, objects=-1):
     model, variables = obbpose_model.construct_mipnerf(0, full, device=dev)
     state = train_boxpose.create_train_state(variables)
     return dict(config=config, model=model, state=state, batch=batch, batch_np=batch_np, prev=full['init'][0:1],
-                B=B, K=K_OBJ, far=far, alpha=alpha, label=label)
+                B=B, K=K_OBJ, far=far, alpha=alpha, label=label, N=model.num_samples)
 
 
 def board_calibration(dev, achieved_tflops):
@@ -144,12 +147,14 @@ def board_calibration(dev, achieved_tflops):
                 vendor_gemm_frac_of_peak=tf * 1e12 / PEAK_BF16, achieved_over_vendor_gemm=achieved_tflops / tf)
 
 
-def cpu_baseline(batch_np, K_OBJ, seconds_budget=15.0):
+def cpu_baseline(batch_np, K_OBJ, n_samples, config, seconds_budget=15.0):
     """The oracle's train_step (fp32 torch-CPU restatement of the reference step) timed on the
-    host cores on a bounded sample of the same workload.  A reported baseline, not a target."""
+    host cores on a bounded sample of the same workload: the first min(B, 512) rays at N = 64 (cfg1 runs its own
+    512-ray batch whole), the first 256 at N = 128, `randomized` and the loss multipliers as the GPU leg has them.
+    A reported baseline, not a target."""
     import torch
     from oracle import durf_ref as R
-    Bc = 256
+    Bc = min(batch_np['pixels'].shape[0], 512 if n_samples <= 64 else 256)
     sub = dict(batch_np)
     sub['rays'] = {k: v[:Bc] for k, v in batch_np['rays'].items()}
     for k in ('pixels', 'depth', 'sky'):
@@ -160,19 +165,27 @@ def cpu_baseline(batch_np, K_OBJ, seconds_budget=15.0):
     cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     params = R.init_params(0, ob['init'], K_OBJ)
-    cfg = dict(R.CONFIG_DEFAULTS, randomized=False)
+    cfg = dict(R.CONFIG_DEFAULTS)
+    for k in cfg:                                # the GPU leg's gin bindings (loss multipliers, randomized, clipping)
+        if hasattr(config, k):
+            cfg[k] = getattr(config, k)
     st = R.new_opt_state(params)
     prev = ob['init'][0:1]
-    mcfg = dict(num_samples=N_SAMPLES)
-    R.train_step(params, st, ob, cfg, mcfg, 5e-4, 3.0, 10.0, prev)      # warm-up
+    mcfg = dict(num_samples=n_samples)
+    g = torch.Generator().manual_seed(0)
+    noise = None
+    if cfg['randomized']:                        # the stratified-sampling draws (they replace the jax PRNG key)
+        noise = dict(t_rand=torch.rand(Bc, n_samples + 1, generator=g), u_rand=torch.rand(Bc, n_samples + 1, generator=g))
+    R.train_step(params, st, ob, cfg, mcfg, 5e-4, 3.0, 10.0, prev, noise=noise)      # warm-up
     n, t0 = 0, time.time()
     while n < 2 or (time.time() - t0 < seconds_budget and n < 20):
-        params, st, _, _ = R.train_step(params, st, ob, cfg, mcfg, 5e-4, 3.0, 10.0, prev)
+        params, st, _, _ = R.train_step(params, st, ob, cfg, mcfg, 5e-4, 3.0, 10.0, prev, noise=noise)
         n += 1
     dt = (time.time() - t0) / n
     return dict(value=Bc / dt, unit='rays/s', cores=cores, kind='port',
                 sample='%d steps of the oracle train_step (fp32 torch-CPU restatement, not JAX) on %d rays '
-                       'of the same workload (N=%d, K=%d), %.2f s/step' % (n, Bc, N_SAMPLES, K_OBJ, dt))
+                       'of the same workload (N=%d, K=%d, randomized=%s), %.2f s/step' % (n, Bc, n_samples, K_OBJ,
+                                                                                        cfg['randomized'], dt))
 
 
 def pmc_traffic(lib_version, workload, rays, kernel):
@@ -255,7 +268,7 @@ def main():
 
     w = setup_workload(args.config, dev, rank, world, rays=args.rays, objects=args.objects)
     config, model, state, batch, batch_np, prev = (w[k] for k in ('config', 'model', 'state', 'batch', 'batch_np', 'prev'))
-    B, K_OBJ, far, alpha, label = w['B'], w['K'], w['far'], w['alpha'], w['label']
+    B, K_OBJ, far, alpha, label, NS = w['B'], w['K'], w['far'], w['alpha'], w['label'], w['N']
     lr, eps = 5e-4, 3.0
 
     def sync():
@@ -307,15 +320,17 @@ def main():
     ops.TIMERS = None
 
     if rank == 0:
-        rows = B * N_SAMPLES
+        rows = B * NS
         hit = float(batch_np['hit_fraction'])
+        enc_bytes = 52 + 4 * (NS + 1) + 2 * 60 * NS          # ray in, t_vals out, bf16 features out
+        fused_bytes = (16 * NS + 4 * (NS + 1) + 12) + (4 * NS + 20) + 4 * (NS + 1)    # composite + the next level's t_vals
         # Roofline.  MLP kernels: MFMA-bound by definition -- algorithmic FLOPs per launch
         # = 2 * 591 872 MAC * samples (one level; the dW launch covers both levels) / live HIP-event time /
         # 2.5 PFLOP/s.  Encode / composite: HBM-bound -- algorithmic bytes per ray-level / time / 8 TB/s.
         mfma = {'mlp_fwd_256_train': 2.0 * MAC_BKGD * rows, 'mlp_bwd_256': 2.0 * MAC_BKGD * rows,
                 'mlp_dw_256': N_LEVELS * 2.0 * MAC_BKGD * rows}
         # (the fused per-ray launch is latency-bound at 4096 rays, DESIGN.md 4: reported, not a tuning target)
-        hbm = {'encode_bkgd': float(ENC_BYTES) * B, 'composite_resample': float(FUSED_RAY_BYTES) * B}
+        hbm = {'encode_bkgd': float(enc_bytes) * B, 'composite_resample': float(fused_bytes) * B}
         info = {}
         for k, (n, s) in totals.items():
             t = s / n
@@ -349,13 +364,13 @@ def main():
             for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
                 print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / args.steps),
                       file=sys.stderr)
-        cb = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(batch_np, K_OBJ)     # rank 0 at N = 1 only
+        cb = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(batch_np, K_OBJ, NS, config)   # rank 0, N = 1 only
         out = dict(metric='train_rays_per_sec', value=B * world * args.steps / dt, unit='rays/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
                    higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload=label + ', 128 samples/ray x 2 levels, 8x256 bkgd MLP + %d 8x128 object MLPs, '
-                                                'full train step' % K_OBJ,
-                               name=args.config, rays_per_gpu=B, global_batch=B * world, num_samples=N_SAMPLES,
+                   config=dict(workload=label + ', %d samples/ray x 2 levels, 8x256 bkgd MLP + %d 8x128 object MLPs, '
+                                                'full train step' % (NS, K_OBJ),
+                               name=args.config, rays_per_gpu=B, global_batch=B * world, num_samples=NS,
                                num_levels=N_LEVELS, objects=K_OBJ, far=far, hit_fraction=hit, randomized=True,
                                pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world),
                    loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,

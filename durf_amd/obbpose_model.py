@@ -10,6 +10,7 @@ all-reduce (train_boxpose.py:253).
 """
 import dataclasses
 import math
+import os
 from typing import Any
 
 import torch
@@ -154,10 +155,24 @@ class MipNerfModel:
     # (csrc/mlp_f32.hip: fp32 encodings, v_mfma_f32_32x32x2_f32 Dense layers, ~16x slower), which evaluates the
     # model in the reference's own arithmetic type (obbpose_model.py:326-327, internal/math.py:22-24)
     mlp_precision: str = 'bf16'
+    # not a reference knob: arithmetic of the OBJECT branch (BoxMLP forward / backward / d(enc), hit rays only) when
+    # mlp_precision == 'bf16'.  'auto' = 'f32' when box-pose optimisation is on (no_pose_opt / no_yaw_opt False, cfg4),
+    # else 'bf16': d(loss)/d(box pose) is a sum over the hit rays that cancels to ~1 % of its summed magnitudes, so the
+    # bf16 rounding of the object branch shows up as tens of per cent on it -- the background MLP, whose
+    # weights only see MLP gradients, stays on the bf16 MFMA kernels either way.
+    obj_precision: str = 'auto'
+
+    def object_precision(self):
+        if self.mlp_precision == 'f32':
+            return 'f32'
+        if self.obj_precision == 'auto':
+            return 'bf16' if (self.no_pose_opt and self.no_yaw_opt) else 'f32'
+        return self.obj_precision
 
     def _check(self):
         bad = []
         if self.mlp_precision not in ('bf16', 'f32'): bad.append('mlp_precision')
+        if self.obj_precision not in ('auto', 'bf16', 'f32'): bad.append('obj_precision')
         if self.ray_shape not in ('cone', 'cylinder'): bad.append('ray_shape')
         if not self.use_viewdirs: bad.append('use_viewdirs=False')
         if (self.min_deg_point, self.max_deg_point, self.deg_view) != (0, 10, 4): bad.append('degrees')
@@ -189,6 +204,8 @@ class MipNerfModel:
         radii = rays.radii.reshape(-1).contiguous()
         near, far = rays.near.reshape(-1).contiguous(), rays.far.reshape(-1).contiguous()
         f32 = self.mlp_precision == 'f32'
+        obj_f32 = bool(Kd) and not f32 and self.object_precision() == 'f32'     # mixed: bf16 background, fp32 objects
+        Kb = 0 if obj_f32 else Kd                                                # objects on the bf16 kernels
         g = _make_generator(rng, dev) if randomized else None
         if randomized and noise is None:
             u = torch.rand(2, B, N + 1, device=dev, generator=g)          # one launch for both levels' noise
@@ -201,22 +218,23 @@ class MipNerfModel:
             (idx, count, slot), cls = ops.compact_all(hit, N)     # cls also counts the boxes each ray hits
         else:
             (idx, count, slot), cls = ops.compact_hits(hit), None
-        view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1] if f32 else None
+        view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1] if (f32 or obj_f32) else None
         packs = {}
         if not f32:                                  # every weight stream in one launch; the K object MLPs sit back
-            o0 = lay.mlp_off['BoxMLP_0'] if Kd else 0    # to back in the flat buffer
-            pk_b, pk_o = ops.pack_weights_all(variables.mlp_flat('MLP_0'), Kd,
-                                              variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]] if Kd else None,
+            o0 = lay.mlp_off['BoxMLP_0'] if Kb else 0    # to back in the flat buffer
+            pk_b, pk_o = ops.pack_weights_all(variables.mlp_flat('MLP_0'), Kb,
+                                              variables.flat[o0:o0 + Kb * lay.mlp_size[W_OBJ]] if Kb else None,
                                               lay.mlp_size[W_OBJ], want_bwd=train)
             packs = {'MLP_0': pk_b}
-            if Kd:
+            if Kb:
                 packs['obj'] = pk_o
         bk = ops.BKGD_RAND if rand_bkgd else (ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY)
         rows = B * N
         cyl = self.ray_shape == 'cylinder'
-        view_tiles_obj = ops.obj_view_tiles(Kd, B, N, dev) if (train and Kd and not f32) else None
+        view_tiles_obj = ops.obj_view_tiles(Kb, B, N, dev) if (train and Kb and not f32) else None
         ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,
-                   packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk, view_tiles_obj=view_tiles_obj)
+                   packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk, view_tiles_obj=view_tiles_obj,
+                   obj_f32=obj_f32 or (f32 and bool(Kd)))
         ret = []
         t_vals = weights = None
         box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
@@ -264,7 +282,7 @@ class MipNerfModel:
                 lvd = None
                 stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
                 mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
-                side = ops.on_side(dev, bool(Kd))          # the object MLPs run in the shadow of the background MLP
+                side = ops.on_side(dev, bool(Kb))          # the object MLPs run in the shadow of the background MLP
                 if dd is not None:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl,
@@ -274,20 +292,32 @@ class MipNerfModel:
                                         count=dd['count'][0:1], stash=stash_b, relu_mask=mask_b,
                                         tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
                     raw_b = ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'])
+                    if os.environ.get('DURF_TAIL_F32', '0') != '0':      # EXPERIMENT: box-hit rays' background raw in fp32
+                        if view27 is None:
+                            view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1]
+                        cnt = int(dd['count'][1])
+                        if cnt:
+                            const = torch.cat([torch.zeros(B, 30, device=dev), torch.ones(B, 30, device=dev)], 1)
+                            rt = ops.mlp_fwd_f32(W_BKGD, IN_BKGD, B, 1, const, view27, variables.mlp_flat('MLP_0'),
+                                                 ray_idx=dd['idx'][1], count=dd['count'][1:2])
+                            raw_b.view(B, N, 4)[dd['idx'][1][:cnt].long()] = rt[:cnt, None, :]
                 else:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl)
                     side.fork()
                     raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
                 slabs = None
-                if Kd:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
+                if obj_f32:                              # object branch in exact fp32 (object_precision)
+                    lvd = self._objects_f32(variables, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha,
+                                            B, N)
+                if Kb:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
                     slabs = ops.ObjSlabs(Kd, B, N, dev, train)      # allocated on the main stream, filled on the side one
                     with side:
                         ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
                                           view_tile=view_tiles_obj if lvl == 0 else None,
                                           disable_integration=self.disable_integration, cylinder=cyl)
                     side.join()
-                raws = slabs.raws() if Kd else []
+                raws = slabs.raws() if Kb else (lvd['raws'] if obj_f32 else [])
             if randomized and self.density_noise > 0:    # :236-240 (added once to the merged raw density)
                 dn = noise['density'][lvl] if 'density' in noise else torch.randn(B, N, device=dev, generator=g)
                 raw_b[:, 3] += self.density_noise * dn.reshape(-1)
@@ -321,7 +351,14 @@ class MipNerfModel:
         _, enc = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction, tile=False, f32=True,
                                  disable_integration=self.disable_integration, cylinder=cyl)
         out = ops.mlp_fwd_f32(W_BKGD, IN_BKGD, rows, N, enc, view27, variables.mlp_flat('MLP_0'), want_act=train)
-        d = dict(raw_b=out[0] if train else out, act_b=out[1] if train else None, raws=[], act_o=[])
+        d = dict(raw_b=out[0] if train else out, act_b=out[1] if train else None)
+        d.update(self._objects_f32(variables, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha, B, N))
+        return d
+
+    def _objects_f32(self, variables, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha, B, N):
+        """the K object MLPs of one level in exact fp32, hit rays only (obbpose_model.py:167-201)"""
+        rows = B * N
+        d = dict(raws=[], act_o=[])
         for k in range(Kd):
             _, enc_k = ops.encode_obj(B, idx[k], count[k:k + 1], t_vals, o_s, d_s, radii, alpha, tile=False, f32=True,
                                       disable_integration=self.disable_integration, cylinder=cyl)

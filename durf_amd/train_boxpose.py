@@ -78,6 +78,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     bg = 0.0 if config.rand_bkgd else (1.0 if config.white_bkgd else 0.5)
     grad = torch.zeros_like(variables.flat)
     f32 = model.mlp_precision == 'f32'
+    obj_f32 = ctx['obj_f32']                    # object branch on the exact-fp32 kernels (MipNerfModel.object_precision)
+    Kb = 0 if obj_f32 else K                    # objects on the bf16 kernels
     bufs = None if f32 else ops.dw_buffers(om.W_BKGD, dev)
     dzs = [None] * L                            # per-level (dz, dz_out) of the bkgd MLP, consumed by ONE dW launch
     dd = ctx.get('dedup')                        # de-duplicated background evaluation (obbpose_model._forward)
@@ -95,7 +97,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
     # optional side stream for the object backward / weight gradients (ops.OVERLAP_*: off by default, see ops.py)
-    side = ops.on_side(dev, bool(K) and not f32 and ops.OVERLAP_BACKWARD)
+    side = ops.on_side(dev, bool(Kb) and not f32 and ops.OVERLAP_BACKWARD)
     # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
     for lvl in reversed(range(L)):
         lv = ctx['levels'][lvl]
@@ -114,6 +116,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             off = lay.mlp_off['MLP_0']
             dz = ops.mlp_bwd_f32(om.W_BKGD, om.IN_BKGD, rows, N, draw, variables.mlp_flat('MLP_0'), fl['act_b'])
             ops.mlp_dw_f32(om.W_BKGD, om.IN_BKGD, rows, N, fl['act_b'], dz, grad[off:off + lay.mlp_size[om.W_BKGD]])
+        if obj_f32:                           # the object branch in fp32: backward, weight gradients, d(enc) -> pose sums
+            fl = lv['f32']
             for k in range(K):
                 ck = ctx['count'][k:k + 1]
                 o = ops.mlp_bwd_f32(om.W_OBJ, om.IN_OBJ, rows, N, draw, variables.mlp_flat('BoxMLP_%d' % k),
@@ -124,6 +128,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                 if pose_opt:
                     ops.encode_obj_bwd(k, ctx['idx'][k], ck, o[1], lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
                                        rays.origins, rays.directions, pose_ts, alpha, pose_sums)
+        if f32:
             continue
         side.fork()                          # the object backward runs in the shadow of the background backward
         if dd is not None:
@@ -132,7 +137,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                    draw_ray_sum=ray_sums[lvl])
         else:
             dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
-        if K:                                 # all K object MLPs: one call (csrc/objects.hip)
+        if Kb:                                # all K object MLPs: one call (csrc/objects.hip)
             with side:
                 ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
                 if pose_opt:                            # d(loss)/d(box pose) through the object encoding, all K at once
@@ -148,8 +153,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             geo = ([rows] * L, [1] * L, [dd['nrows']] * L)
         else:
             geo = ([rows] * L, [N] * L, [None] * L)
-        o0, sz = (lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]) if K else (0, 0)
-        merged = K and not ops.OVERLAP_DW and ops.MERGE_FINALIZE
+        o0, sz = (lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]) if Kb else (0, 0)
+        merged = Kb and not ops.OVERLAP_DW and ops.MERGE_FINALIZE
         if merged:
             # The objects' split-K launch goes FIRST: the finalize launch then finds the background MLP's partials
             # (134 MB, the bulk) still in the 256 MB Infinity Cache -- behind the objects' 0.7 GB operand stream it
@@ -162,7 +167,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                 obj=(K, B, N, ctx['count'], L, po, bo, grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz]))
         else:
             ops.dw_finalize_all(*geo, *bufs, g_b, p_b)
-            if K:
+            if Kb:
                 with side:
                     ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
                                      grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
