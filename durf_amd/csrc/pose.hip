@@ -16,7 +16,10 @@ enum { POSE_ROWS = 21 };   // [0..2] sum g_o ; [3..11] sum g_o (x) o ; [12..20] 
 // split the 60 encoding features (15 each: the per-sample chain of 60 sin / cos / exp is what a launch waits for -- with
 // one wave per ray it was 50 us per object and level, K host-driven launches per level), lanes take the samples, and the
 // per-wave partial d(o'), d(d') meet in LDS in a fixed order.
-template <int P>
+// PRECISE: libm exp / sin / cos (the fp32 object branch and the parity instrument); otherwise the hardware
+// transcendentals (bf16 object branch: |z| < 314.16 after the wrap, where v_sin's z / 2 pi scaling alone loses
+// ~|z| 2^-24 = 2e-5 rad -- two orders below the bf16 rounding of the d(enc) it multiplies).
+template <int P, bool PRECISE>
 __global__ void __launch_bounds__(256)
 k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
                  const float* __restrict__ d_enc, const float* __restrict__ t_vals,
@@ -66,13 +69,8 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
             if (c) z = z + 1.5707963705062866f;
             const float t = 314.15927124023438f;                          // safe_sin wrap (math.py:35-46)
             if (!(fabsf(z) < t)) { float q = fmodf(z, t); if (q != 0.0f && q < 0.0f) q += t; z = q; }
-#ifdef POSE_PRECISE_TRIG
-            const float e = expf(-0.5f * (var[i] * sc * sc));
-            const float cz = cosf(z), sz = sinf(z);
-#else       // hardware exp / sin / cos (|z| < 314.16 after the wrap: abs error ~1e-6, against a 2e-3 gate vs fp64)
-            const float e = __expf(-0.5f * (var[i] * sc * sc));
-            const float cz = __cosf(z), sz = __sinf(z);
-#endif
+            const float e = PRECISE ? expf(-0.5f * (var[i] * sc * sc)) : __expf(-0.5f * (var[i] * sc * sc));
+            const float cz = PRECISE ? cosf(z) : __cosf(z), sz = PRECISE ? sinf(z) : __sinf(z);
             const float g = ge[3 + f] * bw.w[f / 6];
             const float gxf = g * e * sc * cz, gvf = g * (-0.5f * sc * sc) * e * sz;
             if (i == 0) { gx[0] += gxf; gv[0] += gvf; }
@@ -219,18 +217,20 @@ extern "C" {
 static int encode_obj_bwd_launch(void* stream, int K, int B, int N, int k0, const int32_t* idx, const int32_t* count,
                                  const float* d_enc, size_t denc_stride, const float* t_vals, const float* origins_s,
                                  const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                                 const float* pose, const float* barf_w, float* scratch, float* sums) {
+                                 const float* pose, const float* barf_w, float* scratch, float* sums, int precise) {
     DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
     if (B <= 0 || K <= 0) return 0;
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
     hipStream_t s = (hipStream_t)stream;
     dim3 grid(B, K), block(256);
-#define LAUNCH_E(P)                                                                                       \
-    hipLaunchKernelGGL(k_encode_obj_bwd<P>, grid, block, 0, s, B, N, k0, idx, count, d_enc, t_vals,       \
+#define LAUNCH_E2(P, PR)                                                                                  \
+    hipLaunchKernelGGL((k_encode_obj_bwd<P, PR>), grid, block, 0, s, B, N, k0, idx, count, d_enc, t_vals, \
                        origins_s, dirs_s, radii, origins, dirs, pose, bw, scratch, (size_t)B, denc_stride, \
                        (size_t)POSE_ROWS * B)
-    if (N <= 64) LAUNCH_E(1); else if (N <= 128) LAUNCH_E(2); else LAUNCH_E(4);
+#define LAUNCH_E(P) { if (precise) LAUNCH_E2(P, true); else LAUNCH_E2(P, false); }
+    if (N <= 64) LAUNCH_E(1) else if (N <= 128) LAUNCH_E(2) else LAUNCH_E(4)
+#undef LAUNCH_E2
 #undef LAUNCH_E
     hipLaunchKernelGGL(k_pose_reduce, dim3(POSE_ROWS, K), dim3(1024), 0, s, B, count, scratch, sums + k0 * POSE_ROWS);
     DURF_CHECK_LAUNCH("durf_encode_obj_bwd");
@@ -240,17 +240,17 @@ static int encode_obj_bwd_launch(void* stream, int K, int B, int N, int k0, cons
 int durf_encode_obj_bwd(void* stream, int B, int N, int k_obj, const int32_t* idx, const int32_t* count,
                         const float* d_enc, const float* t_vals, const float* origins_s,
                         const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                        const float* pose, const float* barf_w, float* scratch, float* sums) {
+                        const float* pose, const float* barf_w, float* scratch, float* sums, int precise) {
     return encode_obj_bwd_launch(stream, 1, B, N, k_obj, idx, count, d_enc, 0, t_vals, origins_s, dirs_s, radii, origins,
-                                 dirs, pose, barf_w, scratch, sums);
+                                 dirs, pose, barf_w, scratch, sums, precise);
 }
 
 int durf_encode_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
                               const float* d_enc, const float* t_vals, const float* origins_s,
                               const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                              const float* pose, const float* barf_w, float* scratch, float* sums) {
+                              const float* pose, const float* barf_w, float* scratch, float* sums, int precise) {
     return encode_obj_bwd_launch(stream, K, B, N, 0, idx, count, d_enc, (size_t)B * N * DURF_ENC_DIM, t_vals, origins_s,
-                                 dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums);
+                                 dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise);
 }
 
 // sums [K,21] (all levels accumulated) -> adds d(loss)/d(box_centers[ts]) into grad6 [K,6]

@@ -297,7 +297,12 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
          const float* __restrict__ t_vals, const float* __restrict__ origins_s,
          const float* __restrict__ dirs_s, const float* __restrict__ radii,
          const int32_t* __restrict__ hit, int K, int contraction, BarfW barf_w,
-         bf16x8* __restrict__ out_tile, float* __restrict__ out_f32) {
+         bf16x8* __restrict__ out_tile, float* __restrict__ out_f32, size_t idx_stride, size_t f32_stride) {
+    if (OBJ && gridDim.y > 1) {                      // batched objects (fp32 features only): blockIdx.y = object
+        idx += blockIdx.y * idx_stride;
+        count += blockIdx.y;
+        out_f32 += blockIdx.y * f32_stride;
+    }
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t row = gid >> 3;          // sample row (ray-major)
     const int q = (int)(gid & 7);         // which 8-feature vector
@@ -616,7 +621,7 @@ int durf_encode_bkgd(void* stream, int B, int N, const float* t_vals, const floa
     if (out_f32)
         hipLaunchKernelGGL((k_encode<false>), dim3(durf_cdiv((size_t)B * N * 8, 256)), dim3(256), 0,
                            (hipStream_t)stream, B, N, nullptr, nullptr, t_vals, origins_s, dirs_s, radii,
-                           hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32);
+                           hit, K, contraction, BarfW{}, (bf16x8*)out_tile, out_f32, (size_t)0, (size_t)0);
     else
         hipLaunchKernelGGL((k_encode_lane<false>), dim3(durf_cdiv((size_t)B * N, ENC_BLOCK)), dim3(ENC_BLOCK), 0,
                            (hipStream_t)stream, B, N, idx, count, t_vals, origins_s, dirs_s, radii,
@@ -632,6 +637,14 @@ int durf_encode_obj(void* stream, int max_rays, int N, const int32_t* idx, const
                                    out_tile, 0, out_f32);
 }
 
+int durf_encode_obj_f32_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
+                              const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
+                              const float* barf_w, int flags, float* enc) {
+    DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ, "1 <= K <= DURF_MAX_OBJ");
+    return durf::launch_encode_obj(stream, K, B, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags, nullptr, 0,
+                                   enc);
+}
+
 }  // extern "C"
 
 namespace durf {
@@ -640,13 +653,14 @@ int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* i
                       const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
                       const float* barf_w, int flags, void* out_tile, size_t out_stride, float* out_f32) {
     if (max_rays <= 0 || K <= 0) return 0;
-    DURF_REQUIRE(K == 1 || out_f32 == nullptr, "batched object encoding writes bf16 tiles only");
+    DURF_REQUIRE(K == 1 || out_f32 == nullptr || out_tile == nullptr, "batched object encoding: bf16 tiles OR fp32 features");
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
-    if (out_f32)
-        hipLaunchKernelGGL((k_encode<true>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256)), dim3(256), 0,
+    if (out_f32)      // accurate-libm features, row-major [K, max_rays * N, 63]
+        hipLaunchKernelGGL((k_encode<true>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256), K), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
-                           nullptr, 0, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), bw, (bf16x8*)out_tile, out_f32);
+                           nullptr, 0, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), bw, (bf16x8*)out_tile, out_f32,
+                           (size_t)max_rays, (size_t)max_rays * N * 63);
     else
         hipLaunchKernelGGL((k_encode_lane<true>), dim3(durf_cdiv((size_t)max_rays * N, ENC_BLOCK), K), dim3(ENC_BLOCK), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,

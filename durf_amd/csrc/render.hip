@@ -293,22 +293,24 @@ k_composite_resample(int B, int N, int K, const float* __restrict__ raw_bkgd, Ob
 // from the compacted rows of the rays evaluated sample by sample and, after them, the ONE row of each box-hit ray.
 __global__ void __launch_bounds__(256)
 k_expand_raw(int B, int N, const float* __restrict__ raw_c, const int32_t* __restrict__ count,
-             const int32_t* __restrict__ slot, float* __restrict__ raw_full) {
+             const int32_t* __restrict__ slot, float* __restrict__ raw_full, const float* __restrict__ raw_tail) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * N) return;
     const int b = (int)(i / N), n = (int)(i % N);
     const int s0 = slot[b * 2], s1 = slot[b * 2 + 1];
     const size_t src = s0 >= 0 ? (size_t)s0 * N + n : (size_t)count[0] * N + (size_t)s1;
-    *(f32x4*)(raw_full + i * 4) = *(const f32x4*)(raw_c + src * 4);
+    // raw_tail: the box-hit rays' one background evaluation redone in fp32 (object branch in fp32)
+    const float* from = (s0 < 0 && raw_tail) ? raw_tail + (size_t)s1 * 4 : raw_c + src * 4;
+    *(f32x4*)(raw_full + i * 4) = *(const f32x4*)from;
 }
 
 extern "C" {
 
 int durf_expand_raw(void* stream, int B, int N, const float* raw_c, const int32_t* count, const int32_t* slot,
-                    float* raw_full) {
+                    float* raw_full, const float* raw_tail) {
     if (B <= 0) return 0;
     hipLaunchKernelGGL(k_expand_raw, dim3(durf_cdiv((size_t)B * N, 256)), dim3(256), 0, (hipStream_t)stream, B, N, raw_c,
-                       count, slot, raw_full);
+                       count, slot, raw_full, raw_tail);
     DURF_CHECK_LAUNCH("durf_expand_raw");
     return 0;
 }

@@ -10,7 +10,6 @@ all-reduce (train_boxpose.py:253).
 """
 import dataclasses
 import math
-import os
 from typing import Any
 
 import torch
@@ -210,7 +209,8 @@ class MipNerfModel:
         if randomized and noise is None:
             u = torch.rand(2, B, N + 1, device=dev, generator=g)          # one launch for both levels' noise
             noise = dict(t_rand=u[0], u_rand=u[1])
-        use_dd = bool(Kd) and not f32 and ops.DEDUP_HIT_RAYS
+        # (the fp32 object branch needs the box-hit rays' background evaluation as its own rows: always de-duplicated)
+        use_dd = bool(Kd) and not f32 and (ops.DEDUP_HIT_RAYS or obj_f32)
         # ray setup + view encoding + level-0 sample positions: one launch; both compactions: one launch
         o_s, d_s, hit, zo, view, t_vals0 = ops.ray_prologue(rays.origins, rays.directions, pose, ext, rays.viewdirs, near,
                                                             far, N, noise['t_rand'] if randomized else None, self.lindisp)
@@ -235,6 +235,13 @@ class MipNerfModel:
         ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,
                    packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk, view_tiles_obj=view_tiles_obj,
                    obj_f32=obj_f32 or (f32 and bool(Kd)))
+        obj_flat = None
+        if ctx['obj_f32']:                           # BoxMLP_0 .. BoxMLP_{K-1} sit back to back in the flat buffer
+            o0 = lay.mlp_off['BoxMLP_0']
+            obj_flat = variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]]
+            if train:
+                ctx['obj_params_t'] = ops.mlp_f32_transpose(W_OBJ, IN_OBJ, obj_flat, K=Kd, param_stride=lay.mlp_size[W_OBJ])
+        raw_tail = None
         ret = []
         t_vals = weights = None
         box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
@@ -273,8 +280,8 @@ class MipNerfModel:
                 t_vals = ops.resample(t_vals, weights, self.resample_padding,
                                       noise['u_rand'] if randomized else None)
             if f32:
-                lvd = self._level_f32(variables, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count, alpha,
-                                      B, N)
+                lvd = self._level_f32(variables, obj_flat, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count,
+                                      alpha, B, N)
                 raw_b, slabs = lvd['raw_b'], None
                 enc_b = stash_b = mask_b = None
                 raws = lvd['raws']
@@ -291,16 +298,12 @@ class MipNerfModel:
                     raw_c = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], ray_idx=dd['idx'][0],
                                         count=dd['count'][0:1], stash=stash_b, relu_mask=mask_b,
                                         tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
-                    raw_b = ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'])
-                    if os.environ.get('DURF_TAIL_F32', '0') != '0':      # EXPERIMENT: box-hit rays' background raw in fp32
-                        if view27 is None:
-                            view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1]
-                        cnt = int(dd['count'][1])
-                        if cnt:
-                            const = torch.cat([torch.zeros(B, 30, device=dev), torch.ones(B, 30, device=dev)], 1)
-                            rt = ops.mlp_fwd_f32(W_BKGD, IN_BKGD, B, 1, const, view27, variables.mlp_flat('MLP_0'),
-                                                 ray_idx=dd['idx'][1], count=dd['count'][1:2])
-                            raw_b.view(B, N, 4)[dd['idx'][1][:cnt].long()] = rt[:cnt, None, :]
+                    if obj_f32 and raw_tail is None:
+                        # The background MLP's ONE evaluation of every box-hit ray, redone in fp32 (same input at both
+                        # levels: once per step).  Those rays' rendered values -- and through them the head gradients
+                        # that drive d(loss)/d(box pose) -- then carry no bf16 rounding at all.
+                        raw_tail = ops.bkgd_hit_rays_f32(B, view27, variables.mlp_flat('MLP_0'), dd['idx'][1], dd['count'][1:2])
+                    raw_b = ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'], raw_tail=raw_tail)
                 else:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl)
@@ -308,8 +311,8 @@ class MipNerfModel:
                     raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
                 slabs = None
                 if obj_f32:                              # object branch in exact fp32 (object_precision)
-                    lvd = self._objects_f32(variables, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha,
-                                            B, N)
+                    lvd = self._objects_f32(obj_flat, lay.mlp_size[W_OBJ], train, t_vals, o_s, d_s, radii, Kd, cyl, view27,
+                                            idx, count, alpha, B, N)
                 if Kb:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
                     slabs = ops.ObjSlabs(Kd, B, N, dev, train)      # allocated on the main stream, filled on the side one
                     with side:
@@ -344,29 +347,26 @@ class MipNerfModel:
                                           f32=lvd))
         return ret, ctx
 
-    def _level_f32(self, variables, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count, alpha, B, N):
+    def _level_f32(self, variables, obj_flat, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count, alpha, B, N):
         """encodings + MLPs of one level in exact fp32 (mlp_precision='f32'): accurate-libm encodings emitted as
-        fp32, Dense layers on v_mfma_f32_32x32x2_f32 straight from the fp32 parameters; object MLPs one by one."""
+        fp32, Dense layers on v_mfma_f32_32x32x2_f32 straight from the fp32 parameters."""
         rows = B * N
         _, enc = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction, tile=False, f32=True,
                                  disable_integration=self.disable_integration, cylinder=cyl)
         out = ops.mlp_fwd_f32(W_BKGD, IN_BKGD, rows, N, enc, view27, variables.mlp_flat('MLP_0'), want_act=train)
-        d = dict(raw_b=out[0] if train else out, act_b=out[1] if train else None)
-        d.update(self._objects_f32(variables, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha, B, N))
+        d = dict(raw_b=out[0] if train else out, act_b=out[1] if train else None, raws=[], slabs32=None)
+        if Kd:
+            d.update(self._objects_f32(obj_flat, variables.layout.mlp_size[W_OBJ], train, t_vals, o_s, d_s, radii, Kd, cyl,
+                                       view27, idx, count, alpha, B, N))
         return d
 
-    def _objects_f32(self, variables, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha, B, N):
-        """the K object MLPs of one level in exact fp32, hit rays only (obbpose_model.py:167-201)"""
-        rows = B * N
-        d = dict(raws=[], act_o=[])
-        for k in range(Kd):
-            _, enc_k = ops.encode_obj(B, idx[k], count[k:k + 1], t_vals, o_s, d_s, radii, alpha, tile=False, f32=True,
-                                      disable_integration=self.disable_integration, cylinder=cyl)
-            o = ops.mlp_fwd_f32(W_OBJ, IN_OBJ, rows, N, enc_k, view27, variables.mlp_flat('BoxMLP_%d' % k),
-                                ray_idx=idx[k], count=count[k:k + 1], want_act=train)
-            d['raws'].append(o[0] if train else o)
-            d['act_o'].append(o[1] if train else None)
-        return d
+    def _objects_f32(self, obj_flat, stride, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha, B, N):
+        """the K object MLPs of one level in exact fp32, hit rays only (obbpose_model.py:167-201): accurate-libm fp32
+        encodings + the fp32 MFMA forward of all K objects, one launch each (csrc/mlp_f32.hip, durf_objf32_*)"""
+        slabs = ops.ObjSlabsF32(Kd, B, N, t_vals.device, train)
+        ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, obj_flat, stride,
+                             disable_integration=self.disable_integration, cylinder=cyl)
+        return dict(raws=slabs.raws(), slabs32=slabs)
 
     def apply(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
               noise=None):

@@ -313,13 +313,14 @@ class on_side:
 DEDUP_HIT_RAYS = os.environ.get('DURF_DEDUP_HIT_RAYS', '1') != '0'
 
 
-def expand_raw(B, N, raw_c, slot2, count2):
-    """compacted raw (count2[0]*N rows of the sample-by-sample rays, then one row per box-hit ray) -> [B*N,4]"""
+def expand_raw(B, N, raw_c, slot2, count2, raw_tail=None):
+    """compacted raw (count2[0]*N rows of the sample-by-sample rays, then one row per box-hit ray) -> [B*N,4];
+    raw_tail [B,4]: fp32 re-evaluation of the box-hit rays' rows (mlp_fwd_f32 with enc=None), used instead of them"""
     raw_full = torch.empty(B * N, 4, device=raw_c.device)
     # the tail starts at row count2[0]*N: hand the kernel a pointer to that row (device-side count -> device-side offset
     # is not available on the host, so the kernel takes the base and the slot of the tail separately)
-    _lib.check(_lib.lib().durf_expand_raw(_stream(), B, N, _p(_f32(raw_c)), _p(count2), _p(slot2), _p(raw_full)),
-               'durf_expand_raw')
+    _lib.check(_lib.lib().durf_expand_raw(_stream(), B, N, _p(_f32(raw_c)), _p(count2), _p(slot2), _p(raw_full),
+                                          _p(raw_tail)), 'durf_expand_raw')
     return raw_full
 
 
@@ -677,7 +678,7 @@ def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):
 
 
 def encode_obj_bwd(k_obj, idx_k, count_k, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, alpha,
-                   sums, scratch=None):
+                   sums, scratch=None, precise=False):
     """accumulates the 21 pose sums of object k (one level) into sums[k] (sums: [K,21], caller-zeroed)"""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     if scratch is None:
@@ -687,10 +688,11 @@ def encode_obj_bwd(k_obj, idx_k, count_k, d_enc, t_vals, origins_s, dirs_s, radi
     _lib.check(_lib.lib().durf_encode_obj_bwd(_stream(), B, N, k_obj, _p(idx_k), _p(count_k), _p(_f32(d_enc)),
                                               _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
                                               _p(_f32(radii)), _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
-                                              wa, _p(scratch), _p(_f32(sums))), 'durf_encode_obj_bwd')
+                                              wa, _p(scratch), _p(_f32(sums)), int(precise)), 'durf_encode_obj_bwd')
 
 
-def encode_obj_bwd_batch(K, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, alpha, sums):
+def encode_obj_bwd_batch(K, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, alpha, sums,
+                         precise=False):
     """all K objects of one level in one launch pair: idx [K,B], count [K], d_enc [K, B*N, 64] (obj_bwd_batch's slab)"""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     scratch = torch.empty(K * 21 * B, device=t_vals.device)
@@ -699,7 +701,8 @@ def encode_obj_bwd_batch(K, idx, count, d_enc, t_vals, origins_s, dirs_s, radii,
     _lib.check(_lib.lib().durf_encode_obj_bwd_batch(_stream(), int(K), B, N, _p(idx), _p(count), _p(_f32(d_enc)),
                                                     _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
                                                     _p(_f32(radii)), _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
-                                                    wa, _p(scratch), _p(_f32(sums))), 'durf_encode_obj_bwd_batch')
+                                                    wa, _p(scratch), _p(_f32(sums)), int(precise)),
+               'durf_encode_obj_bwd_batch')
 
 
 def pose_finish(pose, sums, want_pos, want_rot, grad6):
@@ -709,29 +712,43 @@ def pose_finish(pose, sums, want_pos, want_rot, grad6):
 
 
 # ---------------------------------------------------------------------------
-# exact-fp32 MLP (csrc/mlp_f32.hip): the parity instrument behind MipNerfModel(mlp_precision='f32')
+# exact-fp32 MLP (csrc/mlp_f32.hip): the object branch of a step with box-pose optimisation (MipNerfModel.object_precision)
+# and the parity instrument behind MipNerfModel(mlp_precision='f32')
 # ---------------------------------------------------------------------------
+def mlp_f32_transpose(width, in_dim, mlp_params, K=1, param_stride=0):
+    """per-layer transposed kernels of K MLPs (the fp32 backward's weight stream); same layout / size as mlp_params"""
+    out = torch.empty_like(mlp_params)
+    _lib.check(_lib.lib().durf_mlp_f32_transpose(_stream(), width, in_dim, int(K), _p(_f32(mlp_params)), int(param_stride),
+                                                 _p(out)), 'durf_mlp_f32_transpose')
+    return out
+
+
 def mlp_fwd_f32(width, in_dim, rows, N, enc_f32, view27, mlp_params, ray_idx=None, count=None, want_act=False):
-    """-> raw [rows,4][, act [rows, ACT]] (row-major fp32; enc_f32 [rows,in_dim], view27 [B,27])"""
-    dev = enc_f32.device
+    """-> raw [rows,4][, act (opaque record buffer for mlp_bwd_f32 / mlp_dw_f32)].  enc_f32 [rows,in_dim] row-major, or
+    None: every row is the background MLP's constant encoding of a box-hit ray (width 256); view27 [B,27]"""
+    dev = view27.device
     L = _lib.lib()
     raw = torch.zeros(rows, 4, device=dev)
-    act = torch.zeros(rows, int(L.durf_mlp_f32_act_floats(width, in_dim)), device=dev) if want_act else None
+    act = torch.empty(tile_rows(rows) * int(L.durf_mlp_f32_act_floats(width, in_dim)), device=dev) if want_act else None
     with _Timed('mlp_fwd_f32_%d' % width):
-        _lib.check(L.durf_mlp_fwd_f32(_stream(), width, in_dim, rows, N, _p(_f32(enc_f32)), _p(_f32(view27)),
-                                      _p(ray_idx), _p(count), _p(_f32(mlp_params)), _p(raw), _p(act)),
+        _lib.check(L.durf_mlp_fwd_f32(_stream(), width, in_dim, rows, N, _p(None if enc_f32 is None else _f32(enc_f32)),
+                                      _p(_f32(view27)), _p(ray_idx), _p(count), _p(_f32(mlp_params)), _p(raw), _p(act)),
                    'durf_mlp_fwd_f32')
     return (raw, act) if want_act else raw
 
 
-def mlp_bwd_f32(width, in_dim, rows, N, draw, mlp_params, act, ray_idx=None, count=None, want_d_enc=False):
-    """-> dz [rows, DZ][, d_enc [rows,64]]"""
+def mlp_bwd_f32(width, in_dim, rows, N, draw, mlp_params, act, ray_idx=None, count=None, want_d_enc=False, params_t=None):
+    """-> dz (opaque record buffer)[, d_enc [rows,64]]"""
     dev = draw.device
     L = _lib.lib()
-    dz = torch.zeros(rows, int(L.durf_mlp_f32_dz_floats(width, in_dim)), device=dev)
+    if params_t is None:
+        params_t = mlp_f32_transpose(width, in_dim, mlp_params)
+    dz = torch.empty(tile_rows(rows) * int(L.durf_mlp_f32_dz_floats(width, in_dim)), device=dev)
     d_enc = torch.zeros(rows, ENC_DIM, device=dev) if want_d_enc else None
-    _lib.check(L.durf_mlp_bwd_f32(_stream(), width, in_dim, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
-                                  _p(_f32(mlp_params)), _p(_f32(act)), _p(dz), _p(d_enc)), 'durf_mlp_bwd_f32')
+    with _Timed('mlp_bwd_f32_%d' % width):
+        _lib.check(L.durf_mlp_bwd_f32(_stream(), width, in_dim, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
+                                      _p(_f32(mlp_params)), _p(_f32(params_t)), _p(_f32(act)), _p(dz), _p(d_enc)),
+                   'durf_mlp_bwd_f32')
     return (dz, d_enc) if want_d_enc else dz
 
 
@@ -740,8 +757,77 @@ def mlp_dw_f32(width, in_dim, rows, N, act, dz, grad_mlp, count=None, nsplit=32)
     dev = act.device
     L = _lib.lib()
     scratch = torch.empty(int(L.durf_mlp_f32_dw_scratch_floats(width, in_dim, nsplit)), device=dev)
-    tiles = torch.empty(3072, dtype=torch.int32, device=dev)
     g = torch.empty_like(grad_mlp)
-    _lib.check(L.durf_mlp_dw_f32(_stream(), width, in_dim, rows, N, _p(count), _p(_f32(act)), _p(_f32(dz)), nsplit,
-                                 _p(scratch), _p(tiles), _p(g)), 'durf_mlp_dw_f32')
+    with _Timed('mlp_dw_f32_%d' % width):
+        _lib.check(L.durf_mlp_dw_f32(_stream(), width, in_dim, rows, N, _p(count), _p(_f32(act)), _p(_f32(dz)), nsplit,
+                                     _p(scratch), _p(g)), 'durf_mlp_dw_f32')
     grad_mlp += g
+
+
+def bkgd_hit_rays_f32(B, view27, bkgd_params, idx1, count1):
+    """the background MLP's one evaluation of every box-hit ray (ray class 1: idx1 / count1), in fp32 -> raw_tail [B,4]
+    (row j = ray idx1[j]); the trunk, whose input is the same for all of them, runs once"""
+    dev = view27.device
+    trunk = torch.empty(257, device=dev)
+    raw_tail = torch.empty(B, 4, device=dev)
+    with _Timed('bkgd_hit_rays_f32'):
+        _lib.check(_lib.lib().durf_bkgd_hit_rays_f32(_stream(), B, _p(_f32(view27)), _p(_f32(bkgd_params)), _p(idx1),
+                                                     _p(count1), _p(trunk), _p(raw_tail)), 'durf_bkgd_hit_rays_f32')
+    return raw_tail
+
+
+class ObjSlabsF32:
+    """[K, ...] slabs of one level for the batched fp32 object calls (durf_objf32_*; strides fixed by the library)"""
+
+    def __init__(self, K, B, N, device, train):
+        L = _lib.lib()
+        self.K, self.B, self.N = K, B, N
+        self.enc = torch.empty(K, B * N, IN_OBJ_, device=device)
+        self.raw = torch.empty(K, B * N, 4, device=device)
+        self.act = torch.empty(K * int(L.durf_objf32_act_stride(B, N)), device=device) if train else None
+        self.dz = self.d_enc = None
+
+    def raws(self):
+        return [self.raw[k] for k in range(self.K)]
+
+
+def objf32_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha, view27, obj_params, param_stride,
+                     disable_integration=False, cylinder=False):
+    """accurate fp32 encodings + fp32 forward of all K object MLPs of one level: two launches"""
+    w = barf_weights(alpha)
+    wa = (C.c_float * 10)(*[float(x) for x in w])
+    L = _lib.lib()
+    with _Timed('objf32_fwd_batch'):
+        _lib.check(L.durf_encode_obj_f32_batch(
+            _stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
+            _p(_f32(radii)), wa, (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0),
+            _p(slabs.enc)), 'durf_encode_obj_f32_batch')
+        _lib.check(L.durf_objf32_fwd_batch(_stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(slabs.enc),
+                                           _p(_f32(view27)), _p(_f32(obj_params)), int(param_stride), _p(slabs.raw),
+                                           _p(slabs.act)), 'durf_objf32_fwd_batch')
+
+
+def objf32_bwd_batch(slabs, idx, count, draw, obj_params, obj_params_t, param_stride, want_d_enc=False):
+    L = _lib.lib()
+    dev = draw.device
+    K, B, N = slabs.K, slabs.B, slabs.N
+    slabs.dz = torch.empty(K * int(L.durf_objf32_dz_stride(B, N)), device=dev)
+    slabs.d_enc = torch.empty(K, B * N, ENC_DIM, device=dev) if want_d_enc else None     # every valid row is written
+    with _Timed('objf32_bwd_batch'):
+        _lib.check(L.durf_objf32_bwd_batch(_stream(), K, B, N, _p(idx), _p(count), _p(_f32(draw)), _p(_f32(obj_params)),
+                                           _p(_f32(obj_params_t)), int(param_stride), _p(slabs.act), _p(slabs.dz),
+                                           _p(slabs.d_enc)), 'durf_objf32_bwd_batch')
+
+
+def objf32_dw_batch(slabs_levels, count, grad_obj, grad_stride, nsplit=2):
+    """weight gradients of all K object MLPs over every level -> grad_obj (flat, K x grad_stride floats), overwritten"""
+    L = _lib.lib()
+    s0 = slabs_levels[0]
+    K, B, N = s0.K, s0.B, s0.N
+    nl = len(slabs_levels)
+    scratch = torch.empty(K * int(L.durf_mlp_f32_dw_scratch_floats(W_OBJ_, IN_OBJ_, nsplit)), device=grad_obj.device)
+    arr = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    with _Timed('objf32_dw_batch'):
+        _lib.check(L.durf_objf32_dw_batch(_stream(), K, B, N, _p(count), nl, arr([s.act for s in slabs_levels]),
+                                          arr([s.dz for s in slabs_levels]), int(nsplit), _p(scratch), _p(grad_obj),
+                                          int(grad_stride)), 'durf_objf32_dw_batch')

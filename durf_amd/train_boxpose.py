@@ -116,18 +116,14 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             off = lay.mlp_off['MLP_0']
             dz = ops.mlp_bwd_f32(om.W_BKGD, om.IN_BKGD, rows, N, draw, variables.mlp_flat('MLP_0'), fl['act_b'])
             ops.mlp_dw_f32(om.W_BKGD, om.IN_BKGD, rows, N, fl['act_b'], dz, grad[off:off + lay.mlp_size[om.W_BKGD]])
-        if obj_f32:                           # the object branch in fp32: backward, weight gradients, d(enc) -> pose sums
-            fl = lv['f32']
-            for k in range(K):
-                ck = ctx['count'][k:k + 1]
-                o = ops.mlp_bwd_f32(om.W_OBJ, om.IN_OBJ, rows, N, draw, variables.mlp_flat('BoxMLP_%d' % k),
-                                    fl['act_o'][k], ray_idx=ctx['idx'][k], count=ck, want_d_enc=pose_opt)
-                ok = lay.mlp_off['BoxMLP_%d' % k]
-                ops.mlp_dw_f32(om.W_OBJ, om.IN_OBJ, rows, N, fl['act_o'][k], o[0] if pose_opt else o,
-                               grad[ok:ok + lay.mlp_size[om.W_OBJ]], count=ck)
-                if pose_opt:
-                    ops.encode_obj_bwd(k, ctx['idx'][k], ck, o[1], lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
-                                       rays.origins, rays.directions, pose_ts, alpha, pose_sums)
+        if obj_f32:                           # the object branch in fp32: backward + d(enc) -> pose sums, all K at once
+            sl = lv['f32']['slabs32']
+            o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
+            ops.objf32_bwd_batch(sl, ctx['idx'], ctx['count'], draw, variables.flat[o0:o0 + K * sz], ctx['obj_params_t'],
+                                 sz, want_d_enc=pose_opt)
+            if pose_opt:
+                ops.encode_obj_bwd_batch(K, ctx['idx'], ctx['count'], sl.d_enc, lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
+                                         rays.origins, rays.directions, pose_ts, alpha, pose_sums, precise=True)
         if f32:
             continue
         side.fork()                          # the object backward runs in the shadow of the background backward
@@ -145,6 +141,9 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                              ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
                                              pose_sums)
     levels = ctx['levels']
+    if obj_f32:                               # weight gradients of the K object MLPs over every level: one launch pair
+        o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
+        ops.objf32_dw_batch([lv['f32']['slabs32'] for lv in levels], ctx['count'], grad[o0:o0 + K * sz], sz)
     if not f32:
         off = lay.mlp_off['MLP_0']
         g_b, p_b = grad[off:off + lay.mlp_size[om.W_BKGD]], variables.mlp_flat('MLP_0')

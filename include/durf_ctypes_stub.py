@@ -113,8 +113,8 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_dw_finalize_levels.argtypes = [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp, vp]
     #   (stream, width, in_dim, nlevels, rows, rows_per_ray, count, part, bpart, grad_mlp, mlp_params)
     L.durf_expand_raw.restype = i32
-    L.durf_expand_raw.argtypes = [vp, i32, i32, vp, vp, vp, vp]
-    #   (stream, B, N, raw_c, count, slot, raw_full)
+    L.durf_expand_raw.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
+    #   (stream, B, N, raw_c, count, slot, raw_full, raw_tail)
     L.durf_mlp_f32_act_floats.restype = u64
     L.durf_mlp_f32_act_floats.argtypes = [i32, i32]
     #   (width, in_dim)
@@ -124,15 +124,39 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_f32_dw_scratch_floats.restype = u64
     L.durf_mlp_f32_dw_scratch_floats.argtypes = [i32, i32, i32]
     #   (width, in_dim, nsplit)
+    L.durf_mlp_f32_transpose.restype = i32
+    L.durf_mlp_f32_transpose.argtypes = [vp, i32, i32, i32, vp, u64, vp]
+    #   (stream, width, in_dim, K, mlp_params, param_stride, params_t)
     L.durf_mlp_fwd_f32.restype = i32
     L.durf_mlp_fwd_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, width, in_dim, rows, N, enc, view27, ray_idx, count, mlp_params, raw, act)
     L.durf_mlp_bwd_f32.restype = i32
-    L.durf_mlp_bwd_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]
-    #   (stream, width, in_dim, rows, N, draw, ray_idx, count, mlp_params, act, dz, d_enc)
+    L.durf_mlp_bwd_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, width, in_dim, rows, N, draw, ray_idx, count, mlp_params, params_t, act, dz, d_enc)
     L.durf_mlp_dw_f32.restype = i32
-    L.durf_mlp_dw_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, i32, vp, vp, vp]
-    #   (stream, width, in_dim, rows, N, count, act, dz, nsplit, scratch, tiles_dev, grad_mlp)
+    L.durf_mlp_dw_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, i32, vp, vp]
+    #   (stream, width, in_dim, rows, N, count, act, dz, nsplit, scratch, grad_mlp)
+    L.durf_bkgd_hit_rays_f32.restype = i32
+    L.durf_bkgd_hit_rays_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
+    #   (stream, B, view27, bkgd_params, idx, count, trunk, raw_tail)
+    L.durf_objf32_act_stride.restype = u64
+    L.durf_objf32_act_stride.argtypes = [i32, i32]
+    #   (B, N)
+    L.durf_objf32_dz_stride.restype = u64
+    L.durf_objf32_dz_stride.argtypes = [i32, i32]
+    #   (B, N)
+    L.durf_encode_obj_f32_batch.restype = i32
+    L.durf_encode_obj_f32_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp]
+    #   (stream, K, B, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags, enc)
+    L.durf_objf32_fwd_batch.restype = i32
+    L.durf_objf32_fwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, u64, vp, vp]
+    #   (stream, K, B, N, idx, count, enc, view27, obj_params, param_stride, raw, act)
+    L.durf_objf32_bwd_batch.restype = i32
+    L.durf_objf32_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, u64, vp, vp, vp]
+    #   (stream, K, B, N, idx, count, draw, obj_params, obj_params_t, param_stride, act, dz, d_enc)
+    L.durf_objf32_dw_batch.restype = i32
+    L.durf_objf32_dw_batch.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), i32, vp, vp, u64]
+    #   (stream, K, B, N, count, nlevels, act, dz, nsplit, scratch, grad_obj, grad_stride)
     L.durf_obj_enc_stride.restype = u64
     L.durf_obj_enc_stride.argtypes = [i32, i32]
     #   (B, N)
@@ -161,11 +185,11 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_dw_finalize_all.argtypes = [vp, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, u64, vp]
     #   (stream, in_bkgd, nseg, rows, rows_per_ray, seg_count, part_bkgd, bpart_bkgd, grad_bkgd, bkgd_params, K, B, N, obj_count, nlevels, in_obj, part_obj, bpart_obj, grad_obj, obj_grad_stride, obj_params)
     L.durf_encode_obj_bwd.restype = i32
-    L.durf_encode_obj_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]
-    #   (stream, B, N, k_obj, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums)
+    L.durf_encode_obj_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp, i32]
+    #   (stream, B, N, k_obj, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise)
     L.durf_encode_obj_bwd_batch.restype = i32
-    L.durf_encode_obj_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp]
-    #   (stream, K, B, N, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums)
+    L.durf_encode_obj_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp, i32]
+    #   (stream, K, B, N, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise)
     L.durf_pose_finish.restype = i32
     L.durf_pose_finish.argtypes = [vp, i32, vp, vp, i32, i32, vp]
     #   (stream, K, pose, sums, want_pos, want_rot, grad6)

@@ -274,29 +274,63 @@ int durf_mlp_dw_finalize_levels(void* stream, int width, int in_dim, int nlevels
  * gradients is exactly what reaches its weights), and durf_mlp_dw_levels takes both kinds of segment. */
 int durf_expand_raw(void* stream, int B, int N, const float* raw_c /* compacted rows, then the tail rows */,
                     const int32_t* count /* device int[2] of durf_compact_hits on the two classes */,
-                    const int32_t* slot /* [B,2] */, float* raw_full /* [B*N,4] */);
+                    const int32_t* slot /* [B,2] */, float* raw_full /* [B*N,4] */,
+                    const float* raw_tail /* nullable [B,4]: row slot[b,1] replaces the tail row of box-hit ray b -- the
+                       fp32 evaluation of durf_mlp_fwd_f32(enc = NULL) when the object branch runs in fp32 */);
 
-/* ---- exact-fp32 MLP: the parity instrument (csrc/mlp_f32.hip) ---------------------------------
+/* ---- exact-fp32 MLP (csrc/mlp_f32.hip) -----------------------------------------------------------
  * The reference's Dense layers are fp32 (obbpose_model.py:326-327; HIGHEST-precision matmul, internal/math.py:22-24).
- * These entry points evaluate the same stack with v_mfma_f32_32x32x2_f32 (exact fp32, 1/16 of the bf16 rate), reading
- * the fp32 flax-layout parameters directly and exchanging ROW-MAJOR fp32 tensors: enc [rows,in_dim] (durf_encode_*'s
- * out_f32), view27 [B,27] (durf_view_enc's out_f32), raw [rows,4], act [rows, durf_mlp_f32_act_floats] (the input of
- * every Dense, recorded by the forward for the backward), dz [rows, durf_mlp_f32_dz_floats] (d loss / d pre-activation
- * of every Dense), d_enc [rows,64] (nullable; caller-zeroed).  ray_idx / count as in durf_mlp_fwd.  The weight
- * gradients are split over `nsplit` sample ranges and summed in a fixed order (deterministic); scratch:
- * durf_mlp_f32_dw_scratch_floats floats, tiles_dev: 3072 device ints.  grad_mlp: flax layout of one MLP, overwritten.
- * MipNerfModel(mlp_precision='f32') routes through these; bench.py never does. */
+ * These entry points evaluate the same stack with v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain over the
+ * input features, bias first; 1/16 of the bf16 MFMA rate), reading the fp32 flax-layout parameters directly.  Two users:
+ * the OBJECT BRANCH of a step with box-pose optimisation (durf_objf32_*: the box-hit rays of cfg4, whose pose gradient
+ * does not survive bf16 rounding) and the parity instrument MipNerfModel(mlp_precision='f32').
+ *   enc [rows,in_dim] row-major fp32 (durf_encode_*'s out_f32); NULL (width 256, in_dim 60 only): every row is the
+ *       constant encoding of a zero-masked Gaussian [0 x 30, 1 x 30] -- the background MLP's ONE evaluation of a
+ *       box-hit ray (durf_expand_raw), with N = 1 and ray_idx / count = that ray class;
+ *   view27 [B,27] (durf_view_enc's out_f32), raw [rows,4];
+ *   act / dz: per-sample records of the forward (the input of every Dense) / backward (d loss / d pre-activation of
+ *       every Dense), durf_mlp_f32_{act,dz}_floats floats per row, ROWS ROUNDED UP TO 32, stored per 32-row tile as
+ *       [tile][float index][32 rows];  opaque to the caller, only passed between these calls;
+ *   params_t: durf_mlp_f32_transpose's output (per-layer transposed kernels, same size and offsets as mlp_params);
+ *   d_enc [rows,64] row-major (nullable; every valid row is overwritten);  ray_idx / count as in durf_mlp_fwd.
+ * Weight gradients are split over `nsplit` sample shares and summed in a fixed order (deterministic); scratch:
+ * durf_mlp_f32_dw_scratch_floats floats.  grad_mlp: flax layout of one MLP, overwritten. */
 size_t durf_mlp_f32_act_floats(int width, int in_dim);
 size_t durf_mlp_f32_dz_floats(int width, int in_dim);
 size_t durf_mlp_f32_dw_scratch_floats(int width, int in_dim, int nsplit);
+int durf_mlp_f32_transpose(void* stream, int width, int in_dim, int K, const float* mlp_params, size_t param_stride,
+                           float* params_t);
 int durf_mlp_fwd_f32(void* stream, int width, int in_dim, size_t rows, int N, const float* enc, const float* view27,
                      const int32_t* ray_idx, const int32_t* count, const float* mlp_params, float* raw,
                      float* act /* nullable: inference */);
 int durf_mlp_bwd_f32(void* stream, int width, int in_dim, size_t rows, int N, const float* draw,
-                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* act,
-                     float* dz, float* d_enc);
+                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* params_t,
+                     const float* act, float* dz, float* d_enc);
 int durf_mlp_dw_f32(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count, const float* act,
-                    const float* dz, int nsplit, float* scratch, int32_t* tiles_dev, float* grad_mlp);
+                    const float* dz, int nsplit, float* scratch, float* grad_mlp);
+/* The background MLP (width 256, in_dim 60) on the box-hit rays in fp32: idx / count = that ray class (durf_compact_classes,
+ * class 1); raw_tail [B,4], row j = ray idx[j] -- what durf_mlp_fwd_f32(enc = NULL) computes, but with Dense_0..Dense_9,
+ * whose input is the same for every such ray, evaluated once (trunk: 257 floats of scratch).  durf_expand_raw's raw_tail. */
+int durf_bkgd_hit_rays_f32(void* stream, int B, const float* view27, const float* bkgd_params, const int32_t* idx,
+                           const int32_t* count, float* trunk, float* raw_tail);
+/* The K object MLPs (width 128, in_dim 63) of one level on the fp32 kernels, ONE launch per phase with the object
+ * index in the grid: idx [K,B] / count [K] from durf_compact_hits; enc [K, B*N, 63]; raw [K, B*N, 4]; act / dz
+ * [K, durf_objf32_{act,dz}_stride floats]; d_enc [K, B*N, 64]; obj_params / obj_params_t: BoxMLP_0 .. BoxMLP_{K-1},
+ * param_stride floats apart.  durf_objf32_dw_batch takes the records of every level (host arrays of nlevels device
+ * pointers) and writes grad_obj [K, grad_stride]; scratch: K * durf_mlp_f32_dw_scratch_floats(128, 63, nsplit). */
+size_t durf_objf32_act_stride(int B, int N);
+size_t durf_objf32_dz_stride(int B, int N);
+int durf_encode_obj_f32_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
+                              const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
+                              const float* barf_w /* host float[10] */, int flags, float* enc /* [K, B*N, 63] */);
+int durf_objf32_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* enc,
+                          const float* view27, const float* obj_params, size_t param_stride, float* raw,
+                          float* act /* nullable: inference */);
+int durf_objf32_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* draw,
+                          const float* obj_params, const float* obj_params_t, size_t param_stride, const float* act,
+                          float* dz, float* d_enc /* nullable */);
+int durf_objf32_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels, const float* const* act,
+                         const float* const* dz, int nsplit, float* scratch, float* grad_obj, size_t grad_stride);
 
 /* The K per-object BoxMLPs of one level as one call each (obbpose_model.py:174-201): every kernel of the
  * per-object path runs ONCE with the object index in blockIdx.y (csrc/objects.hip), on `stream`.
@@ -340,17 +374,19 @@ int durf_dw_finalize_all(void* stream, int in_bkgd, int nseg, const size_t* rows
  * durf_mlp_bwd(..., d_enc) then durf_encode_obj_bwd accumulates 21 per-object sums
  * (scratch: 21*B floats; sums [K,21], zeroed by the caller once per step); durf_pose_finish
  * turns them into d(loss)/d(box_centers[ts]) added to grad6 [K,6]
- * (want_pos = !no_pose_opt, want_rot = !no_yaw_opt, obbpose_model.py:100-104). */
+ * (want_pos = !no_pose_opt, want_rot = !no_yaw_opt, obbpose_model.py:100-104).  precise != 0: libm exp / sin / cos
+ * (behind the fp32 object branch); 0: the hardware transcendentals (behind the bf16 object MLPs). */
 int durf_encode_obj_bwd(void* stream, int B, int N, int k_obj, const int32_t* idx, const int32_t* count,
                         const float* d_enc, const float* t_vals, const float* origins_s,
                         const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                        const float* pose, const float* barf_w, float* scratch, float* sums);
+                        const float* pose, const float* barf_w, float* scratch, float* sums, int precise);
 /* The same for all K objects of a level in one launch pair (blockIdx.y = object): idx [K,B], count [K], d_enc [K, B*N, 64]
  * (the slab durf_obj_bwd_batch fills), pose [K,6], scratch K*21*B floats, sums [K,21] accumulated over levels. */
 int durf_encode_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
                               const float* d_enc, const float* t_vals, const float* origins_s,
                               const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                              const float* pose, const float* barf_w /* host float[10] */, float* scratch, float* sums);
+                              const float* pose, const float* barf_w /* host float[10] */, float* scratch, float* sums,
+                              int precise);
 int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, int want_pos, int want_rot,
                      float* grad6);
 

@@ -52,3 +52,10 @@ def extra_fuzz_seeds(kind):
     n = int(os.environ.get('DURF_FUZZ_EXTRA', '0'))
     base = 1000 if kind == 'FWD' else 2000
     return list(range(base, base + n))
+
+
+def slow_fuzz_seeds(seeds):
+    """seeds that pass but are the slowest cases of their sweep (kept out of the default run for wall-clock only):
+    included whenever DURF_FUZZ_EXTRA is set"""
+    import os
+    return list(seeds) if int(os.environ.get('DURF_FUZZ_EXTRA', '0')) > 0 else []

@@ -183,3 +183,85 @@ def test_box_pose_gradients_fp32_exact(cuda):
     assert float(ob_[:, :3].norm()) > 0 and float(ob_[:, 3:].norm()) > 0
     assert _rel(gb[:, :3], ob_[:, :3]) < 2e-3, 'position grad rel err %g' % _rel(gb[:, :3], ob_[:, :3])
     assert _rel(gb[:, 3:], ob_[:, 3:]) < 2e-3, 'rotation grad rel err %g' % _rel(gb[:, 3:], ob_[:, 3:])
+
+
+def test_object_batch_calls_match_the_single_mlp_calls(cuda):
+    """durf_encode_obj_f32_batch / durf_objf32_{fwd,bwd,dw}_batch (all K objects per launch: the production object
+    branch when the pose is optimised) are the single-MLP fp32 entry points with the object index in the grid: raw,
+    d(enc) and weight gradients BIT-identical per object, ragged hit counts, an object without hits included."""
+    K, B, N, alpha = 4, 96, 32, 4.5
+    g = torch.Generator().manual_seed(3)
+    b = synthetic.make_batch(B, K, seed=17)
+    db = H.device_batch(b, cuda)
+    rays = db['rays']
+    pose = db['init'][b['ts']].contiguous()
+    radii = rays.radii.reshape(-1).contiguous()
+    o_s, d_s, hit, zo = ops.ray_setup(rays.origins, rays.directions, pose, db['ext'].reshape(-1, 3).contiguous())
+    hit[:, 3] = 0                                                      # object 3: no hit ray at all
+    idx, count, slot = ops.compact_hits(hit)
+    assert int(count.max()) > 0 and int(count[3]) == 0
+    t_vals = ops.sample_t(rays.near.reshape(-1).contiguous(), rays.far.reshape(-1).contiguous(), N)
+    view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1]
+    sz = ops.mlp_param_count(128, 63)
+    flat = ((torch.rand(K * sz, generator=g) - 0.5) * 0.2).to(cuda)
+    flat_t = ops.mlp_f32_transpose(128, 63, flat, K=K, param_stride=sz)
+    draw = (torch.randn(B * N, 4, generator=g) * 0.1).to(cuda)
+    slabs = ops.ObjSlabsF32(K, B, N, cuda, True)
+    ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz)
+    ops.objf32_bwd_batch(slabs, idx, count, draw, flat, flat_t, sz, want_d_enc=True)
+    grad = torch.zeros(K * sz, device=cuda)
+    ops.objf32_dw_batch([slabs], count, grad, sz, nsplit=3)
+    for k in range(K):
+        c = int(count[k]) * N
+        ck = count[k:k + 1]
+        _, enc_k = ops.encode_obj(B, idx[k], ck, t_vals, o_s, d_s, radii, alpha, tile=False, f32=True)
+        assert torch.equal(slabs.enc[k, :c], enc_k[:c])
+        pk = flat[k * sz:(k + 1) * sz]
+        raw_k, act_k = ops.mlp_fwd_f32(128, 63, B * N, N, enc_k, view27, pk, ray_idx=idx[k], count=ck, want_act=True)
+        assert torch.equal(slabs.raw[k, :c], raw_k[:c])
+        dz_k, denc_k = ops.mlp_bwd_f32(128, 63, B * N, N, draw, pk, act_k, ray_idx=idx[k], count=ck, want_d_enc=True,
+                                       params_t=flat_t[k * sz:(k + 1) * sz])
+        assert torch.equal(slabs.d_enc[k, :c], denc_k[:c])
+        gk = torch.zeros(sz, device=cuda)
+        ops.mlp_dw_f32(128, 63, B * N, N, act_k, dz_k, gk, count=ck, nsplit=3)
+        assert torch.equal(grad[k * sz:(k + 1) * sz], gk), 'object %d' % k
+    assert float(grad[3 * sz:].abs().max()) == 0.0
+
+
+def test_constant_encoding_rows(cuda):
+    """durf_mlp_fwd_f32 with enc = NULL (the background MLP's one evaluation of a box-hit ray: the encoding of a
+    zero-masked Gaussian, [0 x 30, 1 x 30], obbpose_model.py:205-210) == the same call on that encoding spelled out,
+    and == the fp64 oracle MLP on it"""
+    B, cnt = 77, 41
+    cfg, params, flat, g = _params(256, 60, 9)
+    view_all = torch.randn(B, 27, generator=g)
+    ridx = torch.randperm(B, generator=g)[:B].int()
+    count = torch.tensor([cnt], dtype=torch.int32, device=cuda)
+    const = torch.cat([torch.zeros(B, 30), torch.ones(B, 30)], 1)
+    d = lambda t: t.to(cuda).contiguous()
+    a = ops.mlp_fwd_f32(256, 60, B, 1, None, d(view_all), d(flat), ray_idx=d(ridx), count=count)
+    bb = ops.mlp_fwd_f32(256, 60, B, 1, d(const), d(view_all), d(flat), ray_idx=d(ridx), count=count)
+    assert torch.equal(a, bb) and (a[cnt:] == 0).all()
+    p64 = [[k.double(), b_.double()] for k, b_ in params]
+    rgb, dens = R.mlp_apply(p64, const[:cnt, None, :].double(), view_all[ridx[:cnt].long()].double(), cfg)
+    want = torch.cat([rgb.reshape(cnt, 3), dens.reshape(cnt, 1)], -1)
+    torch.testing.assert_close(a[:cnt].cpu().double(), want, rtol=2e-6, atol=2e-6)
+
+
+def test_background_mlp_on_the_box_hit_rays(cuda):
+    """durf_bkgd_hit_rays_f32 (trunk once + view layer per ray) == durf_mlp_fwd_f32(enc = NULL) to fp32 round-off (the
+    two sum in different orders) and == the fp64 oracle MLP; rows past count untouched."""
+    B, cnt = 203, 57
+    cfg, params, flat, g = _params(256, 60, 11)
+    view_all = torch.randn(B, 27, generator=g)
+    ridx = torch.randperm(B, generator=g).int()
+    count = torch.tensor([cnt], dtype=torch.int32, device=cuda)
+    d = lambda t: t.to(cuda).contiguous()
+    a = ops.mlp_fwd_f32(256, 60, B, 1, None, d(view_all), d(flat), ray_idx=d(ridx), count=count)
+    got = ops.bkgd_hit_rays_f32(B, d(view_all), d(flat), d(ridx), count)
+    torch.testing.assert_close(got[:cnt], a[:cnt], rtol=2e-6, atol=2e-6)
+    const = torch.cat([torch.zeros(cnt, 30), torch.ones(cnt, 30)], 1)
+    p64 = [[k.double(), b_.double()] for k, b_ in params]
+    rgb, dens = R.mlp_apply(p64, const[:, None, :].double(), view_all[ridx[:cnt].long()].double(), cfg)
+    want = torch.cat([rgb.reshape(cnt, 3), dens.reshape(cnt, 1)], -1)
+    torch.testing.assert_close(got[:cnt].cpu().double(), want, rtol=2e-6, atol=2e-6)

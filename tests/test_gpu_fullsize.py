@@ -164,8 +164,8 @@ def test_per_rank_shapes_of_cfg5_and_cfg4_at_128_samples(cuda, K, pose_opt, alph
     (1024 rays x 128 samples x 2 levels): the bf16 production step against the exact-fp32 instrument on the same
     batch, parameters and sampling noise.  The instrument itself is pinned against the oracle at sizes the oracle
     can run (tests/test_gpu_f32_exact.py), so this carries oracle parity to the full sample count: rendered colours
-    2e-2 (SURVEY.md 8c BF16 mode), loss terms 2e-3 rel, MLP gradients 5e-2 norm-wise, pose gradients in direction
-    and scale (see below), plus determinism of the whole gradient."""
+    2e-2 (SURVEY.md 8c BF16 mode), loss terms 2e-3 rel, MLP gradients 5e-2 norm-wise, pose gradients 5e-2 norm-wise
+    (see below), plus determinism of the whole gradient."""
     Bs = 1024
     g = torch.Generator().manual_seed(12)
     noise = dict(t_rand=torch.rand(Bs, N + 1, generator=g).to(cuda), u_rand=torch.rand(Bs, N + 1, generator=g).to(cuda))
@@ -199,19 +199,15 @@ def test_per_rank_shapes_of_cfg5_and_cfg4_at_128_samples(cuda, K, pose_opt, alph
             r = _rel(a['grad'][sl], f['grad'][sl])
             assert r < 5e-2, '%s: bf16 vs exact-fp32 gradient rel err %g' % (name, r)
     if pose_opt:
-        # The pose gradient is a sum over ~100 hit rays x 128 samples with heavy cancellation (at initialisation its
-        # norm is ~1e-2 of the summed magnitudes), so the bf16 forward's rounding (features, activations, a few ReLU
-        # flips) leaves an ABSOLUTE noise floor of ~2-3e-3 on it: measured over seeds / alpha / box noise at this
-        # shape the relative deviation from the exact-fp32 instrument is 3-38 %, inversely proportional to the
-        # gradient's norm (tools/pose_grad_scan.py; carrying the backward's gradients as bf16 hi+lo pairs changed
-        # nothing, so it is not the backward's rounding).  Direction and scale must agree; the chain itself is exact
-        # (2e-3 vs fp64 in exact-fp32 mode, tests/test_gpu_f32_exact.py).
+        # The pose gradient is a sum over ~100 hit rays x 128 samples that cancels to ~1 % of its summed magnitudes, so
+        # bf16 rounding anywhere on the hit rays used to leave 3-38 % on it (round 2; tools/pose_grad_ablate.py shows the
+        # object MLPs and the background MLP's evaluation of the hit rays each carry about half).  With pose optimisation
+        # on the production path now evaluates the box-hit rays in fp32 (MipNerfModel.object_precision), and its pose
+        # gradient must agree with the exact-fp32 instrument's NORM-WISE (measured: ~1e-6; the gate is the 5e-2 the MLP
+        # gradients are held to).
         ga = a['grad'][lay.box[0]:lay.box[1]].view(lay.T, K, 6)[a['ts']]
         gf = f['grad'][lay.box[0]:lay.box[1]].view(lay.T, K, 6)[a['ts']]
         assert float(gf.abs().max()) > 0
         for sl, nm in ((slice(0, 3), 'position'), (slice(3, 6), 'rotation')):
             x, y = ga[:, sl].reshape(-1), gf[:, sl].reshape(-1)
-            cos = float(torch.dot(x, y) / (x.norm() * y.norm()))
-            ratio = float(x.norm() / y.norm())
-            assert cos > 0.85 and 0.6 < ratio < 1.6, 'pose gradient (%s), bf16 vs exact fp32: cos %g, norm ratio %g' % (nm, cos, ratio)
-            assert float((x - y).abs().max()) < 1e-2, 'absolute deviation of the %s gradient' % nm
+            assert _rel(x, y) < 5e-2, 'pose gradient (%s), production precision vs exact fp32: rel err %g' % (nm, _rel(x, y))

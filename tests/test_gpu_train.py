@@ -203,8 +203,12 @@ def test_train_step(cuda, K, N, B):
 
 @pytest.mark.parametrize('K,alpha,tv', [(2, 4.5, 0.0), (1, 10.0, 0.01)])
 def test_box_pose_gradients(cuda, K, alpha, tv):
-    """cfg4: BARF pose optimisation on (no_pose_opt = no_yaw_opt = False).  d(loss)/d(box_centers[ts])
-    through encoding -> frustum Gaussians -> world2object -> Rodrigues vs the oracle's autograd."""
+    """cfg4: BARF pose optimisation on (no_pose_opt = no_yaw_opt = False) in the PRODUCTION precision (bf16 background
+    MLP; the box-hit rays -- object MLPs and the background MLP's one evaluation per hit ray -- in fp32, which is what
+    MipNerfModel.obj_precision = 'auto' selects when the pose is optimised).  d(loss)/d(box_centers[ts]) through
+    encoding -> frustum Gaussians -> world2object -> Rodrigues vs the autograd of the plain fp32 oracle (no bf16
+    rounding on its side): position AND rotation <= 5e-2 norm-wise per object (measured ~1e-4; round 2's all-bf16
+    object branch was held to 6e-2 / 0.2 against a bf16-rounded oracle)."""
     B, N = 1024, 32
     utils.clear_gin()
     utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
@@ -215,14 +219,14 @@ def test_box_pose_gradients(cuda, K, alpha, tv):
     b = synthetic.make_batch(B, K, seed=77 + K, noise_boxes=0.05)
     ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
     model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
+    assert model.mlp_precision == 'bf16' and model.object_precision() == 'f32'
     params = H.oracle_params_from_variables(variables)
     prev_c, prev_d = ob['init'][0:1] + 0.01, db['init'][0:1] + 0.01
     grad, raw, pose = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, alpha, prev_d)
     torch.cuda.synchronize()
     ocfg = dict(R.CONFIG_DEFAULTS, randomized=False, tv_loss_mult=tv)
     mcfg = dict(num_samples=N, no_pose_opt=False, no_yaw_opt=False)
-    _, _, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, mcfg, 5e-4, 3.0, alpha, prev_c,
-                                        mlp_hook=R.mlp_apply_bf16)
+    _, _, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, mcfg, 5e-4, 3.0, alpha, prev_c)
     lay = variables.layout
     got = grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6).cpu()
     want = ograds[0]
@@ -232,9 +236,13 @@ def test_box_pose_gradients(cuda, K, alpha, tv):
     assert float(got[other].abs().max()) == 0.0 and float(want[other].abs().max()) == 0.0
     for k in range(K):
         rp, rr = _rel(got[ts, k, :3], want[ts, k, :3]), _rel(got[ts, k, 3:], want[ts, k, 3:])
-        # rotation gradients are sums with heavy cancellation over rays: bf16 d(enc) noise is amplified
-        assert rp < 6e-2 and rr < 0.2, 'object %d: position rel err %g, rotation rel err %g\ngot %s\nwant %s' % (
+        assert rp < 5e-2 and rr < 5e-2, 'object %d: position rel err %g, rotation rel err %g\ngot %s\nwant %s' % (
             k, rp, rr, got[ts, k], want[ts, k])
+    # the object MLPs' own gradients come out of the fp32 kernels: fp32-class agreement
+    for k in range(K):
+        so = slice(lay.mlp_off['BoxMLP_%d' % k], lay.mlp_off['BoxMLP_%d' % k] + lay.mlp_size[128])
+        og_k = torch.cat([x.reshape(-1) for x in ograds])[so]
+        assert _rel(grad.cpu()[so], og_k) < 5e-3, 'BoxMLP_%d grad rel err %g' % (k, _rel(grad.cpu()[so], og_k))
     # the MLP gradients are unaffected by switching pose optimisation on
     og = torch.cat([x.reshape(-1) for x in ograds])
     sl = slice(lay.mlp_off['MLP_0'], lay.mlp_off['MLP_0'] + lay.mlp_size[256])
@@ -459,13 +467,13 @@ def test_train_step_random_configurations(cuda, seed, precision):
 
 
 @pytest.mark.parametrize('precision', ['bf16', 'f32'])
-@pytest.mark.parametrize('seed', [300, 302, 303] + H.extra_fuzz_seeds('POSE'))
+@pytest.mark.parametrize('seed', [300, 302, 303] + H.extra_fuzz_seeds('POSE') + H.slow_fuzz_seeds([301]))
 def test_box_pose_gradients_random_configurations(cuda, seed, precision):
     """Seeded sweep of the box-pose gradient (cfg4's path: the batched durf_encode_obj_bwd_batch + durf_pose_finish behind
     the object MLPs' d(enc)): K in 1..5, ragged B, alpha below / at the full BARF window, TV prior on and off, position
     or rotation frozen.  f32: against the fp32 oracle's autograd at test_box_pose_gradients_fp32_exact's 2e-3 (5e-3 here:
-    more cancellation with more objects); bf16: direction and scale only -- the bf16 noise floor of this gradient is
-    measured in tools/pose_grad_scan.py."""
+    more cancellation with more objects); bf16 = the production precision (bf16 background MLP, box-hit rays in fp32):
+    5e-2 norm-wise against the same plain fp32 oracle (round 2, all-bf16 object branch: direction and scale only)."""
     import random
     r = random.Random(seed)
     f32 = precision == 'f32'
@@ -491,8 +499,7 @@ def test_box_pose_gradients_random_configurations(cuda, seed, precision):
     torch.cuda.synchronize()
     ocfg = dict(R.CONFIG_DEFAULTS, randomized=False, tv_loss_mult=tv)
     mcfg = dict(num_samples=N, no_pose_opt=no_pose, no_yaw_opt=no_yaw)
-    _, _, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, mcfg, 5e-4, 3.0, alpha, prev_c,
-                                        mlp_hook=None if f32 else R.mlp_apply_bf16)
+    _, _, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, mcfg, 5e-4, 3.0, alpha, prev_c)
     if (ostats['losses'] != ostats['losses']).any():
         pytest.skip('seed %d drew a multi-hit ray (NaN in the reference too)' % seed)
     lay = variables.layout
@@ -508,11 +515,7 @@ def test_box_pose_gradients_random_configurations(cuda, seed, precision):
         if frozen or float(want[:, sl].norm()) == 0.0:
             continue
         g, w = got[:, sl].reshape(-1), want[:, sl].reshape(-1)
-        if f32:
-            assert _rel(g, w) < 5e-3, '%s cols %s rel err %g\ngot %s\nwant %s' % (tag, sl, _rel(g, w), g, w)
-        else:
-            cos = float((g * w).sum() / (g.norm() * w.norm() + 1e-30))
-            ratio = float(g.norm() / (w.norm() + 1e-30))
-            # direction and scale, unless the whole gradient is below the bf16 noise floor (~3e-3 absolute)
-            assert (cos > 0.8 and 0.5 < ratio < 2.0) or float((g - w).abs().max()) < 1e-2, \
-                '%s cols %s cos %g ratio %g\ngot %s\nwant %s' % (tag, sl, cos, ratio, g, w)
+        # (an absolute floor for a component the optimiser has nothing to do with: a gradient that cancels to < 1e-5)
+        tol = 5e-3 if f32 else 5e-2
+        assert _rel(g, w) < tol or float((g - w).abs().max()) < 1e-6, '%s cols %s rel err %g\ngot %s\nwant %s' % (
+            tag, sl, _rel(g, w), g, w)

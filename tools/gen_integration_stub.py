@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """include/durf_hip.h -> the reference-side ctypes binding (include/durf_ctypes_stub.py) and the copy of it
-embedded in INTEGRATION.md, so the documented stub cannot drift from the header:
+embedded in INTEGRATION.md, and the product's own table durf_amd/_sigs.py, so that no copy can drift from the header:
     python tools/gen_integration_stub.py            # rewrite both
     python tools/gen_integration_stub.py --check    # exit 1 if either is stale (tests/test_host_logic.py)
 The parser handles exactly the C subset the header uses (scalar / pointer parameters, /* */ comments)."""
@@ -11,6 +11,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HDR = os.path.join(ROOT, 'include', 'durf_hip.h')
 STUB = os.path.join(ROOT, 'include', 'durf_ctypes_stub.py')
+SIGS = os.path.join(ROOT, 'durf_amd', '_sigs.py')          # the product's own binding table (durf_amd/_lib.py)
 DOC = os.path.join(ROOT, 'INTEGRATION.md')
 BEGIN, END = '<!-- BEGIN GENERATED: tools/gen_integration_stub.py -->', '<!-- END GENERATED -->'
 
@@ -69,6 +70,16 @@ def render():
     return '\n'.join(L)
 
 
+def render_sigs():
+    L = ['"""Argument types of every entry point of libdurf_hip.so -- GENERATED from include/durf_hip.h by',
+         'tools/gen_integration_stub.py (do not edit; `--check` runs in the CPU test-suite)."""', 'import ctypes as C', '',
+         'vp, i32, f32, u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t', '', 'SIGS = {']
+    for name, ret, params in parse_header():
+        L.append('    %r: (%s, [%s]),' % (name, ret, ', '.join(t for t, _ in params)))
+    L += ['}', '']
+    return '\n'.join(L)
+
+
 def doc_with_stub(doc, stub):
     a, b = doc.index(BEGIN), doc.index(END)
     return doc[:a + len(BEGIN)] + '\n```python\n' + stub + '```\n' + doc[b:]
@@ -76,14 +87,17 @@ def doc_with_stub(doc, stub):
 
 def main():
     stub = render()
+    sigs = render_sigs()
     doc = open(DOC).read()
     new_doc = doc_with_stub(doc, stub)
     if '--check' in sys.argv:
-        ok = os.path.exists(STUB) and open(STUB).read() == stub and new_doc == doc
+        ok = (os.path.exists(STUB) and open(STUB).read() == stub and new_doc == doc and
+              os.path.exists(SIGS) and open(SIGS).read() == sigs)
         if not ok:
             print('stale: run python tools/gen_integration_stub.py')
         sys.exit(0 if ok else 1)
     open(STUB, 'w').write(stub)
+    open(SIGS, 'w').write(sigs)
     open(DOC, 'w').write(new_doc)
     print('wrote %s (%d functions) and the block in INTEGRATION.md' % (os.path.relpath(STUB, ROOT), len(parse_header())))
 

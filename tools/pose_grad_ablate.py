@@ -1,5 +1,7 @@
-"""Where the bf16 noise of the box-pose gradient comes from: cfg4's per-rank shape with the object branch in bf16 / fp32
-(MipNerfModel.obj_precision) against the exact-fp32 instrument, true fp32 weights (NOT rounded to bf16), several seeds."""
+"""Where the bf16 noise of the box-pose gradient comes from: cfg4's per-rank shape with the box-hit rays in bf16 / fp32
+(MipNerfModel.obj_precision: the object MLPs AND the background MLP's one evaluation per hit ray) against the exact-fp32
+instrument, true fp32 weights (NOT rounded to bf16), several seeds.  Round-3 finding (profiles/r03_pose_grad_ablation.txt):
+fp32 object MLPs alone leave 10-25 %, an fp32 background evaluation of the hit rays alone 6-18 %, both together 0."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -16,9 +18,7 @@ def run(B, K, N, alpha, noise_boxes, seed, rnd, round_weights=False):
     out, ms = {}, {}
     g = torch.Generator().manual_seed(12)
     noise = dict(t_rand=torch.rand(B, N + 1, generator=g).to(cuda), u_rand=torch.rand(B, N + 1, generator=g).to(cuda))
-    for tag, prec, oprec, tail in (('bf16', 'bf16', 'bf16', '0'), ('mixed', 'bf16', 'f32', '0'), ('tail', 'bf16', 'bf16', '1'),
-                                   ('mix+tl', 'bf16', 'f32', '1'), ('f32', 'f32', 'auto', '0')):
-        os.environ['DURF_TAIL_F32'] = tail
+    for tag, prec, oprec in (('bf16', 'bf16', 'bf16'), ('mixed', 'bf16', 'f32'), ('f32', 'f32', 'auto')):
         utils.clear_gin()
         utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = False\n'
                         'MipNerfModel.no_yaw_opt = False\nMipNerfModel.mlp_precision = %r\nMipNerfModel.obj_precision = %r\n'
@@ -47,7 +47,7 @@ def run(B, K, N, alpha, noise_boxes, seed, rnd, round_weights=False):
     f = out['f32']
     print('B=%4d K=%d N=%3d alpha=%4.1f noise=%.2f seed=%d rnd=%s wround=%s hit=%.3f |f32 pos| %.2e |f32 rot| %.2e' % (
         B, K, N, alpha, noise_boxes, seed, rnd, round_weights, b['hit_fraction'], float(f[:, :3].norm()), float(f[:, 3:].norm())))
-    for tag in ('bf16', 'mixed', 'tail', 'mix+tl'):
+    for tag in ('bf16', 'mixed'):
         a = out[tag]
         print('    %-6s pos %.4f rot %.4f  objW %.4f   loss_and_grad %.2f ms (f32: %.1f ms)' % (
             tag, rel(a[:, :3], f[:, :3]), rel(a[:, 3:], f[:, 3:]), rel(out[tag + '_objw'], out['f32_objw']), ms[tag], ms['f32']))
