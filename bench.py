@@ -22,7 +22,6 @@ cfg2 (CARLA, K=1, far=200), cfg4 (Waymo + box-pose optimisation, 1024 rays/GPU) 
 import argparse
 import json
 import os
-import socket
 import subprocess
 import sys
 import time
@@ -68,6 +67,9 @@ def parse_args():
     ap.add_argument('--no-calibration', action='store_true', help='skip the vendor-GEMM board calibration line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-op time table to stderr')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='one rank, but through the data-parallel path: a world-size-1 RCCL group (DURF_FORCE_DIST=1), so the '
+                         'gradient all-reduce + stream wait run and their per-step cost shows against a plain run')
     ap.add_argument('--selftest-launch', action='store_true',
                     help='CPU/gloo check of the spawn + rendezvous + shard + all-reduce plumbing (no HIP kernels)')
     return ap.parse_args()
@@ -77,14 +79,18 @@ def parse_args():
 # self-launch: one child per GPU, started BEFORE anything in this process touches the GPU
 # ---------------------------------------------------------------------------------------------
 def spawn_ranks(n):
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    port = s.getsockname()[1]
-    s.close()
+    # Rendezvous through a FILE store (train_boxpose.init_distributed reads DURF_RDZV_FILE): there is no port for another
+    # process to take between picking it and binding it.  HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only
+    # supports dmabuf IPC -- without it RCCL's cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid
+    # argument` (the image exports it already; set here in case the caller's environment dropped it).
+    import tempfile
+    fd, rdzv = tempfile.mkstemp(prefix='durf_rdzv_')
+    os.close(fd)
+    os.remove(rdzv)                              # the store creates it
     procs = []
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
-                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), DURF_RDZV_FILE=rdzv,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
     pending = set(range(n))
@@ -99,6 +105,8 @@ def spawn_ranks(n):
                 for q in pending:
                     procs[q].kill()             # exactly the PIDs started above
         time.sleep(0.05)
+    if os.path.exists(rdzv):
+        os.remove(rdzv)
     return rc
 
 
@@ -254,6 +262,8 @@ def main():
     if args.selftest_launch:
         raise SystemExit(selftest_launch(args))
 
+    if args.force_dist:
+        os.environ['DURF_FORCE_DIST'] = '1'
     import torch
     import torch.distributed as dist
     from durf_amd import _lib, obbpose_model, ops, synthetic, train_boxpose, utils
@@ -372,7 +382,10 @@ def main():
                                                 'full train step' % (NS, K_OBJ),
                                name=args.config, rays_per_gpu=B, global_batch=B * world, num_samples=NS,
                                num_levels=N_LEVELS, objects=K_OBJ, far=far, hit_fraction=hit, randomized=True,
-                               pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world),
+                               pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world,
+                               object_precision=model.object_precision() if K_OBJ else None,
+                               collective=('rccl all-reduce, world size %d%s' % (world, ' (forced)' if args.force_dist else ''))
+                               if (world > 1 or args.force_dist) else None),
                    loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,
                    # distribution of the individual steps' GPU time: ms_per_step is the mean over the timed region and
                    # includes any stall (a step far above the median is the host or the runtime, not the kernels)
@@ -380,7 +393,7 @@ def main():
                                 max=step_times[-1],
                                 slow_steps=[i for i, t in enumerate(step_raw) if t > 1.5 * step_times[len(step_times) // 2]]))
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <stdio.h>
 #include "../../include/durf_hip.h"
 

@@ -9,10 +9,11 @@
 //  * the PARITY INSTRUMENT (MipNerfModel.mlp_precision = 'f32', SURVEY.md 8c "F32_EXACT"): every MLP of the model.
 //
 // One workgroup = 32 samples (one MFMA N tile) x W/32 waves; wave w owns output tile w of every Dense (M split), the
-// activations pass between layers through LDS as x[feature][sample], and the fp32 flax-layout weights stream
-// L2 -> registers -> LDS in chunks of KC input rows, double buffered, the next chunk (also across layer boundaries)
-// in flight behind the current chunk's MFMAs.  The 1- and 3-wide heads (density, rgb) are VALU dot products.
-// The backward runs the same loop on per-layer TRANSPOSED weights (durf_mlp_f32_transpose, once per step).
+// activations pass between layers through LDS as x[feature][sample], and the weights stream L2 -> registers -> LDS as
+// CHUNKS of KC input rows from a packed stream (durf_mlp_f32_pack, once per step: the chunks of a whole pass in the
+// order they are consumed, zero-padded to whole tiles, so a chunk is one contiguous, 16-byte aligned block and a
+// load is `descriptor + lane offset + immediate`), double buffered in LDS, DEPTH chunks ahead in registers.  The
+// backward walks a second stream of per-layer TRANSPOSED kernels.  The 1- / 3-wide heads are VALU dot products.
 //
 // Per-sample records, stored per 32-sample tile as [tile][float index][32 samples] ("tile-transposed", so that a
 // wave's accumulator registers store and load them as full 128-byte lines):
@@ -30,15 +31,17 @@ struct F32Spec {
     int act, dz, W, in_dim;
 };
 
-__host__ __device__ inline F32Spec f32_spec(int W, int in_dim) {
-    F32Spec s;
+// (constexpr: the fused kernels are instantiated for the two MLPs of the model and see every offset as an immediate)
+__host__ __device__ constexpr F32Spec f32_spec(int W, int in_dim) {
+    F32Spec s{};
     s.W = W; s.in_dim = in_dim;
     int x = 0, d = 0;
+    size_t woff = 0;
     for (int l = 0; l < 12; l++) {
-        int fi, fo;
-        durf_layer_shape(W, in_dim, l, &fi, &fo);
+        const int fi = l == 0 ? in_dim : (l == 5 ? W + in_dim : (l == 10 ? W + 27 : (l == 11 ? 128 : W)));
+        const int fo = l == 8 ? 1 : (l == 10 ? 128 : (l == 11 ? 3 : W));
         s.L[l].fi = fi; s.L[l].fo = fo;
-        s.L[l].w_off = durf_layer_offset(W, in_dim, l, 0);
+        s.L[l].w_off = woff; woff += (size_t)fi * fo + fo;          // == durf_layer_offset(W, in_dim, l, 0)
         s.L[l].relu = (l <= 7 || l == 10) ? 1 : 0;
         s.L[l].dz_off = d; d += fo;
         if (l == 9) s.L[l].x_off = s.L[8].x_off;           // bottleneck reads h7 like the density head
@@ -57,8 +60,12 @@ struct F32Cfg {
     static constexpr int KC = W == 128 ? 32 : 16; // input rows per weight chunk
     static constexpr int XROWS = W + 64;         // widest Dense input (W + 63) padded
     static constexpr int CMAX = W + 64;          // widest chunk (backward of Dense_5: W + in_dim outputs)
-    static constexpr int PF = KC * CMAX / NT;    // prefetch registers per thread
-    static constexpr int LDS_FLOATS = 2 * XROWS * F32_XS + 2 * 64 * F32_XS + 2 * KC * CMAX + 8 * 4 * 32 + 4 * 32;
+    static constexpr int PFV = (KC * CMAX / 4 + NT - 1) / NT;      // prefetch registers (float4) per thread and chunk
+    // constants fetched once per tile: biases of the 10 MFMA layers [10][W], Dense_8 kernel + bias [W + 1],
+    // Dense_11 kernel + bias [128 * 3 + 3] (padded to 392)
+    static constexpr int CONST_FLOATS = 10 * W + (W + 8) + 392;
+    static constexpr int LDS_FLOATS = 2 * XROWS * F32_XS + 2 * 64 * F32_XS + 2 * KC * CMAX + 8 * 4 * 32 + 4 * 32 + CONST_FLOATS;
+    static constexpr int DEPTH = W == 128 ? 4 : 2;       // register sets of the weight prefetch (F32Sched)
 };
 
 __device__ __forceinline__ int c_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -69,426 +76,485 @@ __device__ __forceinline__ size_t f32_rows(size_t rows, int N, const int32_t* co
     return c < rows ? c : rows;
 }
 
-// ---- weight chunks: global -> registers (issue) -> LDS (commit) ---------------------------------------------------
-// chunk = rows [r0, r0 + KC) x columns [0, C) of a row-major matrix with `stride` floats per row, `R` valid rows and
-// `cv` valid columns (the rest is zero-filled: partial last chunk, padded output tiles)
-template <int C, int KC, int NT, int PF>
-__device__ __forceinline__ void chunk_issue(float (&pf)[PF], const float* __restrict__ M, int stride, int R, int cv, int r0,
-                                            int tid) {
-    constexpr int E = KC * C / NT;
-    static_assert(E * NT == KC * C && E <= PF, "chunk does not divide over the workgroup");
+// ---- static chunk schedule ----------------------------------------------------------------------------------------
+// A pass over an MLP is a fixed sequence of weight chunks (KC input rows x C output columns of one Dense after the
+// other), known at compile time.  Chunk g is consumed from LDS buffer g & 1; at step g the workgroup commits chunk
+// g + 1 from its registers to the other buffer and issues the loads of chunk g + DEPTH into the register set that
+// chunk g occupied, so a chunk's loads have DEPTH - 1 chunks of MFMA time (across layer boundaries) to arrive.
+template <int W, bool BWD>
+struct F32Sched {
+    static constexpr int KC = F32Cfg<W>::KC;
+    static constexpr int NL = 10;
+    // forward: Dense_0..7, 9, 10 (the 1- and 3-wide heads are VALU work); backward: Dense_10, 9, 7, .. 1, 0
+    __host__ __device__ static constexpr int layer(int i) {
+        if (!BWD) return i <= 7 ? i : i + 1;
+        return i == 0 ? 10 : (i == 1 ? 9 : 9 - i);
+    }
+    // output columns of the chunk matrix, padded to whole 32-wide tiles (backward: the inputs whose gradient is
+    // propagated -- Dense_10: the W bottleneck-fed ones; Dense_5: trunk + encoding; Dense_0: the encoding)
+    __host__ __device__ static constexpr int cols(int i) {
+        const int l = layer(i);
+        if (!BWD) return l == 10 ? 128 : W;
+        return l == 5 ? W + 64 : (l == 0 ? 64 : W);
+    }
+    // reduction rows covered by the schedule (the stream is zero-padded beyond the actual count)
+    __host__ __device__ static constexpr int rows(int i) {
+        const int l = layer(i);
+        if (BWD) return l == 10 ? 128 : W;
+        return l == 0 ? 64 : (l == 5 ? W + 64 : (l == 10 ? W + 32 : W));
+    }
+    __host__ __device__ static constexpr int nchunk(int i) { return (rows(i) + KC - 1) / KC; }
+    __host__ __device__ static constexpr int total() { int t = 0; for (int i = 0; i < NL; i++) t += nchunk(i); return t; }
+    __host__ __device__ static constexpr int layer_of(int g) { int i = 0; while (g >= nchunk(i)) { g -= nchunk(i); i++; } return i; }
+    __host__ __device__ static constexpr int chunk_of(int g) { int i = 0; while (g >= nchunk(i)) { g -= nchunk(i); i++; } return g; }
+    // float offset of chunk g in the packed stream
+    __host__ __device__ static constexpr size_t chunk_off(int g) {
+        size_t o = 0;
+        for (int h = 0; h < g; h++) o += (size_t)KC * cols(layer_of(h));
+        return o;
+    }
+    __host__ __device__ static constexpr size_t stream_floats() { return chunk_off(total()); }
+};
+
+// packed streams of one MLP: [forward stream | backward stream]; element (chunk g, row rr, column c) of the forward
+// stream = kernel_l[c_g KC + rr][c], of the backward stream = kernel_l[c][c_g KC + rr] (transposed), zero outside
+template <int W, int IN>
+__global__ void __launch_bounds__(256)
+k_f32_pack(const float* __restrict__ P, float* __restrict__ ws, size_t p_stride, size_t ws_stride) {
+    constexpr F32Spec S = f32_spec(W, IN);
+    using SF = F32Sched<W, false>;
+    using SB = F32Sched<W, true>;
+    constexpr size_t NF = SF::stream_floats(), NB = SB::stream_floats();
+    P += blockIdx.y * p_stride; ws += blockIdx.y * ws_stride;
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NF + NB) return;
+    const bool bwd = e >= NF;
+    size_t rem = bwd ? e - NF : e;
+    float v = 0.0f;
+    bool done = false;
+    static_for<0, 10>([&](auto i_) {
+        constexpr int i = decltype(i_)::value;
+        if (done) return;
+        // same decode for both streams, with their own tables
+        const size_t sz = bwd ? (size_t)SB::nchunk(i) * SB::KC * SB::cols(i) : (size_t)SF::nchunk(i) * SF::KC * SF::cols(i);
+        if (rem >= sz) { rem -= sz; return; }
+        done = true;
+        const int C = bwd ? SB::cols(i) : SF::cols(i);
+        const int l = bwd ? SB::layer(i) : SF::layer(i);
+        const int r = (int)(rem / C), c = (int)(rem % C);
+        const int fi = S.L[l].fi, fo = S.L[l].fo;
+        if (!bwd) { if (r < fi && c < fo) v = P[S.L[l].w_off + (size_t)r * fo + c]; }
+        else {
+            const int cv = l == 10 ? W : fi;                  // the view-fed inputs of Dense_10 are not propagated
+            if (r < fo && c < cv) v = P[S.L[l].w_off + (size_t)c * fo + r];
+        }
+    });
+    ws[e] = v;
+}
+
+// ---- weight chunks: stream -> registers (issue) -> LDS (commit), 16 bytes per lane ------------------------------
+template <int C, int KC, int NT, int PFV>
+__device__ __forceinline__ void chunk_issue(f32x4 (&pf)[PFV], __amdgpu_buffer_rsrc_t rs, unsigned byte_off, int tid) {
+    constexpr int V4 = KC * C / 4, E = (V4 + NT - 1) / NT;
+    static_assert(E <= PFV, "prefetch registers");
 #pragma unroll
     for (int j = 0; j < E; j++) {
         const int idx = tid + NT * j;
-        const int r = idx / C, c = idx - r * C;
-        pf[j] = (r0 + r < R && c < cv) ? M[(size_t)(r0 + r) * stride + c] : 0.0f;
+        if (E * NT == V4 || idx < V4) pf[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, idx * 16, byte_off, 0));
     }
 }
-template <int C, int KC, int NT, int PF>
-__device__ __forceinline__ void chunk_commit(const float (&pf)[PF], float* wb, int tid) {
-    constexpr int E = KC * C / NT;
+template <int C, int KC, int NT, int PFV>
+__device__ __forceinline__ void chunk_commit(const f32x4 (&pf)[PFV], float* wb, int tid) {
+    constexpr int V4 = KC * C / 4, E = (V4 + NT - 1) / NT;
 #pragma unroll
-    for (int j = 0; j < E; j++) wb[tid + NT * j] = pf[j];
+    for (int j = 0; j < E; j++) {
+        const int idx = tid + NT * j;
+        if (E * NT == V4 || idx < V4) *(f32x4*)(wb + idx * 4) = pf[j];
+    }
 }
 
-// acc[j] += chunk^T x for this wave's output tiles mo = wave + NW j  (A = chunk[k][32 mo + m], B = x[k][n])
+// acc[j] += chunk^T x for this wave's output tiles mo = wave + NW j  (A = chunk[k][32 mo + m], B = x[k][n]).
+// The operand reads are issued from inline asm RING k-steps ahead of the MFMA that consumes them, with counted
+// s_waitcnt lgkmcnt (LDS reads return in order): left to itself hipcc issues each pair of reads right before its
+// MFMA and waits lgkmcnt(0), i.e. every 64-cycle MFMA also pays an LDS round trip.
+template <int OFF>
+__device__ __forceinline__ float lds_read4(unsigned addr) {
+    float r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// the operands are valid once at most N younger LDS reads are outstanding; every register an MFMA after the wait reads
+// is tied to it, so that hipcc cannot move that MFMA above the wait
+template <int N>
+__device__ __forceinline__ void lds_wait4(float& u, float& v) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(u), "+v"(v) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(float& u, float& v, float& w) {
+    asm volatile("s_waitcnt lgkmcnt(%3)" : "+v"(u), "+v"(v), "+v"(w) : "n"(N));
+}
+#define F32_MMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0)
 template <int C, int KC, int NW, int TPW>
 __device__ __forceinline__ void chunk_mma(const float* wb, const float* xr, int wave, int lane, f32x16 (&acc)[TPW]) {
     const int m = lane & 31, kk = lane >> 5;
-    const bool two = TPW > 1 && wave + NW < C / 32;
     if (wave >= C / 32) return;
+    constexpr int KS = KC / 2, RING = KS < 4 ? KS : 4;
+    const unsigned xb_ = lds_addr_of((const char*)(xr + kk * F32_XS + m));
+    const unsigned a0_ = lds_addr_of((const char*)(wb + kk * C + 32 * wave + m));
+    const bool two = TPW > 1 && wave + NW < C / 32;
     if (two) {
-#pragma unroll
-        for (int ks = 0; ks < KC / 2; ks++) {
-            const float b = xr[(2 * ks + kk) * F32_XS + m];
-            const float a0 = wb[(2 * ks + kk) * C + 32 * wave + m];
-            const float a1 = wb[(2 * ks + kk) * C + 32 * (wave + NW) + m];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-            acc[TPW - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b, acc[TPW - 1], 0, 0, 0);
-        }
+        float b[RING], a0[RING], a1[RING];
+        static_for<0, RING>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            b[j] = lds_read4<j * 2 * F32_XS * 4>(xb_);
+            a0[j] = lds_read4<j * 2 * C * 4>(a0_);
+            a1[j] = lds_read4<(j * 2 * C + 32 * NW) * 4>(a0_);
+        });
+        static_for<0, KS>([&](auto k_) {
+            constexpr int ks = decltype(k_)::value, later = (KS - 1 - ks) < (RING - 1) ? (KS - 1 - ks) : (RING - 1);
+            lds_wait4<3 * later>(b[ks % RING], a0[ks % RING], a1[ks % RING]);
+            F32_MMA(a0[ks % RING], b[ks % RING], acc[0]);
+            F32_MMA(a1[ks % RING], b[ks % RING], acc[TPW - 1]);
+            if constexpr (ks + RING < KS) {
+                b[ks % RING] = lds_read4<(ks + RING) * 2 * F32_XS * 4>(xb_);
+                a0[ks % RING] = lds_read4<(ks + RING) * 2 * C * 4>(a0_);
+                a1[ks % RING] = lds_read4<((ks + RING) * 2 * C + 32 * NW) * 4>(a0_);
+            }
+        });
     } else {
-#pragma unroll
-        for (int ks = 0; ks < KC / 2; ks++) {
-            const float b = xr[(2 * ks + kk) * F32_XS + m];
-            const float a0 = wb[(2 * ks + kk) * C + 32 * wave + m];
-            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b, acc[0], 0, 0, 0);
-        }
+        float b[RING], a0[RING];
+        static_for<0, RING>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            b[j] = lds_read4<j * 2 * F32_XS * 4>(xb_);
+            a0[j] = lds_read4<j * 2 * C * 4>(a0_);
+        });
+        static_for<0, KS>([&](auto k_) {
+            constexpr int ks = decltype(k_)::value, later = (KS - 1 - ks) < (RING - 1) ? (KS - 1 - ks) : (RING - 1);
+            lds_wait4<2 * later>(b[ks % RING], a0[ks % RING]);
+            F32_MMA(a0[ks % RING], b[ks % RING], acc[0]);
+            if constexpr (ks + RING < KS) {
+                b[ks % RING] = lds_read4<(ks + RING) * 2 * F32_XS * 4>(xb_);
+                a0[ks % RING] = lds_read4<(ks + RING) * 2 * C * 4>(a0_);
+            }
+        });
     }
 }
 
-// State of the weight pipeline: which LDS buffer holds the next chunk to consume
-struct F32Pipe { float* wbuf; int par; int tid, wave, lane; };
-
-// One Dense through the chunk pipeline.  On entry the registers `pf` hold chunk 0 of THIS matrix (issued by the
-// previous call / the prologue); on exit they hold chunk 0 of the NEXT matrix (Mn; nullptr: none).
-//   M [R][stride] row-major, cv valid columns of C;  x: LDS activations [>= ceil(R / KC) KC][F32_XS]
-template <int W, int C, int CN, int TPW>
-__device__ __forceinline__ void dense_f32(F32Pipe& p, float (&pf)[F32Cfg<W>::PF], const float* __restrict__ M, int stride,
-                                          int R, int cv, const float* x, f32x16 (&acc)[TPW],
-                                          const float* __restrict__ Mn, int stride_n, int Rn, int cvn) {
-    using Cf = F32Cfg<W>;
-    constexpr int KC = Cf::KC, NT = Cf::NT, NW = Cf::NW, PF = Cf::PF;
-    constexpr int CB = KC * Cf::CMAX;                   // floats per LDS weight buffer
-    const int nchunk = (R + KC - 1) / KC;
-    chunk_commit<C, KC, NT, PF>(pf, p.wbuf + p.par * CB, p.tid);
-    __syncthreads();                                    // chunk 0 and the previous layer's x are visible
-    for (int c = 0; c < nchunk; c++) {
-        const bool last = c + 1 == nchunk;
-        if (!last) chunk_issue<C, KC, NT, PF>(pf, M, stride, R, cv, (c + 1) * KC, p.tid);
-        else if (Mn) chunk_issue<CN, KC, NT, PF>(pf, Mn, stride_n, Rn, cvn, 0, p.tid);
-        chunk_mma<C, KC, NW, TPW>(p.wbuf + p.par * CB, x + c * KC * F32_XS, p.wave, p.lane, acc);
-        p.par ^= 1;
-        if (!last) {
-            chunk_commit<C, KC, NT, PF>(pf, p.wbuf + p.par * CB, p.tid);
-            __syncthreads();
-        }
-    }
+// Record accesses (tile-transposed act / dz blocks) through a buffer descriptor rebuilt per tile: element (float index f,
+// sample n) sits at byte (f * 32 + n) * 4, so the 16 accesses of an epilogue are `descriptor + one lane offset + an
+// immediate` with the record's offset in an SGPR -- as plain pointers they are 16 64-bit addresses per layer that hipcc
+// keeps live across the whole unrolled pass (hundreds of spills).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t f32_rsrc(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void rec_store(__amdgpu_buffer_rsrc_t rs, int f, int n, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, (unsigned)((f * 32 + n) * 4), 0, 0);
+}
+// lane part (wave tile, half, sample) in a register, (record offset + in-tile row) * 128 bytes as scalar / immediate
+template <int F0>
+__device__ __forceinline__ void rec_store_t(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, int r, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs, lane_off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128),
+                                          F0 * 128, 0);
+}
+template <int F0>
+__device__ __forceinline__ float rec_load_t(__amdgpu_buffer_rsrc_t rs, unsigned lane_off, int r) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, lane_off + (unsigned)(((r & 3) + 8 * (r >> 2)) * 128),
+                                                                         F0 * 128, 0));
 }
 
-// Every workgroup reads every weight of its MLP once, chunk by chunk, one chunk ahead -- and a launch's workgroups all
-// start together on an L2 that last saw these weights before the optimizer rewrote them, so every chunk would cost one
-// L2 miss (~2 us) on every CU at once.  Instead each workgroup first touches one line in 128 bytes of a 1/8 slice of
-// the parameters (workgroups are dealt round-robin to the 8 XCDs: id / 8 walks one XCD's workgroups), so that each
-// XCD's L2 is filled once, early, by its own workgroups while the first layers run.  Returns a value that depends on
-// the loads (the caller keeps it alive to the end of the kernel so that the wait for them is never on the critical path).
-__device__ __forceinline__ float f32_warm_l2(const float* __restrict__ P, size_t params, int tid, int nt) {
-    const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
-    const size_t lines = (params + 31) / 32, per = (lines + 7) / 8;
-    const size_t l0 = (size_t)((wg >> 3) & 7) * per;
-    float w = 0.0f;
-    for (size_t j = tid; j < per; j += nt) {
-        const size_t l = l0 + j;
-        if (l < lines) w += P[l * 32];
-    }
-    return w;
-}
-#ifndef F32_WARM
-#define F32_WARM 1
-#endif
-
-struct F32FwdBatch { size_t enc, idx, params, raw, act; };        // per-object strides (floats; idx: int32 elements)
-struct F32BwdBatch { size_t idx, params, act, dz, d_enc; };
+struct F32FwdBatch { size_t enc, idx, params, ws, raw, act; };        // per-object strides (floats; idx: int32 elements)
+struct F32BwdBatch { size_t idx, params, ws, act, dz, d_enc; };
 
 // ---------------------------------------------------------------------------------------------
 // forward: obbpose_model.py:305-354 / :369-418 in fp32
 //   enc == nullptr: every row is evaluated on the constant encoding of a zero-masked Gaussian ([0 x 30, 1 x 30]): the
 //   background MLP's single evaluation of a box-hit ray (obbpose_model.py:205-210; include/durf_hip.h durf_expand_raw)
 // ---------------------------------------------------------------------------------------------
-template <int W>
+template <int W, int IN, bool TRAIN>
 __global__ void __launch_bounds__(W * 2)
-k_mlp_fwd_f32(F32Spec S, size_t rows, int N, const float* __restrict__ enc, const float* __restrict__ view,
+k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __restrict__ view,
               const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
-              const float* __restrict__ P, float* __restrict__ raw, float* __restrict__ act, F32FwdBatch bs) {
+              const float* __restrict__ P, const float* __restrict__ ws, float* __restrict__ raw, float* __restrict__ act,
+              F32FwdBatch bs) {
     using Cf = F32Cfg<W>;
+    using Sc = F32Sched<W, false>;
+    constexpr F32Spec S = f32_spec(W, IN);
     constexpr int NT = Cf::NT, XR = Cf::XROWS;
+    constexpr int D = Cf::DEPTH, KC = Cf::KC, PFV = Cf::PFV, CB = KC * Cf::CMAX, TOTAL = Sc::total();
+    constexpr int in_dim = IN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xa = lds;
     float* xb = xa + XR * F32_XS;
     float* encs = xb + XR * F32_XS;                     // the block's encoding, kept for the skip concatenation
-    float* wbuf = encs + 2 * 64 * F32_XS;               // (second half of the enc region: backward only)
+    float* vws = encs + 64 * F32_XS;                    // the block's view directions [27 (32)][32]
+    float* wbuf = encs + 2 * 64 * F32_XS;
     float* red = wbuf + 2 * Cf::KC * Cf::CMAX;          // [8 parts][4 outputs][32 samples] head partial sums
+    float* cst = red + 8 * 4 * 32 + 4 * 32;             // biases [10][W] | Dense_8 [W + 8] | Dense_11 [392]
+    float* w8s = cst + 10 * W;
+    float* w11s = w8s + W + 8;
     if (gridDim.y > 1) {
         const size_t k = blockIdx.y;
         if (enc) enc += k * bs.enc;
-        ray_idx += k * bs.idx; count += k; P += k * bs.params; raw += k * bs.raw;
-        if (act) act += k * bs.act;
+        ray_idx += k * bs.idx; count += k; P += k * bs.params; ws += k * bs.ws; raw += k * bs.raw;
+        if (TRAIN) act += k * bs.act;
     }
     const size_t nrows = f32_rows(rows, N, count);
-    const size_t row0 = (size_t)blockIdx.x * 32;
-    if (row0 >= nrows) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hi = lane >> 5;
-    const int in_dim = S.in_dim;
-    float* at = act ? act + (size_t)blockIdx.x * S.act * 32 : nullptr;         // this tile's record block
-    F32Pipe p{wbuf, 0, tid, wave, lane};
-    float pf[Cf::PF];
-
-    // x0 = enc (rows in_dim..63 zero)
-    for (int idx = tid; idx < 64 * 32; idx += NT) {
-        const int f = idx & 63, nn = idx >> 6;
-        float v = 0.0f;
-        if (f < in_dim && row0 + nn < nrows) v = enc ? enc[(row0 + nn) * (size_t)in_dim + f] : ((f >= 30 && f < 60) ? 1.0f : 0.0f);
-        encs[f * F32_XS + nn] = v;
-        xa[f * F32_XS + nn] = v;
-    }
-    chunk_issue<W, Cf::KC, NT, Cf::PF>(pf, P + S.L[0].w_off, W, in_dim, W, 0, tid);
-    const float warm = F32_WARM ? f32_warm_l2(P, S.L[11].w_off + 128 * 3 + 3, tid, NT) : 0.0f;
-    __syncthreads();
-    if (at)
-        for (int idx = tid; idx < in_dim * 32; idx += NT) at[(S.L[0].x_off + (idx >> 5)) * 32 + (idx & 31)] = encs[(idx >> 5) * F32_XS + (idx & 31)];
-
-    float* cur = xa;
-    float* nxt = xb;
-    f32x16 acc[1];
-    auto init_bias = [&](const float* bias, int fo) {
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int o = 32 * wave + c_row(r, hi);
-            acc[0][r] = (wave < fo / 32) ? bias[o] : 0.0f;
-        }
-    };
-    // this wave's output tile -> the next Dense's input (LDS) and its record (global)
-    auto store_out = [&](int fo, int relu, int x_off_next) {
-        if (wave < fo / 32) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int o = 32 * wave + c_row(r, hi);
-                float v = acc[0][r];
-                if (relu) v = (v != v) ? v : fmaxf(v, 0.0f);        // jnp.maximum(x, 0) propagates NaN; fmaxf would drop it
-                nxt[o * F32_XS + n] = v;
-                if (at) at[(x_off_next + o) * 32 + n] = v;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, 0x7fffffff, 0x00020000);
+    // constants of the MLP: biases (the initial accumulators) and the head kernels, once per workgroup
+    static_for<0, 10>([&](auto i_) {
+        constexpr int i = decltype(i_)::value, l = i <= 7 ? i : i + 1;
+        for (int o = tid; o < W; o += NT) cst[i * W + o] = o < S.L[l].fo ? P[S.L[l].w_off + (size_t)S.L[l].fi * S.L[l].fo + o] : 0.0f;
+    });
+    for (int idx = tid; idx < W + 1; idx += NT) w8s[idx] = P[S.L[8].w_off + idx];
+    for (int idx = tid; idx < 128 * 3 + 3; idx += NT) w11s[idx] = P[S.L[11].w_off + idx];
+    // The grid is capped (the row count lives on the device: a grid sized for the capacity would be thousands of
+    // workgroups that only exit, and an early-exit workgroup of a 120 KB-LDS kernel still costs its dispatch: measured
+    // 48 us for 12 288 of them at cfg4); a workgroup walks its 32-row tiles.
+    for (size_t tile = blockIdx.x; tile * 32 < nrows; tile += gridDim.x) {
+        const size_t row0 = tile * 32;
+        const __amdgpu_buffer_rsrc_t ra = f32_rsrc(TRAIN ? act + tile * S.act * 32 : nullptr);   // this tile's record block
+        const unsigned lane_off = (unsigned)(((32 * wave + 4 * hi) * 32 + n) * 4);
+        __syncthreads();                                                       // the previous tile is done with the LDS
+        f32x4 pf[D][PFV];
+        static_for<0, D>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            if constexpr (g < TOTAL) chunk_issue<Sc::cols(Sc::layer_of(g)), KC, NT, PFV>(pf[g % D], rs, (unsigned)(Sc::chunk_off(g) * 4), tid);
+        });
+        // the samples' view directions and encodings (x0 = enc, rows in_dim..63 zero)
+        for (int idx = tid; idx < 32 * 32; idx += NT) {
+            const int f = idx & 31, nn = idx >> 5;
+            float v = 0.0f;
+            if (f < 27 && row0 + nn < nrows) {
+                size_t ray = (row0 + nn) / (size_t)N;
+                if (ray_idx) ray = (size_t)ray_idx[ray];
+                v = view[ray * 27 + f];
             }
+            vws[f * F32_XS + nn] = v;
         }
-    };
-    // 1- / 3-wide heads: out[c][n] = b[c] + sum_k Wl[k][c] x[k][n] as 8 interleaved partial chains, summed in order
-    auto head = [&](const float* Wl, int fi, int fo, float (&out)[3]) {
-        const int part = tid >> 5, nn = tid & 31;
-        if (part < 8) {
-            float s[3] = {0.0f, 0.0f, 0.0f};
-            for (int k = part; k < fi; k += 8) {
-                const float xv = cur[k * F32_XS + nn];
-                for (int c = 0; c < fo; c++) s[c] = fmaf(Wl[k * fo + c], xv, s[c]);
-            }
-            for (int c = 0; c < fo; c++) red[(part * 4 + c) * 32 + nn] = s[c];
+        for (int idx = tid; idx < 64 * 32; idx += NT) {
+            const int f = idx & 63, nn = idx >> 6;
+            float v = 0.0f;
+            if (f < in_dim && row0 + nn < nrows) v = enc ? enc[(row0 + nn) * (size_t)in_dim + f] : ((f >= 30 && f < 60) ? 1.0f : 0.0f);
+            encs[f * F32_XS + nn] = v;
+            xa[f * F32_XS + nn] = v;
         }
+        chunk_commit<Sc::cols(0), KC, NT, PFV>(pf[0], wbuf, tid);
         __syncthreads();
-        if (tid < 32)
-            for (int c = 0; c < fo; c++) {
-                float s = Wl[fi * fo + c];
-                for (int q = 0; q < 8; q++) s += red[(q * 4 + c) * 32 + nn];
-                out[c] = s;
+        if (TRAIN)
+            for (int idx = tid; idx < in_dim * 32; idx += NT) rec_store(ra, S.L[0].x_off + (idx >> 5), idx & 31, encs[(idx >> 5) * F32_XS + (idx & 31)]);
+
+        f32x16 acc[1];
+        float dens3[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
+        // 1- / 3-wide heads: out[c][n] = b[c] + sum_k Wl[k][c] x[k][n] as 8 interleaved partial chains, summed in order
+        auto head = [&](const float* Wl, const float* x, int fi, int fo, float (&out)[3]) {
+            const int part = tid >> 5, nn = tid & 31;
+            if (part < 8) {
+                float sm[3] = {0.0f, 0.0f, 0.0f};
+                for (int k = part; k < fi; k += 8) {
+                    const float xv = x[k * F32_XS + nn];
+                    for (int c = 0; c < fo; c++) sm[c] = fmaf(Wl[k * fo + c], xv, sm[c]);
+                }
+                for (int c = 0; c < fo; c++) red[(part * 4 + c) * 32 + nn] = sm[c];
             }
-        __syncthreads();
-    };
-    const auto& L = S.L;
-#define WL(l) (P + L[l].w_off)
-#define SWAP() { float* t_ = cur; cur = nxt; nxt = t_; }
-    // Dense_0 .. Dense_3
-    init_bias(WL(0) + (size_t)L[0].fi * W, W);
-    dense_f32<W, W, W, 1>(p, pf, WL(0), W, L[0].fi, W, cur, acc, WL(1), W, W, W);
-    store_out(W, 1, L[1].x_off); SWAP();
-    for (int l = 1; l <= 3; l++) {
-        init_bias(WL(l) + (size_t)W * W, W);
-        dense_f32<W, W, W, 1>(p, pf, WL(l), W, W, W, cur, acc, WL(l + 1), W, L[l + 1].fi, W);
-        store_out(W, 1, L[l + 1].x_off); SWAP();
-    }
-    // Dense_4 -> x5 = [h4, enc]   (obbpose_model.py:333-334)
-    init_bias(WL(4) + (size_t)W * W, W);
-    dense_f32<W, W, W, 1>(p, pf, WL(4), W, W, W, cur, acc, WL(5), W, L[5].fi, W);
-    store_out(W, 1, L[5].x_off);
-    for (int idx = tid; idx < 64 * 32; idx += NT) {
-        const int f = idx >> 5, nn = idx & 31;
-        const float v = encs[f * F32_XS + nn];
-        nxt[(W + f) * F32_XS + nn] = v;
-        if (at && f < in_dim) at[(L[5].x_off + W + f) * 32 + nn] = v;
-    }
-    SWAP();
-    // Dense_5 .. Dense_7
-    for (int l = 5; l <= 7; l++) {
-        init_bias(WL(l) + (size_t)L[l].fi * W, W);
-        // after Dense_7 comes the bottleneck (Dense_9): the density head (Dense_8) is a VALU dot product
-        const int ln = l == 7 ? 9 : l + 1;
-        dense_f32<W, W, W, 1>(p, pf, WL(l), W, L[l].fi, W, cur, acc, WL(ln), W, W, W);
-        store_out(W, 1, L[ln == 9 ? 8 : ln].x_off); SWAP();
-    }
-    __syncthreads();
-    float dens3[3], rgb[3];
-    head(WL(8), W, 1, dens3);                          // density head on h7
-    // Dense_9 (bottleneck, linear) -> x10 = [bottleneck, view]   (:339, :346-347)
-    init_bias(WL(9) + (size_t)W * W, W);
-    dense_f32<W, W, 128, 1>(p, pf, WL(9), W, W, W, cur, acc, WL(10), 128, L[10].fi, 128);
-    store_out(W, 0, L[10].x_off);
-    for (int idx = tid; idx < 32 * 32; idx += NT) {
-        const int f = idx >> 5, nn = idx & 31;
-        float v = 0.0f;
-        if (f < 27 && row0 + nn < nrows) {
-            size_t ray = (row0 + nn) / (size_t)N;
-            if (ray_idx) ray = (size_t)ray_idx[ray];
-            v = view[ray * 27 + f];
+            __syncthreads();
+            if (tid < 32)
+                for (int c = 0; c < fo; c++) {
+                    float sm = Wl[fi * fo + c];
+                    for (int q = 0; q < 8; q++) sm += red[(q * 4 + c) * 32 + nn];
+                    out[c] = sm;
+                }
+            __syncthreads();
+        };
+        static_for<0, TOTAL>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            constexpr int i = Sc::layer_of(g), c = Sc::chunk_of(g), l = Sc::layer(i), C = Sc::cols(i);
+            const float* xin = (i & 1) ? xb : xa;
+            float* xout = (i & 1) ? xa : xb;
+            if constexpr (g + 1 < TOTAL) chunk_commit<Sc::cols(Sc::layer_of(g + 1)), KC, NT, PFV>(pf[(g + 1) % D], wbuf + ((g + 1) & 1) * CB, tid);
+            if constexpr (g + D < TOTAL) chunk_issue<Sc::cols(Sc::layer_of(g + D)), KC, NT, PFV>(pf[(g + D) % D], rs, (unsigned)(Sc::chunk_off(g + D) * 4), tid);
+            if constexpr (c == 0) {                                    // the bias is the initial accumulator
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[0][r] = cst[i * W + ((32 * wave + c_row(r, hi)) & (W - 1))];
+            }
+            chunk_mma<C, KC, Cf::NW, 1>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
+            if constexpr (c == Sc::nchunk(i) - 1) {
+                // this wave's output tile -> the next Dense's input (LDS) and its record (global)
+                constexpr int lrec = l == 7 ? 8 : (l == 9 ? 10 : l + 1);    // h7 is x8 (density head and bottleneck); bottleneck -> x10
+                if (wave < C / 32) {
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int o = 32 * wave + c_row(r, hi);
+                        float v = acc[0][r];
+                        if (l != 9) v = (v != v) ? v : fmaxf(v, 0.0f);     // jnp.maximum(x, 0) propagates NaN; fmaxf would drop it
+                        xout[o * F32_XS + n] = v;
+                        if (TRAIN) rec_store_t<S.L[lrec].x_off>(ra, lane_off, r, v);
+                    }
+                }
+                if constexpr (l == 4) {                                 // x5 = [h4, enc]   (obbpose_model.py:333-334)
+                    for (int idx = tid; idx < 64 * 32; idx += NT) {
+                        const int f = idx >> 5, nn = idx & 31;
+                        const float v = encs[f * F32_XS + nn];
+                        xout[(W + f) * F32_XS + nn] = v;
+                        if (TRAIN && f < in_dim) rec_store(ra, S.L[5].x_off + W + f, nn, v);
+                    }
+                }
+                if constexpr (l == 9) {                                 // x10 = [bottleneck, view]   (:339, :346-347)
+                    for (int idx = tid; idx < 32 * 32; idx += NT) {
+                        const int f = idx >> 5, nn = idx & 31;
+                        const float v = vws[f * F32_XS + nn];
+                        xout[(W + f) * F32_XS + nn] = v;
+                        if (TRAIN && f < 27) rec_store(ra, S.L[10].x_off + W + f, nn, v);
+                    }
+                }
+            }
+            __syncthreads();
+            if constexpr (c == Sc::nchunk(i) - 1 && l == 7) head(w8s, xout, W, 1, dens3);           // density head on h7
+            if constexpr (c == Sc::nchunk(i) - 1 && l == 10) head(w11s, xout, 128, 3, rgb);         // rgb head on hc
+        });
+        if (tid < 32 && row0 + tid < nrows) {
+            const f32x4 o = {rgb[0], rgb[1], rgb[2], dens3[0]};
+            *(f32x4*)(raw + (row0 + tid) * 4) = o;
         }
-        nxt[(W + f) * F32_XS + nn] = v;
-        if (at && f < 27) at[(L[10].x_off + W + f) * 32 + nn] = v;
     }
-    SWAP();
-    // Dense_10 (view layer, 128 wide, relu) -> hc
-    init_bias(WL(10) + (size_t)L[10].fi * 128, 128);
-    dense_f32<W, 128, 128, 1>(p, pf, WL(10), 128, L[10].fi, 128, cur, acc, nullptr, 0, 0, 0);
-    store_out(128, 1, L[11].x_off); SWAP();
-    __syncthreads();
-    head(WL(11), 128, 3, rgb);                         // rgb head on hc
-    if (tid < 32 && row0 + tid < nrows) {
-        const f32x4 o = {rgb[0], rgb[1], rgb[2], dens3[0]};
-        *(f32x4*)(raw + (row0 + tid) * 4) = o;
-    }
-    if (warm == 1.2345e-33f) raw[0] = warm;            // never true for real parameters; keeps the warm-up loads alive
-#undef WL
-#undef SWAP
 }
 
 // ---------------------------------------------------------------------------------------------
-// per-layer transposed weights for the backward: PT[w_off(l) + m * fi + k] = P[w_off(l) + k * fo + m]
+// backward (data path): d(loss)/d(pre-activation) of every Dense, d(loss)/d(enc) (stored when d_enc != nullptr)
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256)
-k_f32_transpose(F32Spec S, size_t params, const float* __restrict__ P, float* __restrict__ PT, size_t p_stride,
-                size_t pt_stride) {
-    P += blockIdx.y * p_stride; PT += blockIdx.y * pt_stride;
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= params) return;
-    int l = 11;
-    while (l > 0 && i < S.L[l].w_off) l--;
-    const size_t j = i - S.L[l].w_off;
-    const int fi = S.L[l].fi, fo = S.L[l].fo;
-    if (j >= (size_t)fi * fo) { PT[i] = P[i]; return; }         // bias: copied
-    const int m = (int)(j / fi), k = (int)(j - (size_t)m * fi);
-    PT[i] = P[S.L[l].w_off + (size_t)k * fo + m];
-}
-
-// ---------------------------------------------------------------------------------------------
-// backward (data path): d(loss)/d(pre-activation) of every Dense, optionally d(loss)/d(enc)
-// ---------------------------------------------------------------------------------------------
-template <int W>
+template <int W, int IN>
 __global__ void __launch_bounds__(W * 2)
-k_mlp_bwd_f32(F32Spec S, size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
-              const int32_t* __restrict__ count, const float* __restrict__ P, const float* __restrict__ PT,
+k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
+              const int32_t* __restrict__ count, const float* __restrict__ P, const float* __restrict__ ws,
               const float* __restrict__ act, float* __restrict__ dz, float* __restrict__ d_enc, F32BwdBatch bs) {
     using Cf = F32Cfg<W>;
-    constexpr int NT = Cf::NT, XR = Cf::XROWS, CE = W + 64;
+    using Sc = F32Sched<W, true>;
+    constexpr F32Spec S = f32_spec(W, IN);
+    constexpr int NT = Cf::NT, XR = Cf::XROWS;
+    constexpr int D = Cf::DEPTH, KC = Cf::KC, PFV = Cf::PFV, CB = KC * Cf::CMAX, TOTAL = Sc::total();
+    constexpr int in_dim = IN;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* xa = lds;
     float* xb = xa + XR * F32_XS;
     float* denc = xb + XR * F32_XS;                     // [64][XS] d(enc), accumulated over Dense_5 and Dense_0
     float* wbuf = denc + 2 * 64 * F32_XS;
     float* gsm = wbuf + 2 * Cf::KC * Cf::CMAX + 8 * 4 * 32;     // [4][32] head gradients of the block's samples
+    float* w8s = gsm + 4 * 32 + 10 * W;                          // Dense_8 / Dense_11 kernels (same slots as the forward's)
+    float* w11s = w8s + W + 8;
     if (gridDim.y > 1) {
         const size_t k = blockIdx.y;
-        ray_idx += k * bs.idx; count += k; P += k * bs.params; PT += k * bs.params; act += k * bs.act; dz += k * bs.dz;
+        ray_idx += k * bs.idx; count += k; P += k * bs.params; ws += k * bs.ws; act += k * bs.act; dz += k * bs.dz;
         if (d_enc) d_enc += k * bs.d_enc;
     }
+    ws += F32Sched<W, false>::stream_floats();                   // the backward stream follows the forward one
     const size_t nrows = f32_rows(rows, N, count);
-    const size_t row0 = (size_t)blockIdx.x * 32;
-    if (row0 >= nrows) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int n = lane & 31, hi = lane >> 5;
-    const int in_dim = S.in_dim;
-    const float* at = act + (size_t)blockIdx.x * S.act * 32;
-    float* zt = dz + (size_t)blockIdx.x * S.dz * 32;
-    const auto& L = S.L;
-    F32Pipe p{wbuf, 0, tid, wave, lane};
-    float pf[Cf::PF];
-#define WT(l) (PT + L[l].w_off)
-    // Dense_10's transposed kernel [128][W + 27]: only the W bottleneck-fed columns are propagated
-    chunk_issue<W, Cf::KC, NT, Cf::PF>(pf, WT(10), L[10].fi, 128, W, 0, tid);
-    const float warm = F32_WARM ? f32_warm_l2(PT, L[11].w_off, tid, NT) : 0.0f;
-    // head gradients (object MLPs gather their rows of the [B*N,4] buffer through ray_idx); rows past nrows: zero
-    if (tid < 32) {
-        const size_t row = row0 + tid;
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        if (row < nrows) {
-            size_t src = row;
-            if (ray_idx) src = (size_t)ray_idx[row / (size_t)N] * (size_t)N + row % (size_t)N;
-            g = *(const f32x4*)(draw + src * 4);
-        }
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)ws, 0, 0x7fffffff, 0x00020000);
+    for (int idx = tid; idx < W; idx += NT) w8s[idx] = P[S.L[8].w_off + idx];
+    for (int idx = tid; idx < 128 * 3; idx += NT) w11s[idx] = P[S.L[11].w_off + idx];
+    for (size_t tile = blockIdx.x; tile * 32 < nrows; tile += gridDim.x) {      // capped grid, see the forward
+        const size_t row0 = tile * 32;
+        const __amdgpu_buffer_rsrc_t ra = f32_rsrc(act + tile * S.act * 32), rz = f32_rsrc(dz + tile * S.dz * 32);
+        const unsigned lane_off = (unsigned)(((32 * wave + 4 * hi) * 32 + n) * 4);
+        __syncthreads();                                                       // the previous tile is done with the LDS
+        f32x4 pf[D][PFV];
+        static_for<0, D>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            if constexpr (g < TOTAL) chunk_issue<Sc::cols(Sc::layer_of(g)), KC, NT, PFV>(pf[g % D], rs, (unsigned)(Sc::chunk_off(g) * 4), tid);
+        });
+        // head gradients (object MLPs gather their rows of the [B*N,4] buffer through ray_idx); rows past nrows: zero
+        if (tid < 32) {
+            const size_t row = row0 + tid;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            if (row < nrows) {
+                size_t src = row;
+                if (ray_idx) src = (size_t)ray_idx[row / (size_t)N] * (size_t)N + row % (size_t)N;
+                g = *(const f32x4*)(draw + src * 4);
+            }
 #pragma unroll
-        for (int c = 0; c < 4; c++) gsm[c * 32 + tid] = g[c];
-        zt[(L[11].dz_off + 0) * 32 + tid] = g[0]; zt[(L[11].dz_off + 1) * 32 + tid] = g[1];
-        zt[(L[11].dz_off + 2) * 32 + tid] = g[2]; zt[L[8].dz_off * 32 + tid] = g[3];
-    }
-    for (int idx = tid; idx < 64 * 32; idx += NT) denc[(idx >> 5) * F32_XS + (idx & 31)] = 0.0f;
-    __syncthreads();
-    float* cur = xa;
-    float* nxt = xb;
-    // Dense_11 (rgb head, 128 -> 3): d hc = W11 dz11, masked by Dense_10's ReLU -> dz10
-    {
-        const float* W11 = P + L[11].w_off;
+            for (int c = 0; c < 4; c++) gsm[c * 32 + tid] = g[c];
+            rec_store(rz, S.L[11].dz_off + 0, tid, g[0]); rec_store(rz, S.L[11].dz_off + 1, tid, g[1]);
+            rec_store(rz, S.L[11].dz_off + 2, tid, g[2]); rec_store(rz, S.L[8].dz_off, tid, g[3]);
+        }
+        __syncthreads();
+        // Dense_11 (rgb head, 128 -> 3): d hc = W11 dz11, masked by Dense_10's ReLU -> dz10
         for (int idx = tid; idx < 128 * 32; idx += NT) {
             const int k = idx >> 5, nn = idx & 31;
             float v = 0.0f;
 #pragma unroll
-            for (int c = 0; c < 3; c++) v = fmaf(W11[k * 3 + c], gsm[c * 32 + nn], v);
-            const float h = at[(L[11].x_off + k) * 32 + nn];
+            for (int c = 0; c < 3; c++) v = fmaf(w11s[k * 3 + c], gsm[c * 32 + nn], v);
+            const float h = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (unsigned)(((S.L[11].x_off + k) * 32 + nn) * 4), 0, 0));
             v = h > 0.0f ? v : 0.0f;
-            cur[k * F32_XS + nn] = v;
-            zt[(L[10].dz_off + k) * 32 + nn] = v;
+            xa[k * F32_XS + nn] = v;
+            rec_store(rz, S.L[10].dz_off + k, nn, v);
         }
-    }
-    f32x16 acc[2];
-    auto zero_acc = [&]() {
+        chunk_commit<Sc::cols(0), KC, NT, PFV>(pf[0], wbuf, tid);
+        __syncthreads();
+        f32x16 acc[2];
+        float hm[16];                      // the producer's ReLU outputs at this lane's 16 positions: fetched at the first
+                                           // chunk of a layer, applied in its epilogue (a round trip hidden behind the MFMAs)
+        static_for<0, TOTAL>([&](auto g_) {
+            constexpr int g = decltype(g_)::value;
+            constexpr int i = Sc::layer_of(g), c = Sc::chunk_of(g), l = Sc::layer(i), C = Sc::cols(i);
+            const float* xin = (i & 1) ? xb : xa;
+            float* xout = (i & 1) ? xa : xb;
+            if constexpr (g + 1 < TOTAL) chunk_commit<Sc::cols(Sc::layer_of(g + 1)), KC, NT, PFV>(pf[(g + 1) % D], wbuf + ((g + 1) & 1) * CB, tid);
+            if constexpr (g + D < TOTAL) chunk_issue<Sc::cols(Sc::layer_of(g + D)), KC, NT, PFV>(pf[(g + D) % D], rs, (unsigned)(Sc::chunk_off(g + D) * 4), tid);
+            if constexpr (c == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
-    };
-    // d x (first Wp features) -> dz of the producing Dense (masked by its ReLU output, read from the act record at h_off)
-    auto store_dz = [&](int Wp, int relu, int h_off, int dz_off, const float* extra_w) {
-        if (wave < Wp / 32) {
+                for (int r = 0; r < 16; r++) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+                if constexpr (l != 0 && l != 10) {
+                    constexpr int h_off = S.L[l == 9 ? 8 : l].x_off;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int k = 32 * wave + c_row(r, hi);
-                float v = acc[0][r];
-                if (extra_w) v += extra_w[k] * gsm[3 * 32 + n];          // h7 also feeds the density head: + W8 dz8
-                if (relu) { const float h = at[(h_off + k) * 32 + n]; v = h > 0.0f ? v : 0.0f; }
-                nxt[k * F32_XS + n] = v;
-                zt[(dz_off + k) * 32 + n] = v;
+                    for (int r = 0; r < 16; r++) hm[r] = rec_load_t<h_off>(ra, lane_off, r);
+                }
+            }
+            chunk_mma<C, KC, Cf::NW, 2>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
+            if constexpr (c == Sc::nchunk(i) - 1) {
+                if constexpr (l != 0) {
+                    // d x_l (its first W features) -> dz of the Dense that produced them, masked by that Dense's ReLU output
+                    // (the record x_l itself; the bottleneck, Dense_9, is linear; h7 = x8 also feeds the density head)
+                    constexpr int lp = l == 10 ? 9 : (l == 9 ? 7 : l - 1);                  // the producer
+                    constexpr bool relu = l != 10;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int k = 32 * wave + c_row(r, hi);
+                        float v = acc[0][r];
+                        if (l == 9) v += w8s[k] * gsm[3 * 32 + n];
+                        if (relu) v = hm[r] > 0.0f ? v : 0.0f;
+                        xout[k * F32_XS + n] = v;
+                        rec_store_t<S.L[lp].dz_off>(rz, lane_off, r, v);
+                    }
+                    if constexpr (l == 5) {            // skip connection: output tiles W/32 and W/32 + 1 are d enc
+                        if (wave < 2) {
+#pragma unroll
+                            for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] = acc[1][r];
+                        }
+                    }
+                } else {                               // Dense_0: d enc += W0 dz0
+                    if (wave < 2) {
+#pragma unroll
+                        for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] += acc[0][r];
+                    }
+                }
+            }
+            __syncthreads();
+        });
+        if (d_enc) {
+            for (int idx = tid; idx < 32 * 64; idx += NT) {
+                const int nn = idx >> 6, k = idx & 63;
+                if (row0 + nn < nrows) d_enc[(row0 + nn) * 64 + k] = k < in_dim ? denc[k * F32_XS + nn] : 0.0f;
             }
         }
-    };
-#define SWAP() { float* t_ = cur; cur = nxt; nxt = t_; }
-    // Dense_10: d [bottleneck] = W10[:W] dz10 -> dz9 (linear)
-    zero_acc();
-    dense_f32<W, W, W, 2>(p, pf, WT(10), L[10].fi, 128, W, cur, acc, WT(9), W, W, W);
-    store_dz(W, 0, 0, L[9].dz_off, nullptr); SWAP();
-    // Dense_9 (+ Dense_8): d h7 -> dz7
-    zero_acc();
-    dense_f32<W, W, W, 2>(p, pf, WT(9), W, W, W, cur, acc, WT(7), W, W, W);
-    store_dz(W, 1, L[8].x_off, L[7].dz_off, P + L[8].w_off); SWAP();
-    // Dense_7, Dense_6: d h6 -> dz6, d h5 -> dz5
-    zero_acc();
-    dense_f32<W, W, W, 2>(p, pf, WT(7), W, W, W, cur, acc, WT(6), W, W, W);
-    store_dz(W, 1, L[7].x_off, L[6].dz_off, nullptr); SWAP();
-    zero_acc();
-    if (d_enc) dense_f32<W, W, CE, 2>(p, pf, WT(6), W, W, W, cur, acc, WT(5), L[5].fi, W, L[5].fi);
-    else dense_f32<W, W, W, 2>(p, pf, WT(6), W, W, W, cur, acc, WT(5), L[5].fi, W, W);
-    store_dz(W, 1, L[6].x_off, L[5].dz_off, nullptr); SWAP();
-    // Dense_5: d [h4, enc] -> dz4 and (skip connection) d enc
-    zero_acc();
-    if (d_enc) {
-        dense_f32<W, CE, W, 2>(p, pf, WT(5), L[5].fi, W, L[5].fi, cur, acc, WT(4), W, W, W);
-        // tiles W/32 and W/32 + 1 are the d enc part: wave t of the second round owns tile NW + t
-        if (wave < 2) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] = acc[1][r];
-        }
-    } else {
-        dense_f32<W, W, W, 2>(p, pf, WT(5), L[5].fi, W, W, cur, acc, WT(4), W, W, W);
     }
-    store_dz(W, 1, L[5].x_off, L[4].dz_off, nullptr); SWAP();
-    // Dense_4 .. Dense_1
-    for (int l = 4; l >= 1; l--) {
-        zero_acc();
-        if (l > 1) dense_f32<W, W, W, 2>(p, pf, WT(l), W, W, W, cur, acc, WT(l - 1), W, W, W);
-        else if (d_enc) dense_f32<W, W, 64, 2>(p, pf, WT(1), W, W, W, cur, acc, WT(0), in_dim, W, in_dim);
-        else dense_f32<W, W, W, 2>(p, pf, WT(1), W, W, W, cur, acc, nullptr, 0, 0, 0);
-        store_dz(W, 1, L[l].x_off, L[l - 1].dz_off, nullptr); SWAP();
-    }
-    // Dense_0: d enc += W0 dz0
-    if (d_enc) {
-        zero_acc();
-        dense_f32<W, 64, W, 2>(p, pf, WT(0), in_dim, W, in_dim, cur, acc, nullptr, 0, 0, 0);
-        if (wave < 2) {
-#pragma unroll
-            for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] += acc[0][r];
-        }
-        __syncthreads();
-        for (int idx = tid; idx < 32 * 64; idx += NT) {
-            const int nn = idx >> 6, k = idx & 63;
-            if (row0 + nn < nrows) d_enc[(row0 + nn) * 64 + k] = denc[k * F32_XS + nn];
-        }
-    }
-    if (warm == 1.2345e-33f) zt[0] = warm;             // never true for real parameters; keeps the warm-up loads alive
-#undef WT
-#undef SWAP
 }
 
 // ---------------------------------------------------------------------------------------------
-// weight gradients: dW_l[k, m] = sum_n x_l[n, k] dz_l[n, m]  (row fi of x_l = 1: the bias).  One workgroup (4 waves)
+// weight gradients: dW_l[k, m] = sum_n x_l[n, k] dz_l[n, m]; db_l[m] = sum_n dz_l[n, m] (VALU column sums, carried by
+// the first k tile of every column tile: a bias row appended to x_l would cost a whole extra k tile of MFMAs per layer,
+// +25 % on a 128-wide Dense).  One workgroup (4 waves)
 // per (32 x 32 output tile, sample split, object); a wave walks its share of the 32-sample tiles -- the A / B
 // operands of a tile's 16 MFMAs are 4 + 4 float4 per lane straight from the tile-transposed records (a lane's 16
 // samples are the contiguous half [16 kk, 16 kk + 16) of a 128-byte line) -- then the four waves' accumulators are
@@ -502,6 +568,7 @@ struct F32TileTab { int base[13]; };          // output tiles of Dense_l: [base[
 __global__ void __launch_bounds__(256)
 k_mlp_dw_f32(F32Spec S, F32TileTab T, F32DwArgs a, int nsplit, size_t params, float* __restrict__ part) {
     __shared__ float red[3][16][64];
+    __shared__ float redb[3][32];
     const int t = blockIdx.x, sp = blockIdx.y;
     int l = 11;
     while (l > 0 && t < T.base[l]) l--;
@@ -514,7 +581,8 @@ k_mlp_dw_f32(F32Spec S, F32TileTab T, F32DwArgs a, int nsplit, size_t params, fl
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[r] = 0.0f;
     const int k = 32 * ki + i, m = 32 * mj + i;
-    const int krow = Ly.x_off + (k < Ly.fi ? k : 0);            // clamped: rows >= fi are the bias row / padding
+    const int krow = Ly.x_off + (k < Ly.fi ? k : 0);            // clamped: rows >= fi are padding
+    float bsum = 0.0f;                                           // this lane's share of db[m] (ki == 0 tiles)
     const int mrow = Ly.dz_off + (m < Ly.fo ? m : 0);
     for (int sgi = 0; sgi < a.nseg; sgi++) {
         const F32DwSeg sg = a.seg[sgi];
@@ -542,9 +610,9 @@ k_mlp_dw_f32(F32Spec S, F32TileTab T, F32DwArgs a, int nsplit, size_t params, fl
             for (int j = 0; j < 16; j++) {
                 const bool ok = s0 + j < nrows;
                 float x = av[j >> 2][j & 3], z = bv[j >> 2][j & 3];
-                x = k < Ly.fi ? x : (k == Ly.fi ? 1.0f : 0.0f);
-                x = ok ? x : 0.0f;
+                x = (ok && k < Ly.fi) ? x : 0.0f;
                 z = (ok && m < Ly.fo) ? z : 0.0f;
+                bsum += z;
                 acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x, z, acc, 0, 0, 0);
             }
             if (more) {
@@ -553,9 +621,11 @@ k_mlp_dw_f32(F32Spec S, F32TileTab T, F32DwArgs a, int nsplit, size_t params, fl
             }
         }
     }
+    bsum += __shfl_xor(bsum, 32, 64);                            // the two sample halves of column m
     if (wave > 0) {
 #pragma unroll
         for (int r = 0; r < 16; r++) red[wave - 1][r][lane] = acc[r];
+        if (lane < 32) redb[wave - 1][lane] = bsum;
     }
     __syncthreads();
     if (wave == 0) {
@@ -564,8 +634,9 @@ k_mlp_dw_f32(F32Spec S, F32TileTab T, F32DwArgs a, int nsplit, size_t params, fl
         for (int r = 0; r < 16; r++) {
             const float v = ((acc[r] + red[0][r][lane]) + red[1][r][lane]) + red[2][r][lane];
             const int kr = 32 * ki + c_row(r, kk);
-            if (kr <= Ly.fi && m < Ly.fo) pp[(size_t)kr * Ly.fo + m] = v;
+            if (kr < Ly.fi && m < Ly.fo) pp[(size_t)kr * Ly.fo + m] = v;
         }
+        if (ki == 0 && lane < 32 && m < Ly.fo) pp[(size_t)Ly.fi * Ly.fo + m] = ((bsum + redb[0][lane]) + redb[1][lane]) + redb[2][lane];
     }
 }
 
@@ -600,6 +671,8 @@ k_bkgd_const_trunk(F32Spec S, const float* __restrict__ P, float* __restrict__ o
         const float* Wl = P + Ly.w_off;
         const float* xin = x[cur];
         float s = 0.0f;
+        // (measured: unroll 16 -- 16 loads in flight per thread -- is the fastest form hipcc makes of this loop; fully
+        // unrolled float4 variants spill at the register cap of a 512 / 1024-thread workgroup and run 3 x slower)
 #pragma unroll 16
         for (int k = g; k < Ly.fi; k += 4) s = fmaf(Wl[(size_t)k * 256 + o], xin[k], s);
         part[g][o] = s;
@@ -673,34 +746,41 @@ namespace {
 F32TileTab tile_table(const F32Spec& S) {
     F32TileTab T;
     int nt = 0;
-    for (int l = 0; l < 12; l++) {            // k tiles cover fi inputs + the bias row
+    for (int l = 0; l < 12; l++) {
         T.base[l] = nt;
-        nt += ((S.L[l].fi + 1 + 31) / 32) * ((S.L[l].fo + 31) / 32);
+        nt += ((S.L[l].fi + 31) / 32) * ((S.L[l].fo + 31) / 32);
     }
     T.base[12] = nt;
     return T;
 }
 
-template <int W>
-int launch_fwd(hipStream_t s, const F32Spec& S, size_t rows, int N, const float* enc, const float* view27,
-               const int32_t* ray_idx, const int32_t* count, const float* P, float* raw, float* act, int K,
-               const F32FwdBatch& bs) {
+template <int W, int IN>
+int launch_fwd(hipStream_t s, size_t rows, int N, const float* enc, const float* view27, const int32_t* ray_idx,
+               const int32_t* count, const float* P, const float* ws, float* raw, float* act, int K, const F32FwdBatch& bs) {
     constexpr int lds = F32Cfg<W>::LDS_FLOATS * (int)sizeof(float);
-    (void)hipFuncSetAttribute((const void*)k_mlp_fwd_f32<W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k_mlp_fwd_f32<W>, dim3(durf_cdiv(rows, 32), K), dim3(W * 2), lds, s, S, rows, N, enc, view27, ray_idx,
-                       count, P, raw, act, bs);
+    const unsigned nt_ = durf_cdiv(rows, 32), cap = K > 1 ? 128u : 512u;          // workgroups per MLP (see k_mlp_fwd_f32)
+    const dim3 grid(nt_ < cap ? nt_ : cap, K), block(W * 2);
+    if (act) {
+        (void)hipFuncSetAttribute((const void*)k_mlp_fwd_f32<W, IN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_mlp_fwd_f32<W, IN, true>), grid, block, lds, s, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs);
+    } else {
+        (void)hipFuncSetAttribute((const void*)k_mlp_fwd_f32<W, IN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL((k_mlp_fwd_f32<W, IN, false>), grid, block, lds, s, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs);
+    }
     return 0;
 }
-template <int W>
-int launch_bwd(hipStream_t s, const F32Spec& S, size_t rows, int N, const float* draw, const int32_t* ray_idx,
-               const int32_t* count, const float* P, const float* PT, const float* act, float* dz, float* d_enc, int K,
-               const F32BwdBatch& bs) {
+template <int W, int IN>
+int launch_bwd(hipStream_t s, size_t rows, int N, const float* draw, const int32_t* ray_idx, const int32_t* count,
+               const float* P, const float* ws, const float* act, float* dz, float* d_enc, int K, const F32BwdBatch& bs) {
     constexpr int lds = F32Cfg<W>::LDS_FLOATS * (int)sizeof(float);
-    (void)hipFuncSetAttribute((const void*)k_mlp_bwd_f32<W>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(k_mlp_bwd_f32<W>, dim3(durf_cdiv(rows, 32), K), dim3(W * 2), lds, s, S, rows, N, draw, ray_idx, count,
-                       P, PT, act, dz, d_enc, bs);
+    const unsigned nt_ = durf_cdiv(rows, 32), cap = K > 1 ? 128u : 512u;
+    const dim3 grid(nt_ < cap ? nt_ : cap, K), block(W * 2);
+    (void)hipFuncSetAttribute((const void*)k_mlp_bwd_f32<W, IN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((k_mlp_bwd_f32<W, IN>), grid, block, lds, s, rows, N, draw, ray_idx, count, P, ws, act, dz, d_enc, bs);
     return 0;
 }
+template <int W, int IN>
+size_t wstream_floats() { return F32Sched<W, false>::stream_floats() + F32Sched<W, true>::stream_floats(); }
 size_t tile_rows(size_t rows) { return (rows + 31) / 32 * 32; }
 
 }  // namespace
@@ -712,41 +792,44 @@ size_t durf_mlp_f32_dz_floats(int width, int in_dim) { return (size_t)f32_spec(w
 size_t durf_mlp_f32_dw_scratch_floats(int width, int in_dim, int nsplit) {
     return (size_t)nsplit * durf_layer_offset(width, in_dim, 12, 0);
 }
+size_t durf_mlp_f32_wstream_floats(int width) { return width == 256 ? wstream_floats<256, 60>() : wstream_floats<128, 63>(); }
 
-int durf_mlp_f32_transpose(void* stream, int width, int in_dim, int K, const float* mlp_params, size_t param_stride,
-                           float* params_t) {
-    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+#define F32_REQUIRE_MLP(width, in_dim)                                                               \
+    DURF_REQUIRE((width == 256 && in_dim == 60) || (width == 128 && in_dim == 63),                   \
+                 "built for the two MLPs of the model: (width, in_dim) = (256, 60) or (128, 63)")
+
+int durf_mlp_f32_pack(void* stream, int width, int in_dim, int K, const float* mlp_params, size_t param_stride,
+                      float* wstream) {
+    F32_REQUIRE_MLP(width, in_dim);
     if (K <= 0) return 0;
-    const F32Spec S = f32_spec(width, in_dim);
-    const size_t params = durf_layer_offset(width, in_dim, 12, 0);
-    hipLaunchKernelGGL(k_f32_transpose, dim3(durf_cdiv(params, 256), K), dim3(256), 0, (hipStream_t)stream, S, params,
-                       mlp_params, params_t, param_stride, param_stride);
-    DURF_CHECK_LAUNCH("durf_mlp_f32_transpose");
+    const size_t n = durf_mlp_f32_wstream_floats(width);
+    if (width == 256)
+        hipLaunchKernelGGL((k_f32_pack<256, 60>), dim3(durf_cdiv(n, 256), K), dim3(256), 0, (hipStream_t)stream, mlp_params, wstream, param_stride, n);
+    else
+        hipLaunchKernelGGL((k_f32_pack<128, 63>), dim3(durf_cdiv(n, 256), K), dim3(256), 0, (hipStream_t)stream, mlp_params, wstream, param_stride, n);
+    DURF_CHECK_LAUNCH("durf_mlp_f32_pack");
     return 0;
 }
 
 int durf_mlp_fwd_f32(void* stream, int width, int in_dim, size_t rows, int N, const float* enc, const float* view27,
-                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, float* raw, float* act) {
-    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
-    DURF_REQUIRE(in_dim > 0 && in_dim <= DURF_ENC_DIM, "in_dim <= 64");
-    DURF_REQUIRE(enc != nullptr || in_dim == 60, "the constant encoding (enc == NULL) is the background MLP's");
+                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* wstream,
+                     float* raw, float* act) {
+    F32_REQUIRE_MLP(width, in_dim);
+    DURF_REQUIRE(enc != nullptr || width == 256, "the constant encoding (enc == NULL) is the background MLP's");
     if (rows == 0) return 0;
-    const F32Spec S = f32_spec(width, in_dim);
-    if (width == 256) launch_fwd<256>((hipStream_t)stream, S, rows, N, enc, view27, ray_idx, count, mlp_params, raw, act, 1, F32FwdBatch{});
-    else launch_fwd<128>((hipStream_t)stream, S, rows, N, enc, view27, ray_idx, count, mlp_params, raw, act, 1, F32FwdBatch{});
+    if (width == 256) launch_fwd<256, 60>((hipStream_t)stream, rows, N, enc, view27, ray_idx, count, mlp_params, wstream, raw, act, 1, F32FwdBatch{});
+    else launch_fwd<128, 63>((hipStream_t)stream, rows, N, enc, view27, ray_idx, count, mlp_params, wstream, raw, act, 1, F32FwdBatch{});
     DURF_CHECK_LAUNCH("durf_mlp_fwd_f32");
     return 0;
 }
 
 int durf_mlp_bwd_f32(void* stream, int width, int in_dim, size_t rows, int N, const float* draw,
-                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* params_t,
+                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* wstream,
                      const float* act, float* dz, float* d_enc) {
-    DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
-    DURF_REQUIRE(in_dim > 0 && in_dim <= DURF_ENC_DIM, "in_dim <= 64");
+    F32_REQUIRE_MLP(width, in_dim);
     if (rows == 0) return 0;
-    const F32Spec S = f32_spec(width, in_dim);
-    if (width == 256) launch_bwd<256>((hipStream_t)stream, S, rows, N, draw, ray_idx, count, mlp_params, params_t, act, dz, d_enc, 1, F32BwdBatch{});
-    else launch_bwd<128>((hipStream_t)stream, S, rows, N, draw, ray_idx, count, mlp_params, params_t, act, dz, d_enc, 1, F32BwdBatch{});
+    if (width == 256) launch_bwd<256, 60>((hipStream_t)stream, rows, N, draw, ray_idx, count, mlp_params, wstream, act, dz, d_enc, 1, F32BwdBatch{});
+    else launch_bwd<128, 63>((hipStream_t)stream, rows, N, draw, ray_idx, count, mlp_params, wstream, act, dz, d_enc, 1, F32BwdBatch{});
     DURF_CHECK_LAUNCH("durf_mlp_bwd_f32");
     return 0;
 }
@@ -769,12 +852,18 @@ int durf_mlp_dw_f32(void* stream, int width, int in_dim, size_t rows, int N, con
     return 0;
 }
 
+int durf_bkgd_const_trunk_f32(void* stream, const float* bkgd_params, float* trunk) {
+    const F32Spec S = f32_spec(DURF_W_BKGD, 60);
+    hipLaunchKernelGGL(k_bkgd_const_trunk, dim3(1), dim3(1024), 0, (hipStream_t)stream, S, bkgd_params, trunk);
+    DURF_CHECK_LAUNCH("durf_bkgd_const_trunk_f32");
+    return 0;
+}
+
 int durf_bkgd_hit_rays_f32(void* stream, int B, const float* view27, const float* bkgd_params, const int32_t* idx,
-                           const int32_t* count, float* trunk /* [257] scratch */, float* raw_tail) {
+                           const int32_t* count, const float* trunk, float* raw_tail) {
     if (B <= 0) return 0;
     const F32Spec S = f32_spec(DURF_W_BKGD, 60);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bkgd_const_trunk, dim3(1), dim3(1024), 0, s, S, bkgd_params, trunk);
     hipLaunchKernelGGL(k_bkgd_hit_rays, dim3(durf_cdiv(B, HITRAYS_PER_WG)), dim3(128), 0, s, S, bkgd_params, trunk, view27, idx,
                        count, raw_tail);
     DURF_CHECK_LAUNCH("durf_bkgd_hit_rays_f32");
@@ -786,26 +875,26 @@ size_t durf_objf32_act_stride(int B, int N) { return tile_rows((size_t)B * N) * 
 size_t durf_objf32_dz_stride(int B, int N) { return tile_rows((size_t)B * N) * f32_spec(DURF_W_OBJ, 63).dz; }
 
 int durf_objf32_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* enc,
-                          const float* view27, const float* obj_params, size_t param_stride, float* raw, float* act) {
+                          const float* view27, const float* obj_params, size_t param_stride, const float* wstream,
+                          float* raw, float* act) {
     DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ, "1 <= K <= DURF_MAX_OBJ");
     if (B <= 0) return 0;
     const size_t rows = (size_t)B * N;
-    const F32Spec S = f32_spec(DURF_W_OBJ, 63);
-    F32FwdBatch bs{rows * 63, (size_t)B, param_stride, rows * 4, durf_objf32_act_stride(B, N)};
-    launch_fwd<DURF_W_OBJ>((hipStream_t)stream, S, rows, N, enc, view27, idx, count, obj_params, raw, act, K, bs);
+    F32FwdBatch bs{rows * 63, (size_t)B, param_stride, durf_mlp_f32_wstream_floats(DURF_W_OBJ), rows * 4, durf_objf32_act_stride(B, N)};
+    launch_fwd<DURF_W_OBJ, 63>((hipStream_t)stream, rows, N, enc, view27, idx, count, obj_params, wstream, raw, act, K, bs);
     DURF_CHECK_LAUNCH("durf_objf32_fwd_batch");
     return 0;
 }
 
 int durf_objf32_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* draw,
-                          const float* obj_params, const float* obj_params_t, size_t param_stride, const float* act,
+                          const float* obj_params, size_t param_stride, const float* wstream, const float* act,
                           float* dz, float* d_enc) {
     DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ, "1 <= K <= DURF_MAX_OBJ");
     if (B <= 0) return 0;
     const size_t rows = (size_t)B * N;
-    const F32Spec S = f32_spec(DURF_W_OBJ, 63);
-    F32BwdBatch bs{(size_t)B, param_stride, durf_objf32_act_stride(B, N), durf_objf32_dz_stride(B, N), rows * DURF_ENC_DIM};
-    launch_bwd<DURF_W_OBJ>((hipStream_t)stream, S, rows, N, draw, idx, count, obj_params, obj_params_t, act, dz, d_enc, K, bs);
+    F32BwdBatch bs{(size_t)B, param_stride, durf_mlp_f32_wstream_floats(DURF_W_OBJ), durf_objf32_act_stride(B, N),
+                   durf_objf32_dz_stride(B, N), rows * DURF_ENC_DIM};
+    launch_bwd<DURF_W_OBJ, 63>((hipStream_t)stream, rows, N, draw, idx, count, obj_params, wstream, act, dz, d_enc, K, bs);
     DURF_CHECK_LAUNCH("durf_objf32_bwd_batch");
     return 0;
 }

@@ -33,8 +33,9 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
     const int kb = blockIdx.y;                      // object within this call
     k_obj += kb;
     idx += kb * idx_stride; count += kb; d_enc += kb * denc_stride; rows_out += kb * rows_stride;
-    const int j = blockIdx.x;
-    if (j >= *count) return;                        // whole workgroup
+    // capped grid (the hit count lives on the device; thousands of workgroups that only exit cost their dispatch)
+    const int nj = *count < B ? *count : B;
+    for (int j = blockIdx.x; j < nj; j += gridDim.x) {
     const int b = idx[j];
     const float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
     const float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
@@ -96,7 +97,7 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
         for (int i = 0; i < 3; i++) { part[wv][i] = go[i]; part[wv][3 + i] = gd[i]; }
     }
     __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x == 0) {
 #pragma unroll
     for (int i = 0; i < 3; i++) {
         go[i] = ((part[0][i] + part[1][i]) + part[2][i]) + part[3][i];
@@ -138,6 +139,9 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
             rows_out[(size_t)(12 + i * 3 + q) * B + j] = gu[i] * dw[q];
         }
     }
+    }   // thread 0
+    __syncthreads();                                // part[] is reused by the next ray
+    }   // rays
 }
 
 __global__ void __launch_bounds__(1024)
@@ -223,7 +227,7 @@ static int encode_obj_bwd_launch(void* stream, int K, int B, int N, int k0, cons
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(B, K), block(256);
+    dim3 grid(B < 256 ? B : 256, K), block(256);
 #define LAUNCH_E2(P, PR)                                                                                  \
     hipLaunchKernelGGL((k_encode_obj_bwd<P, PR>), grid, block, 0, s, B, N, k0, idx, count, d_enc, t_vals, \
                        origins_s, dirs_s, radii, origins, dirs, pose, bw, scratch, (size_t)B, denc_stride, \

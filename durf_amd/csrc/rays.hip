@@ -303,16 +303,15 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
         count += blockIdx.y;
         out_f32 += blockIdx.y * f32_stride;
     }
-    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride over (sample, 8-feature vector) pairs: the object launches cap their grid (the hit count lives on the
+    // device; a grid sized for the capacity is thousands of workgroups that only exit)
+    const int nrays = OBJ ? (*count < rays ? *count : rays) : rays;
+    const size_t total = (size_t)nrays * N * 8;
+    for (size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (size_t)gridDim.x * blockDim.x) {
     const size_t row = gid >> 3;          // sample row (ray-major)
     const int q = (int)(gid & 7);         // which 8-feature vector
     const int j = (int)(row / N), n = (int)(row % N);
-    if (j >= rays) return;
-    int b = j;
-    if (OBJ) {
-        if (j >= *count) return;
-        b = idx[j];
-    }
+    const int b = OBJ ? idx[j] : j;
     const float t0 = t_vals[(size_t)b * (N + 1) + n], t1 = t_vals[(size_t)b * (N + 1) + n + 1];
     float o[3] = {origins_s[b * 3], origins_s[b * 3 + 1], origins_s[b * 3 + 2]};
     float d[3] = {dirs_s[b * 3], dirs_s[b * 3 + 1], dirs_s[b * 3 + 2]};
@@ -360,6 +359,7 @@ k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __rest
             if (p < dim) out_f32[row * dim + p] = v[e];
         }
     }
+    }   // grid stride
 }
 
 // K3/K4, bf16-only fast path (sin/exp on the hardware transcendental units: abs error ~1e-4 at
@@ -657,7 +657,7 @@ int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* i
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
     if (out_f32)      // accurate-libm features, row-major [K, max_rays * N, 63]
-        hipLaunchKernelGGL((k_encode<true>), dim3(durf_cdiv((size_t)max_rays * N * 8, 256), K), dim3(256), 0,
+        hipLaunchKernelGGL((k_encode<true>), dim3(std::min(durf_cdiv((size_t)max_rays * N * 8, 256), K > 1 ? 512u : 4096u), K), dim3(256), 0,
                            (hipStream_t)stream, max_rays, N, idx, count, t_vals, origins_s, dirs_s, radii,
                            nullptr, 0, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), bw, (bf16x8*)out_tile, out_f32,
                            (size_t)max_rays, (size_t)max_rays * N * 63);

@@ -211,6 +211,17 @@ class MipNerfModel:
             noise = dict(t_rand=u[0], u_rand=u[1])
         # (the fp32 object branch needs the box-hit rays' background evaluation as its own rows: always de-duplicated)
         use_dd = bool(Kd) and not f32 and (ops.DEDUP_HIT_RAYS or obj_f32)
+        tail_side = trunk = None
+        if obj_f32:
+            # The background MLP's ONE evaluation of every box-hit ray is redone in fp32: those rays' rendered values --
+            # and through them the head gradients that drive d(loss)/d(box pose) -- then carry no bf16 rounding at all
+            # (DESIGN.md 2).  Its trunk sees the same input for every such ray and depends on the parameters only: one
+            # workgroup, started here on a side stream so that it runs beside the small per-ray launches below (beside
+            # the persistent MLP kernels it would wait for a CU and slow them: measured).
+            tail_side = ops.side_stream(dev)
+            tail_side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(tail_side):
+                trunk = ops.bkgd_const_trunk_f32(variables.mlp_flat('MLP_0'))
         # ray setup + view encoding + level-0 sample positions: one launch; both compactions: one launch
         o_s, d_s, hit, zo, view, t_vals0 = ops.ray_prologue(rays.origins, rays.directions, pose, ext, rays.viewdirs, near,
                                                             far, N, noise['t_rand'] if randomized else None, self.lindisp)
@@ -239,8 +250,9 @@ class MipNerfModel:
         if ctx['obj_f32']:                           # BoxMLP_0 .. BoxMLP_{K-1} sit back to back in the flat buffer
             o0 = lay.mlp_off['BoxMLP_0']
             obj_flat = variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]]
-            if train:
-                ctx['obj_params_t'] = ops.mlp_f32_transpose(W_OBJ, IN_OBJ, obj_flat, K=Kd, param_stride=lay.mlp_size[W_OBJ])
+            ctx['obj_ws'] = ops.mlp_f32_pack(W_OBJ, IN_OBJ, obj_flat, K=Kd, param_stride=lay.mlp_size[W_OBJ])
+        if f32:
+            ctx['bkgd_ws'] = ops.mlp_f32_pack(W_BKGD, IN_BKGD, variables.mlp_flat('MLP_0'))
         raw_tail = None
         ret = []
         t_vals = weights = None
@@ -269,6 +281,13 @@ class MipNerfModel:
         if cls is not None:
             dd = dict(idx=cls[0], count=cls[1], slot=cls[2], nrows=cls[1][2:3], multi_hit=cls[1][3])
             ctx['dedup'] = dd
+        if obj_f32:
+            # ... and the view layer + rgb head per box-hit ray on top of it (same input at both levels: once per step)
+            tail_side.wait_stream(torch.cuda.current_stream())           # ray classes, view27
+            with torch.cuda.stream(tail_side):
+                raw_tail = ops.bkgd_hit_rays_f32(B, view27, variables.mlp_flat('MLP_0'), dd['idx'][1], dd['count'][1:2],
+                                                 trunk=trunk)
+            raw_tail.record_stream(torch.cuda.current_stream())
         t_next = None
         for lvl in range(self.num_levels):
             last = lvl == self.num_levels - 1
@@ -280,7 +299,7 @@ class MipNerfModel:
                 t_vals = ops.resample(t_vals, weights, self.resample_padding,
                                       noise['u_rand'] if randomized else None)
             if f32:
-                lvd = self._level_f32(variables, obj_flat, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count,
+                lvd = self._level_f32(variables, obj_flat, ctx, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count,
                                       alpha, B, N)
                 raw_b, slabs = lvd['raw_b'], None
                 enc_b = stash_b = mask_b = None
@@ -298,11 +317,9 @@ class MipNerfModel:
                     raw_c = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], ray_idx=dd['idx'][0],
                                         count=dd['count'][0:1], stash=stash_b, relu_mask=mask_b,
                                         tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
-                    if obj_f32 and raw_tail is None:
-                        # The background MLP's ONE evaluation of every box-hit ray, redone in fp32 (same input at both
-                        # levels: once per step).  Those rays' rendered values -- and through them the head gradients
-                        # that drive d(loss)/d(box pose) -- then carry no bf16 rounding at all.
-                        raw_tail = ops.bkgd_hit_rays_f32(B, view27, variables.mlp_flat('MLP_0'), dd['idx'][1], dd['count'][1:2])
+                    if tail_side is not None:                # the fp32 hit-ray evaluation (side stream) must have landed
+                        torch.cuda.current_stream().wait_stream(tail_side)
+                        tail_side = None
                     raw_b = ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'], raw_tail=raw_tail)
                 else:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
@@ -311,8 +328,8 @@ class MipNerfModel:
                     raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
                 slabs = None
                 if obj_f32:                              # object branch in exact fp32 (object_precision)
-                    lvd = self._objects_f32(obj_flat, lay.mlp_size[W_OBJ], train, t_vals, o_s, d_s, radii, Kd, cyl, view27,
-                                            idx, count, alpha, B, N)
+                    lvd = self._objects_f32(obj_flat, lay.mlp_size[W_OBJ], ctx['obj_ws'], train, t_vals, o_s, d_s, radii, Kd, cyl,
+                                            view27, idx, count, alpha, B, N)
                 if Kb:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
                     slabs = ops.ObjSlabs(Kd, B, N, dev, train)      # allocated on the main stream, filled on the side one
                     with side:
@@ -347,24 +364,25 @@ class MipNerfModel:
                                           f32=lvd))
         return ret, ctx
 
-    def _level_f32(self, variables, obj_flat, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count, alpha, B, N):
+    def _level_f32(self, variables, obj_flat, ctx, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count, alpha, B, N):
         """encodings + MLPs of one level in exact fp32 (mlp_precision='f32'): accurate-libm encodings emitted as
         fp32, Dense layers on v_mfma_f32_32x32x2_f32 straight from the fp32 parameters."""
         rows = B * N
         _, enc = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction, tile=False, f32=True,
                                  disable_integration=self.disable_integration, cylinder=cyl)
-        out = ops.mlp_fwd_f32(W_BKGD, IN_BKGD, rows, N, enc, view27, variables.mlp_flat('MLP_0'), want_act=train)
+        out = ops.mlp_fwd_f32(W_BKGD, IN_BKGD, rows, N, enc, view27, variables.mlp_flat('MLP_0'), want_act=train,
+                              wstream=ctx['bkgd_ws'])
         d = dict(raw_b=out[0] if train else out, act_b=out[1] if train else None, raws=[], slabs32=None)
         if Kd:
-            d.update(self._objects_f32(obj_flat, variables.layout.mlp_size[W_OBJ], train, t_vals, o_s, d_s, radii, Kd, cyl,
-                                       view27, idx, count, alpha, B, N))
+            d.update(self._objects_f32(obj_flat, variables.layout.mlp_size[W_OBJ], ctx['obj_ws'], train, t_vals, o_s, d_s, radii,
+                                       Kd, cyl, view27, idx, count, alpha, B, N))
         return d
 
-    def _objects_f32(self, obj_flat, stride, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha, B, N):
+    def _objects_f32(self, obj_flat, stride, ws, train, t_vals, o_s, d_s, radii, Kd, cyl, view27, idx, count, alpha, B, N):
         """the K object MLPs of one level in exact fp32, hit rays only (obbpose_model.py:167-201): accurate-libm fp32
         encodings + the fp32 MFMA forward of all K objects, one launch each (csrc/mlp_f32.hip, durf_objf32_*)"""
         slabs = ops.ObjSlabsF32(Kd, B, N, t_vals.device, train)
-        ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, obj_flat, stride,
+        ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, obj_flat, stride, ws,
                              disable_integration=self.disable_integration, cylinder=cyl)
         return dict(raws=slabs.raws(), slabs32=slabs)
 

@@ -715,39 +715,44 @@ def pose_finish(pose, sums, want_pos, want_rot, grad6):
 # exact-fp32 MLP (csrc/mlp_f32.hip): the object branch of a step with box-pose optimisation (MipNerfModel.object_precision)
 # and the parity instrument behind MipNerfModel(mlp_precision='f32')
 # ---------------------------------------------------------------------------
-def mlp_f32_transpose(width, in_dim, mlp_params, K=1, param_stride=0):
-    """per-layer transposed kernels of K MLPs (the fp32 backward's weight stream); same layout / size as mlp_params"""
-    out = torch.empty_like(mlp_params)
-    _lib.check(_lib.lib().durf_mlp_f32_transpose(_stream(), width, in_dim, int(K), _p(_f32(mlp_params)), int(param_stride),
-                                                 _p(out)), 'durf_mlp_f32_transpose')
+def mlp_f32_pack(width, in_dim, mlp_params, K=1, param_stride=0):
+    """fp32 weight streams of K MLPs (durf_mlp_f32_pack): the wide Dense kernels as the chunks the fp32 forward / the
+    backward (transposed) consume, in order; re-packed whenever the parameters change"""
+    L = _lib.lib()
+    out = torch.empty(int(K) * int(L.durf_mlp_f32_wstream_floats(width)), device=mlp_params.device)
+    _lib.check(L.durf_mlp_f32_pack(_stream(), width, in_dim, int(K), _p(_f32(mlp_params)), int(param_stride), _p(out)),
+               'durf_mlp_f32_pack')
     return out
 
 
-def mlp_fwd_f32(width, in_dim, rows, N, enc_f32, view27, mlp_params, ray_idx=None, count=None, want_act=False):
+def mlp_fwd_f32(width, in_dim, rows, N, enc_f32, view27, mlp_params, ray_idx=None, count=None, want_act=False,
+                wstream=None):
     """-> raw [rows,4][, act (opaque record buffer for mlp_bwd_f32 / mlp_dw_f32)].  enc_f32 [rows,in_dim] row-major, or
     None: every row is the background MLP's constant encoding of a box-hit ray (width 256); view27 [B,27]"""
     dev = view27.device
     L = _lib.lib()
+    if wstream is None:
+        wstream = mlp_f32_pack(width, in_dim, mlp_params)
     raw = torch.zeros(rows, 4, device=dev)
     act = torch.empty(tile_rows(rows) * int(L.durf_mlp_f32_act_floats(width, in_dim)), device=dev) if want_act else None
     with _Timed('mlp_fwd_f32_%d' % width):
         _lib.check(L.durf_mlp_fwd_f32(_stream(), width, in_dim, rows, N, _p(None if enc_f32 is None else _f32(enc_f32)),
-                                      _p(_f32(view27)), _p(ray_idx), _p(count), _p(_f32(mlp_params)), _p(raw), _p(act)),
-                   'durf_mlp_fwd_f32')
+                                      _p(_f32(view27)), _p(ray_idx), _p(count), _p(_f32(mlp_params)), _p(wstream), _p(raw),
+                                      _p(act)), 'durf_mlp_fwd_f32')
     return (raw, act) if want_act else raw
 
 
-def mlp_bwd_f32(width, in_dim, rows, N, draw, mlp_params, act, ray_idx=None, count=None, want_d_enc=False, params_t=None):
+def mlp_bwd_f32(width, in_dim, rows, N, draw, mlp_params, act, ray_idx=None, count=None, want_d_enc=False, wstream=None):
     """-> dz (opaque record buffer)[, d_enc [rows,64]]"""
     dev = draw.device
     L = _lib.lib()
-    if params_t is None:
-        params_t = mlp_f32_transpose(width, in_dim, mlp_params)
+    if wstream is None:
+        wstream = mlp_f32_pack(width, in_dim, mlp_params)
     dz = torch.empty(tile_rows(rows) * int(L.durf_mlp_f32_dz_floats(width, in_dim)), device=dev)
     d_enc = torch.zeros(rows, ENC_DIM, device=dev) if want_d_enc else None
     with _Timed('mlp_bwd_f32_%d' % width):
         _lib.check(L.durf_mlp_bwd_f32(_stream(), width, in_dim, rows, N, _p(_f32(draw)), _p(ray_idx), _p(count),
-                                      _p(_f32(mlp_params)), _p(_f32(params_t)), _p(_f32(act)), _p(dz), _p(d_enc)),
+                                      _p(_f32(mlp_params)), _p(wstream), _p(_f32(act)), _p(dz), _p(d_enc)),
                    'durf_mlp_bwd_f32')
     return (dz, d_enc) if want_d_enc else dz
 
@@ -764,11 +769,20 @@ def mlp_dw_f32(width, in_dim, rows, N, act, dz, grad_mlp, count=None, nsplit=32)
     grad_mlp += g
 
 
-def bkgd_hit_rays_f32(B, view27, bkgd_params, idx1, count1):
+def bkgd_const_trunk_f32(bkgd_params):
+    """Dense_0 .. Dense_9 of the background MLP on the constant encoding every box-hit ray feeds it ([0 x 30, 1 x 30]), in
+    fp32 -> trunk [257] (bottleneck, density): depends on the parameters only, once per step"""
+    trunk = torch.empty(257, device=bkgd_params.device)
+    _lib.check(_lib.lib().durf_bkgd_const_trunk_f32(_stream(), _p(_f32(bkgd_params)), _p(trunk)), 'durf_bkgd_const_trunk_f32')
+    return trunk
+
+
+def bkgd_hit_rays_f32(B, view27, bkgd_params, idx1, count1, trunk=None):
     """the background MLP's one evaluation of every box-hit ray (ray class 1: idx1 / count1), in fp32 -> raw_tail [B,4]
-    (row j = ray idx1[j]); the trunk, whose input is the same for all of them, runs once"""
+    (row j = ray idx1[j]): the view layer and the rgb head per ray on top of bkgd_const_trunk_f32's output"""
     dev = view27.device
-    trunk = torch.empty(257, device=dev)
+    if trunk is None:
+        trunk = bkgd_const_trunk_f32(bkgd_params)
     raw_tail = torch.empty(B, 4, device=dev)
     with _Timed('bkgd_hit_rays_f32'):
         _lib.check(_lib.lib().durf_bkgd_hit_rays_f32(_stream(), B, _p(_f32(view27)), _p(_f32(bkgd_params)), _p(idx1),
@@ -791,7 +805,7 @@ class ObjSlabsF32:
         return [self.raw[k] for k in range(self.K)]
 
 
-def objf32_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha, view27, obj_params, param_stride,
+def objf32_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha, view27, obj_params, param_stride, wstream,
                      disable_integration=False, cylinder=False):
     """accurate fp32 encodings + fp32 forward of all K object MLPs of one level: two launches"""
     w = barf_weights(alpha)
@@ -803,11 +817,11 @@ def objf32_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha,
             _p(_f32(radii)), wa, (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0),
             _p(slabs.enc)), 'durf_encode_obj_f32_batch')
         _lib.check(L.durf_objf32_fwd_batch(_stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(slabs.enc),
-                                           _p(_f32(view27)), _p(_f32(obj_params)), int(param_stride), _p(slabs.raw),
-                                           _p(slabs.act)), 'durf_objf32_fwd_batch')
+                                           _p(_f32(view27)), _p(_f32(obj_params)), int(param_stride), _p(wstream),
+                                           _p(slabs.raw), _p(slabs.act)), 'durf_objf32_fwd_batch')
 
 
-def objf32_bwd_batch(slabs, idx, count, draw, obj_params, obj_params_t, param_stride, want_d_enc=False):
+def objf32_bwd_batch(slabs, idx, count, draw, obj_params, param_stride, wstream, want_d_enc=False):
     L = _lib.lib()
     dev = draw.device
     K, B, N = slabs.K, slabs.B, slabs.N
@@ -815,11 +829,11 @@ def objf32_bwd_batch(slabs, idx, count, draw, obj_params, obj_params_t, param_st
     slabs.d_enc = torch.empty(K, B * N, ENC_DIM, device=dev) if want_d_enc else None     # every valid row is written
     with _Timed('objf32_bwd_batch'):
         _lib.check(L.durf_objf32_bwd_batch(_stream(), K, B, N, _p(idx), _p(count), _p(_f32(draw)), _p(_f32(obj_params)),
-                                           _p(_f32(obj_params_t)), int(param_stride), _p(slabs.act), _p(slabs.dz),
+                                           int(param_stride), _p(wstream), _p(slabs.act), _p(slabs.dz),
                                            _p(slabs.d_enc)), 'durf_objf32_bwd_batch')
 
 
-def objf32_dw_batch(slabs_levels, count, grad_obj, grad_stride, nsplit=2):
+def objf32_dw_batch(slabs_levels, count, grad_obj, grad_stride, nsplit=8):
     """weight gradients of all K object MLPs over every level -> grad_obj (flat, K x grad_stride floats), overwritten"""
     L = _lib.lib()
     s0 = slabs_levels[0]

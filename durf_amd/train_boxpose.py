@@ -34,11 +34,28 @@ def create_train_state(variables):
     return TrainState(variables, torch.zeros_like(variables.flat), torch.zeros_like(variables.flat), 0)
 
 
+def _force_dist():
+    """DURF_FORCE_DIST=1: take the data-parallel code path (RCCL all-reduce of the gradient, stream ordering behind
+    it, inv_world, stats cadence) even with ONE rank -- a world-size-1 `nccl` group; how the collective path is
+    exercised and timed on a one-GPU box (tests/test_gpu_dist.py, bench.py --force-dist)"""
+    import os
+    return os.environ.get('DURF_FORCE_DIST', '0') != '0'
+
+
 def _dist():
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _force_dist()):
         return dist
     return None
+
+
+# DURF_BUCKET_ALLREDUCE=1 (multi-rank only): the K object MLPs' gradients are final before the background MLP's
+# weight-gradient launch (the longest kernel of a step) starts, so their slice of the flat buffer is all-reduced behind
+# it and only [box_centers | MLP_0] after it -- two collectives instead of one, the first one free.  Costs a separate
+# finalize launch for the objects (~30 us); off by default until it has been measured on a multi-GPU node.
+def _bucketed():
+    import os
+    return os.environ.get('DURF_BUCKET_ALLREDUCE', '0') != '0'
 
 
 def level_multipliers(config, level, num_levels):
@@ -53,9 +70,11 @@ def level_multipliers(config, level, num_levels):
             0.000001]
 
 
-def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=None):
+def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=None, objects_ready=None):
     """value_and_grad(loss_fn) (train_boxpose.py:67-252) for this rank's shard.
-    Returns (grad_flat, raw stats dict of device tensors, pose)."""
+    Returns (grad_flat, raw stats dict of device tensors, pose).
+    objects_ready(grad_slice): called as soon as the K object MLPs' gradients are final (before the background MLP's
+    weight-gradient launch is issued) -- the hook of the bucketed all-reduce; forces the objects' own finalize launch."""
     pose_opt = not (model.no_pose_opt and model.no_yaw_opt)
     rays = batch['rays']
     L = model.num_levels
@@ -114,13 +133,14 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         if f32:                               # exact-fp32 parity instrument: per-MLP fp32 backward + weight gradients
             fl = lv['f32']
             off = lay.mlp_off['MLP_0']
-            dz = ops.mlp_bwd_f32(om.W_BKGD, om.IN_BKGD, rows, N, draw, variables.mlp_flat('MLP_0'), fl['act_b'])
+            dz = ops.mlp_bwd_f32(om.W_BKGD, om.IN_BKGD, rows, N, draw, variables.mlp_flat('MLP_0'), fl['act_b'],
+                                 wstream=ctx['bkgd_ws'])
             ops.mlp_dw_f32(om.W_BKGD, om.IN_BKGD, rows, N, fl['act_b'], dz, grad[off:off + lay.mlp_size[om.W_BKGD]])
         if obj_f32:                           # the object branch in fp32: backward + d(enc) -> pose sums, all K at once
             sl = lv['f32']['slabs32']
             o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
-            ops.objf32_bwd_batch(sl, ctx['idx'], ctx['count'], draw, variables.flat[o0:o0 + K * sz], ctx['obj_params_t'],
-                                 sz, want_d_enc=pose_opt)
+            ops.objf32_bwd_batch(sl, ctx['idx'], ctx['count'], draw, variables.flat[o0:o0 + K * sz], sz, ctx['obj_ws'],
+                                 want_d_enc=pose_opt)
             if pose_opt:
                 ops.encode_obj_bwd_batch(K, ctx['idx'], ctx['count'], sl.d_enc, lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
                                          rays.origins, rays.directions, pose_ts, alpha, pose_sums, precise=True)
@@ -144,6 +164,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     if obj_f32:                               # weight gradients of the K object MLPs over every level: one launch pair
         o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
         ops.objf32_dw_batch([lv['f32']['slabs32'] for lv in levels], ctx['count'], grad[o0:o0 + K * sz], sz)
+        if objects_ready is not None:
+            objects_ready(grad[o0:o0 + K * sz])
     if not f32:
         off = lay.mlp_off['MLP_0']
         g_b, p_b = grad[off:off + lay.mlp_size[om.W_BKGD]], variables.mlp_flat('MLP_0')
@@ -153,7 +175,11 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         else:
             geo = ([rows] * L, [N] * L, [None] * L)
         o0, sz = (lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]) if Kb else (0, 0)
-        merged = Kb and not ops.OVERLAP_DW and ops.MERGE_FINALIZE
+        merged = Kb and not ops.OVERLAP_DW and ops.MERGE_FINALIZE and objects_ready is None
+        if Kb and objects_ready is not None:           # bucketed all-reduce: the objects' gradients first, finalized on their own
+            ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
+                             grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
+            objects_ready(grad[o0:o0 + K * sz])
         if merged:
             # The objects' split-K launch goes FIRST: the finalize launch then finds the background MLP's partials
             # (134 MB, the bulk) still in the 256 MB Infinity Cache -- behind the objects' 0.7 GB operand stream it
@@ -166,7 +192,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                 obj=(K, B, N, ctx['count'], L, po, bo, grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz]))
         else:
             ops.dw_finalize_all(*geo, *bufs, g_b, p_b)
-            if Kb:
+            if Kb and objects_ready is None:
                 with side:
                     ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
                                      grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
@@ -220,13 +246,17 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     `print_every` steps (:440), so a driver passes `step % print_every == 0`; the scalars returned on the other
     steps are this rank's shard-local values."""
     variables = state.variables
-    grad, raw, pose = loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=noise)
     dist = _dist()
+    pending = []
+    lay = variables.layout
+    bucket = dist is not None and _bucketed() and lay.K > 0
+    ready = (lambda g_obj: pending.append(dist.all_reduce(g_obj, async_op=True))) if bucket else None
+    grad, raw, pose = loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=noise, objects_ready=ready)
     world = 1
-    pending = None
     if dist is not None:                                    # lax.pmean(grad) (:253)
         world = dist.get_world_size()
-        pending = dist.all_reduce(grad, async_op=True)
+        rest = grad[:lay.mlp_off['BoxMLP_0']] if bucket else grad        # [box_centers | MLP_0] when the objects went ahead
+        pending.append(dist.all_reduce(rest, async_op=True))
     L = model.num_levels
     if dist is None or not reduce_stats:
         out = _assemble_stats(config, batch, raw, prev, ops.STATS_ASSEMBLE | ops.STATS_PSNR)
@@ -236,8 +266,8 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
         out /= world
         ops.train_stats(raw['norms'], raw['sums'], None, None, None, None, [r[4] for r in raw['ret']],
                         _stat_mults(config), ops.STATS_PSNR, out=out)
-    if pending is not None:
-        pending.wait()                                      # orders the current stream behind the collective
+    for work in pending:
+        work.wait()                                         # orders the current stream behind the collective(s)
     st = ops.stats_views(out, L)
     gs = ops.clip_adam(variables.flat, state.m, state.v, grad, 1.0 / world, float(config.grad_max_val),
                        float(config.grad_max_norm), float(lr), state.step)
@@ -268,12 +298,22 @@ def init_distributed(backend=None):
     local = int(os.environ.get('LOCAL_RANK', '0'))
     if torch.cuda.is_available():
         local = local % max(torch.cuda.device_count(), 1)     # several ranks may share a GPU in tests (gloo)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or _force_dist()) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get('DURF_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        rdzv = os.environ.get('DURF_RDZV_FILE')             # bench.py's own spawner: a file store, no port to race for
+        if rdzv:
+            dist.init_process_group(backend=backend, init_method='file://' + rdzv, rank=rank, world_size=world)
+        elif world == 1 and 'MASTER_ADDR' not in os.environ:      # DURF_FORCE_DIST on a single process
+            import tempfile
+            path = os.path.join(tempfile.gettempdir(), 'durf_rdzv_%d' % os.getpid())
+            if os.path.exists(path):
+                os.remove(path)
+            dist.init_process_group(backend=backend, init_method='file://' + path, rank=0, world_size=1)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 
 
@@ -368,6 +408,14 @@ def train_loop(model, config, state, dataset, test_dataset=None, train_dir=None,
             losses = torch.stack([torch.as_tensor(t[0]).float().reshape(()) for t in trace])
             psnrs = torch.stack([torch.as_tensor(t[1]).float().reshape(()) for t in trace])
             gn = torch.stack([torch.as_tensor(t[2]).float().reshape(()) for t in trace])
+            d_ = _dist()
+            if d_ is not None and d_.get_world_size() > 1:
+                # the reference's stats_trace holds pmean'd stats of EVERY step (train_boxpose.py:255,440); here only
+                # the logging step's were all-reduced, so average the window's loss / psnr over the ranks now -- one
+                # small collective per print_every steps (the gradient norm is global already: it is taken after pmean)
+                lp = torch.stack([losses, psnrs])
+                d_.all_reduce(lp)
+                losses, psnrs = lp[0] / world, lp[1] / world
             steps_per_sec = len(trace) / max(time.time() - t_loop, 1e-9)
             rec = dict(loss=float(stats.loss), avg_loss=float(losses.mean()), avg_psnr=float(psnrs.mean()),
                        max_grad_norm=float(gn.max()), lr=lr, eps=eps, alpha=alpha,

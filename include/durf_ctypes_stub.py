@@ -124,18 +124,24 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_f32_dw_scratch_floats.restype = u64
     L.durf_mlp_f32_dw_scratch_floats.argtypes = [i32, i32, i32]
     #   (width, in_dim, nsplit)
-    L.durf_mlp_f32_transpose.restype = i32
-    L.durf_mlp_f32_transpose.argtypes = [vp, i32, i32, i32, vp, u64, vp]
-    #   (stream, width, in_dim, K, mlp_params, param_stride, params_t)
+    L.durf_mlp_f32_wstream_floats.restype = u64
+    L.durf_mlp_f32_wstream_floats.argtypes = [i32]
+    #   (width)
+    L.durf_mlp_f32_pack.restype = i32
+    L.durf_mlp_f32_pack.argtypes = [vp, i32, i32, i32, vp, u64, vp]
+    #   (stream, width, in_dim, K, mlp_params, param_stride, wstream)
     L.durf_mlp_fwd_f32.restype = i32
-    L.durf_mlp_fwd_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp]
-    #   (stream, width, in_dim, rows, N, enc, view27, ray_idx, count, mlp_params, raw, act)
+    L.durf_mlp_fwd_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, width, in_dim, rows, N, enc, view27, ray_idx, count, mlp_params, wstream, raw, act)
     L.durf_mlp_bwd_f32.restype = i32
     L.durf_mlp_bwd_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp]
-    #   (stream, width, in_dim, rows, N, draw, ray_idx, count, mlp_params, params_t, act, dz, d_enc)
+    #   (stream, width, in_dim, rows, N, draw, ray_idx, count, mlp_params, wstream, act, dz, d_enc)
     L.durf_mlp_dw_f32.restype = i32
     L.durf_mlp_dw_f32.argtypes = [vp, i32, i32, u64, i32, vp, vp, vp, i32, vp, vp]
     #   (stream, width, in_dim, rows, N, count, act, dz, nsplit, scratch, grad_mlp)
+    L.durf_bkgd_const_trunk_f32.restype = i32
+    L.durf_bkgd_const_trunk_f32.argtypes = [vp, vp, vp]
+    #   (stream, bkgd_params, trunk)
     L.durf_bkgd_hit_rays_f32.restype = i32
     L.durf_bkgd_hit_rays_f32.argtypes = [vp, i32, vp, vp, vp, vp, vp, vp]
     #   (stream, B, view27, bkgd_params, idx, count, trunk, raw_tail)
@@ -149,11 +155,11 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_encode_obj_f32_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp]
     #   (stream, K, B, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags, enc)
     L.durf_objf32_fwd_batch.restype = i32
-    L.durf_objf32_fwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, u64, vp, vp]
-    #   (stream, K, B, N, idx, count, enc, view27, obj_params, param_stride, raw, act)
+    L.durf_objf32_fwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, u64, vp, vp, vp]
+    #   (stream, K, B, N, idx, count, enc, view27, obj_params, param_stride, wstream, raw, act)
     L.durf_objf32_bwd_batch.restype = i32
-    L.durf_objf32_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, u64, vp, vp, vp]
-    #   (stream, K, B, N, idx, count, draw, obj_params, obj_params_t, param_stride, act, dz, d_enc)
+    L.durf_objf32_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, u64, vp, vp, vp, vp]
+    #   (stream, K, B, N, idx, count, draw, obj_params, param_stride, wstream, act, dz, d_enc)
     L.durf_objf32_dw_batch.restype = i32
     L.durf_objf32_dw_batch.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), i32, vp, vp, u64]
     #   (stream, K, B, N, count, nlevels, act, dz, nsplit, scratch, grad_obj, grad_stride)

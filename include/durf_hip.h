@@ -291,32 +291,39 @@ int durf_expand_raw(void* stream, int B, int N, const float* raw_c /* compacted 
  *   act / dz: per-sample records of the forward (the input of every Dense) / backward (d loss / d pre-activation of
  *       every Dense), durf_mlp_f32_{act,dz}_floats floats per row, ROWS ROUNDED UP TO 32, stored per 32-row tile as
  *       [tile][float index][32 rows];  opaque to the caller, only passed between these calls;
- *   params_t: durf_mlp_f32_transpose's output (per-layer transposed kernels, same size and offsets as mlp_params);
+ *   wstream: durf_mlp_f32_pack's output, durf_mlp_f32_wstream_floats(width) floats per MLP -- the kernels of the ten
+ *       wide Dense layers as the chunks the forward / the backward (transposed) consume, in order, zero-padded to whole
+ *       tiles (re-packed after every optimizer step, like the bf16 weight streams); mlp_params still supplies biases and
+ *       the 1- / 3-wide heads;  (width, in_dim) must be (256, 60) or (128, 63), the two MLPs of the model;
  *   d_enc [rows,64] row-major (nullable; every valid row is overwritten);  ray_idx / count as in durf_mlp_fwd.
  * Weight gradients are split over `nsplit` sample shares and summed in a fixed order (deterministic); scratch:
  * durf_mlp_f32_dw_scratch_floats floats.  grad_mlp: flax layout of one MLP, overwritten. */
 size_t durf_mlp_f32_act_floats(int width, int in_dim);
 size_t durf_mlp_f32_dz_floats(int width, int in_dim);
 size_t durf_mlp_f32_dw_scratch_floats(int width, int in_dim, int nsplit);
-int durf_mlp_f32_transpose(void* stream, int width, int in_dim, int K, const float* mlp_params, size_t param_stride,
-                           float* params_t);
+size_t durf_mlp_f32_wstream_floats(int width);
+int durf_mlp_f32_pack(void* stream, int width, int in_dim, int K, const float* mlp_params, size_t param_stride,
+                      float* wstream /* [K, durf_mlp_f32_wstream_floats] */);
 int durf_mlp_fwd_f32(void* stream, int width, int in_dim, size_t rows, int N, const float* enc, const float* view27,
-                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, float* raw,
-                     float* act /* nullable: inference */);
+                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* wstream,
+                     float* raw, float* act /* nullable: inference */);
 int durf_mlp_bwd_f32(void* stream, int width, int in_dim, size_t rows, int N, const float* draw,
-                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* params_t,
-                     const float* act, float* dz, float* d_enc);
+                     const int32_t* ray_idx, const int32_t* count, const float* mlp_params, const float* wstream,
+                     const float* act, float* dz, float* d_enc /* nullable */);
 int durf_mlp_dw_f32(void* stream, int width, int in_dim, size_t rows, int N, const int32_t* count, const float* act,
                     const float* dz, int nsplit, float* scratch, float* grad_mlp);
-/* The background MLP (width 256, in_dim 60) on the box-hit rays in fp32: idx / count = that ray class (durf_compact_classes,
- * class 1); raw_tail [B,4], row j = ray idx[j] -- what durf_mlp_fwd_f32(enc = NULL) computes, but with Dense_0..Dense_9,
- * whose input is the same for every such ray, evaluated once (trunk: 257 floats of scratch).  durf_expand_raw's raw_tail. */
+/* The background MLP (width 256, in_dim 60) on the box-hit rays in fp32 -- what durf_mlp_fwd_f32(enc = NULL) computes, in
+ * two parts: Dense_0 .. Dense_9, whose input is the same for every such ray, ONCE per step (durf_bkgd_const_trunk_f32:
+ * parameters -> trunk [257] = bottleneck, density), then the view layer and the rgb head per ray (durf_bkgd_hit_rays_f32:
+ * idx / count = that ray class (durf_compact_classes, class 1); raw_tail [B,4], row j = ray idx[j]: durf_expand_raw's
+ * raw_tail). */
+int durf_bkgd_const_trunk_f32(void* stream, const float* bkgd_params, float* trunk);
 int durf_bkgd_hit_rays_f32(void* stream, int B, const float* view27, const float* bkgd_params, const int32_t* idx,
-                           const int32_t* count, float* trunk, float* raw_tail);
+                           const int32_t* count, const float* trunk, float* raw_tail);
 /* The K object MLPs (width 128, in_dim 63) of one level on the fp32 kernels, ONE launch per phase with the object
  * index in the grid: idx [K,B] / count [K] from durf_compact_hits; enc [K, B*N, 63]; raw [K, B*N, 4]; act / dz
- * [K, durf_objf32_{act,dz}_stride floats]; d_enc [K, B*N, 64]; obj_params / obj_params_t: BoxMLP_0 .. BoxMLP_{K-1},
- * param_stride floats apart.  durf_objf32_dw_batch takes the records of every level (host arrays of nlevels device
+ * [K, durf_objf32_{act,dz}_stride floats]; d_enc [K, B*N, 64]; obj_params: BoxMLP_0 .. BoxMLP_{K-1}, param_stride
+ * floats apart; wstream: durf_mlp_f32_pack(128, 63, K, ...)'s output.  durf_objf32_dw_batch takes the records of every level (host arrays of nlevels device
  * pointers) and writes grad_obj [K, grad_stride]; scratch: K * durf_mlp_f32_dw_scratch_floats(128, 63, nsplit). */
 size_t durf_objf32_act_stride(int B, int N);
 size_t durf_objf32_dz_stride(int B, int N);
@@ -324,10 +331,10 @@ int durf_encode_obj_f32_batch(void* stream, int K, int B, int N, const int32_t* 
                               const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
                               const float* barf_w /* host float[10] */, int flags, float* enc /* [K, B*N, 63] */);
 int durf_objf32_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* enc,
-                          const float* view27, const float* obj_params, size_t param_stride, float* raw,
-                          float* act /* nullable: inference */);
+                          const float* view27, const float* obj_params, size_t param_stride, const float* wstream,
+                          float* raw, float* act /* nullable: inference */);
 int durf_objf32_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* draw,
-                          const float* obj_params, const float* obj_params_t, size_t param_stride, const float* act,
+                          const float* obj_params, size_t param_stride, const float* wstream, const float* act,
                           float* dz, float* d_enc /* nullable */);
 int durf_objf32_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels, const float* const* act,
                          const float* const* dz, int nsplit, float* scratch, float* grad_obj, size_t grad_stride);

@@ -113,3 +113,84 @@ def test_two_ranks_through_bench_workload_with_distinct_shards(cuda, tmp_path):
     assert not torch.equal(a['first_pixel'], b['first_pixel']), 'the ranks train on distinct shards'
     assert a['losses'][0] != b['losses'][0] and a['losses'][1] != b['losses'][1]      # shard-local scalars
     assert a['losses'][2] == b['losses'][2]                                            # all-reduced when logged
+
+
+def _rccl_worker(_i, out_dir, force, bucket, pose_opt):
+    """one process; force: through a world-size-1 `nccl` (= RCCL) group, else the plain single-GPU path"""
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'DURF_DIST_BACKEND', 'DURF_RDZV_FILE'):
+        os.environ.pop(k, None)
+    os.environ['DURF_FORCE_DIST'] = '1' if force else '0'
+    os.environ['DURF_BUCKET_ALLREDUCE'] = '1' if bucket else '0'
+    sys.path.insert(0, ROOT)
+    import bench
+    from durf_amd import train_boxpose
+    r, w, local = train_boxpose.init_distributed()
+    import torch.distributed as dist
+    assert dist.is_initialized() == bool(force)
+    if force:
+        assert dist.get_backend() == 'nccl' and train_boxpose._dist() is not None
+    dev = torch.device('cuda', local)
+    wl = bench.setup_workload('cfg4' if pose_opt else 'cfg3', dev, 0, 1, rays=256)
+    state, losses = wl['state'], []
+    rng = 0
+    for i in range(3):
+        state, stats, rng, _ = train_boxpose.train_step(wl['model'], wl['config'], rng, state, wl['batch'], 5e-4, 3.0,
+                                                        wl['alpha'], wl['prev'], reduce_stats=(i == 2))
+        losses.append(float(stats.loss))
+    torch.cuda.synchronize()
+    torch.save(dict(flat=state.variables.flat.cpu(), m=state.m.cpu(), losses=losses),
+               os.path.join(out_dir, 'rccl_%d_%d.pt' % (force, bucket)))
+    if force:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('pose_opt', [False, True])
+def test_train_step_through_rccl_world_size_one(cuda, tmp_path, pose_opt):
+    """The data-parallel code path with its PRODUCTION backend: DURF_FORCE_DIST=1 builds a world-size-1 `nccl` group
+    (RCCL: the one-GPU box cannot host more ranks), so train_step issues the asynchronous gradient all-reduce, waits
+    for it on the compute stream, folds 1 / world into clip + Adam and all-reduces the logged scalars on the logging
+    step.  Three steps must leave parameters, Adam moments and losses BIT-identical to the plain path -- also with
+    the objects' gradients all-reduced ahead of the background MLP's (DURF_BUCKET_ALLREDUCE=1: two collectives)."""
+    for force, bucket in ((0, 0), (1, 0), (1, 1)):
+        mp.spawn(_rccl_worker, args=(str(tmp_path), force, bucket, pose_opt), nprocs=1, join=True)
+    base = torch.load(os.path.join(str(tmp_path), 'rccl_0_0.pt'))
+    for tag in ('rccl_1_0.pt', 'rccl_1_1.pt'):
+        got = torch.load(os.path.join(str(tmp_path), tag))
+        assert torch.equal(got['flat'], base['flat']) and torch.equal(got['m'], base['m']), tag
+        assert got['losses'] == base['losses'], tag
+
+
+def _bucket_worker(rank, world, port, out_dir, bucket):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), DURF_DIST_BACKEND='gloo', DURF_BUCKET_ALLREDUCE='1' if bucket else '0')
+    sys.path.insert(0, ROOT)
+    import bench
+    from durf_amd import train_boxpose
+    r, w, local = train_boxpose.init_distributed()
+    dev = torch.device('cuda', local)
+    wl = bench.setup_workload('cfg3', dev, r, w, rays=256)
+    state, rng = wl['state'], 1000 * r
+    for i in range(2):
+        state, stats, rng, _ = train_boxpose.train_step(wl['model'], wl['config'], rng, state, wl['batch'], 5e-4, 3.0,
+                                                        wl['alpha'], wl['prev'], reduce_stats=False)
+    torch.cuda.synchronize()
+    if r == 0:
+        torch.save(state.variables.flat.cpu(), os.path.join(out_dir, 'bucket_%d.pt' % bucket))
+    import torch.distributed as dist
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_gives_the_same_parameters(cuda, tmp_path):
+    """two ranks (gloo): objects' gradient slice all-reduced ahead of [box_centers | MLP_0] == one all-reduce of the
+    flat buffer, bit for bit (same element-wise sums, same kernels)"""
+    for bucket in (0, 1):
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        mp.spawn(_bucket_worker, args=(2, port, str(tmp_path), bucket), nprocs=2, join=True)
+    a = torch.load(os.path.join(str(tmp_path), 'bucket_0.pt'))
+    b = torch.load(os.path.join(str(tmp_path), 'bucket_1.pt'))
+    assert torch.equal(a, b)

@@ -204,11 +204,11 @@ def test_object_batch_calls_match_the_single_mlp_calls(cuda):
     view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1]
     sz = ops.mlp_param_count(128, 63)
     flat = ((torch.rand(K * sz, generator=g) - 0.5) * 0.2).to(cuda)
-    flat_t = ops.mlp_f32_transpose(128, 63, flat, K=K, param_stride=sz)
+    ws = ops.mlp_f32_pack(128, 63, flat, K=K, param_stride=sz)
     draw = (torch.randn(B * N, 4, generator=g) * 0.1).to(cuda)
     slabs = ops.ObjSlabsF32(K, B, N, cuda, True)
-    ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz)
-    ops.objf32_bwd_batch(slabs, idx, count, draw, flat, flat_t, sz, want_d_enc=True)
+    ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz, ws)
+    ops.objf32_bwd_batch(slabs, idx, count, draw, flat, sz, ws, want_d_enc=True)
     grad = torch.zeros(K * sz, device=cuda)
     ops.objf32_dw_batch([slabs], count, grad, sz, nsplit=3)
     for k in range(K):
@@ -217,10 +217,12 @@ def test_object_batch_calls_match_the_single_mlp_calls(cuda):
         _, enc_k = ops.encode_obj(B, idx[k], ck, t_vals, o_s, d_s, radii, alpha, tile=False, f32=True)
         assert torch.equal(slabs.enc[k, :c], enc_k[:c])
         pk = flat[k * sz:(k + 1) * sz]
-        raw_k, act_k = ops.mlp_fwd_f32(128, 63, B * N, N, enc_k, view27, pk, ray_idx=idx[k], count=ck, want_act=True)
+        wsz = ws.numel() // K
+        raw_k, act_k = ops.mlp_fwd_f32(128, 63, B * N, N, enc_k, view27, pk, ray_idx=idx[k], count=ck, want_act=True,
+                                       wstream=ws[k * wsz:(k + 1) * wsz])
         assert torch.equal(slabs.raw[k, :c], raw_k[:c])
         dz_k, denc_k = ops.mlp_bwd_f32(128, 63, B * N, N, draw, pk, act_k, ray_idx=idx[k], count=ck, want_d_enc=True,
-                                       params_t=flat_t[k * sz:(k + 1) * sz])
+                                       wstream=ws[k * wsz:(k + 1) * wsz])
         assert torch.equal(slabs.d_enc[k, :c], denc_k[:c])
         gk = torch.zeros(sz, device=cuda)
         ops.mlp_dw_f32(128, 63, B * N, N, act_k, dz_k, gk, count=ck, nsplit=3)
