@@ -67,6 +67,10 @@ def parse_args():
     ap.add_argument('--no-calibration', action='store_true', help='skip the vendor-GEMM board calibration line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-op time table to stderr')
+    ap.add_argument('--mode', default='train', choices=['train', 'eval'],
+                    help="eval: a 'step' renders one 320x480 test image (153 600 rays, chunk 8192, randomized=False) through "
+                         'render_image -- the reference logs this as eval rays/sec (train_boxpose.py:548-568)')
+    ap.add_argument('--chunk', type=int, default=8192, help='render_image chunk (eval mode)')
     ap.add_argument('--force-dist', action='store_true',
                     help='one rank, but through the data-parallel path: a world-size-1 RCCL group (DURF_FORCE_DIST=1), so the '
                          'gradient all-reduce + stream wait run and their per-step cost shows against a plain run')
@@ -255,8 +259,71 @@ def selftest_launch(args):
     return 0 if ok else 1
 
 
+def eval_main(args):
+    """--mode eval: the inference path the reference times at every test render (train_boxpose.py:548-568,
+    obbpose_model.py:421-479): render_image over a full 320 x 480 image in chunks of 8192 rays, deterministic sampling.
+    A step = one image.  value = rendered rays per second; roofline = the fused background-MLP forward (inference
+    form: no stash), algorithmic FLOPs per launch / live HIP-event time / 2.5 PFLOP/s."""
+    import torch
+    from durf_amd import obbpose_model, ops, synthetic, train_boxpose, utils
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    w = setup_workload(args.config, dev, rays=args.rays, objects=args.objects)
+    config, model, state = w['config'], w['model'], w['state']
+    H, W = 320, 480
+    b = synthetic.make_batch(H * W, w['K'], seed=7, far=w['far'], allow_multi_hit=True)
+    db = synthetic.device_batch(b, dev)
+    rays = utils.namedtuple_map(lambda r: r.reshape(H, W, -1), db['rays'])
+    fn = train_boxpose.make_render_fn(model, config, state.variables)
+    render = lambda: obbpose_model.render_image(fn, rays, db['init'], db['ext'], b['ts'], 0, w['alpha'], chunk=args.chunk)
+    ops.TIMED_NAMES = {'mlp_fwd_256', 'encode_bkgd', 'composite_fwd'}
+    ops.TIMERS = {}
+    prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]
+    for e in prewarm:
+        e.record()
+    for _ in range(max(args.warmup, 2)):
+        render()
+    torch.cuda.synchronize()
+    ops.TIMERS = {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    e0.record()
+    for _ in range(args.steps):
+        rgb, dist_, acc = render()
+    e1.record()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    totals = ops.timer_totals()
+    ops.TIMERS = None
+    NS = w['N']
+    nchunks = (H * W + args.chunk - 1) // args.chunk
+    n, sec = totals['mlp_fwd_256']
+    rows = H * W * NS                                    # per level, all chunks of one image
+    per_image = sec / args.steps                         # the background forward of both levels, all chunks
+    fl = N_LEVELS * 2.0 * MAC_BKGD * rows
+    busy = sum(s_ for _, s_ in totals.values()) / args.steps
+    roof = dict(bound='mfma', kernel='mlp_fwd_256 (inference)', achieved=fl / per_image / 1e12, peak=PEAK_BF16 / 1e12,
+                unit='TFLOP/s', frac=fl / per_image / PEAK_BF16, traffic=None, launch_us=sec / n * 1e6,
+                launches_per_image=n // args.steps,
+                timed_kernels_ms_per_image={k: v[1] / args.steps * 1e3 for k, v in totals.items()},
+                # GPU time of an image outside the three timed kernels (object MLPs, per-ray launches, idle gaps)
+                other_ms_per_image=(e0.elapsed_time(e1) / args.steps) - busy * 1e3)
+    out = dict(metric='eval_rays_per_sec', value=H * W * args.steps / dt, unit='rays/s', n_gpus=1, steps=args.steps,
+               warmup=max(args.warmup, 2), ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
+               vs_baseline=None, dtype='bf16', data='synthetic',
+               config=dict(workload=w['label'] + ', render_image of one %dx%d image (%d rays) in %d chunks of %d, %d samples/ray '
+                                                 'x 2 levels, deterministic sampling' % (H, W, H * W, nchunks, args.chunk, NS),
+                           name=args.config, mode='eval', image=[H, W], chunk=args.chunk, num_samples=NS, objects=w['K'],
+                           hit_fraction=float(b['hit_fraction'])),
+               roofline=roof, cpu_baseline=None,
+               checksum=dict(rgb_mean=float(rgb.mean()), acc_mean=float(acc.mean())))
+    print(json.dumps(out))
+
+
 def main():
     args = parse_args()
+    if args.mode == 'eval':
+        raise SystemExit(eval_main(args))
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))        # parent: spawns and waits; no GPU call in this process
     if args.selftest_launch:

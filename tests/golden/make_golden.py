@@ -23,6 +23,9 @@ CASES = {   # name: (B, K, N, randomized, alpha, seed)
     'static_K0_N64': (48, 0, 64, False, 10.0, 101),
     'dynamic_K1_N32': (64, 1, 32, False, 10.0, 102),
     'dynamic_K3_N32_rand_alpha': (96, 3, 32, True, 4.5, 103),
+    # the shape the metric is quoted on (BASELINE.json configs[2], bench.py cfg3): Waymo knobs (far 40, LIDAR depth /
+    # near / empty + sky losses), K = 3, 128 samples/ray x 2 levels, stratified sampling with injected draws
+    'waymo_K3_N128': (256, 3, 128, True, 10.0, 104),
 }
 
 
