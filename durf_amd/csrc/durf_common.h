@@ -143,11 +143,7 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 // 16-byte store of a streamed-once tensor (activation stash, dz): non-temporal, so the stream does
 // not compete with the packed weights for L2 (measured on the fused forward / backward: nt 784 / 643 us,
 // plain 826 / 700, sc1 816 / 747, sc0 sc1 807 / 745)
-#if defined(STREAM_NO_NT)
-#define STREAM_STORE(ptr, val) (*(bf16x8*)(ptr) = (val))
-#else
 #define STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (bf16x8*)(ptr))
-#endif
 
 // ---- batched (per-object) launches ---------------------------------------------------------
 // The K object MLPs use [K, ...] slabs with uniform strides (include/durf_hip.h, durf_obj_*): the

@@ -365,11 +365,7 @@ __host__ __device__ constexpr int dw_stages(int nc) { return DW_LDS_BYTES / (nc 
 // tile.  Hidden in asm, the loads are ordered only by this kernel's own counted waits.
 // (M0 = LDS byte address of the 1 KB chunk; saved/restored because hipcc owns M0.)
 // nt: the operands are read exactly once (measured -6 % per launch vs the default cache policy)
-#if defined(DW_NO_NT)
-#define DW_DMA_POLICY ""
-#else
 #define DW_DMA_POLICY " nt"
-#endif
 __device__ __forceinline__ void lds_dma16(i32x4 rsrc, unsigned soff, unsigned voff, unsigned lds_addr) {
     unsigned keep;
     asm volatile("s_nop 4\n\t"
@@ -593,12 +589,6 @@ __device__ __forceinline__ void dw_job(const durf::DwLevels& lv, const DwArgs& a
 }
 
 
-#ifdef DW_TRACE
-__device__ unsigned long long g_dw_trace[4 * 4096];
-extern "C" int durf_debug_dw_trace(void* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_dw_trace), sizeof(g_dw_trace));
-}
-#endif
 
 template <int W>
 __global__ void __launch_bounds__(512, 2)
@@ -612,25 +602,6 @@ k_dw_all(durf::DwLevels lv, DwArgs a) {
     for (int i = 1; i < 12; i++) oi += ((int)blockIdx.x >= a.first_wg[i]) ? 1 : 0;
     const int job = a.order[oi], sp = (int)blockIdx.x - a.first_wg[oi];
     const int ns = a.nsplit[job];
-#ifdef DW_TRACE
-    const unsigned long long t_start = wall_clock64();
-    struct TraceEnd {
-        unsigned long long t0; int job, sp;
-        __device__ ~TraceEnd() {
-            if (threadIdx.x == 0) {
-                unsigned hwid;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
-                unsigned xcc;
-                asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-                const int slot = job * 256 + sp;
-                g_dw_trace[4 * slot] = t0;
-                g_dw_trace[4 * slot + 1] = wall_clock64();
-                g_dw_trace[4 * slot + 2] = ((unsigned long long)xcc << 32) | hwid;
-                g_dw_trace[4 * slot + 3] = ((unsigned long long)job << 32) | (unsigned)sp;
-            }
-        }
-    } trace_end{t_start, job, sp};
-#endif
 #define DW_CALL(...) dw_job<__VA_ARGS__>(lv, a, job, ns, sp, a.part[job], a.bpart[job], smem)
     switch (job) {
         case 0: DW_CALL(S::KW, S::KE, 0); break;

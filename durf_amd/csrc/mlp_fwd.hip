@@ -234,12 +234,6 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
     if (TRAIN && RELU) mask_carry = make_uint4(mb[0], mb[1], mb[2], mb[3]);
 }
 
-#ifdef FWD_TRACE
-__device__ unsigned long long g_fwd_trace[256 * 80];
-extern "C" int durf_debug_fwd_trace(void* dst) {
-    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_fwd_trace), sizeof(g_fwd_trace));
-}
-#endif
 
 template <int W, bool TRAIN>
 __global__ void __launch_bounds__(512, 2)
@@ -297,14 +291,7 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
   // Persistent workgroup: one CU holds one workgroup (136 KB of LDS), so looping over the
   // 256-sample blocks here instead of relaunching hides every block's start-up (first weight
   // group + encoding fetch) behind the previous block's last stages.
-#ifdef FWD_TRACE
-  int trace_i = 0;
-  if (threadIdx.x == 0) g_fwd_trace[blockIdx.x * 80 + 78] = wall_clock64();
-#endif
   for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-#ifdef FWD_TRACE
-    if (threadIdx.x == 0 && trace_i < 76) g_fwd_trace[blockIdx.x * 80 + trace_i++] = wall_clock64();
-#endif
     const bool has_next = blk + gridDim.x < nblk;
     const size_t tile32 = blk * 8 + wave;
     const size_t row = tile32 * 32 + (lane & 31);
@@ -418,9 +405,6 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
 #undef ST
 #undef MK
   }
-#ifdef FWD_TRACE
-  if (threadIdx.x == 0) g_fwd_trace[blockIdx.x * 80 + 79] = wall_clock64();
-#endif
 }
 
 // ---------------------------------------------------------------------------

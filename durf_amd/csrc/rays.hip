@@ -438,9 +438,6 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
                 const int f = q * 8 + e - OFF;
                 if (f >= 0 && f < 60) { const int d = (f % 30) / 3; last = d > last ? d : last; }
             }
-#if defined(ENC_EXP) && ENC_EXP == 2      // tuning experiment: the arithmetic with 1/8 of the stores
-            if (q != 0) continue;
-#endif
             if (last == deg) {
                 bf16x8 o8;
 #pragma unroll
@@ -448,21 +445,10 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
                 // non-temporal: the tile is written once and read once by the fused MLP (measured 18.7 -> 17.9 us at
                 // 4096 rays, 125 -> 113 us at 32 768; the kernel is bound by its store path: with the arithmetic
                 // compiled out the same stores take 14.8 / 105 us)
-#if defined(ENC_NO_NT)
-                *(bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16) = o8;
-#else
                 __builtin_nontemporal_store(o8, (bf16x8*)(base + ((q >> 1) * 64 + (q & 1) * 32) * 16));
-#endif
             }
         }
     };
-#if defined(ENC_EXP) && ENC_EXP == 1      // tuning experiment: the stores without the arithmetic
-#pragma unroll
-    for (int i = 0; i < 64; i++) feat[i] = t0 + (float)i;
-#pragma unroll
-    for (int deg = 0; deg < 10; deg++) flush(deg);
-    return;
-#endif
     // Range reduction of the 60 sine arguments.  safe_sin wraps |y| >= 100 pi by an exact fmod (wrap_100pi below the
     // sine).  v_sin_f32 works in revolutions and any integer may be dropped, so v_fract(y / 2 pi) does the same job in
     // one op when the arguments are moderate.  Differences from the exact wrap: it ignores that the reference's 100 pi

@@ -1,5 +1,6 @@
-"""Per-workgroup timeline of the weight-gradient launch (needs a -DDW_TRACE variant build:
-tools/build_variant.sh trace -DDW_TRACE;  DURF_LIB_PATH=durf_amd/variants/libdurf_trace.so python tools/dw_trace.py)."""
+"""Per-workgroup timeline of the weight-gradient launch.  The instrumentation is not in the product kernels: apply
+tools/experiments/kernel_instrumentation.patch (git apply), then  tools/build_variant.sh trace -DDW_TRACE;
+DURF_LIB_PATH=durf_amd/variants/libdurf_trace.so python tools/dw_trace.py;  git checkout durf_amd/csrc."""
 import ctypes as C
 import os
 import sys

@@ -1,4 +1,5 @@
-"""Per-workgroup / per-block timeline of the fused forward (needs a -DFWD_TRACE variant build)."""
+"""Per-workgroup / per-block timeline of the fused forward (needs tools/experiments/kernel_instrumentation.patch applied
+and a -DFWD_TRACE variant build, see tools/dw_trace.py)."""
 import ctypes as C
 import os
 import sys
