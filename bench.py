@@ -271,7 +271,7 @@ def eval_main(args):
     w = setup_workload(args.config, dev, rays=args.rays, objects=args.objects)
     config, model, state = w['config'], w['model'], w['state']
     H, W = 320, 480
-    b = synthetic.make_batch(H * W, w['K'], seed=7, far=w['far'], allow_multi_hit=True)
+    b = synthetic.make_batch(H * W, w['K'], seed=7, far=w['far'])
     db = synthetic.device_batch(b, dev)
     rays = utils.namedtuple_map(lambda r: r.reshape(H, W, -1), db['rays'])
     fn = train_boxpose.make_render_fn(model, config, state.variables)
@@ -316,7 +316,9 @@ def eval_main(args):
                            name=args.config, mode='eval', image=[H, W], chunk=args.chunk, num_samples=NS, objects=w['K'],
                            hit_fraction=float(b['hit_fraction'])),
                roofline=roof, cpu_baseline=None,
-               checksum=dict(rgb_mean=float(rgb.mean()), acc_mean=float(acc.mean())))
+               # (pixels of rays that hit two boxes are non-finite, as in the reference: obbpose_model.py:120-122)
+               checksum=dict(rgb_mean=float(torch.nanmean(rgb)), acc_mean=float(torch.nanmean(acc)),
+                             nonfinite_pixels=int((~torch.isfinite(rgb).all(-1)).sum())))
     print(json.dumps(out))
 
 
@@ -459,10 +461,21 @@ def main():
                    step_ms=dict(p50=step_times[len(step_times) // 2], p90=step_times[(9 * len(step_times)) // 10],
                                 max=step_times[-1],
                                 slow_steps=[i for i, t in enumerate(step_raw) if t > 1.5 * step_times[len(step_times) // 2]]))
-        print(json.dumps(out))
+    else:
+        out = None
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # the ONE JSON line goes out last, after the process group is gone: RCCL prints a version banner to stdout when it
+        # initialises / finalises, and a parser that reads the last line of stdout must find the result there
+        sys.stdout.flush()
+        try:                                    # RCCL's banner sits in the C stdio buffer until the process exits
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except OSError:
+            pass
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == '__main__':

@@ -278,23 +278,26 @@ k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __res
               StatMults m, int mode, float* __restrict__ out) {
     // terms given: the per-ray loss terms [LT_ROWS, B] of every level are reduced HERE (the order of k_reduce_rows, so
     // the sums are the ones durf_loss_bwd's own reduction launch would have produced) and left in sums [L, LT_ROWS]
-    __shared__ float s_w[16];
-    if ((mode & 1) && terms.p[0] != nullptr) {
-        for (int row = 0; row < L * LT_ROWS; row++) {
+    // (one WAVE per row, all rows at once -- as a loop over rows with two barriers each this launch took 34 us -- and
+    // every wave replays the order of additions of k_reduce_rows: its 1024 threads' strided partial sums, the xor-shuffle
+    // tree of each of its 16 waves, then those 16 in order)
+    __shared__ float s_sum[DURF_MAX_LEVELS * LT_ROWS];
+    const bool reduce_here = (mode & 1) && terms.p[0] != nullptr;
+    if (reduce_here) {
+        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+        for (int row = wave; row < L * LT_ROWS; row += 16) {
             const float* p = terms.p[row / LT_ROWS] + (size_t)(row % LT_ROWS) * B;
-            float v = 0.0f;
-            for (int i = threadIdx.x; i < B; i += 1024) v += p[i];
+            float a = 0.0f;
+            for (int vw = 0; vw < 16; vw++) {
+                float v = 0.0f;
+                for (int i = 64 * vw + lane; i < B; i += 1024) v += p[i];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-            if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = v;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                float a = s_w[0];
-                for (int w = 1; w < 16; w++) a += s_w[w];
-                sums[row] = a;
+                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+                a = vw == 0 ? v : a + v;
             }
-            __syncthreads();
+            if (lane == 0) { s_sum[row] = a; sums[row] = a; }
         }
+        __syncthreads();
     }
     if (threadIdx.x != 0) return;
     float* rows = out + 1;
@@ -317,7 +320,7 @@ k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __res
         float loss = wl2;
         for (int l = 0; l < L; l++) {
             const float* nr = norms + l * 5;
-            const float* sm = sums + l * 7;
+            const float* sm = reduce_here ? s_sum + l * 7 : sums + l * 7;
             const float D = fmaxf(nr[1], 1.0f), S = fmaxf(nr[2], 1.0f);
             const float v[13] = {sm[0] / nr[0], sm[1] / nr[4], sm[2] / D, sm[3] / D, sm[4] / D, sm[5] / S, sm[6],
                                  sq_prev, sq_t, sx, sy, sz, syaw};

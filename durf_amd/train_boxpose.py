@@ -271,6 +271,7 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     st = ops.stats_views(out, L)
     gs = ops.clip_adam(variables.flat, state.m, state.v, grad, 1.0 / world, float(config.grad_max_val),
                        float(config.grad_max_norm), float(lr), state.step)
+    model.prefetch_const_trunk(variables)                   # (fp32 hit-ray path only) the next step's parameter-only work
     new_state = TrainState(variables, state.m, state.v, state.step + 1)
     ret = raw['ret']
     stats = utils.Stats(
