@@ -278,26 +278,42 @@ k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __res
               StatMults m, int mode, float* __restrict__ out) {
     // terms given: the per-ray loss terms [LT_ROWS, B] of every level are reduced HERE (the order of k_reduce_rows, so
     // the sums are the ones durf_loss_bwd's own reduction launch would have produced) and left in sums [L, LT_ROWS]
-    // (one WAVE per row, all rows at once -- as a loop over rows with two barriers each this launch took 34 us -- and
-    // every wave replays the order of additions of k_reduce_rows: its 1024 threads' strided partial sums, the xor-shuffle
-    // tree of each of its 16 waves, then those 16 in order)
+    // (all rows at once: the 1024 threads form the same strided partial sums, xor-shuffle trees and in-order sum of the 16
+    // waves as k_reduce_rows -- bit-identical sums -- but row by row that was 2 barriers and a dependent round trip to
+    // memory per row, 34 us a launch; here every thread has the loads of 14 rows in flight together and there is one barrier)
     __shared__ float s_sum[DURF_MAX_LEVELS * LT_ROWS];
+    __shared__ float s_w[14][16];
     const bool reduce_here = (mode & 1) && terms.p[0] != nullptr;
     if (reduce_here) {
-        const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-        for (int row = wave; row < L * LT_ROWS; row += 16) {
-            const float* p = terms.p[row / LT_ROWS] + (size_t)(row % LT_ROWS) * B;
-            float a = 0.0f;
-            for (int vw = 0; vw < 16; vw++) {
-                float v = 0.0f;
-                for (int i = 64 * vw + lane; i < B; i += 1024) v += p[i];
+        const int nrow = L * LT_ROWS;
+        for (int r0 = 0; r0 < nrow; r0 += 14) {
+            float v[14];
+            const float* p[14];
 #pragma unroll
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-                a = vw == 0 ? v : a + v;
+            for (int r = 0; r < 14; r++) {
+                const int row = r0 + r < nrow ? r0 + r : nrow - 1;
+                p[r] = terms.p[row / LT_ROWS] + (size_t)(row % LT_ROWS) * B;
+                v[r] = 0.0f;
             }
-            if (lane == 0) { s_sum[row] = a; sums[row] = a; }
+            for (int i = threadIdx.x; i < B; i += 1024) {
+#pragma unroll
+                for (int r = 0; r < 14; r++) v[r] += p[r][i];
+            }
+#pragma unroll
+            for (int r = 0; r < 14; r++) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) v[r] += __shfl_xor(v[r], o, 64);
+                if ((threadIdx.x & 63) == 0) s_w[r][threadIdx.x >> 6] = v[r];
+            }
+            __syncthreads();
+            if (threadIdx.x < 14 && r0 + (int)threadIdx.x < nrow) {
+                float a = s_w[threadIdx.x][0];
+                for (int w = 1; w < 16; w++) a += s_w[threadIdx.x][w];
+                s_sum[r0 + threadIdx.x] = a;
+                sums[r0 + threadIdx.x] = a;
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (threadIdx.x != 0) return;
     float* rows = out + 1;

@@ -544,7 +544,9 @@ int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, c
                       int lindisp, float* t_vals) {
     DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
     if (B <= 0) return 0;
-    hipLaunchKernelGGL(k_ray_prologue, dim3(durf_cdiv((size_t)B * (N + 1), 256)), dim3(256), 0, (hipStream_t)stream, B,
+    // the grid covers the largest of the three index spaces (rays, view-encoding features, sample positions)
+    const size_t items = std::max((size_t)B * (N + 1), (size_t)B * DURF_VIEW_DIM);
+    hipLaunchKernelGGL(k_ray_prologue, dim3(durf_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, B,
                        K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, (__bf16*)view_bf16, near,
                        far, t_rand, lindisp, t_vals);
     DURF_CHECK_LAUNCH("durf_ray_prologue");
