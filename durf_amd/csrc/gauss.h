@@ -42,3 +42,29 @@ __device__ __forceinline__ Gauss frustum_gaussian(float t0, float t1, const floa
     return g;
 }
 
+
+// one IPE feature f in [0,60): mip.py:273-282 with basis [2^i I3] (accurate libm path, used when
+// the caller asks for fp32 features; the bf16-only path is k_encode_lane below).
+__device__ __forceinline__ float ipe_feature(const Gauss& g, int f) {
+    const int c = f / 30, r = f - c * 30, deg = r / 3, j = r - deg * 3;
+    const float sc = (float)(1 << deg);
+    float y = g.x[j] * sc;
+    if (c) y = y + 1.5707963705062866f;
+    const float yv = g.var[j] * sc * sc;
+    return expf(-0.5f * yv) * safe_sin(y);
+}
+
+// The 8 consecutive features [8 q, 8 q + 8) of one sample's OBJECT encoding (63 features padded to 64): the sample's
+// coordinates, then the BARF-weighted IPE (mip.weighted_ipe, mip.py:182-223; weight index = feature / 6).  Shared by
+// k_encode<true> (rays.hip) and the fp32 forward that encodes its own tiles (mlp_f32.hip): bit-identical features.
+__device__ __forceinline__ void obj_features8(const Gauss& g, const BarfW& w, int q, float (&v)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int p = q * 8 + e;
+        float val;
+        if (p < 3) val = g.x[p];
+        else if (p < 63) { const int f = p - 3; val = w.w[f / 6] * ipe_feature(g, f); }
+        else val = 0.0f;
+        v[e] = val;
+    }
+}

@@ -24,6 +24,7 @@
 // Weight gradients: dW_l = x_l^T dz_l (the bias is a row of ones appended to x_l), split over the samples, partials
 // summed in a fixed order (deterministic, no atomics).
 #include "mlp_spec.h"
+#include "gauss.h"
 
 struct F32Layer { int fi, fo, x_off, dz_off, relu; size_t w_off; };
 struct F32Spec {
@@ -263,6 +264,9 @@ __device__ __forceinline__ float rec_load_t(__amdgpu_buffer_rsrc_t rs, unsigned 
 }
 
 struct F32FwdBatch { size_t enc, idx, params, ws, raw, act; };        // per-object strides (floats; idx: int32 elements)
+// the object forward can encode its own tiles (accurate-libm object IPE of rays.hip's k_encode<true>, bit-identical): the
+// inputs of durf_encode_obj
+struct F32Enc { const float* t_vals; const float* origins_s; const float* dirs_s; const float* radii; BarfW w; int flags; };
 struct F32BwdBatch { size_t idx, params, ws, act, dz, d_enc; };
 
 // ---------------------------------------------------------------------------------------------
@@ -270,12 +274,12 @@ struct F32BwdBatch { size_t idx, params, ws, act, dz, d_enc; };
 //   enc == nullptr: every row is evaluated on the constant encoding of a zero-masked Gaussian ([0 x 30, 1 x 30]): the
 //   background MLP's single evaluation of a box-hit ray (obbpose_model.py:205-210; include/durf_hip.h durf_expand_raw)
 // ---------------------------------------------------------------------------------------------
-template <int W, int IN, bool TRAIN>
+template <int W, int IN, bool TRAIN, bool ENC>
 __global__ void __launch_bounds__(W * 2)
 k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __restrict__ view,
               const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
               const float* __restrict__ P, const float* __restrict__ ws, float* __restrict__ raw, float* __restrict__ act,
-              F32FwdBatch bs) {
+              F32FwdBatch bs, F32Enc ei) {
     using Cf = F32Cfg<W>;
     using Sc = F32Sched<W, false>;
     constexpr F32Spec S = f32_spec(W, IN);
@@ -333,12 +337,31 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
             }
             vws[f * F32_XS + nn] = v;
         }
-        for (int idx = tid; idx < 64 * 32; idx += NT) {
-            const int f = idx & 63, nn = idx >> 6;
-            float v = 0.0f;
-            if (f < in_dim && row0 + nn < nrows) v = enc ? enc[(row0 + nn) * (size_t)in_dim + f] : ((f >= 30 && f < 60) ? 1.0f : 0.0f);
-            encs[f * F32_XS + nn] = v;
-            xa[f * F32_XS + nn] = v;
+        if constexpr (ENC) {
+            // thread = (sample tid >> 3, 8-feature vector tid & 7): the tile's 32 x 64 encoding in one pass of 256 threads
+            static_assert(!ENC || NT == 256, "in-kernel encoding is the object MLP's (W = 128)");
+            const int nn = tid >> 3, q = tid & 7;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (row0 + nn < nrows) {
+                const size_t row = row0 + nn;
+                const int b = ray_idx[row / (size_t)N], n_ = (int)(row % (size_t)N);
+                const float t0 = ei.t_vals[(size_t)b * (N + 1) + n_], t1 = ei.t_vals[(size_t)b * (N + 1) + n_ + 1];
+                const float o[3] = {ei.origins_s[b * 3], ei.origins_s[b * 3 + 1], ei.origins_s[b * 3 + 2]};
+                const float d[3] = {ei.dirs_s[b * 3], ei.dirs_s[b * 3 + 1], ei.dirs_s[b * 3 + 2]};
+                Gauss g = frustum_gaussian(t0, t1, o, d, ei.radii[b], (ei.flags & DURF_ENC_CYLINDER) != 0);
+                if (ei.flags & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
+                obj_features8(g, ei.w, q, v);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; e++) { encs[(8 * q + e) * F32_XS + nn] = v[e]; xa[(8 * q + e) * F32_XS + nn] = v[e]; }
+        } else {
+            for (int idx = tid; idx < 64 * 32; idx += NT) {
+                const int f = idx & 63, nn = idx >> 6;
+                float v = 0.0f;
+                if (f < in_dim && row0 + nn < nrows) v = enc ? enc[(row0 + nn) * (size_t)in_dim + f] : ((f >= 30 && f < 60) ? 1.0f : 0.0f);
+                encs[f * F32_XS + nn] = v;
+                xa[f * F32_XS + nn] = v;
+            }
         }
         chunk_commit<Sc::cols(0), KC, NT, PFV>(pf[0], wbuf, tid);
         __syncthreads();
@@ -559,6 +582,11 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
 // operands of a tile's 16 MFMAs are 4 + 4 float4 per lane straight from the tile-transposed records (a lane's 16
 // samples are the contiguous half [16 kk, 16 kk + 16) of a 128-byte line) -- then the four waves' accumulators are
 // summed in order through LDS.  Partials are summed over the splits in a fixed order by k_dw_f32_reduce.
+// (Measured at cfg4, 85 us for 33 us of MFMA work: the records are re-read by every column / k tile -- 630 MB per launch for
+// 160 MB of records.  Three other layouts were built and measured slower: a wave owning a column tile and all k tiles of a
+// strip straight from memory (150-230 us), the same through cooperative LDS staging (130-320 us) -- both need the operand
+// reads ahead of the MFMAs the way chunk_mma issues them, hipcc serialises each MFMA behind its LDS read -- and this
+// layout with coalesced loads staged through wave-private LDS (94 us) or 4 tiles of prefetch (192 us: occupancy 1).)
 // ---------------------------------------------------------------------------------------------
 #define F32_MAX_SEG 4
 struct F32DwSeg { const float* act; const float* dz; const int32_t* count; size_t rows; int N; };
@@ -754,19 +782,31 @@ F32TileTab tile_table(const F32Spec& S) {
     return T;
 }
 
+template <int W, int IN, bool TRAIN, bool ENC>
+void launch_fwd_k(hipStream_t s, dim3 grid, size_t rows, int N, const float* enc, const float* view27, const int32_t* ray_idx,
+                  const int32_t* count, const float* P, const float* ws, float* raw, float* act, const F32FwdBatch& bs,
+                  const F32Enc& ei) {
+    constexpr int lds = F32Cfg<W>::LDS_FLOATS * (int)sizeof(float);
+    (void)hipFuncSetAttribute((const void*)k_mlp_fwd_f32<W, IN, TRAIN, ENC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((k_mlp_fwd_f32<W, IN, TRAIN, ENC>), grid, dim3(W * 2), lds, s, rows, N, enc, view27, ray_idx, count, P, ws,
+                       raw, act, bs, ei);
+}
+// ei != nullptr (W = 128 only): the kernel encodes its own tiles from the ray data instead of reading `enc`
 template <int W, int IN>
 int launch_fwd(hipStream_t s, size_t rows, int N, const float* enc, const float* view27, const int32_t* ray_idx,
-               const int32_t* count, const float* P, const float* ws, float* raw, float* act, int K, const F32FwdBatch& bs) {
-    constexpr int lds = F32Cfg<W>::LDS_FLOATS * (int)sizeof(float);
+               const int32_t* count, const float* P, const float* ws, float* raw, float* act, int K, const F32FwdBatch& bs,
+               const F32Enc* ei = nullptr) {
     const unsigned nt_ = durf_cdiv(rows, 32), cap = K > 1 ? 128u : 512u;          // workgroups per MLP (see k_mlp_fwd_f32)
-    const dim3 grid(nt_ < cap ? nt_ : cap, K), block(W * 2);
-    if (act) {
-        (void)hipFuncSetAttribute((const void*)k_mlp_fwd_f32<W, IN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((k_mlp_fwd_f32<W, IN, true>), grid, block, lds, s, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs);
-    } else {
-        (void)hipFuncSetAttribute((const void*)k_mlp_fwd_f32<W, IN, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL((k_mlp_fwd_f32<W, IN, false>), grid, block, lds, s, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs);
+    const dim3 grid(nt_ < cap ? nt_ : cap, K);
+    if constexpr (W == 128) {
+        if (ei) {
+            if (act) launch_fwd_k<W, IN, true, true>(s, grid, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs, *ei);
+            else launch_fwd_k<W, IN, false, true>(s, grid, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs, *ei);
+            return 0;
+        }
     }
+    if (act) launch_fwd_k<W, IN, true, false>(s, grid, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs, F32Enc{});
+    else launch_fwd_k<W, IN, false, false>(s, grid, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs, F32Enc{});
     return 0;
 }
 template <int W, int IN>
@@ -876,12 +916,17 @@ size_t durf_objf32_dz_stride(int B, int N) { return tile_rows((size_t)B * N) * f
 
 int durf_objf32_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* enc,
                           const float* view27, const float* obj_params, size_t param_stride, const float* wstream,
-                          float* raw, float* act) {
+                          float* raw, float* act, const float* t_vals, const float* origins_s, const float* dirs_s,
+                          const float* radii, const float* barf_w, int flags) {
     DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ, "1 <= K <= DURF_MAX_OBJ");
     if (B <= 0) return 0;
     const size_t rows = (size_t)B * N;
+    DURF_REQUIRE(enc != nullptr || (t_vals && origins_s && dirs_s && radii && barf_w), "enc, or the ray data to encode from");
     F32FwdBatch bs{rows * 63, (size_t)B, param_stride, durf_mlp_f32_wstream_floats(DURF_W_OBJ), rows * 4, durf_objf32_act_stride(B, N)};
-    launch_fwd<DURF_W_OBJ, 63>((hipStream_t)stream, rows, N, enc, view27, idx, count, obj_params, wstream, raw, act, K, bs);
+    F32Enc ei{t_vals, origins_s, dirs_s, radii, BarfW{}, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER)};
+    if (!enc) for (int i = 0; i < 10; i++) ei.w.w[i] = barf_w[i];
+    launch_fwd<DURF_W_OBJ, 63>((hipStream_t)stream, rows, N, enc, view27, idx, count, obj_params, wstream, raw, act, K, bs,
+                               enc ? nullptr : &ei);
     DURF_CHECK_LAUNCH("durf_objf32_fwd_batch");
     return 0;
 }

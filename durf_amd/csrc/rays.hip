@@ -280,17 +280,6 @@ __device__ __forceinline__ void contract_gaussian(Gauss& g) {
     }
 }
 
-// one IPE feature f in [0,60): mip.py:273-282 with basis [2^i I3] (accurate libm path, used when
-// the caller asks for fp32 features; the bf16-only path is k_encode_lane below).
-__device__ __forceinline__ float ipe_feature(const Gauss& g, int f) {
-    const int c = f / 30, r = f - c * 30, deg = r / 3, j = r - deg * 3;
-    const float sc = (float)(1 << deg);
-    float y = g.x[j] * sc;
-    if (c) y = y + 1.5707963705062866f;
-    const float yv = g.var[j] * sc * sc;
-    return expf(-0.5f * yv) * safe_sin(y);
-}
-
 template <bool OBJ>
 __global__ void __launch_bounds__(256)
 k_encode(int rays, int N, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,

@@ -796,7 +796,7 @@ class ObjSlabsF32:
     def __init__(self, K, B, N, device, train):
         L = _lib.lib()
         self.K, self.B, self.N = K, B, N
-        self.enc = torch.empty(K, B * N, IN_OBJ_, device=device)
+        self.enc = None                       # only filled by objf32_fwd_batch(fused_encode=False)
         self.raw = torch.empty(K, B * N, 4, device=device)
         self.act = torch.empty(K * int(L.durf_objf32_act_stride(B, N)), device=device) if train else None
         self.dz = self.d_enc = None
@@ -806,19 +806,24 @@ class ObjSlabsF32:
 
 
 def objf32_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha, view27, obj_params, param_stride, wstream,
-                     disable_integration=False, cylinder=False):
-    """accurate fp32 encodings + fp32 forward of all K object MLPs of one level: two launches"""
+                     disable_integration=False, cylinder=False, fused_encode=True):
+    """accurate fp32 encodings + fp32 forward of all K object MLPs of one level: ONE launch (the forward encodes its own
+    tiles); fused_encode=False: durf_encode_obj_f32_batch into slabs.enc first, then the forward reads it (bit-identical)"""
     w = barf_weights(alpha)
     wa = (C.c_float * 10)(*[float(x) for x in w])
     L = _lib.lib()
+    flags = (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0)
     with _Timed('objf32_fwd_batch'):
-        _lib.check(L.durf_encode_obj_f32_batch(
-            _stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
-            _p(_f32(radii)), wa, (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0),
-            _p(slabs.enc)), 'durf_encode_obj_f32_batch')
-        _lib.check(L.durf_objf32_fwd_batch(_stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(slabs.enc),
-                                           _p(_f32(view27)), _p(_f32(obj_params)), int(param_stride), _p(wstream),
-                                           _p(slabs.raw), _p(slabs.act)), 'durf_objf32_fwd_batch')
+        if not fused_encode:
+            slabs.enc = torch.empty(slabs.K, slabs.B * slabs.N, IN_OBJ_, device=t_vals.device)
+            _lib.check(L.durf_encode_obj_f32_batch(
+                _stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(_f32(t_vals)), _p(_f32(origins_s)),
+                _p(_f32(dirs_s)), _p(_f32(radii)), wa, flags, _p(slabs.enc)), 'durf_encode_obj_f32_batch')
+        _lib.check(L.durf_objf32_fwd_batch(_stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count),
+                                           _p(None if fused_encode else slabs.enc), _p(_f32(view27)), _p(_f32(obj_params)),
+                                           int(param_stride), _p(wstream), _p(slabs.raw), _p(slabs.act), _p(_f32(t_vals)),
+                                           _p(_f32(origins_s)), _p(_f32(dirs_s)), _p(_f32(radii)), wa, flags),
+                   'durf_objf32_fwd_batch')
 
 
 def objf32_bwd_batch(slabs, idx, count, draw, obj_params, param_stride, wstream, want_d_enc=False):

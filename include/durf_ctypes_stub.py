@@ -155,8 +155,8 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_encode_obj_f32_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32, vp]
     #   (stream, K, B, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags, enc)
     L.durf_objf32_fwd_batch.restype = i32
-    L.durf_objf32_fwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, u64, vp, vp, vp]
-    #   (stream, K, B, N, idx, count, enc, view27, obj_params, param_stride, wstream, raw, act)
+    L.durf_objf32_fwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), i32]
+    #   (stream, K, B, N, idx, count, enc, view27, obj_params, param_stride, wstream, raw, act, t_vals, origins_s, dirs_s, radii, barf_w, flags)
     L.durf_objf32_bwd_batch.restype = i32
     L.durf_objf32_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, u64, vp, vp, vp, vp]
     #   (stream, K, B, N, idx, count, draw, obj_params, param_stride, wstream, act, dz, d_enc)

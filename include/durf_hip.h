@@ -330,9 +330,12 @@ size_t durf_objf32_dz_stride(int B, int N);
 int durf_encode_obj_f32_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
                               const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
                               const float* barf_w /* host float[10] */, int flags, float* enc /* [K, B*N, 63] */);
-int durf_objf32_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* enc,
+int durf_objf32_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
+                          const float* enc /* nullable: the kernel then encodes its own tiles from the ray data below,
+                                              bit-identical to durf_encode_obj_f32_batch, one launch less per level */,
                           const float* view27, const float* obj_params, size_t param_stride, const float* wstream,
-                          float* raw, float* act /* nullable: inference */);
+                          float* raw, float* act /* nullable: inference */, const float* t_vals, const float* origins_s,
+                          const float* dirs_s, const float* radii, const float* barf_w /* host float[10] */, int flags);
 int durf_objf32_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* draw,
                           const float* obj_params, size_t param_stride, const float* wstream, const float* act,
                           float* dz, float* d_enc /* nullable */);

@@ -207,7 +207,18 @@ def test_object_batch_calls_match_the_single_mlp_calls(cuda):
     ws = ops.mlp_f32_pack(128, 63, flat, K=K, param_stride=sz)
     draw = (torch.randn(B * N, 4, generator=g) * 0.1).to(cuda)
     slabs = ops.ObjSlabsF32(K, B, N, cuda, True)
-    ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz, ws)
+    ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz, ws, fused_encode=False)
+    # the production call encodes inside the forward (one launch less per level): same raw, same records, bit for bit
+    fused = ops.ObjSlabsF32(K, B, N, cuda, True)
+    ops.objf32_fwd_batch(fused, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz, ws)
+    for k in range(K):
+        c = int(count[k]) * N
+        assert torch.equal(fused.raw[k, :c], slabs.raw[k, :c]), 'object %d: fused encode' % k
+    astride = fused.act.numel() // K
+    for k in range(K):
+        nt = (int(count[k]) * N + 31) // 32
+        rec = ops._lib.lib().durf_mlp_f32_act_floats(128, 63) * 32
+        assert torch.equal(fused.act[k * astride:k * astride + nt * rec], slabs.act[k * astride:k * astride + nt * rec])
     ops.objf32_bwd_batch(slabs, idx, count, draw, flat, sz, ws, want_d_enc=True)
     grad = torch.zeros(K * sz, device=cuda)
     ops.objf32_dw_batch([slabs], count, grad, sz, nsplit=3)

@@ -44,18 +44,19 @@ def timeit(label, fn, n=20):
 slabs = ops.ObjSlabsF32(K, B, N, dev, True)
 ws = ops.mlp_f32_pack(128, 63, flat, K=K, param_stride=sz)
 timeit('pack object weight streams', lambda: ops.mlp_f32_pack(128, 63, flat, K=K, param_stride=sz))
-timeit('fp32 encode + forward (one level)', lambda: ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz, ws))
+timeit('fp32 forward, encoding fused (one level)', lambda: ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz, ws))
+timeit('fp32 encode + forward, two launches', lambda: ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, flat, sz, ws, fused_encode=False))
 import ctypes as C
 from durf_amd import _lib
 L = _lib.lib()
 S = torch.cuda.current_stream().cuda_stream
-timeit('  forward alone', lambda: L.durf_objf32_fwd_batch(S, K, B, N, idx.data_ptr(), count.data_ptr(), slabs.enc.data_ptr(),
-                                                         view27.data_ptr(), flat.data_ptr(), sz, ws.data_ptr(), slabs.raw.data_ptr(),
-                                                         slabs.act.data_ptr()))
+timeit('  forward alone (reads the encoding)', lambda: L.durf_objf32_fwd_batch(
+    S, K, B, N, idx.data_ptr(), count.data_ptr(), slabs.enc.data_ptr(), view27.data_ptr(), flat.data_ptr(), sz, ws.data_ptr(),
+    slabs.raw.data_ptr(), slabs.act.data_ptr(), None, None, None, None, None, 0))
 timeit('fp32 backward + d(enc) (one level)', lambda: ops.objf32_bwd_batch(slabs, idx, count, draw, flat, sz, ws, want_d_enc=True))
 timeit('fp32 backward, no d(enc)', lambda: ops.objf32_bwd_batch(slabs, idx, count, draw, flat, sz, ws, want_d_enc=False))
 grad = torch.zeros(K * sz, device=dev)
-for ns in (1, 2, 4, 8):
+for ns in (2, 4, 8, 16):
     timeit('fp32 weight gradients (two levels), nsplit %d' % ns, lambda: ops.objf32_dw_batch([slabs, slabs], count, grad, sz, nsplit=ns))
 timeit('background MLP, box-hit rays, fp32', lambda: ops.bkgd_hit_rays_f32(B, view27, variables.mlp_flat('MLP_0'), cls[0][1], cls[1][1:2])
        if hasattr(ops, 'bkgd_hit_rays_f32') else ops.mlp_fwd_f32(256, 60, B, 1, None, view27, variables.mlp_flat('MLP_0'),
