@@ -67,6 +67,9 @@ def parse_args():
     ap.add_argument('--no-calibration', action='store_true', help='skip the vendor-GEMM board calibration line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-op time table to stderr')
+    ap.add_argument('--main-priority', type=int, default=0,
+                    help='experiment: run the step loop on a stream of this priority (-1 = high), so that side-stream work '
+                         '(DURF_OVERLAP_OBJECTS) only fills what the main stream leaves idle')
     ap.add_argument('--mode', default='train', choices=['train', 'eval'],
                     help="eval: a 'step' renders one 320x480 test image (153 600 rays, chunk 8192, randomized=False) through "
                          'render_image -- the reference logs this as eval rays/sec (train_boxpose.py:548-568)')
@@ -360,6 +363,10 @@ def main():
         return train_boxpose.train_step(model, config, rng, state, batch, lr, eps, alpha, prev,
                                         reduce_stats=(i % config.print_every == 0))
 
+    if args.main_priority != 0:
+        main_stream = torch.cuda.Stream(device=dev, priority=args.main_priority)
+        main_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main_stream)
     rng = 1000 * rank                                  # stratified-sampling noise differs per rank
     # The warm-up runs exactly what the timed region runs, the live HIP-event timers included, after --prewarm-events
     # timing events have been recorded and parked: when the number of live timing events of a process first passes
