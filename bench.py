@@ -325,6 +325,17 @@ def eval_main(args):
     print(json.dumps(out))
 
 
+def flush_c_stdio():
+    """RCCL prints a version banner through C stdio when a communicator is created; with stdout redirected it stays in the
+    C buffer until the process exits, i.e. it would land AFTER the JSON line.  Flushed right after initialisation (all
+    ranks) and once more before the result is printed."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except OSError:
+        pass
+
+
 def main():
     args = parse_args()
     if args.mode == 'eval':
@@ -341,6 +352,7 @@ def main():
     from durf_amd import _lib, obbpose_model, ops, synthetic, train_boxpose, utils
 
     rank, world, local = train_boxpose.init_distributed()
+    flush_c_stdio()       # RCCL's version banner (every rank, C stdio, otherwise flushed at exit -- after rank 0's JSON line)
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     if world > torch.cuda.device_count():
@@ -383,6 +395,7 @@ def main():
     for i in range(args.warmup):
         state, stats, rng, _ = step(state, rng, i)
     sync()
+    flush_c_stdio()       # (the communicator, and with it the banner, is created lazily by the first collective)
     # live HIP-event timers over the timed region (recorded on the launch stream): the kernels the roofline
     # reports, or every wrapped op with --profile-ops (every timed op costs two event records)
     ops.TIMERS = {}                                    # drop the warm-up's records
@@ -477,11 +490,7 @@ def main():
         # the ONE JSON line goes out last, after the process group is gone: RCCL prints a version banner to stdout when it
         # initialises / finalises, and a parser that reads the last line of stdout must find the result there
         sys.stdout.flush()
-        try:                                    # RCCL's banner sits in the C stdio buffer until the process exits
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
+        flush_c_stdio()
         print(json.dumps(out), flush=True)
 
 
