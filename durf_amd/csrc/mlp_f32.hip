@@ -585,8 +585,10 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
 // (Measured at cfg4, 85 us for 33 us of MFMA work: the records are re-read by every column / k tile -- 630 MB per launch for
 // 160 MB of records.  Three other layouts were built and measured slower: a wave owning a column tile and all k tiles of a
 // strip straight from memory (150-230 us), the same through cooperative LDS staging (130-320 us) -- both need the operand
-// reads ahead of the MFMAs the way chunk_mma issues them, hipcc serialises each MFMA behind its LDS read -- and this
-// layout with coalesced loads staged through wave-private LDS (94 us) or 4 tiles of prefetch (192 us: occupancy 1).)
+// reads ahead of the MFMAs the way chunk_mma issues them, hipcc serialises each MFMA behind its LDS read; with such an
+// inline-asm operand ring and zero-filled staging the strip still took 130 us (fewer, longer workgroups: 13 units x
+// splits x objects against 172 tiles) -- and this layout with coalesced loads staged through wave-private LDS (94 us) or
+// 4 tiles of prefetch (192 us: occupancy 1).)
 // ---------------------------------------------------------------------------------------------
 #define F32_MAX_SEG 4
 struct F32DwSeg { const float* act; const float* dz; const int32_t* count; size_t rows; int N; };
