@@ -81,7 +81,39 @@ k_adam(size_t n, float* __restrict__ p, float* __restrict__ m, float* __restrict
     p[i] = p[i] - lr * mh / (sqrtf(vh) + eps);
 }
 
+// A ray that hits two boxes is garbage in the reference (obbpose_model.py:120-122): its colours are NaN, the loss is NaN,
+// and d(loss)/d(theta) is NaN wherever its samples reach -- all of the background MLP, and in the object MLPs every weight
+// column whose unit is active on one of them -- which jnp.nan_to_num then turns into a zero gradient
+// (train_boxpose.py:263).  This path never evaluates such a ray (it is on no box's compacted list), so the outcome is
+// stated per segment of the flat gradient: MLP_0, and the MLP and pose columns of every box such a ray hits, are set to
+// NaN -- before the data-parallel all-reduce, where the reference's pmean sees its NaNs -- and durf_clip_adam's scrub does
+// the rest.  A handful of workgroups that exit at once when no such ray exists.
+__global__ void __launch_bounds__(256)
+k_poison_multi_hit(size_t n, float* __restrict__ g, const int32_t* __restrict__ cls_count, size_t box_floats, int K,
+                   size_t mlp0_floats, size_t obj_floats) {
+    if (cls_count[3] == 0) return;
+    const unsigned bits = (unsigned)cls_count[4];
+    const float qn = __builtin_nanf("");
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        bool p;
+        if (i < box_floats) p = (bits >> ((i / 6) % K)) & 1u;                           // box_centers [T, K, 6]
+        else if (i < box_floats + mlp0_floats) p = true;                                // MLP_0: every ray runs through it
+        else p = (bits >> ((i - box_floats - mlp0_floats) / obj_floats)) & 1u;          // BoxMLP_k
+        if (p) g[i] = qn;
+    }
+}
+
 extern "C" {
+
+int durf_poison_multi_hit(void* stream, size_t n, float* grad, const int32_t* cls_count, size_t box_floats, int K,
+                          size_t mlp0_floats, size_t obj_floats) {
+    DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ && box_floats + mlp0_floats + (size_t)K * obj_floats == n,
+                 "flat layout: box_centers | MLP_0 | K object MLPs");
+    hipLaunchKernelGGL(k_poison_multi_hit, dim3(32), dim3(256), 0, (hipStream_t)stream, n, grad, cls_count, box_floats, K,
+                       mlp0_floats, obj_floats);
+    DURF_CHECK_LAUNCH("durf_poison_multi_hit");
+    return 0;
+}
 
 size_t durf_optim_scratch_floats(size_t n) {
     return 2 * (size_t)durf_cdiv(n, OPT_BLOCK * OPT_PER_THREAD) + 4;

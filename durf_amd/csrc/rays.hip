@@ -110,27 +110,29 @@ k_ray_setup(int B, int K, const float* __restrict__ origins, const float* __rest
 // CLASSES = true (2 blocks): the two ray classes of the de-duplicated background evaluation (durf_expand_raw):
 //   class 0 = rays that hit no box or several (evaluated sample by sample), class 1 = rays that hit exactly one.
 //   Block 0 also writes dyn[b] = number of boxes ray b hits, count[2] = count0 * N + count1 (the valid rows of the
-//   compacted buffers) and count[3] = number of rays that hit several boxes.
+//   compacted buffers), count[3] = number of rays that hit several boxes and count[4] = bit k set: box k is hit by such
+//   a ray (durf_poison_multi_hit).
 template <bool CLASSES>
 __device__ __forceinline__ void compact_hits_block(int k, int B, int K, int N, const int32_t* __restrict__ hit,
                                                    int32_t* __restrict__ idx, int32_t* __restrict__ count,
                                                    int32_t* __restrict__ slot, int32_t* __restrict__ dyn) {
     const int KS = CLASSES ? 2 : K;                  // columns of slot
     __shared__ int wave_tot[16];
-    __shared__ int base_s, multi_s;
+    __shared__ int base_s, multi_s, bits_s;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (threadIdx.x == 0) { base_s = 0; multi_s = 0; }
+    if (threadIdx.x == 0) { base_s = 0; multi_s = 0; bits_s = 0; }
     __syncthreads();
-    int multi = 0;
+    int multi = 0, bits = 0;
     for (int b0 = 0; b0 < B; b0 += 1024) {
         const int b = b0 + threadIdx.x;
         int h = 0;
         if (b < B) {
             if (CLASSES) {
                 int nh = 0;
-                for (int j = 0; j < K; j++) nh += hit[b * K + j] != 0;
+                int hb = 0;
+                for (int j = 0; j < K; j++) { const int hj = hit[b * K + j] != 0; nh += hj; hb |= hj << j; }
                 h = k == 0 ? (nh != 1) : (nh == 1);
-                if (k == 0) { dyn[b] = nh; multi += nh > 1; }
+                if (k == 0) { dyn[b] = nh; multi += nh > 1; if (nh > 1) bits |= hb; }
             } else {
                 h = hit[b * K + k] != 0;
             }
@@ -152,7 +154,7 @@ __device__ __forceinline__ void compact_hits_block(int k, int B, int K, int N, c
         __syncthreads();
     }
     if (CLASSES && k == 0) {
-        if (multi) atomicAdd(&multi_s, multi);       // integer: order-independent
+        if (multi) { atomicAdd(&multi_s, multi); atomicOr(&bits_s, bits); }       // integer: order-independent
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -160,6 +162,7 @@ __device__ __forceinline__ void compact_hits_block(int k, int B, int K, int N, c
         if (CLASSES && k == 0) {
             count[2] = base_s * N + (B - base_s);
             count[3] = multi_s;
+            count[4] = bits_s;
         }
     }
 }

@@ -93,7 +93,7 @@ def compact_all(hit, N):
     dev = hit.device
     i32 = lambda *sh: torch.empty(*sh, dtype=torch.int32, device=dev)
     idx, count, slot = i32(K, B), i32(K), i32(B, K)
-    idx2, count4, slot2, dyn = i32(2, B), i32(4), i32(B, 2), i32(B)
+    idx2, count4, slot2, dyn = i32(2, B), i32(5), i32(B, 2), i32(B)
     _lib.check(_lib.lib().durf_compact_all(_stream(), B, K, N, _p(hit), _p(idx), _p(count), _p(slot), _p(idx2),
                                            _p(count4), _p(slot2), _p(dyn)), 'durf_compact_all')
     return (idx, count, slot), (idx2, count4, slot2, dyn)
@@ -116,12 +116,13 @@ def compact_hits(hit):
 
 
 def compact_classes(hit, N):
-    """-> idx[2,B], count[4] (class-0 rays, class-1 rays, valid compacted rows, multi-hit rays), slot[B,2], dyn[B]:
+    """-> idx[2,B], count[5] (class-0 rays, class-1 rays, valid compacted rows, multi-hit rays, bit mask of the boxes
+    they hit), slot[B,2], dyn[B]:
     the ray classes of the de-duplicated background evaluation (class 1 = rays that hit exactly one box)"""
     B, K = hit.shape
     dev = hit.device
     idx = torch.empty(2, B, dtype=torch.int32, device=dev)
-    count = torch.empty(4, dtype=torch.int32, device=dev)
+    count = torch.empty(5, dtype=torch.int32, device=dev)
     slot = torch.empty(B, 2, dtype=torch.int32, device=dev)
     dyn = torch.empty(B, dtype=torch.int32, device=dev)
     _lib.check(_lib.lib().durf_compact_classes(_stream(), B, K, N, _p(hit), _p(idx), _p(count), _p(slot), _p(dyn)),
@@ -662,6 +663,12 @@ def dw_finalize_all(rows_l, n_l, count_l, part, bpart, grad_bkgd, bkgd_params, o
     with _Timed('mlp_dw_finalize_256'):
         _lib.check(_lib.lib().durf_dw_finalize_all(_stream(), IN_BKGD, L, rows_a, n_a, cnt_a, _p(part), _p(bpart),
                                                    _p(grad_bkgd), _p(_f32(bkgd_params)), *oa), 'durf_dw_finalize_all')
+
+
+def poison_multi_hit(grad, cls_count, box_floats, K, mlp0_floats, obj_floats):
+    """reference semantics of rays that hit two boxes (durf_poison_multi_hit): NaN into the gradient segments they touch"""
+    _lib.check(_lib.lib().durf_poison_multi_hit(_stream(), grad.numel(), _p(_f32(grad)), _p(cls_count), int(box_floats), int(K),
+                                                int(mlp0_floats), int(obj_floats)), 'durf_poison_multi_hit')
 
 
 def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):

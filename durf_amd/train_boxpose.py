@@ -161,10 +161,19 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                              ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
                                              pose_sums)
     levels = ctx['levels']
+
+    def poison():
+        # rays that hit two boxes: the reference's gradient is NaN -> 0 for everything they touch (ops.poison_multi_hit);
+        # on the local gradient, before whoever all-reduces it
+        if dd is not None and lay.K > 1:
+            ops.poison_multi_hit(grad, dd['count'], lay.box[1] - lay.box[0], lay.K, lay.mlp_size[om.W_BKGD],
+                                 lay.mlp_size[om.W_OBJ])
+
     if obj_f32:                               # weight gradients of the K object MLPs over every level: one launch pair
         o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
         ops.objf32_dw_batch([lv['f32']['slabs32'] for lv in levels], ctx['count'], grad[o0:o0 + K * sz], sz)
         if objects_ready is not None:
+            poison()
             objects_ready(grad[o0:o0 + K * sz])
     if not f32:
         off = lay.mlp_off['MLP_0']
@@ -179,6 +188,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         if Kb and objects_ready is not None:           # bucketed all-reduce: the objects' gradients first, finalized on their own
             ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
                              grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
+            poison()
             objects_ready(grad[o0:o0 + K * sz])
         if merged:
             # The objects' split-K launch goes FIRST: the finalize launch then finds the background MLP's partials
@@ -210,6 +220,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
         grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)[ctx['ts']] += g6
     pose = ret[0][7][0]
+    poison()
     if dd is not None:
         multi = dd['multi_hit']
     else:

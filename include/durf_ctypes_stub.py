@@ -202,6 +202,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_optim_scratch_floats.restype = u64
     L.durf_optim_scratch_floats.argtypes = [u64]
     #   (n)
+    L.durf_poison_multi_hit.restype = i32
+    L.durf_poison_multi_hit.argtypes = [vp, u64, vp, vp, u64, i32, u64, u64]
+    #   (stream, n, grad, cls_count, box_floats, K, mlp0_floats, obj_floats)
     L.durf_clip_adam.restype = i32
     L.durf_clip_adam.argtypes = [vp, u64, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp]
     #   (stream, n, params, m, v, grad, inv_world, max_val, max_norm, lr, step, scratch, stats)

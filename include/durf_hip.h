@@ -79,8 +79,8 @@ int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* i
                       int32_t* count, int32_t* slot);
 /* The two ray classes of the de-duplicated background evaluation (durf_expand_raw) from hit [B,K] in one launch:
  * class 0 = rays that hit no box or several, class 1 = rays that hit exactly one.  idx [2,B], slot [B,2] as above;
- * count [4] = {class-0 rays, class-1 rays, class0 * N + class1 (valid rows of the compacted buffers), rays that hit
- * several boxes}; dyn [B] = boxes hit per ray (obbpose_model.py:257 `jnp.array(ret_masks).sum(axis=0)`). */
+ * count [5] = {class-0 rays, class-1 rays, class0 * N + class1 (valid rows of the compacted buffers), rays that hit
+ * several boxes, bit k set: box k is hit by such a ray}; dyn [B] = boxes hit per ray (obbpose_model.py:257 `jnp.array(ret_masks).sum(axis=0)`). */
 int durf_compact_classes(void* stream, int B, int K, int N, const int32_t* hit, int32_t* idx, int32_t* count,
                          int32_t* slot, int32_t* dyn);
 /* Both compactions in one launch (a training step needs both): the per-object lists of durf_compact_hits and the two
@@ -404,6 +404,13 @@ int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, 
  * flax.optim.Adam).  grad is scaled by inv_world (pmean), scrubbed and clipped in place;
  * stats[4] = {grad_norm, grad_abs_max, clip multiplier, grad_norm_clipped}. */
 size_t durf_optim_scratch_floats(size_t n);
+/* Reference semantics of rays that hit two boxes (obbpose_model.py:120-122: NaN colours -> NaN loss -> NaN gradient of
+ * everything their path touches -> nan_to_num -> 0, train_boxpose.py:263): when cls_count[3] (durf_compact_classes) is
+ * non-zero, the gradient segments of MLP_0 and of the boxes in cls_count[4] (their BoxMLP and their box_centers columns)
+ * are set to NaN -- call it on the complete local gradient BEFORE the data-parallel all-reduce; durf_clip_adam scrubs.
+ * Flat layout: box_centers (box_floats = T*K*6) | MLP_0 | K object MLPs of obj_floats each.  Exits at once otherwise. */
+int durf_poison_multi_hit(void* stream, size_t n, float* grad, const int32_t* cls_count, size_t box_floats, int K,
+                          size_t mlp0_floats, size_t obj_floats);
 int durf_clip_adam(void* stream, size_t n, float* params, float* m, float* v, float* grad, float inv_world,
                    float max_val, float max_norm, float lr, int step, float* scratch, float* stats);
 

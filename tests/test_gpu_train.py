@@ -519,3 +519,67 @@ def test_box_pose_gradients_random_configurations(cuda, seed, precision):
         tol = 5e-3 if f32 else 5e-2
         assert _rel(g, w) < tol or float((g - w).abs().max()) < 1e-6, '%s cols %s rel err %g\ngot %s\nwant %s' % (
             tag, sl, _rel(g, w), g, w)
+
+
+def test_a_ray_that_hits_two_boxes_poisons_the_step_like_the_reference(cuda):
+    """Rays that hit two boxes are garbage in the reference (obbpose_model.py:120-122 sums their object-frame origins, the
+    background mask becomes -1, variances go negative): their colours are NaN, the loss is NaN, and d(loss)/d(theta) is NaN
+    wherever such a ray's samples reach -- which `jnp.nan_to_num` then turns into a ZERO gradient (train_boxpose.py:263).
+    In the oracle (autograd through the reference's formulation) that is every entry of the background MLP here, and in
+    an object MLP every weight column whose unit is ReLU-active on one of those samples.  The HIP path never evaluates
+    those rays (they belong to no box's compacted list), so it states the outcome at segment granularity instead
+    (durf_poison_multi_hit): MLP_0 and the MLPs of the boxes such a ray hits get a zero gradient, a box no such ray hits
+    keeps learning.  After one step from zero Adam moments: MLP_0 unchanged on both sides; a hit box unchanged here and
+    mostly unchanged in the oracle (the columns of units dead on those samples still move there -- DESIGN.md section 2
+    lists this as the one place the step's result is deliberately coarser than the reference's)."""
+    B, K, N = 256, 3, 32
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
+                    'Config.randomized = False\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
+                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.0\n' % N)
+    config = utils.configured(utils.Config)
+    b = None
+    for seed in range(400, 460):                      # a batch with at least one two-box ray that leaves a box untouched
+        c = synthetic.make_batch(B, K, seed=seed, allow_multi_hit=True)
+        ob = H.oracle_batch(c)
+        rays = ob['rays']
+        pose = ob['init'][c['ts']]
+        mats = R.aa2matrix(pose[:, 3:]).expand(B, K, 3, 3)
+        oo, do = R.world2object_rpy(rays.origins, rays.directions, pose[:, :3].expand(B, K, 3), mats)
+        dims = ob['ext'].expand(B, K, 3)
+        hit = R.ray_box_intersection(oo, do, -dims, dims)[2]
+        multi = hit.sum(-1) > 1
+        touched = hit[multi].sum(0) > 0
+        if multi.any() and not touched.all() and (hit[:, ~touched].sum() > 0):
+            b, free = c, [k for k in range(K) if not bool(touched[k])]
+            break
+    assert b is not None, 'no seed produced the wanted batch'
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(7, db, device=cuda)
+    params = H.oracle_params_from_variables(variables)
+    flat0 = variables.flat.clone()
+    state = train_boxpose.create_train_state(variables)
+    state, stats, _, _ = train_boxpose.train_step(model, config, 0, state, db, 5e-4, 3.0, 10.0, db['init'][0:1])
+    torch.cuda.synchronize()
+    ocfg = dict(R.CONFIG_DEFAULTS, randomized=False, tv_loss_mult=0.0)
+    p2, _, ostats, _ = R.train_step(params, R.new_opt_state(params), ob, ocfg, dict(num_samples=N), 5e-4, 3.0, 10.0,
+                                    ob['init'][0:1], mlp_hook=R.mlp_apply_bf16)
+    assert not torch.isfinite(ostats['loss']) and not torch.isfinite(stats.loss.cpu()), 'NaN loss on both sides'
+    assert int(stats.multi_hit_rays) == int(multi.sum())
+    lay = variables.layout
+    new_ref = torch.cat([x.reshape(-1) for x in R.params_leaves(p2)])
+    moved = (state.variables.flat - flat0).abs().cpu()
+    moved_ref = (new_ref - flat0.cpu()).abs()
+    for name in lay.mlp_names():
+        w, _ = lay.mlp_dims(name)
+        sl = slice(lay.mlp_off[name], lay.mlp_off[name] + lay.mlp_size[w])
+        is_free = name != 'MLP_0' and int(name.split('_')[1]) in free
+        if is_free:
+            assert float(moved_ref[sl].max()) > 0 and float(moved[sl].max()) > 0, name + ': untouched box keeps learning'
+        elif name == 'MLP_0':
+            assert float(moved_ref[sl].max()) == 0.0, name + ': the reference semantics leave it unchanged'
+            assert float(moved[sl].max()) == 0.0, name + ': zero gradient here as well'
+        else:
+            assert float((moved_ref[sl] > 0).float().mean()) < 0.25, name + ': NaN reaches most of a hit box in the oracle'
+            assert float(moved[sl].max()) == 0.0, name + ': zero gradient for the whole box here'
