@@ -260,14 +260,19 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
 
 # The K object MLPs touch ~10 % of the rays: their launches are small and latency-bound.  DURF_OVERLAP_OBJECTS issues the
 # object work of a stage on a side HIP stream, forked after the background encode / the loss kernel and joined before its
-# results are consumed, so that it can run beside the background kernel of the same stage:
-#   0 (default) everything on one stream;   1 the object forward;   3 forward + backward;   2 forward + backward + dW.
-# Measured at cfg3, five interleaved runs per mode on one box (ms/step): 0: 4.889 / 4.982, 1: 4.924, 3: 5.004, 2: 4.835 /
-# 4.929 -- only the weight-gradient overlap pays (-1.1 %), and it costs the background weight-gradient launch +64 us (its
-# workgroups share CUs and HBM with the object ones), i.e. it trades the dominant kernel's own time for step time.  The
-# default keeps the kernels' timings clean; the switch stays for measurements.
-_MODE = os.environ.get('DURF_OVERLAP_OBJECTS', '0')
-OVERLAP_OBJECTS = _MODE != '0'
+# results are consumed:
+#   2 (default) forward + backward + weight gradients;   0 everything on one stream;   1 the object forward;   3 forward + backward.
+# The persistent background forward / backward (one workgroup per CU) leave the object launches no CU until their own
+# tail, so 1 and 3 measure like 0; what pays is that the objects' weight-gradient launch, queued behind their backward on
+# the side stream, starts in the tail of the background backward instead of after it.  Round 3, three interleaved runs per
+# mode on one box, k rays/s: cfg3 0: 949 / 948 / 950, 2: 960 / 961 / 954;  cfg2 0: 958 / 960 / 947, 2: 972 / 962 / 961;
+# cfg5 0: 704 / 712 / 709, 2: 721 / 702 / 721;  cfg4 (objects on the fp32 kernels, main stream): no change.  The
+# background weight-gradient launch then shares its first ~100 us with the objects' (1444-1452 -> 1506-1515 us, HIP events),
+# which is what bench.py's roofline line reports.  Moving ONLY the objects' weight gradients to the side stream, started
+# together with the background ones, is destructive (background launch 1725-1777 us, 898-910 k rays/s): measured, dropped.
+_MODE = os.environ.get('DURF_OVERLAP_OBJECTS', '2')
+OVERLAP_MODE = _MODE
+OVERLAP_OBJECTS = _MODE in ('1', '2', '3')
 OVERLAP_BACKWARD = _MODE in ('2', '3')
 OVERLAP_DW = _MODE == '2'
 MERGE_FINALIZE = os.environ.get('DURF_MERGE_FINALIZE', '1') != '0'    # A/B switch: one finalize launch pair for all MLPs
@@ -286,7 +291,7 @@ class on_side:
     the side stream waits for everything issued so far on the current stream; join(): the reverse."""
 
     def __init__(self, device, enabled=True):
-        self.enabled = enabled and OVERLAP_OBJECTS and device.type == 'cuda'
+        self.enabled = bool(enabled) and device.type == 'cuda'
         self.side = side_stream(device) if self.enabled else None
         self.ctx = None
 
