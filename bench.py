@@ -475,7 +475,7 @@ def main():
                                object_precision=model.object_precision() if K_OBJ else None,
                                # object MLP launches on a side HIP stream (ops.py DURF_OVERLAP_OBJECTS): with '2' the timed
                                # background kernels' durations include what runs beside them
-                               object_streams=(ops.OVERLAP_MODE if K_OBJ and model.object_precision() == 'bf16' else None),
+                               object_streams=(ops.overlap_mode(B * NS) if K_OBJ and model.object_precision() == 'bf16' else None),
                                collective=('rccl all-reduce, world size %d%s' % (world, ' (forced)' if args.force_dist else ''))
                                if (world > 1 or args.force_dist) else None),
                    loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,

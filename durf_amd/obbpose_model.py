@@ -315,7 +315,7 @@ class MipNerfModel:
                 lvd = None
                 stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
                 mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
-                side = ops.on_side(dev, bool(Kb) and ops.OVERLAP_OBJECTS)          # the object MLPs run in the shadow of the background MLP
+                side = ops.on_side(dev, bool(Kb) and ops.overlap_forward(rows))          # the object MLPs run in the shadow of the background MLP
                 if dd is not None:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl,

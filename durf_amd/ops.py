@@ -261,7 +261,7 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
 # The K object MLPs touch ~10 % of the rays: their launches are small and latency-bound.  DURF_OVERLAP_OBJECTS issues the
 # object work of a stage on a side HIP stream, forked after the background encode / the loss kernel and joined before its
 # results are consumed:
-#   2 (default) forward + backward + weight gradients;   0 everything on one stream;   1 the object forward;   3 forward + backward.
+#   2 forward + backward + weight gradients;   0 everything on one stream;   1 the object forward;   3 forward + backward.
 # The persistent background forward / backward (one workgroup per CU) leave the object launches no CU until their own
 # tail, so 1 and 3 measure like 0; what pays is that the objects' weight-gradient launch, queued behind their backward on
 # the side stream, starts in the tail of the background backward instead of after it.  Round 3, three interleaved runs per
@@ -270,11 +270,32 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
 # background weight-gradient launch then shares its first ~100 us with the objects' (1444-1452 -> 1506-1515 us, HIP events),
 # which is what bench.py's roofline line reports.  Moving ONLY the objects' weight gradients to the side stream, started
 # together with the background ones, is destructive (background launch 1725-1777 us, 898-910 k rays/s): measured, dropped.
-_MODE = os.environ.get('DURF_OVERLAP_OBJECTS', '2')
-OVERLAP_MODE = _MODE
-OVERLAP_OBJECTS = _MODE in ('1', '2', '3')
-OVERLAP_BACKWARD = _MODE in ('2', '3')
-OVERLAP_DW = _MODE == '2'
+# The same switch costs at small batches, where every kernel is one latency-bound round and a fork / join is one more
+# dependency in the chain (cfg3 shape, k rays/s, 0 vs 2: 512 rays 595 -> 545-559, 1024 rays 750-756 -> 745, 2048 rays 883
+# -> 902-908, 4096 rays above): 'auto' (default) = 2 from 2048 x 128 sample rows per step (4 rounds of background blocks), else 0.
+_MODE = os.environ.get('DURF_OVERLAP_OBJECTS', 'auto')
+OVERLAP_MIN_ROWS = 2048 * 128
+
+
+def overlap_mode(rows):
+    """'0' .. '3' for a step (or a render chunk) of `rows` sample rows per level"""
+    if _MODE == 'auto':
+        return '2' if rows >= OVERLAP_MIN_ROWS else '0'
+    return _MODE
+
+
+def overlap_forward(rows):
+    return overlap_mode(rows) in ('1', '2', '3')
+
+
+def overlap_backward(rows):
+    return overlap_mode(rows) in ('2', '3')
+
+
+def overlap_dw(rows):
+    return overlap_mode(rows) == '2'
+
+
 MERGE_FINALIZE = os.environ.get('DURF_MERGE_FINALIZE', '1') != '0'    # A/B switch: one finalize launch pair for all MLPs
 _SIDE = {}
 

@@ -115,8 +115,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
-    # optional side stream for the object backward / weight gradients (ops.OVERLAP_*: off by default, see ops.py)
-    side = ops.on_side(dev, bool(Kb) and not f32 and ops.OVERLAP_BACKWARD)
+    # side stream for the object backward / weight gradients (ops.overlap_mode)
+    side = ops.on_side(dev, bool(Kb) and not f32 and ops.overlap_backward(rows))
     # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
     for lvl in reversed(range(L)):
         lv = ctx['levels'][lvl]
@@ -184,7 +184,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         else:
             geo = ([rows] * L, [N] * L, [None] * L)
         o0, sz = (lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]) if Kb else (0, 0)
-        merged = Kb and not ops.OVERLAP_DW and ops.MERGE_FINALIZE and objects_ready is None
+        merged = Kb and not ops.overlap_dw(rows) and ops.MERGE_FINALIZE and objects_ready is None
         if Kb and objects_ready is not None:           # bucketed all-reduce: the objects' gradients first, finalized on their own
             ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
                              grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])

@@ -1,0 +1,241 @@
+"""numpy-backed stand-ins for `jax`, `flax`, `gin` and `absl` under which the reference's OWN modules run unmodified.
+
+Build container only (/root/reference is not on the GPU box).  The reference is JAX + flax and neither is installable
+here, but what its hot path uses of them is small: array arithmetic (`jax.numpy` -> numpy, float64), `lax.stop_gradient`,
+`jax.linearize` (central differences), `jax.random.uniform` (replayed from a queue the test fills), and of flax.linen the
+module mechanics -- dataclass fields, `@nn.compact`, `self.param`, children named `<Class>_<n>` in order of construction,
+`Dense`, `model.apply({'params': tree}, ...)`.  `load()` registers the stand-ins, imports `internal.{math,mip,mip360,
+box_helpers,utils,obbpose_model}` from /root/reference and returns them; `unload()` restores `sys.modules`.
+
+A stand-in pins nothing about JAX's or XLA's arithmetic.  What it does pin is the reference's source text: formulas,
+argument order, axes, masks, the order of the level loop and of the PRNG draws are executed as written, not restated.
+No reference text is copied: the modules are imported from where they lie.
+"""
+import dataclasses
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = '/root/reference'
+_NAMES = ('jax', 'jax.numpy', 'jax.lax', 'jax.random', 'jax.scipy', 'jax.nn', 'flax', 'flax.linen', 'flax.nn', 'flax.struct',
+          'flax.optim', 'gin', 'gin.config', 'absl', 'absl.flags')
+
+
+def available():
+    return os.path.isdir(os.path.join(REF, 'internal'))
+
+
+class Uniform:
+    """jax.random.uniform(key, shape, minval=0, maxval=1): replays queued U[0,1) arrays, in the order the reference draws"""
+    queue = []
+
+    @classmethod
+    def uniform(cls, key, shape, dtype=None, minval=0.0, maxval=1.0):
+        u = cls.queue.pop(0)
+        assert list(u.shape) == list(shape), (u.shape, shape)
+        return u * (maxval - minval) + minval
+
+
+class _JArr(np.ndarray):
+    """jnp arrays are immutable: `u += x` rebinds u to a NEW (broadcast) array where numpy would write in place"""
+    __iadd__ = lambda self, o: self + o
+    __isub__ = lambda self, o: self - o
+    __imul__ = lambda self, o: self * o
+    __itruediv__ = lambda self, o: self / o
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# flax.linen: the module mechanics the reference's model uses
+# ---------------------------------------------------------------------------------------------------------------------
+_active = []          # modules whose __call__ is executing (innermost last): the parent of whatever is constructed now
+
+
+def _wrap_call(fn):
+    def call(self, *a, **k):
+        _active.append(self)
+        self._counts = {}
+        try:
+            return fn(self, *a, **k)
+        finally:
+            _active.pop()
+    call.__wrapped__ = fn
+    return call
+
+
+class Module:
+    def __init_subclass__(cls, **kw):
+        super().__init_subclass__(**kw)
+        if '__call__' in cls.__dict__:
+            cls.__call__ = _wrap_call(cls.__dict__['__call__'])
+        dataclasses.dataclass(cls, eq=False, repr=False)          # flax turns every Module subclass into a dataclass
+
+    def __post_init__(self):
+        self._counts = {}
+        self._params = None
+        if _active:                                               # constructed inside a parent's compact __call__
+            parent = _active[-1]
+            n = parent._counts.get(type(self).__name__, 0)
+            parent._counts[type(self).__name__] = n + 1
+            self._params = parent._params.setdefault('%s_%d' % (type(self).__name__, n), {})
+
+    def param(self, name, init_fn, *init_args):
+        if name not in self._params:                              # model.init: the initializer's value
+            self._params[name] = init_fn(None, *init_args)
+        return self._params[name]
+
+    def apply(self, variables, *args, rngs=None, **kwargs):
+        self._params = variables['params']
+        return self(*args, **kwargs)
+
+
+class Dense(Module):
+    features: int = 0
+    kernel_init: object = None
+    use_bias: bool = True
+
+    def __call__(self, x):
+        kernel = self.param('kernel', lambda rng: (_ for _ in ()).throw(KeyError('no kernel given')))
+        y = np.matmul(x, kernel)
+        return y + self.param('bias', lambda rng: np.zeros(self.features)) if self.use_bias else y
+
+
+def _linen():
+    nn = types.ModuleType('flax.linen')
+    nn.Module, nn.Dense = Module, Dense
+    nn.compact = lambda f: f
+    nn.relu = lambda x: np.maximum(x, 0.0)
+    nn.sigmoid = lambda x: 1.0 / (1.0 + np.exp(-x))
+    nn.softplus = lambda x: np.logaddexp(x, 0.0)
+    return nn
+
+
+def _install():
+    jnp = types.ModuleType('jax.numpy')
+    for name in dir(np):
+        if not name.startswith('_'):
+            setattr(jnp, name, getattr(np, name))
+    jnp.ndarray = np.ndarray
+    jnp.arange = lambda *a, **k: np.arange(*a, **k).view(_JArr)
+    jnp.matmul = lambda a, b, precision=None: np.matmul(a, b)
+    jnp.linalg = np.linalg
+    jnp.float32 = np.float64                       # the check runs in float64 on both sides
+    jnp.array = lambda x, dtype=None: np.array(x, dtype=np.float64 if dtype in (None, np.float64) else dtype)
+    lax = types.ModuleType('jax.lax')
+    lax.stop_gradient = lambda x: x
+    lax.Precision = types.SimpleNamespace(HIGHEST=None)
+    random = types.ModuleType('jax.random')
+    random.uniform = Uniform.uniform
+    random.normal = lambda key, shape, dtype=None: np.zeros(shape)
+    random.randint = lambda key, shape, lo, hi: np.zeros(shape)          # randint(0, 1) == 0 (mip.py:324)
+    random.split = lambda key, num=2: tuple(key for _ in range(num))
+    random.PRNGKey = lambda seed: seed
+    jax = types.ModuleType('jax')
+
+    def linearize(f, x):
+        def jvp(t, h=1e-6):
+            return (f(x + h * t) - f(x - h * t)) / (2 * h)
+        return f(x), jvp
+    jax.linearize = linearize
+    jax.vmap = lambda f, in_axes=0, out_axes=0: f
+    jnn = types.ModuleType('jax.nn')
+    jnn.initializers = types.SimpleNamespace(glorot_uniform=lambda: None)
+    jsp = types.ModuleType('jax.scipy')
+    jax.numpy, jax.lax, jax.random, jax.nn, jax.scipy = jnp, lax, random, jnn, jsp
+
+    nn = _linen()
+    flax = types.ModuleType('flax')
+    fnn = types.ModuleType('flax.nn')
+    fnn.relu, fnn.sigmoid, fnn.softplus = nn.relu, nn.sigmoid, nn.softplus
+    struct = types.ModuleType('flax.struct')
+    struct.dataclass = dataclasses.dataclass
+    optim = types.ModuleType('flax.optim')
+    optim.Optimizer = object
+    flax.linen, flax.nn, flax.struct, flax.optim = nn, fnn, struct, optim
+
+    gin = types.ModuleType('gin')
+
+    def configurable(*a, **k):                     # @gin.configurable, @gin.configurable(), @gin.configurable('name')
+        if len(a) == 1 and callable(a[0]) and not k:
+            return a[0]
+        return lambda f: f
+    gin.configurable = configurable
+    gin.add_config_file_search_path = lambda p: None
+    gcfg = types.ModuleType('gin.config')
+    gcfg.external_configurable = lambda f, module=None, name=None: f
+    gin.config = gcfg
+
+    absl = types.ModuleType('absl')
+    flags = types.ModuleType('absl.flags')
+    def _flag_attr(name):                          # DEFINE_* are only called from functions
+        if name.startswith('DEFINE_'):
+            return lambda *a, **k: None
+        raise AttributeError(name)
+    flags.__getattr__ = _flag_attr
+    flags.FLAGS = types.SimpleNamespace()
+    absl.flags = flags
+
+    sys.modules.update({'jax': jax, 'jax.numpy': jnp, 'jax.lax': lax, 'jax.random': random, 'jax.scipy': jsp, 'jax.nn': jnn,
+                        'flax': flax, 'flax.linen': nn, 'flax.nn': fnn, 'flax.struct': struct, 'flax.optim': optim,
+                        'gin': gin, 'gin.config': gcfg, 'absl': absl, 'absl.flags': flags})
+
+
+_saved = None
+
+
+def _drop_internal():
+    for k in [k for k in sys.modules if k == 'internal' or k.startswith('internal.')]:
+        del sys.modules[k]
+
+
+def load(modules=('math', 'mip', 'mip360', 'box_helpers', 'utils', 'obbpose_model')):
+    """-> namespace of the reference's modules, imported unmodified under the stand-ins"""
+    global _saved
+    assert available(), 'reference tree not present'
+    _saved = {k: sys.modules.get(k) for k in _NAMES}
+    _install()
+    sys.path.insert(0, REF)
+    _drop_internal()
+    return types.SimpleNamespace(**{n: importlib.import_module('internal.' + n) for n in modules})
+
+
+def unload():
+    global _saved
+    if REF in sys.path:
+        sys.path.remove(REF)
+    _drop_internal()
+    for k, v in (_saved or {}).items():
+        if v is None:
+            sys.modules.pop(k, None)
+        else:
+            sys.modules[k] = v
+    _saved = None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# running the reference's model
+# ---------------------------------------------------------------------------------------------------------------------
+def flax_tree(params):
+    """the oracle's params dict (torch, oracle/durf_ref.py) -> the flax variable tree the reference's model.apply takes"""
+    tree = {'box_centers': params['box_centers'].detach().double().numpy()}
+    for name, layers in params.items():
+        if name != 'box_centers':
+            tree[name] = {'Dense_%d' % i: {'kernel': k.detach().double().numpy(), 'bias': b.detach().double().numpy()}
+                          for i, (k, b) in enumerate(layers)}
+    return {'params': tree}
+
+
+def run_model(ref, model_kwargs, params, rays, ext, ts, randomized, white_bkgd, alpha, uniforms=()):
+    """MipNerfModel(**model_kwargs).apply(...) of the reference (obbpose_model.py:68-261) on numpy float64 inputs.
+    rays: the oracle's Rays namedtuple (torch); uniforms: the U[0,1) arrays its PRNG draws are replaced with, in order."""
+    f = lambda t: t.detach().double().numpy()
+    r = ref.utils.BoxRays(*[f(getattr(rays, n)) for n in ref.utils.BoxRays._fields])
+    tree = flax_tree(params)
+    model = ref.obbpose_model.MipNerfModel(**model_kwargs)
+    Uniform.queue = [np.asarray(u, dtype=np.float64) for u in uniforms]
+    out = model.apply(tree, 0, r, tree['params']['box_centers'], f(ext), np.array([int(ts)]), randomized=randomized,
+                      rand_bkgd=False, white_bkgd=white_bkgd, alpha=alpha)
+    assert not Uniform.queue, 'the reference drew fewer uniforms than expected'
+    return out

@@ -583,3 +583,34 @@ def test_a_ray_that_hits_two_boxes_poisons_the_step_like_the_reference(cuda):
         else:
             assert float((moved_ref[sl] > 0).float().mean()) < 0.25, name + ': NaN reaches most of a hit box in the oracle'
             assert float(moved[sl].max()) == 0.0, name + ': zero gradient for the whole box here'
+
+
+@pytest.mark.parametrize('pose_opt', [False, True])
+def test_side_stream_modes_give_the_same_parameters(cuda, monkeypatch, pose_opt):
+    """ops.overlap_mode: from 2048 x 128 sample rows per step the object MLP launches go to a side HIP stream ('2'); below,
+    everything stays on one stream ('0').  The streams change WHEN a kernel runs, never what it computes: three steps from
+    the same state in each mode end in bit-identical parameters, moments and loss (the batch here is far below the
+    threshold, so the mode is forced)."""
+    B, K, N = 512, 3, 32
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.obj_precision = "bf16"\n'
+                    'MipNerfModel.no_pose_opt = %s\nMipNerfModel.no_yaw_opt = %s\n'
+                    'Config.randomized = True\nConfig.rand_bkgd = False\n' % (N, not pose_opt, not pose_opt))
+    config = utils.configured(utils.Config)
+    db = H.device_batch(synthetic.make_batch(B, K, seed=77), cuda)
+    results = {}
+    for mode in ('0', '2', '3', '1'):
+        monkeypatch.setattr(ops, '_MODE', mode)
+        assert ops.overlap_mode(B * N) == mode
+        model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
+        state = train_boxpose.create_train_state(variables)
+        prev, rng = db['init'][0:1], 3
+        for _ in range(3):
+            state, stats, rng, pose = train_boxpose.train_step(model, config, rng, state, db, 5e-4, 3.0, 10.0, prev)
+        torch.cuda.synchronize()
+        results[mode] = (state.variables.flat.clone(), state.m.clone(), state.v.clone(), stats.loss.clone())
+    for mode in ('2', '3', '1'):
+        for a, b in zip(results['0'], results[mode]):
+            assert torch.equal(a, b), 'mode %s differs from the single-stream step' % mode
+    monkeypatch.setattr(ops, '_MODE', 'auto')
+    assert ops.overlap_mode(2048 * 128) == '2' and ops.overlap_mode(2048 * 128 - 1) == '0'
