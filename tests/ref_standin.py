@@ -5,7 +5,9 @@ here, but what its hot path uses of them is small: array arithmetic (`jax.numpy`
 `jax.linearize` (central differences), `jax.random.uniform` (replayed from a queue the test fills), and of flax.linen the
 module mechanics -- dataclass fields, `@nn.compact`, `self.param`, children named `<Class>_<n>` in order of construction,
 `Dense`, `model.apply({'params': tree}, ...)`.  `load()` registers the stand-ins, imports `internal.{math,mip,mip360,
-box_helpers,utils,obbpose_model}` from /root/reference and returns them; `unload()` restores `sys.modules`.
+box_helpers,utils,obbpose_model}` from /root/reference and returns them (`train=True`: also /root/reference/train_boxpose.py,
+whose `train_step` then runs with `jax.value_and_grad` handing back a supplied gradient tree and `lax.pmean` the identity);
+`unload()` restores `sys.modules`.
 
 A stand-in pins nothing about JAX's or XLA's arithmetic.  What it does pin is the reference's source text: formulas,
 argument order, axes, masks, the order of the level loop and of the PRNG draws are executed as written, not restated.
@@ -13,6 +15,7 @@ No reference text is copied: the modules are imported from where they lie.
 """
 import dataclasses
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -20,7 +23,7 @@ import types
 import numpy as np
 
 REF = '/root/reference'
-_NAMES = ('jax', 'jax.numpy', 'jax.lax', 'jax.random', 'jax.scipy', 'jax.nn', 'flax', 'flax.linen', 'flax.nn', 'flax.struct',
+_NAMES = ('jax', 'jax.numpy', 'jax.lax', 'jax.random', 'jax.scipy', 'jax.nn', 'jax.tree_util', 'flax', 'flax.linen', 'flax.nn', 'flax.struct',
           'flax.optim', 'gin', 'gin.config', 'absl', 'absl.flags')
 
 
@@ -45,6 +48,70 @@ class _JArr(np.ndarray):
     __isub__ = lambda self, o: self - o
     __imul__ = lambda self, o: self * o
     __itruediv__ = lambda self, o: self / o
+
+
+class StopGrad:
+    """lax.stop_gradient under finite differences: 'record' stores what every call sees at the base point, 'replay' hands
+    those values back in call order at a perturbed point -- so a central difference of the reference's loss treats them as
+    the constants the derivative treats them as.  None: identity."""
+    mode, tape, pos = None, [], 0
+
+    @classmethod
+    def stop_gradient(cls, x):
+        if cls.mode == 'record':
+            cls.tape.append(np.array(x, copy=True))
+        elif cls.mode == 'replay':
+            x = cls.tape[cls.pos]
+            cls.pos += 1
+        return x
+
+    @classmethod
+    def start(cls, mode):
+        cls.mode, cls.pos = mode, 0
+        if mode == 'record':
+            cls.tape = []
+
+
+class Hooks:
+    """jax.value_and_grad(loss_fn, has_aux=True)(variables): the stand-in evaluates loss_fn, keeps the closure (so a test can
+    evaluate the reference's own loss at other points) and returns the gradient tree `grad_provider(variables)` supplies
+    (the oracle's autograd result) -- the reference's post-processing then runs on it as written."""
+    loss_fn = None
+    grad_provider = None
+
+
+def tree_leaves(tree):
+    if isinstance(tree, dict):
+        return [x for k in sorted(tree) for x in tree_leaves(tree[k])]
+    return [tree]
+
+
+def tree_map(fn, tree):
+    if isinstance(tree, dict):
+        return {k: tree_map(fn, v) for k, v in tree.items()}
+    return fn(tree)
+
+
+class _Any:
+    """whatever the train script imports beside the hot path (tensorboard, checkpoints, datasets, plotting)"""
+    def __call__(self, *a, **k):
+        return self
+
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return self
+
+
+class _AnyModule(types.ModuleType):
+    def __getattr__(self, name):
+        if name.startswith('__'):
+            raise AttributeError(name)
+        return _Any()
+
+
+_DUMMIES = ('absl.app', 'flax.core', 'flax.metrics', 'flax.metrics.tensorboard', 'flax.training', 'flax.training.checkpoints',
+            'matplotlib', 'matplotlib.pyplot', 'internal.obbpose_dataset', 'internal.c2f_obb_dataset', 'internal.vis')
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -124,7 +191,8 @@ def _install():
     jnp.float32 = np.float64                       # the check runs in float64 on both sides
     jnp.array = lambda x, dtype=None: np.array(x, dtype=np.float64 if dtype in (None, np.float64) else dtype)
     lax = types.ModuleType('jax.lax')
-    lax.stop_gradient = lambda x: x
+    lax.stop_gradient = StopGrad.stop_gradient
+    lax.pmean = lambda x, axis_name=None: x
     lax.Precision = types.SimpleNamespace(HIGHEST=None)
     random = types.ModuleType('jax.random')
     random.uniform = Uniform.uniform
@@ -140,10 +208,27 @@ def _install():
         return f(x), jvp
     jax.linearize = linearize
     jax.vmap = lambda f, in_axes=0, out_axes=0: f
+    import functools
+    tu = types.ModuleType('jax.tree_util')
+    tu.tree_map = tree_map
+    tu.tree_leaves = tree_leaves
+    tu.tree_reduce = lambda fn, tree, initializer=0: functools.reduce(fn, tree_leaves(tree), initializer)
+    jax.tree_util, jax.tree_map = tu, tree_map
+
+    def value_and_grad(f, has_aux=False):
+        def run(x):
+            Hooks.loss_fn = f
+            out = f(x)
+            grad = Hooks.grad_provider(x) if Hooks.grad_provider else tree_map(np.zeros_like, x)
+            return out, grad
+        return run
+    jax.value_and_grad = value_and_grad
+    jax.config = _Any()
     jnn = types.ModuleType('jax.nn')
     jnn.initializers = types.SimpleNamespace(glorot_uniform=lambda: None)
     jsp = types.ModuleType('jax.scipy')
     jax.numpy, jax.lax, jax.random, jax.nn, jax.scipy = jnp, lax, random, jnn, jsp
+    sys.modules['jax.tree_util'] = tu
 
     nn = _linen()
     flax = types.ModuleType('flax')
@@ -190,7 +275,7 @@ def _drop_internal():
         del sys.modules[k]
 
 
-def load(modules=('math', 'mip', 'mip360', 'box_helpers', 'utils', 'obbpose_model')):
+def load(modules=('math', 'mip', 'mip360', 'box_helpers', 'utils', 'obbpose_model'), train=False):
     """-> namespace of the reference's modules, imported unmodified under the stand-ins"""
     global _saved
     assert available(), 'reference tree not present'
@@ -198,7 +283,17 @@ def load(modules=('math', 'mip', 'mip360', 'box_helpers', 'utils', 'obbpose_mode
     _install()
     sys.path.insert(0, REF)
     _drop_internal()
-    return types.SimpleNamespace(**{n: importlib.import_module('internal.' + n) for n in modules})
+    ns = types.SimpleNamespace(**{n: importlib.import_module('internal.' + n) for n in modules})
+    if train:      # /root/reference/train_boxpose.py: train_step (:49-321); everything it imports beside the hot path is a dummy
+        for name in _DUMMIES:
+            sys.modules[name] = _AnyModule(name)
+        sys.modules['absl'].app = sys.modules['absl.app']
+        sys.modules['flax'].core = sys.modules['flax.core']
+        spec = importlib.util.spec_from_file_location('ref_train_boxpose', os.path.join(REF, 'train_boxpose.py'))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        ns.train_boxpose = mod
+    return ns
 
 
 def unload():
@@ -206,6 +301,10 @@ def unload():
     if REF in sys.path:
         sys.path.remove(REF)
     _drop_internal()
+    for name in _DUMMIES:
+        sys.modules.pop(name, None)
+    StopGrad.start(None)
+    Hooks.loss_fn = Hooks.grad_provider = None
     for k, v in (_saved or {}).items():
         if v is None:
             sys.modules.pop(k, None)
