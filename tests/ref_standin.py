@@ -72,6 +72,10 @@ class StopGrad:
             cls.tape = []
 
 
+class Devices:
+    count = 1
+
+
 class Hooks:
     """jax.value_and_grad(loss_fn, has_aux=True)(variables): the stand-in evaluates loss_fn, keeps the closure (so a test can
     evaluate the reference's own loss at other points) and returns the gradient tree `grad_provider(variables)` supplies
@@ -224,6 +228,11 @@ def _install():
         return run
     jax.value_and_grad = value_and_grad
     jax.config = _Any()
+    # one host; `Devices.count` devices (tests set it to exercise render_image's padding to a multiple of the device count)
+    jax.host_id = lambda: 0
+    jax.host_count = lambda: 1
+    jax.device_count = lambda: Devices.count
+    jax.local_device_count = lambda: Devices.count
     jnn = types.ModuleType('jax.nn')
     jnn.initializers = types.SimpleNamespace(glorot_uniform=lambda: None)
     jsp = types.ModuleType('jax.scipy')

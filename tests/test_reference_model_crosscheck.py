@@ -64,3 +64,49 @@ def test_model_call_matches_the_oracle(ref, case):
         _close(g[7][1], w[7][1], 0.0, case + ' box_rot[0]')
         _close(np.asarray(g[8]).reshape(-1), w[8].reshape(-1).double(), 0.0, case + ' dyn_mask')
         _close(g[9], w[9], 1e-12, case + ' zo')
+
+
+@pytest.mark.parametrize('devices,chunk', [(1, 64), (3, 50)])
+def test_render_image_matches_the_oracle(ref, devices, chunk):
+    """obbpose_model.render_image (:421-479), from its own source: flattening of the [H, W] rays, chunking, padding of a
+    chunk to a multiple of the device count with edge rays, sharding, un-sharding, dropping the padding, re-assembly --
+    around a render function that does what train_boxpose.py:377-397 does (pmap over the shards of
+    all_gather(model.apply(..., randomized=False, rand_bkgd=False)))."""
+    case = 'ref_model_K3_N32_rand'
+    c = G.CASES[case]
+    ob, params, _ = G.inputs(case)
+    Himg, Wimg = 8, 12                                     # 96 rays; chunk 50 with 3 devices: 50 -> 51, 46 -> 48
+    f = lambda t: t.detach().double().numpy()
+    rays_hw = ref.utils.BoxRays(*[f(getattr(ob['rays'], n)).reshape(Himg, Wimg, -1) for n in ref.utils.BoxRays._fields])
+    tree = ref_standin.flax_tree(params)
+    model = ref.obbpose_model.MipNerfModel(**c['model'])
+
+    def render_fn(rng, batch):                             # pmap(in_axes 0 on the batch) of all_gather(model.apply(...))
+        per_device = []
+        for d in range(ref_standin.Devices.count):
+            rays_d = ref.utils.namedtuple_map(lambda r: r[d], batch['rays'])
+            per_device.append(model.apply(tree, 0, rays_d, batch['init'][0], batch['ext'][0], batch['ts'][0], randomized=False,
+                                          white_bkgd=False, rand_bkgd=False, alpha=batch['alpha'][0]))
+        gathered = []
+        for lvl in range(len(per_device[0])):
+            entries = []
+            for i in range(10):
+                if i == 7:                                 # [box_pose, box_rot]: a list per device
+                    e = [np.stack([np.asarray(dev[lvl][7][j]) for dev in per_device]) for j in range(2)]
+                    entries.append([np.stack([x] * len(per_device)) for x in e])
+                else:
+                    g = np.stack([np.asarray(dev[lvl][i]) for dev in per_device])          # all_gather: [devices, ...]
+                    entries.append(np.stack([g] * len(per_device)))                        # on every device
+            gathered.append(entries)
+        return gathered
+
+    ref_standin.Devices.count = devices
+    try:
+        got = ref.obbpose_model.render_image(render_fn, rays_hw, tree['params']['box_centers'], f(ob['ext']),
+                                             np.array([int(ob['ts'])]), None, c['alpha'], chunk=chunk)
+    finally:
+        ref_standin.Devices.count = 1
+    rays_t = type(ob['rays'])(*[getattr(ob['rays'], n).reshape(Himg, Wimg, -1) for n in type(ob['rays'])._fields])
+    want = R.render_image(params, rays_t, ob['ts'], ob['ext'], c['alpha'], chunk=chunk, cfg=c['model'])
+    for g, w, nm in zip(got, want, ('rgb', 'distance', 'acc')):
+        _close(g, w, 1e-6, 'render_image ' + nm)
