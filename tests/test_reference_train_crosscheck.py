@@ -23,28 +23,12 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from durf_amd import obbpose_model, synthetic, utils  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+import make_ref_train_golden as G  # noqa: E402  (cases, inputs, the runner of the reference's train_step)
 from oracle import durf_ref as R  # noqa: E402
-from tests import helpers as H  # noqa: E402
 from tests import ref_standin  # noqa: E402
-from tests.ref_standin import Hooks, StopGrad, Uniform  # noqa: E402
 
 pytestmark = pytest.mark.skipif(not ref_standin.available(), reason='reference tree not present')
-
-CASES = {
-    # Waymo knobs, pose optimisation with the TV prior, box-weighted rgb loss, weight decay, stratified sampling
-    'K3_pose_opt_rand': dict(B=96, K=3, N=32, seed=311, alpha=4.5, eps=0.7,
-                             config=dict(randomized=True, tv_loss_mult=1e-2, box_loss_mult=2, weight_decay_mult=1e-3),
-                             model=dict(no_pose_opt=False, no_yaw_opt=False)),
-    # frozen poses, deterministic sampling, white background, single-scale loss
-    'K1_frozen_det': dict(B=64, K=1, N=32, seed=312, alpha=10.0, eps=3.0,
-                          config=dict(randomized=False, white_bkgd=True, disable_multiscale_loss=True),
-                          model=dict(no_pose_opt=True, no_yaw_opt=True)),
-    # yaw only, static model (boxes select rays only), cylinder rays
-    'K2_yaw_only_static': dict(B=64, K=2, N=32, seed=313, alpha=10.0, eps=0.2,
-                               config=dict(randomized=True, tv_loss_mult=1e-3),
-                               model=dict(no_pose_opt=True, no_yaw_opt=False, dynamics=False, ray_shape='cylinder')),
-}
 
 
 @pytest.fixture(scope='module')
@@ -52,69 +36,6 @@ def ref():
     mods = ref_standin.load(train=True)
     yield mods
     ref_standin.unload()
-
-
-class _Optimizer:
-    def __init__(self, target):
-        self.target, self.applied, self.lr = target, None, None
-
-    def apply_gradient(self, grad, learning_rate=None):
-        new = _Optimizer(self.target)
-        new.applied, new.lr = grad, learning_rate
-        return new
-
-
-class _State:
-    def __init__(self, optimizer):
-        self.optimizer = optimizer
-
-    def replace(self, optimizer):
-        return _State(optimizer)
-
-
-def _setup(case):
-    c = CASES[case]
-    B, K, N, seed = c['B'], c['K'], c['N'], c['seed']
-    b = synthetic.make_batch(B, K, seed=seed, noise_boxes=0.3)
-    cb = {k: (torch.tensor(v) if isinstance(v, np.ndarray) else v) for k, v in b.items() if k != 'rays'}
-    utils.clear_gin()
-    _, variables = obbpose_model.construct_mipnerf(seed, cb, device='cpu')
-    g = torch.Generator().manual_seed(seed)
-    for nm in variables.layout.mlp_names():
-        for i in range(12):
-            bias = variables['params'][nm]['Dense_%d' % i]['bias']
-            bias.copy_((torch.rand(bias.shape, generator=g) - 0.5) * 0.1)
-    dt = torch.float64
-    noise = dict(t_rand=torch.rand(B, N + 1, generator=g, dtype=dt), u_rand=torch.rand(B, N + 1, generator=g, dtype=dt))
-    ob = H.oracle_batch(b, dt)
-    params = H.oracle_params_from_variables(variables, dt)
-    # poses a step away from the initial ones, and a `prev` that differs from both: the TV and offset terms are non-trivial
-    params['box_centers'] = params['box_centers'] + 0.05 * torch.randn(params['box_centers'].shape, generator=g, dtype=dt)
-    prev = ob['init'][0:1] + 0.02 * torch.randn(ob['init'][0:1].shape, generator=g, dtype=dt)
-    config = dict(R.CONFIG_DEFAULTS, **c['config'])
-    model_cfg = dict(num_samples=N, density_noise=0.0, **c['model'])
-    return c, b, ob, params, prev, noise, config, model_cfg
-
-
-def _oracle(params, ob, config, model_cfg, c, prev, noise):
-    leaves = [z.detach().clone().requires_grad_(True) for z in R.params_leaves(params)]
-    p = R.set_leaves(params, leaves)
-    loss, S, _ = R.loss_fn(p, ob, config, model_cfg, c['eps'], c['alpha'], prev, noise=noise if config['randomized'] else None)
-    grads = torch.autograd.grad(loss, leaves, allow_unused=True)
-    grads = [torch.zeros_like(z) if gr is None else gr for gr, z in zip(grads, leaves)]
-    return S, grads
-
-
-def _tree_of(params, leaves):
-    """flat oracle leaves -> flax-shaped numpy tree"""
-    return ref_standin.flax_tree(R.set_leaves(params, list(leaves)))
-
-
-def _ref_batch(ref, ob, b):
-    f = lambda t: t.detach().double().numpy()
-    rays = ref.utils.BoxRays(*[f(getattr(ob['rays'], n)) for n in ref.utils.BoxRays._fields])
-    return dict(rays=rays, init=f(ob['init']), ext=f(ob['ext']), ts=np.array([int(b['ts'])]), depth=f(ob['depth']),
-                sky=f(ob['sky']), pixels=f(ob['pixels']), target=f(ob['target']))
 
 
 def _close(got, want, tol, what):
@@ -128,10 +49,10 @@ def _close(got, want, tol, what):
         assert err <= tol * max(1.0, np.abs(want[fin]).max()), '%s: %g (scale %g)' % (what, err, np.abs(want[fin]).max())
 
 
-@pytest.mark.parametrize('case', sorted(CASES))
+@pytest.mark.parametrize('case', sorted(G.CASES))
 def test_train_step_matches_the_oracle(ref, case):
-    c, b, ob, params, prev, noise, config, model_cfg = _setup(case)
-    S, grads = _oracle(params, ob, config, model_cfg, c, prev, noise)
+    c, b, ob, params, prev, noise, config, model_cfg = G.setup(case)
+    S, grads = G.oracle(params, ob, config, model_cfg, c, prev, noise)
     # plant what nan_to_num is there for (train_boxpose.py:263) in the gradient both sides post-process
     planted = [gr.clone() for gr in grads]
     flat1 = planted[1].reshape(-1)
@@ -139,20 +60,9 @@ def test_train_step_matches_the_oracle(ref, case):
     planted[2].reshape(-1)[5] = -1e3
     g2, gmax, gnorm, gnorm_c = R.grad_postprocess(planted, config)
 
-    rconf = ref.utils.Config(**{k: v for k, v in config.items() if k in ref.utils.Config.__dataclass_fields__})
-    model = ref.obbpose_model.MipNerfModel(**model_cfg)
-    tree = ref_standin.flax_tree(params)
-    Hooks.grad_provider = lambda x: _tree_of(params, planted)
-    uniforms = [noise['t_rand'].numpy(), noise['u_rand'].numpy()] if config['randomized'] else []
-    Uniform.queue = [u.copy() for u in uniforms]
-    StopGrad.start(None)
-    state = _State(_Optimizer(tree))
-    new_state, stats, _, pose = ref.train_boxpose.train_step(model, rconf, 0, state, _ref_batch(ref, ob, b), 5e-4, c['eps'],
-                                                             c['alpha'], prev.numpy())
-    assert not Uniform.queue
+    new_state, stats, pose, ref_loss, (_, _, _, _, _, _, _, _, tree) = G.run_reference(ref, case, G.tree_of(params, planted))
     # ---- the logged scalars of loss_fn ----
-    for k in ('loss', 'losses', 'obj_losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses', 'tv_losses',
-              'sampling_stats', 'offsets', 'offset_x', 'offset_y', 'offset_z', 'offset_yaw', 'weight_l2'):
+    for k in G.SCALARS:
         _close(getattr(stats, k), S[k], 1e-6, case + ' ' + k)
     _close(stats.psnrs, R.mse_to_psnr(S['losses'].detach()), 1e-6, case + ' psnrs')
     _close(pose, S['pose'], 0.0, case + ' pose')
@@ -160,70 +70,27 @@ def test_train_step_matches_the_oracle(ref, case):
     _close(stats.grad_abs_max, gmax, 1e-12, 'grad_abs_max')
     _close(stats.grad_norm, gnorm, 1e-12, 'grad_norm')
     _close(stats.grad_norm_clipped, gnorm_c, 1e-12, 'grad_norm_clipped')
-    applied = new_state.optimizer.applied
-    want = _tree_of(params, g2)
-    for (a, w) in zip(ref_standin.tree_leaves(applied), ref_standin.tree_leaves(want)):
+    want = G.tree_of(params, g2)
+    for (a, w) in zip(ref_standin.tree_leaves(new_state.optimizer.applied), ref_standin.tree_leaves(want)):
         np.testing.assert_allclose(a, w, rtol=1e-12, atol=0)
     assert new_state.optimizer.lr == 5e-4
 
     # ---- the gradient: central differences of the reference's own loss_fn closure, stop_gradients replayed ----
-    loss_fn = Hooks.loss_fn
-    # (train_step re-binds its argument `eps` to 1e-6 for nan_to_num AFTER differentiating (:262); the closure shares that
-    # variable, so evaluated later it would see the near-loss interval 1e-6: put the step's value back in the cell)
-    loss_fn.__closure__[loss_fn.__code__.co_freevars.index('eps')].cell_contents = c['eps']
-
-    def ref_loss(tr, mode):
-        Uniform.queue = [u.copy() for u in uniforms]
-        StopGrad.start(mode)
-        return float(loss_fn(tr)[0])
-
-    base = ref_loss(tree, 'record')
-    _close(base, S['loss'], 1e-6, 'loss at the base point')
-    names = ['box_centers'] + [n for n in params if n != 'box_centers']
-    leaves = R.params_leaves(params)
-    gen = torch.Generator().manual_seed(c['seed'] + 1)
+    _close(ref_loss(tree, 'record'), S['loss'], 1e-6, 'loss at the base point')
+    dirs = G.directions(params, b, c['seed'])
+    quot = G.reference_derivatives(ref_loss, params, tree, dirs)
     checked = 0
-    ts = int(b['ts'])
-    for target in names:
-        vs = []
-        for leaf, owner in zip(leaves, _owners(params)):
-            v = torch.randn(leaf.shape, generator=gen, dtype=torch.float64) if owner == target else torch.zeros_like(leaf)
-            if owner == target == 'box_centers':        # only this step's timestep row takes part
-                keep = torch.zeros_like(v)
-                keep[ts] = 1.0
-                v = v * keep
-            vs.append(v)
+    for (target, vs), q in zip(dirs, quot):
         want_d = float(sum((gr * v).sum() for gr, v in zip(grads, vs)))
-        scale = float(sum((gr * (v != 0)).pow(2).sum() for gr, v in zip(grads, vs)) ** 0.5)
-        vnorm = float(sum((v * v).sum() for v in vs) ** 0.5)
-        # Step 1e-8 (float64: rounding ~1e-8 absolute on a loss of order 1).  Larger steps are visibly not converged here: a
-        # pose change of h moves a sample at distance 40 by 40 h, i.e. the 2^9-frequency features by 2e4 h rad, and every ReLU
-        # kink crossed inside +-h costs O(h) -- measured along MLP_0: 5.4704567 / 5.4760067 / 5.4770035 / 5.4772226 at
-        # h = 1e-5 .. 1e-8 against the oracle's 5.4772226; along the poses -0.0931474 / -0.0894100 / -0.0893671 /
-        # -0.0893671 against -0.0893671.
-        # A kink that happens to lie within ~h of the base point spoils ONE step size without being an error (MLP_0 of
-        # K1_frozen_det: 0.13813533 / 0.13675854 / 0.13619184 at 1e-7 / 1e-8 / 1e-9 against 0.13619179), so three step sizes
-        # are taken: the best must reproduce the oracle to 1e-5, every one to 3 %.
-        quotients = []
-        for h in (1e-7, 1e-8, 1e-9):
-            plus = _tree_of(params, [z + h * v for z, v in zip(leaves, vs)])
-            minus = _tree_of(params, [z - h * v for z, v in zip(leaves, vs)])
-            quotients.append((ref_loss(plus, 'replay') - ref_loss(minus, 'replay')) / (2 * h))
-        got_d = min(quotients, key=lambda q: abs(q - want_d))
-        assert abs(got_d - want_d) <= 1e-5 * abs(want_d) + 2e-7, '%s along %s: reference %s, oracle %.8g' % (
-            case, target, quotients, want_d)
-        assert all(abs(q - want_d) <= 3e-2 * abs(want_d) + 1e-6 for q in quotients), (case, target, quotients, want_d)
+        # Step sizes 1e-7 / 1e-8 / 1e-9 (float64: rounding ~1e-8 absolute on a loss of order 1).  Larger steps are visibly not
+        # converged here: a pose change of h moves a sample at distance 40 by 40 h, i.e. the 2^9-frequency features by
+        # 2e4 h rad, and every ReLU kink crossed inside +-h costs O(h) -- measured along MLP_0: 5.4704567 / 5.4760067 /
+        # 5.4770035 / 5.4772226 at h = 1e-5 .. 1e-8 against the oracle's 5.4772226.  A kink that happens to lie within ~h of
+        # the base point spoils ONE step size without being an error (MLP_0 of K1_frozen_det: 0.13813533 / 0.13675854 /
+        # 0.13619184 against 0.13619179): the best of the three must reproduce the oracle to 1e-5, every one to 3 %.
+        got_d = min(q, key=lambda x: abs(x - want_d))
+        assert abs(got_d - want_d) <= 1e-5 * abs(want_d) + 2e-7, '%s along %s: reference %s, oracle %.8g' % (case, target, q, want_d)
+        assert all(abs(x - want_d) <= 3e-2 * abs(want_d) + 1e-6 for x in q), (case, target, q, want_d)
         print('%s: d(loss) along %s: reference (central difference) %.8g, oracle (autograd) %.8g' % (case, target, got_d, want_d))
-        checked += scale > 0
+        checked += want_d != 0.0
     assert checked >= 2
-    StopGrad.start(None)
-    Hooks.grad_provider = None
-
-
-def _owners(params):
-    """which parameter group each leaf of R.params_leaves belongs to"""
-    out = ['box_centers']
-    names = ['MLP_0'] + sorted([k for k in params if k.startswith('BoxMLP_')], key=lambda s: int(s.split('_')[1]))
-    for n in names:
-        out += [n, n] * len(params[n])
-    return out
