@@ -74,6 +74,8 @@ def parse_args():
                     help="eval: a 'step' renders one 320x480 test image (153 600 rays, chunk 8192, randomized=False) through "
                          'render_image -- the reference logs this as eval rays/sec (train_boxpose.py:548-568)')
     ap.add_argument('--chunk', type=int, default=8192, help='render_image chunk (eval mode)')
+    ap.add_argument('--one-call', action='store_true',
+                    help='eval mode: every chunk through the single C entry point durf_forward (no per-kernel timers)')
     ap.add_argument('--force-dist', action='store_true',
                     help='one rank, but through the data-parallel path: a world-size-1 RCCL group (DURF_FORCE_DIST=1), so the '
                          'gradient all-reduce + stream wait run and their per-step cost shows against a plain run')
@@ -277,9 +279,9 @@ def eval_main(args):
     b = synthetic.make_batch(H * W, w['K'], seed=7, far=w['far'])
     db = synthetic.device_batch(b, dev)
     rays = utils.namedtuple_map(lambda r: r.reshape(H, W, -1), db['rays'])
-    fn = train_boxpose.make_render_fn(model, config, state.variables)
+    fn = train_boxpose.make_render_fn(model, config, state.variables, one_call=args.one_call)
     render = lambda: obbpose_model.render_image(fn, rays, db['init'], db['ext'], b['ts'], 0, w['alpha'], chunk=args.chunk)
-    ops.TIMED_NAMES = {'mlp_fwd_256', 'encode_bkgd', 'composite_fwd'}
+    ops.TIMED_NAMES = {'mlp_fwd_256', 'encode_bkgd', 'composite_fwd', 'forward_call'}
     ops.TIMERS = {}
     prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]
     for e in prewarm:
@@ -300,6 +302,20 @@ def eval_main(args):
     ops.TIMERS = None
     NS = w['N']
     nchunks = (H * W + args.chunk - 1) // args.chunk
+    if args.one_call:                                    # the kernels are launched from C: only the whole call is timed
+        n, sec = totals['forward_call']
+        fl = N_LEVELS * 2.0 * MAC_BKGD * H * W * NS
+        out = dict(metric='eval_rays_per_sec', value=H * W * args.steps / dt, unit='rays/s', n_gpus=1, steps=args.steps,
+                   warmup=max(args.warmup, 2), ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
+                   vs_baseline=None, dtype='bf16', data='synthetic',
+                   config=dict(workload=w['label'] + ', render_image, every chunk of %d rays ONE durf_forward call' % args.chunk,
+                               name=args.config, mode='eval', one_call=True, image=[H, W], chunk=args.chunk, num_samples=NS,
+                               objects=w['K']),
+                   roofline=dict(bound='mfma', kernel='durf_forward (whole chunk)', achieved=fl / (sec / args.steps) / 1e12,
+                                 peak=PEAK_BF16 / 1e12, unit='TFLOP/s', frac=fl / (sec / args.steps) / PEAK_BF16, traffic=None,
+                                 launch_us=sec / n * 1e6), cpu_baseline=None)
+        print(json.dumps(out))
+        return
     n, sec = totals['mlp_fwd_256']
     rows = H * W * NS                                    # per level, all chunks of one image
     per_image = sec / args.steps                         # the background forward of both levels, all chunks

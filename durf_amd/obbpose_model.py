@@ -411,6 +411,35 @@ class MipNerfModel:
             trunk = ops.bkgd_const_trunk_f32(variables.mlp_flat('MLP_0'))
         variables._trunk_cache = (trunk, variables.flat._version)
 
+    def apply_one_call(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha, noise=None):
+        """`apply` through ONE library call (durf_forward, csrc/forward.hip): the orchestration of `_forward(train=False)`
+        done in C for hosts that are not Python; same arguments, same list of 10-tuples, bit-identical results
+        (tests/test_gpu_forward_call.py).  bf16 MLPs, objects on the bf16 kernels, no density noise."""
+        self._check()
+        lay = variables.layout
+        K = lay.K
+        if self.mlp_precision != 'bf16' or (K and (not self.dynamics or self.object_precision() != 'bf16')):
+            raise NotImplementedError('durf_forward covers the bf16 inference path (dynamics=True, bf16 object MLPs)')
+        if randomized and self.density_noise > 0:
+            raise NotImplementedError('durf_forward applies no density noise')
+        B, N = rays.origins.shape[0], self.num_samples
+        dev = rays.origins.device
+        if randomized and noise is None:
+            u = torch.rand(2, B, N + 1, device=dev, generator=_make_generator(rng, dev))
+            noise = dict(t_rand=u[0], u_rand=u[1])
+        pose = variables['params']['box_centers'][int(ts)].contiguous()
+        flags = ((ops.ENC_CONTRACT if self.contraction else 0) | (ops.ENC_NO_INTEGRATION if self.disable_integration else 0) |
+                 (ops.ENC_CYLINDER if self.ray_shape == 'cylinder' else 0))
+        o0 = lay.mlp_off['BoxMLP_0'] if K else 0
+        bk = ops.BKGD_RAND if rand_bkgd else (ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY)
+        outs, dyn, zo = ops.forward_call(
+            rays, pose, ext.reshape(-1, 3).contiguous() if K else None, variables.mlp_flat('MLP_0'),
+            variables.flat[o0:o0 + K * lay.mlp_size[W_OBJ]] if K else None, lay.mlp_size[W_OBJ], N, self.num_levels, alpha, flags,
+            lindisp=self.lindisp, bkgd_mode=bk, density_bias=self.density_bias, resample_padding=self.resample_padding,
+            t_rand=noise['t_rand'] if randomized else None, u_rand=noise['u_rand'] if randomized else None)
+        box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
+        return [tuple(o) + ([pose[:, :3], box_rot0], dyn, zo) for o in outs]
+
     def apply(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
               noise=None):
         """model.apply(variables, key, rays, init, ext, ts, randomized=, rand_bkgd=, white_bkgd=,

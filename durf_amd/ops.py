@@ -883,3 +883,53 @@ def objf32_dw_batch(slabs_levels, count, grad_obj, grad_stride, nsplit=8):
         _lib.check(L.durf_objf32_dw_batch(_stream(), K, B, N, _p(count), nl, arr([s.act for s in slabs_levels]),
                                           arr([s.dz for s in slabs_levels]), int(nsplit), _p(scratch), _p(grad_obj),
                                           int(grad_stride)), 'durf_objf32_dw_batch')
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the whole inference forward as one C call (csrc/forward.hip, include/durf_hip.h durf_forward)
+# ---------------------------------------------------------------------------------------------------------------------
+FORWARD_MAX_LEVELS = 4
+_vp4 = C.c_void_p * FORWARD_MAX_LEVELS
+
+
+class ForwardArgs(C.Structure):
+    """durf_forward_args (include/durf_hip.h), field for field"""
+    _fields_ = ([(n, C.c_int) for n in ('B', 'N', 'K', 'num_levels', 'enc_flags', 'lindisp', 'bkgd_mode')] +
+                [('density_bias', C.c_float), ('resample_padding', C.c_float), ('barf_w', C.c_float * 10)] +
+                [(n, C.c_void_p) for n in ('origins', 'directions', 'viewdirs', 'radii', 'near', 'far', 'pose', 'ext',
+                                           'bkgd_params', 'obj_params')] +
+                [('obj_param_stride', C.c_size_t), ('t_rand', C.c_void_p), ('u_rand', C.c_void_p)] +
+                [(n, _vp4) for n in ('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')] +
+                [('dyn_mask', C.c_void_p), ('zo', C.c_void_p)])
+
+
+def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp=False,
+                 bkgd_mode=BKGD_GREY, density_bias=-1.0, resample_padding=0.01, t_rand=None, u_rand=None):
+    """MipNerfModel.__call__ in inference as ONE library call (durf_forward): -> list[num_levels] of
+    (rgb, depth, acc, weights, t_vals, t_mids, t_dists), dyn_mask [B,1] int32, zo [B]"""
+    B, K = rays.origins.shape[0], pose.shape[0]
+    dev = rays.origins.device
+    L = _lib.lib()
+    f = lambda *sh: torch.empty(*sh, device=dev)
+    outs = [(f(B, 3), f(B), f(B), f(B, N), f(B, N + 1), f(B, N), f(B, N)) for _ in range(num_levels)]
+    dyn, zo = torch.empty(B, 1, dtype=torch.int32, device=dev), f(B)
+    a = ForwardArgs()
+    a.B, a.N, a.K, a.num_levels, a.enc_flags, a.lindisp, a.bkgd_mode = B, N, K, num_levels, enc_flags, int(lindisp), bkgd_mode
+    a.density_bias, a.resample_padding = density_bias, resample_padding
+    a.barf_w = (C.c_float * 10)(*[float(x) for x in barf_weights(alpha)])
+    flat1 = lambda t: _p(_f32(t.reshape(-1).contiguous()))
+    keep = [t.reshape(-1).contiguous() for t in (rays.radii, rays.near, rays.far)]
+    a.origins, a.directions, a.viewdirs = _p(_f32(rays.origins)), _p(_f32(rays.directions)), _p(_f32(rays.viewdirs))
+    a.radii, a.near, a.far = (_p(_f32(t)) for t in keep)
+    a.pose, a.ext = (_p(_f32(pose)) if K else None), (_p(_f32(ext)) if K else None)
+    a.bkgd_params = _p(_f32(bkgd_params))
+    a.obj_params, a.obj_param_stride = (_p(_f32(obj_params)) if K else None), int(obj_param_stride)
+    a.t_rand, a.u_rand = _p(t_rand), _p(u_rand)
+    for i, name in enumerate(('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')):
+        setattr(a, name, _vp4(*([o[i].data_ptr() for o in outs] + [None] * (FORWARD_MAX_LEVELS - num_levels))))
+    a.dyn_mask, a.zo = _p(dyn), _p(zo)
+    ws = torch.empty(int(L.durf_forward_workspace_bytes(B, N, K)), dtype=torch.uint8, device=dev)
+    assert ws.data_ptr() % 256 == 0
+    with _Timed('forward_call'):
+        _lib.check(L.durf_forward(_stream(), C.byref(a), _p(ws)), 'durf_forward')
+    return outs, dyn, zo

@@ -364,11 +364,14 @@ def make_schedules(config):
     return lr_fn, eps_fn, alpha_fn
 
 
-def make_render_fn(model, config, variables):
-    """render_eval_fn (train_boxpose.py:377-390): test-mode model.apply; the all-gather lives in render_image."""
+def make_render_fn(model, config, variables, one_call=False):
+    """render_eval_fn (train_boxpose.py:377-390): test-mode model.apply; the all-gather lives in render_image.
+    one_call: each chunk through the single C entry point durf_forward (MipNerfModel.apply_one_call; bit-identical)."""
+    apply = model.apply_one_call if one_call else model.apply
+
     def render_fn(rng, batch):
-        return model.apply(variables, rng, batch['rays'], batch['init'], batch['ext'], batch['ts'],
-                           randomized=False, rand_bkgd=False, white_bkgd=config.white_bkgd, alpha=batch['alpha'])
+        return apply(variables, rng, batch['rays'], batch['init'], batch['ext'], batch['ts'],
+                     randomized=False, rand_bkgd=False, white_bkgd=config.white_bkgd, alpha=batch['alpha'])
     return render_fn
 
 

@@ -115,6 +115,12 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_expand_raw.restype = i32
     L.durf_expand_raw.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp]
     #   (stream, B, N, raw_c, count, slot, raw_full, raw_tail)
+    L.durf_forward_workspace_bytes.restype = u64
+    L.durf_forward_workspace_bytes.argtypes = [i32, i32, i32]
+    #   (B, N, K)
+    L.durf_forward.restype = i32
+    L.durf_forward.argtypes = [vp, vp, vp]
+    #   (stream, args, workspace)
     L.durf_mlp_f32_act_floats.restype = u64
     L.durf_mlp_f32_act_floats.argtypes = [i32, i32]
     #   (width, in_dim)

@@ -278,6 +278,39 @@ int durf_expand_raw(void* stream, int B, int N, const float* raw_c /* compacted 
                     const float* raw_tail /* nullable [B,4]: row slot[b,1] replaces the tail row of box-hit ray b -- the
                        fp32 evaluation of durf_mlp_fwd_f32(enc = NULL) when the object branch runs in fp32 */);
 
+/* ---- the whole inference forward as ONE call (csrc/forward.hip) ----------------------------------------
+ * MipNerfModel.__call__ (obbpose_model.py:68-261) as render_eval_fn runs it (train_boxpose.py:377-390): ray setup, per-object
+ * hit lists, weight packing, and per level the background encoding + 8x256 MLP (rays that hit exactly one box evaluated
+ * once: durf_expand_raw), the K object MLPs on their hit rays, merge + volumetric rendering, and the resampling that
+ * feeds the next level -- the stage entry points above in the order durf_amd/obbpose_model.py issues them for
+ * train=False, on `stream`, bf16 MLPs, results bit-identical to that path.  For hosts that are not Python: SURVEY 8b's
+ * `durf_forward`.  All pointers are device pointers of caller-owned buffers except barf_w (host values inside the
+ * struct); `workspace` holds every intermediate: durf_forward_workspace_bytes(B, N, K) bytes, 256-byte aligned, free
+ * to reuse once the stream has passed the call.  density_noise is not applied (inference: randomized=False; with
+ * t_rand / u_rand given the sampling is stratified as in training). */
+#define DURF_FORWARD_MAX_LEVELS 4
+typedef struct durf_forward_args {
+    int B, N, K, num_levels;            /* rays, MipNerfModel.num_samples, boxes (0: static model), num_levels */
+    int enc_flags;                      /* DURF_ENC_CONTRACT | DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER */
+    int lindisp, bkgd_mode;             /* MipNerfModel.lindisp; 0 grey 0.5 / 1 white / 2 none (rand_bkgd handled by the caller) */
+    float density_bias, resample_padding;
+    float barf_w[10];                   /* weighted_ipe's per-degree weights for this step's alpha (mip.py:217-218) */
+    const float *origins, *directions, *viewdirs, *radii, *near, *far;     /* Rays fields, [B,3] x3, [B] x3 */
+    const float *pose, *ext;            /* box_centers[ts] [K,6], half extents [K,3] */
+    const float *bkgd_params;           /* MLP_0: Dense_0..11 (kernel[in,out], bias) flat */
+    const float *obj_params;            /* BoxMLP_0 .. BoxMLP_{K-1}, obj_param_stride floats apart */
+    size_t obj_param_stride;
+    const float *t_rand, *u_rand;       /* nullable [B,N+1] each: randomized=False */
+    /* outputs, per level: rgb [B,3], depth / acc [B], weights / t_mids / t_dists [B,N], t_vals [B,N+1] */
+    float *rgb[DURF_FORWARD_MAX_LEVELS], *depth[DURF_FORWARD_MAX_LEVELS], *acc[DURF_FORWARD_MAX_LEVELS];
+    float *weights[DURF_FORWARD_MAX_LEVELS], *t_vals[DURF_FORWARD_MAX_LEVELS], *t_mids[DURF_FORWARD_MAX_LEVELS];
+    float *t_dists[DURF_FORWARD_MAX_LEVELS];
+    int32_t* dyn_mask;                  /* [B] boxes hit per ray (the 10-tuple's dyn_mask) */
+    float* zo;                          /* [B] */
+} durf_forward_args;
+size_t durf_forward_workspace_bytes(int B, int N, int K);
+int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
+
 /* ---- exact-fp32 MLP (csrc/mlp_f32.hip) -----------------------------------------------------------
  * The reference's Dense layers are fp32 (obbpose_model.py:326-327; HIGHEST-precision matmul, internal/math.py:22-24).
  * These entry points evaluate the same stack with v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain over the

@@ -1,0 +1,85 @@
+"""durf_forward (csrc/forward.hip): MipNerfModel.__call__ in inference as ONE C call -- SURVEY 8b's coarse entry point for
+hosts that are not Python.  It issues the same stage kernels in the same order as durf_amd/obbpose_model.py does for
+train=False, so its results must be BIT-identical to MipNerfModel.apply; and through that path it inherits the parity
+with the oracle (and with the reference's own model outputs: tests/test_golden_ref_model.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+import make_ref_model_golden as G  # noqa: E402
+from durf_amd import obbpose_model, ops, synthetic, utils  # noqa: E402
+from tests import helpers as H  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b, what):
+    assert len(a) == len(b)
+    for lvl, (x, y) in enumerate(zip(a, b)):
+        for i in range(7):
+            # (rays that hit two boxes render NaN on both paths: compare with NaN == NaN)
+            assert torch.allclose(x[i], y[i], rtol=0, atol=0, equal_nan=True), '%s: level %d output %d differs' % (what, lvl, i)
+        assert torch.equal(x[7][0], y[7][0]) and torch.equal(x[7][1], y[7][1])
+        assert torch.equal(x[8].reshape(-1).int(), y[8].reshape(-1).int()), what + ': dyn_mask'
+        assert torch.allclose(x[9], y[9], rtol=0, atol=0, equal_nan=True), what + ': zo'
+
+
+@pytest.mark.parametrize('B,K,N,randomized,knobs', [
+    (4096, 3, 128, False, {}),                                   # a render chunk of the metric's shape
+    (1000, 1, 64, True, {}),                                     # ragged ray count, stratified sampling
+    (777, 0, 32, False, {}),                                     # static model
+    (640, 8, 32, True, dict(ray_shape='cylinder', disable_integration=True)),
+    (512, 2, 96, False, dict(contraction=False, lindisp=False)),
+])
+def test_one_call_forward_is_bit_identical_to_apply(cuda, B, K, N, randomized, knobs):
+    utils.clear_gin()
+    lines = ['MipNerfModel.num_samples = %d' % N, 'MipNerfModel.density_noise = 0.0', 'MipNerfModel.no_pose_opt = True',
+             'MipNerfModel.no_yaw_opt = True'] + ['MipNerfModel.%s = %r' % kv for kv in knobs.items()]
+    utils.parse_gin('\n'.join(lines).replace("'", '"') + '\n')
+    b = synthetic.make_batch(B, K, seed=900 + K, allow_multi_hit=K > 1)
+    db = H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+    g = torch.Generator(device='cpu').manual_seed(4)
+    noise = dict(t_rand=torch.rand(B, N + 1, generator=g).to(cuda), u_rand=torch.rand(B, N + 1, generator=g).to(cuda))
+    for white in (False, True):
+        kw = dict(randomized=randomized, rand_bkgd=False, white_bkgd=white, alpha=6.5, noise=noise if randomized else None)
+        want = model.apply(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], **kw)
+        got = model.apply_one_call(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], **kw)
+        _same(got, want, 'B=%d K=%d N=%d' % (B, K, N))
+
+
+def test_one_call_forward_reproduces_the_reference_model_outputs(cuda):
+    """... and directly: the fixture made by the reference's own MipNerfModel.__call__ (tests/golden/ref_model_*.npz)"""
+    case = 'ref_model_waymo_K3_N128'
+    c = G.CASES[case]
+    gold = np.load(os.path.join(ROOT, 'tests', 'golden', case + '.npz'))
+    b, variables_cpu, noise = G.build(case)
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = 128\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\n')
+    model = utils.configured(obbpose_model.MipNerfModel)
+    variables = variables_cpu.like(variables_cpu.flat.to(cuda))
+    db = H.device_batch(b, cuda)
+    nz = {k: v.float().to(cuda) for k, v in noise.items()}
+    ret = model.apply_one_call(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], randomized=True, rand_bkgd=False,
+                               white_bkgd=False, alpha=c['alpha'], noise=nz)
+    for lvl in range(2):
+        for i, (nm, tol) in enumerate(zip(G.NAMES, (2e-2, 2e-2 * 40, 2e-2, 2e-2, 2e-2 * 40))):
+            np.testing.assert_allclose(ret[lvl][i].double().cpu().numpy(), gold['l%d_%s' % (lvl, nm)], rtol=0, atol=tol)
+    np.testing.assert_array_equal(ret[0][8].reshape(-1).cpu().numpy(), gold['dyn_mask'])
+
+
+def test_workspace_size_and_argument_checks(cuda):
+    L = ops._lib.lib()
+    assert L.durf_forward_workspace_bytes(4096, 128, 3) > L.durf_forward_workspace_bytes(4096, 128, 0) > 0
+    a = ops.ForwardArgs()
+    a.B, a.N, a.K, a.num_levels = 16, 48, 0, 2                   # num_samples not a multiple of 32
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=cuda)
+    import ctypes
+    assert L.durf_forward(None, ctypes.byref(a), ws.data_ptr()) != 0
+    assert b'num_samples' in L.durf_last_error()
