@@ -1,0 +1,233 @@
+// durf_loss_backward / durf_train_step: value_and_grad(loss_fn) of train_step (train_boxpose.py:49-321) for one shard as ONE
+// C call -- the orchestration durf_amd/train_boxpose.py (loss_and_grad, train_step) and obbpose_model.py (_forward, train)
+// do in Python, for hosts that are not Python (durf_forward / durf_loss_backward / durf_clip_adam).  No kernel
+// of its own: the stage entry points of this library in the order the Python path issues them on ONE stream, every
+// intermediate carved out of a caller-owned workspace.  Scope: the benchmarked training configuration -- bf16 MLPs,
+// frozen box poses (no_pose_opt and no_yaw_opt), >= 2 levels, no density noise, no weight decay, fixed background colour.
+// Results are bit-identical to train_boxpose.train_step (tests/test_gpu_train_call.py).
+#include "durf_common.h"
+#include "../../include/durf_hip.h"
+
+namespace {
+
+struct Carver {
+    char* base;
+    size_t off;
+    void* take(size_t bytes) {
+        off = (off + 255) & ~(size_t)255;
+        void* p = base ? base + off : nullptr;
+        off += bytes;
+        return p;
+    }
+};
+
+constexpr int ML = DURF_FORWARD_MAX_LEVELS;
+
+struct TrainWs {
+    float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *draw, *part, *bpart, *opart, *obpart, *scratch;
+    float *raw_c[ML], *raw_b[ML], *obj_raw[ML], *terms[ML];
+    int32_t *hit, *idx_obj, *count_obj, *slot_obj, *idx_cls, *count_cls, *slot_cls;
+    void *view, *wf_bkgd, *wb_bkgd, *wf_obj, *wb_obj, *view_tile, *obj_view_tile;
+    void *enc[ML], *stash[ML], *mask[ML], *dz[ML], *dz_out[ML];
+    void *obj_enc[ML], *obj_stash[ML], *obj_mask[ML], *obj_dz[ML], *obj_dz_out[ML];
+    size_t total;
+};
+
+TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params) {
+    Carver c{(char*)workspace, 0};
+    TrainWs w{};
+    const size_t rows = (size_t)B * N, Kc = K > 0 ? K : 1, trows = (rows + 31) / 32 * 32;
+    w.o_s = (float*)c.take((size_t)B * 3 * 4);
+    w.d_s = (float*)c.take((size_t)B * 3 * 4);
+    w.hit = (int32_t*)c.take((size_t)B * Kc * 4);
+    w.view = c.take((size_t)B * 32 * 2);
+    w.idx_obj = (int32_t*)c.take(Kc * B * 4);
+    w.count_obj = (int32_t*)c.take(Kc * 4);
+    w.slot_obj = (int32_t*)c.take((size_t)B * Kc * 4);
+    w.idx_cls = (int32_t*)c.take((size_t)2 * B * 4);
+    w.count_cls = (int32_t*)c.take(8 * 4);
+    w.slot_cls = (int32_t*)c.take((size_t)2 * B * 4);
+    w.wf_bkgd = c.take(durf_wpack_fwd_bytes(256));
+    w.wb_bkgd = c.take(durf_wpack_bwd_bytes(256));
+    w.wf_obj = c.take(Kc * durf_wpack_fwd_bytes(128));
+    w.wb_obj = c.take(Kc * durf_wpack_bwd_bytes(128));
+    w.view_tile = c.take(trows * 32 * 2);
+    w.obj_view_tile = c.take(K > 0 ? (size_t)K * durf_obj_view_stride(B, N) : 0);
+    w.norms = (float*)c.take((size_t)L * 5 * 4);
+    w.prep = (float*)c.take((size_t)2 * 5 * B * 4);
+    w.ray_sums = (float*)c.take((size_t)L * B * 4 * 4);
+    w.sums = (float*)c.take((size_t)L * 7 * 4);
+    w.draw = (float*)c.take(rows * 4 * 4);
+    w.part = (float*)c.take(durf_dw_part_floats(256) * 4);
+    w.bpart = (float*)c.take(durf_dw_bpart_floats(256) * 4);
+    w.opart = (float*)c.take(K > 0 ? (size_t)K * durf_dw_part_floats(128) * 4 : 0);
+    w.obpart = (float*)c.take(K > 0 ? (size_t)K * durf_dw_bpart_floats(128) * 4 : 0);
+    w.scratch = (float*)c.take(durf_optim_scratch_floats(n_params) * 4);
+    for (int l = 0; l < L; l++) {
+        w.terms[l] = (float*)c.take((size_t)7 * B * 4);
+        w.enc[l] = c.take(trows * 64 * 2);
+        w.raw_c[l] = (float*)c.take(rows * 4 * 4);
+        w.raw_b[l] = (float*)c.take(rows * 4 * 4);
+        w.stash[l] = c.take(durf_mlp_stash_bytes(256, rows));
+        w.mask[l] = c.take(durf_mlp_mask_bytes(rows));
+        w.dz[l] = c.take(durf_mlp_stash_bytes(256, rows));
+        w.dz_out[l] = c.take(trows * 16 * 2);
+        if (K > 0) {
+            w.obj_enc[l] = c.take((size_t)K * durf_obj_enc_stride(B, N));
+            w.obj_raw[l] = (float*)c.take((size_t)K * rows * 4 * 4);
+            w.obj_stash[l] = c.take((size_t)K * durf_mlp_stash_bytes(128, rows));
+            w.obj_mask[l] = c.take((size_t)K * durf_mlp_mask_bytes(rows));
+            w.obj_dz[l] = c.take((size_t)K * durf_mlp_stash_bytes(128, rows));
+            w.obj_dz_out[l] = c.take((size_t)K * durf_obj_dzout_stride(B, N));
+        }
+    }
+    w.total = (c.off + 255) & ~(size_t)255;
+    return w;
+}
+
+int check_args(const durf_train_args* a, void* workspace) {
+    DURF_REQUIRE(a != nullptr && workspace != nullptr, "arguments and workspace");
+    const durf_forward_args& f = a->f;
+    DURF_REQUIRE(f.B > 0 && f.N % 32 == 0 && f.N >= 32 && f.N <= 256, "B > 0, num_samples a multiple of 32 in [32, 256]");
+    DURF_REQUIRE(f.K >= 0 && f.K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
+    DURF_REQUIRE(f.num_levels >= 2 && f.num_levels <= DURF_FORWARD_MAX_LEVELS, "2 <= num_levels <= DURF_FORWARD_MAX_LEVELS");
+    DURF_REQUIRE(((size_t)workspace & 255) == 0, "workspace aligned to 256 bytes");
+    DURF_REQUIRE(a->box_floats + a->mlp0_floats + (size_t)f.K * a->obj_floats == a->n_params,
+                 "flat layout: box_centers | MLP_0 | K object MLPs");
+    DURF_REQUIRE(f.bkgd_params == a->params + a->box_floats &&
+                 (f.K == 0 || (f.obj_params == a->params + a->box_floats + a->mlp0_floats && f.obj_param_stride == a->obj_floats)),
+                 "f.bkgd_params / f.obj_params point into params");
+    DURF_REQUIRE(f.bkgd_mode == 0 || f.bkgd_mode == 1, "fixed background colour (grey or white)");
+    return 0;
+}
+
+#define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)
+
+int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
+    const durf_forward_args& f = a->f;
+    const int B = f.B, N = f.N, K = f.K, L = f.num_levels;
+    const size_t rows = (size_t)B * N;
+    hipStream_t hs = (hipStream_t)stream;
+    int rc;
+    // ---- forward (obbpose_model.py:68-261), activations stashed ----
+    STEP(durf_ray_prologue(stream, B, K, N, f.origins, f.directions, f.pose, f.ext, w.o_s, w.d_s, w.hit, f.zo, f.viewdirs, w.view,
+                           f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0]));
+    if (K > 0)
+        STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
+                              f.dyn_mask));
+    else
+        STEP((int)hipMemsetAsync(f.dyn_mask, 0, (size_t)B * 4, hs));
+    STEP(durf_pack_weights_all(stream, f.bkgd_params, 60, w.wf_bkgd, w.wb_bkgd, K, f.obj_params, f.obj_param_stride, 63, w.wf_obj,
+                               w.wb_obj));
+    const float* raw_obj[ML][DURF_MAX_OBJ];
+    for (int l = 0; l < L; l++)
+        for (int k = 0; k < K; k++) raw_obj[l][k] = w.obj_raw[l] + (size_t)k * rows * 4;
+    const int obj_flags = f.enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER);
+    for (int lvl = 0; lvl < L; lvl++) {
+        float* t_vals = f.t_vals[lvl];
+        if (K > 0) {
+            STEP(durf_encode_bkgd(stream, B, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags, w.enc[lvl], nullptr, w.idx_cls,
+                                  w.count_cls));
+            STEP(durf_mlp_fwd(stream, 256, rows, N, w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c[lvl], w.stash[lvl],
+                              w.mask[lvl], w.idx_cls + B, w.count_cls + 1));
+            STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], nullptr));
+            STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, f.radii, f.barf_w, obj_flags,
+                                    w.view, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
+                                    lvl == 0 ? w.obj_view_tile : nullptr));
+        } else {
+            STEP(durf_encode_bkgd(stream, B, N, t_vals, w.o_s, w.d_s, f.radii, nullptr, 0, f.enc_flags, w.enc[lvl], nullptr, nullptr,
+                                  nullptr));
+            STEP(durf_mlp_fwd(stream, 256, rows, N, w.enc[lvl], w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl],
+                              w.mask[lvl], nullptr, nullptr));
+        }
+        if (lvl + 1 < L)        // composite + resample + the loss normalisers of this (level 0 only) and the next level: one launch
+            STEP(durf_composite_resample(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, t_vals, w.d_s, f.density_bias,
+                                         f.bkgd_mode, f.rgb[lvl], f.depth[lvl], f.acc[lvl], f.weights[lvl], f.t_mids[lvl],
+                                         f.t_dists[lvl], f.resample_padding, f.u_rand, f.t_vals[lvl + 1], a->lossmult, a->gt_depth,
+                                         a->sky, f.dyn_mask, f.zo, a->eps, a->box_loss_mult, lvl, a->disable_multiscale,
+                                         lvl == 0 ? w.prep : nullptr, lvl == 0 ? w.norms : nullptr, w.prep + (size_t)5 * B,
+                                         w.norms + (size_t)(lvl + 1) * 5));
+        // (the last level launches no composite: durf_loss_bwd recomputes it and fills its rendered outputs)
+    }
+    // ---- losses + backward (train_boxpose.py:67-252), last level first ----
+    if (K > 0)
+        STEP(durf_expand_view(stream, rows, N, w.view, w.idx_cls, w.count_cls, w.view_tile, w.idx_cls + B, w.count_cls + 1));
+    else
+        STEP(durf_expand_view(stream, rows, N, w.view, nullptr, nullptr, w.view_tile, nullptr, nullptr));
+    for (int lvl = L - 1; lvl >= 0; lvl--) {
+        const bool last = lvl == L - 1;
+        float* rs = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;
+        STEP(durf_loss_bwd(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, f.t_vals[lvl], w.d_s, a->pixels, a->lossmult,
+                           a->gt_depth, a->sky, f.dyn_mask, f.zo, w.norms + (size_t)lvl * 5, a->eps, a->level_mults[lvl],
+                           a->box_loss_mult, lvl, a->disable_multiscale, a->bg, f.density_bias, w.draw, w.terms[lvl], nullptr,
+                           last ? f.rgb[lvl] : nullptr, last ? f.depth[lvl] : nullptr, last ? f.acc[lvl] : nullptr,
+                           last ? f.weights[lvl] : nullptr, last ? f.t_mids[lvl] : nullptr, last ? f.t_dists[lvl] : nullptr, rs));
+        if (K > 0) {
+            STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw, w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
+                              nullptr, w.idx_cls + B, w.count_cls + 1, rs));
+            STEP(durf_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw, w.wb_obj, w.obj_mask[lvl], w.obj_dz[lvl],
+                                    w.obj_dz_out[lvl], nullptr));
+        } else {
+            STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw, nullptr, nullptr, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl], nullptr,
+                              nullptr, nullptr, nullptr));
+        }
+    }
+    // ---- weight gradients of every MLP over every level: the objects' split-K partials, the background's, one finalize ----
+    STEP((int)hipMemsetAsync(a->grad, 0, a->n_params * 4, hs));
+    const void *enc[ML], *vt[ML], *stash[ML], *dz[ML], *dzo[ML], *ovt[ML];
+    size_t seg_rows[ML];
+    int per_ray[ML];
+    const int32_t* seg_count[ML];
+    for (int l = 0; l < L; l++) {
+        vt[l] = w.view_tile; ovt[l] = w.obj_view_tile;
+        seg_rows[l] = rows;
+        per_ray[l] = K > 0 ? 1 : N;                           // de-duplicated: one segment of count_cls[2] valid rows
+        seg_count[l] = K > 0 ? w.count_cls + 2 : nullptr;
+    }
+    if (K > 0) {
+        for (int l = 0; l < L; l++) { enc[l] = w.obj_enc[l]; stash[l] = w.obj_stash[l]; dz[l] = w.obj_dz[l]; dzo[l] = w.obj_dz_out[l]; }
+        STEP(durf_obj_dw_partials(stream, K, B, N, w.count_obj, L, enc, ovt, stash, dz, dzo, w.opart, w.obpart));
+    }
+    for (int l = 0; l < L; l++) { enc[l] = w.enc[l]; stash[l] = w.stash[l]; dz[l] = w.dz[l]; dzo[l] = w.dz_out[l]; }
+    STEP(durf_mlp_dw_levels(stream, 256, L, seg_rows, per_ray, seg_count, enc, vt, stash, dz, dzo, w.part, w.bpart));
+    float* g_bkgd = a->grad + a->box_floats;
+    float* g_obj = g_bkgd + a->mlp0_floats;
+    STEP(durf_dw_finalize_all(stream, 60, L, seg_rows, per_ray, seg_count, w.part, w.bpart, g_bkgd, f.bkgd_params, K, K ? B : 0,
+                              K ? N : 0, K ? w.count_obj : nullptr, K ? L : 1, 63, K ? w.opart : nullptr, K ? w.obpart : nullptr,
+                              K ? g_obj : nullptr, K ? a->obj_floats : 0, K ? f.obj_params : nullptr));
+    if (K > 1)                  // rays that hit two boxes: the reference's NaN -> zero update (durf_poison_multi_hit)
+        STEP(durf_poison_multi_hit(stream, a->n_params, a->grad, w.count_cls, a->box_floats, K, a->mlp0_floats, a->obj_floats));
+    // ---- the logged scalars (utils.Stats), one launch ----
+    const float* tv[ML];
+    const float* terms[ML];
+    for (int l = 0; l < L; l++) { tv[l] = f.t_vals[l]; terms[l] = w.terms[l]; }
+    STEP(durf_train_stats(stream, L, K, N, w.norms, w.sums, nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
+                          K ? a->target6 : nullptr, tv, a->stat_mults, 3 /* assemble | psnr */, a->stats, terms, B));
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params) {
+    return carve(nullptr, B, N, K, num_levels, n_params).total;
+}
+
+int durf_loss_backward(void* stream, const durf_train_args* a, void* workspace) {
+    int rc = check_args(a, workspace);
+    if (rc != 0) return rc;
+    return loss_backward(stream, a, carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params));
+}
+
+int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
+    int rc = check_args(a, workspace);
+    if (rc != 0) return rc;
+    DURF_REQUIRE(a->adam_m && a->adam_v && a->grad_stats, "Adam moments and grad_stats");
+    const TrainWs w = carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params);
+    STEP(loss_backward(stream, a, w));
+    return durf_clip_adam(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, 1.0f, a->max_val, a->max_norm, a->lr, a->step,
+                          w.scratch, a->grad_stats);
+}
+
+}  // extern "C"

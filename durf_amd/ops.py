@@ -903,6 +903,36 @@ class ForwardArgs(C.Structure):
                 [('dyn_mask', C.c_void_p), ('zo', C.c_void_p)])
 
 
+class TrainArgs(C.Structure):
+    """durf_train_args (include/durf_hip.h), field for field"""
+    _fields_ = ([('f', ForwardArgs)] +
+                [(n, C.c_void_p) for n in ('lossmult', 'pixels', 'gt_depth', 'sky', 'target6', 'prev6')] +
+                [('eps', C.c_float), ('box_loss_mult', C.c_float), ('bg', C.c_float), ('disable_multiscale', C.c_int),
+                 ('level_mults', (C.c_float * 6) * FORWARD_MAX_LEVELS), ('stat_mults', C.c_float * 6), ('params', C.c_void_p)] +
+                [(n, C.c_size_t) for n in ('n_params', 'box_floats', 'mlp0_floats', 'obj_floats')] +
+                [(n, C.c_void_p) for n in ('grad', 'stats', 'adam_m', 'adam_v')] +
+                [('lr', C.c_float), ('max_val', C.c_float), ('max_norm', C.c_float), ('step', C.c_int), ('grad_stats', C.c_void_p)])
+
+
+def _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
+                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep):
+    B, K = rays.origins.shape[0], pose.shape[0]
+    a.B, a.N, a.K, a.num_levels, a.enc_flags, a.lindisp, a.bkgd_mode = B, N, K, num_levels, enc_flags, int(lindisp), bkgd_mode
+    a.density_bias, a.resample_padding = density_bias, resample_padding
+    a.barf_w = (C.c_float * 10)(*[float(x) for x in barf_weights(alpha)])
+    flat = [t.reshape(-1).contiguous() for t in (rays.radii, rays.near, rays.far)]
+    keep.extend(flat)
+    a.origins, a.directions, a.viewdirs = _p(_f32(rays.origins)), _p(_f32(rays.directions)), _p(_f32(rays.viewdirs))
+    a.radii, a.near, a.far = (_p(_f32(t)) for t in flat)
+    a.pose, a.ext = (_p(_f32(pose)) if K else None), (_p(_f32(ext)) if K else None)
+    a.bkgd_params = _p(_f32(bkgd_params))
+    a.obj_params, a.obj_param_stride = (_p(_f32(obj_params)) if K else None), int(obj_param_stride)
+    a.t_rand, a.u_rand = _p(t_rand), _p(u_rand)
+    for i, name in enumerate(('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')):
+        setattr(a, name, _vp4(*([o[i].data_ptr() for o in outs] + [None] * (FORWARD_MAX_LEVELS - num_levels))))
+    a.dyn_mask, a.zo = _p(dyn), _p(zo)
+
+
 def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp=False,
                  bkgd_mode=BKGD_GREY, density_bias=-1.0, resample_padding=0.01, t_rand=None, u_rand=None):
     """MipNerfModel.__call__ in inference as ONE library call (durf_forward): -> list[num_levels] of
@@ -914,22 +944,51 @@ def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, 
     outs = [(f(B, 3), f(B), f(B), f(B, N), f(B, N + 1), f(B, N), f(B, N)) for _ in range(num_levels)]
     dyn, zo = torch.empty(B, 1, dtype=torch.int32, device=dev), f(B)
     a = ForwardArgs()
-    a.B, a.N, a.K, a.num_levels, a.enc_flags, a.lindisp, a.bkgd_mode = B, N, K, num_levels, enc_flags, int(lindisp), bkgd_mode
-    a.density_bias, a.resample_padding = density_bias, resample_padding
-    a.barf_w = (C.c_float * 10)(*[float(x) for x in barf_weights(alpha)])
-    flat1 = lambda t: _p(_f32(t.reshape(-1).contiguous()))
-    keep = [t.reshape(-1).contiguous() for t in (rays.radii, rays.near, rays.far)]
-    a.origins, a.directions, a.viewdirs = _p(_f32(rays.origins)), _p(_f32(rays.directions)), _p(_f32(rays.viewdirs))
-    a.radii, a.near, a.far = (_p(_f32(t)) for t in keep)
-    a.pose, a.ext = (_p(_f32(pose)) if K else None), (_p(_f32(ext)) if K else None)
-    a.bkgd_params = _p(_f32(bkgd_params))
-    a.obj_params, a.obj_param_stride = (_p(_f32(obj_params)) if K else None), int(obj_param_stride)
-    a.t_rand, a.u_rand = _p(t_rand), _p(u_rand)
-    for i, name in enumerate(('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')):
-        setattr(a, name, _vp4(*([o[i].data_ptr() for o in outs] + [None] * (FORWARD_MAX_LEVELS - num_levels))))
-    a.dyn_mask, a.zo = _p(dyn), _p(zo)
+    keep = []
+    _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
+                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep)
     ws = torch.empty(int(L.durf_forward_workspace_bytes(B, N, K)), dtype=torch.uint8, device=dev)
     assert ws.data_ptr() % 256 == 0
     with _Timed('forward_call'):
         _lib.check(L.durf_forward(_stream(), C.byref(a), _p(ws)), 'durf_forward')
     return outs, dyn, zo
+
+
+def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_floats, N, num_levels, alpha, enc_flags,
+               lossmult, pixels, gt_depth, sky, target6, prev6, eps, box_loss_mult, bg, disable_multiscale, level_mults,
+               stat_mults, lr, max_val, max_norm, step, lindisp=False, bkgd_mode=BKGD_GREY, density_bias=-1.0,
+               resample_padding=0.01, t_rand=None, u_rand=None, update=True):
+    """One shard's training step as ONE library call (durf_train_step; update=False: durf_loss_backward, parameters
+    untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None)"""
+    B, K = rays.origins.shape[0], pose.shape[0]
+    dev = rays.origins.device
+    L = _lib.lib()
+    f = lambda *sh: torch.empty(*sh, device=dev)
+    outs = [(f(B, 3), f(B), f(B), f(B, N), f(B, N + 1), f(B, N), f(B, N)) for _ in range(num_levels)]
+    dyn, zo = torch.empty(B, 1, dtype=torch.int32, device=dev), f(B)
+    grad, stats, gstats = torch.empty_like(params_flat), f(2 + 17 * num_levels), f(4)
+    a = TrainArgs()
+    keep = []
+    o0 = box_floats + mlp0_floats
+    _fill_forward_args(a.f, rays, pose, ext, params_flat[box_floats:o0], params_flat[o0:] if K else None, obj_floats, N, num_levels,
+                       alpha, enc_flags, lindisp, bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep)
+    hold = [t.reshape(-1).contiguous() for t in (lossmult, gt_depth, sky)] + [pixels.contiguous()]
+    a.lossmult, a.gt_depth, a.sky, a.pixels = (_p(_f32(t)) for t in hold)
+    hold += [target6.contiguous(), prev6.contiguous()] if K else []
+    a.target6, a.prev6 = (_p(_f32(hold[-2])), _p(_f32(hold[-1]))) if K else (None, None)
+    a.eps, a.box_loss_mult, a.bg, a.disable_multiscale = float(eps), float(box_loss_mult), float(bg), int(disable_multiscale)
+    for lvl in range(num_levels):
+        for i in range(6):
+            a.level_mults[lvl][i] = float(level_mults[lvl][i])
+    a.stat_mults = (C.c_float * 6)(*[float(x) for x in stat_mults])
+    a.params, a.n_params = _p(_f32(params_flat)), params_flat.numel()
+    a.box_floats, a.mlp0_floats, a.obj_floats = int(box_floats), int(mlp0_floats), int(obj_floats)
+    a.grad, a.stats, a.grad_stats = _p(grad), _p(stats), _p(gstats)
+    a.adam_m, a.adam_v = _p(_f32(m)), _p(_f32(v))
+    a.lr, a.max_val, a.max_norm, a.step = float(lr), float(max_val), float(max_norm), int(step)
+    ws = torch.empty(int(L.durf_train_workspace_bytes(B, N, K, num_levels, params_flat.numel())), dtype=torch.uint8, device=dev)
+    assert ws.data_ptr() % 256 == 0
+    with _Timed('train_call'):
+        fn = L.durf_train_step if update else L.durf_loss_backward
+        _lib.check(fn(_stream(), C.byref(a), _p(ws)), 'durf_train_step' if update else 'durf_loss_backward')
+    return outs, dyn, zo, grad, stats, (gstats if update else None)

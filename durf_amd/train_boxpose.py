@@ -297,6 +297,59 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     return new_state, stats, new_rng, pose.clone()
 
 
+def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, update=True):
+    """`train_step` through ONE library call (durf_train_step, csrc/train.hip): the orchestration of loss_and_grad /
+    train_step done in C for hosts that are not Python; same arguments, same (new_state, stats, rng, pose), bit-identical
+    results (tests/test_gpu_train_call.py).  Scope of the C entry point: bf16 MLPs, frozen box poses, >= 2 levels, no density
+    noise, no weight decay, fixed background colour, one device.  update=False: gradient and scalars only
+    (durf_loss_backward) -> (grad, stats buffer views, per-level outputs)."""
+    model._check()
+    variables = state.variables
+    lay = variables.layout
+    K, L, N = lay.K, model.num_levels, model.num_samples
+    if (model.mlp_precision != 'bf16' or not (model.no_pose_opt and model.no_yaw_opt) or (K and not model.dynamics) or L < 2 or
+            config.weight_decay_mult != 0 or config.rand_bkgd or (config.randomized and model.density_noise > 0) or
+            _dist() is not None):
+        raise NotImplementedError('durf_train_step covers the single-device bf16 step with frozen box poses (see csrc/train.hip)')
+    rays = batch['rays']
+    B = rays.origins.shape[0]
+    dev = variables.flat.device
+    if config.randomized and noise is None:
+        u = torch.rand(2, B, N + 1, device=dev, generator=om._make_generator(rng, dev))
+        noise = dict(t_rand=u[0], u_rand=u[1])
+    ts = int(batch['ts'])
+    pose = variables['params']['box_centers'][ts].contiguous()
+    flags = ((ops.ENC_CONTRACT if model.contraction else 0) | (ops.ENC_NO_INTEGRATION if model.disable_integration else 0) |
+             (ops.ENC_CYLINDER if model.ray_shape == 'cylinder' else 0))
+    outs, dyn, zo, grad, out, gs = ops.train_call(
+        rays, pose, batch['ext'].reshape(-1, 3).contiguous() if K else None, variables.flat, state.m, state.v,
+        lay.box[1] - lay.box[0], lay.mlp_size[om.W_BKGD], lay.mlp_size[om.W_OBJ], N, L, alpha, flags,
+        rays.lossmult, batch['pixels'][..., :3], batch['depth'], batch['sky'], batch['target'] if K else None,
+        prev[0] if K else None, eps, config.box_loss_mult, 1.0 if config.white_bkgd else 0.5, config.disable_multiscale_loss,
+        [level_multipliers(config, lvl, L) for lvl in range(L)], _stat_mults(config), lr, config.grad_max_val,
+        config.grad_max_norm, state.step, lindisp=model.lindisp, bkgd_mode=ops.BKGD_WHITE if config.white_bkgd else ops.BKGD_GREY,
+        density_bias=model.density_bias, resample_padding=model.resample_padding,
+        t_rand=noise['t_rand'] if config.randomized else None, u_rand=noise['u_rand'] if config.randomized else None,
+        update=update)
+    box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
+    ret = [tuple(o) + ([pose[:, :3], box_rot0], dyn, zo) for o in outs]
+    st = ops.stats_views(out, L)
+    if not update:
+        return grad, st, ret
+    pose_out = ret[0][7][0]
+    stats = utils.Stats(
+        loss=st['loss'], obj_losses=st['obj_losses'], losses=st['losses'], d_losses=st['d_losses'],
+        n_losses=st['n_losses'], e_losses=st['e_losses'], s_losses=st['s_losses'],
+        distr_losses=st['distr_losses'], tv_losses=st['tv_losses'], sampling_stats=st['sampling_stats'],
+        offsets=st['offsets'], offset_x=st['offset_x'], offset_y=st['offset_y'], offset_z=st['offset_z'],
+        offset_yaw=st['offset_yaw'], pose=pose_out, weights=[r[3] for r in ret], samples=[r[4] for r in ret],
+        weight_l2=st['weight_l2'], psnr=st['psnrs'][-1], psnrs=st['psnrs'], obj_psnr=st['obj_psnrs'][-1],
+        grad_norm=gs[0], grad_abs_max=gs[1], grad_norm_clipped=gs[3],
+        multi_hit_rays=(dyn > 1).sum() if K > 1 else torch.zeros((), dtype=torch.int64, device=dev))
+    new_rng = (int(rng) + 1) if isinstance(rng, int) else rng
+    return TrainState(variables, state.m, state.v, state.step + 1), stats, new_rng, pose_out.clone()
+
+
 # ---------------------------------------------------------------------------
 # data-parallel plumbing (one process per GPU; jax.pmap's role, train_boxpose.py:370-374)
 # ---------------------------------------------------------------------------

@@ -121,6 +121,15 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_forward.restype = i32
     L.durf_forward.argtypes = [vp, vp, vp]
     #   (stream, args, workspace)
+    L.durf_train_workspace_bytes.restype = u64
+    L.durf_train_workspace_bytes.argtypes = [i32, i32, i32, i32, u64]
+    #   (B, N, K, num_levels, n_params)
+    L.durf_loss_backward.restype = i32
+    L.durf_loss_backward.argtypes = [vp, vp, vp]
+    #   (stream, args, workspace)
+    L.durf_train_step.restype = i32
+    L.durf_train_step.argtypes = [vp, vp, vp]
+    #   (stream, args, workspace)
     L.durf_mlp_f32_act_floats.restype = u64
     L.durf_mlp_f32_act_floats.argtypes = [i32, i32]
     #   (width, in_dim)

@@ -311,6 +311,38 @@ typedef struct durf_forward_args {
 size_t durf_forward_workspace_bytes(int B, int N, int K);
 int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
 
+/* ---- one shard's training step as ONE call (csrc/train.hip) ------------------------------------------------
+ * durf_loss_backward: value_and_grad(loss_fn) of train_step (train_boxpose.py:67-252) -- the forward with activations
+ * stashed, the losses, the backward, the weight gradients of every MLP, the reference's multi-hit outcome
+ * (durf_poison_multi_hit) and the logged scalars -- in the order durf_amd/train_boxpose.py issues them, on `stream`,
+ * bit-identical to that path.  A data-parallel host all-reduces `grad` (and `stats` when it logs) and calls
+ * durf_clip_adam (lax.pmean, train_boxpose.py:253-255); durf_train_step = durf_loss_backward + durf_clip_adam with
+ * inv_world = 1 for a single device.  Scope: the benchmarked configuration -- bf16 MLPs, frozen box poses (no_pose_opt
+ * and no_yaw_opt: box_centers get a zero gradient), >= 2 levels, no density noise, no weight decay, fixed background
+ * colour (f.bkgd_mode 0 / 1, bg = 0.5 / 1.0).  `f` carries the rays, boxes, draws and -- as outputs -- each level's
+ * rendered values; f.bkgd_params / f.obj_params must point into `params`.  workspace:
+ * durf_train_workspace_bytes(B, N, K, num_levels, n_params) bytes, 256-byte aligned. */
+typedef struct durf_train_args {
+    durf_forward_args f;
+    const float *lossmult, *pixels, *gt_depth, *sky;     /* Rays.lossmult [B], batch pixels [B,3], depth [B], sky [B] */
+    const float *target6, *prev6;                         /* batch target [K,6], prev[0] [K,6]: offsets / TV statistics */
+    float eps, box_loss_mult, bg;                         /* near-loss interval; Config.box_loss_mult; background colour */
+    int disable_multiscale;                               /* Config.disable_multiscale_loss */
+    float level_mults[DURF_FORWARD_MAX_LEVELS][6];        /* per level: rgb, sky, depth, near, empty, distortion (train_boxpose.py:211-220) */
+    float stat_mults[6];                                  /* coarse, sky, depth, near, empty, tv loss multipliers (durf_train_stats) */
+    float* params;                                        /* flat parameters: box_centers | MLP_0 | K x BoxMLP */
+    size_t n_params, box_floats, mlp0_floats, obj_floats;
+    float* grad;                                          /* [n_params] out: d(loss)/d(params) of this shard, not post-processed */
+    float* stats;                                         /* [2 + 17 num_levels] out: durf_train_stats layout */
+    float *adam_m, *adam_v;                               /* durf_train_step only: Adam moments [n_params] */
+    float lr, max_val, max_norm;                          /*   learning rate, Config.grad_max_val, Config.grad_max_norm */
+    int step;                                             /*   optimizer step count (0 for the first update) */
+    float* grad_stats;                                    /*   [4] out: grad_norm, grad_abs_max, clip multiplier, grad_norm_clipped */
+} durf_train_args;
+size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params);
+int durf_loss_backward(void* stream, const durf_train_args* args, void* workspace);
+int durf_train_step(void* stream, const durf_train_args* args, void* workspace);
+
 /* ---- exact-fp32 MLP (csrc/mlp_f32.hip) -----------------------------------------------------------
  * The reference's Dense layers are fp32 (obbpose_model.py:326-327; HIGHEST-precision matmul, internal/math.py:22-24).
  * These entry points evaluate the same stack with v_mfma_f32_32x32x2_f32 (exact fp32: bitwise an fmaf chain over the

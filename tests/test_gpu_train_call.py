@@ -1,0 +1,92 @@
+"""durf_train_step / durf_loss_backward (csrc/train.hip): one shard's training step as ONE C call -- with durf_forward the
+coarse entry points SURVEY 8b proposed for hosts that are not Python.  They issue the same stage kernels in the same order as
+durf_amd/train_boxpose.py does, so parameters, Adam moments, the gradient, every logged scalar and every rendered output must
+be BIT-identical to train_step / loss_and_grad -- which are the paths the parity tests measure against the oracle and
+against the reference's own train_step (tests/test_golden_ref_train.py)."""
+import pytest
+import torch
+
+from durf_amd import obbpose_model, synthetic, train_boxpose, utils
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _eq(a, b, what):
+    assert torch.allclose(a, b, rtol=0, atol=0, equal_nan=True), what
+
+
+@pytest.mark.parametrize('B,K,N,randomized,extra', [
+    (4096, 3, 128, True, ''),                                            # the benchmarked shape (cfg3)
+    (1000, 1, 64, True, 'Config.white_bkgd = True\nConfig.box_loss_mult = 2\n'),
+    (777, 0, 32, False, 'Config.disable_multiscale_loss = True\n'),      # static model, ragged ray count
+    (640, 8, 32, True, 'MipNerfModel.ray_shape = "cylinder"\nMipNerfModel.disable_integration = True\n'),
+    (512, 2, 32, False, 'MipNerfModel.num_levels = 3\n'),
+])
+def test_one_call_train_step_is_bit_identical_to_train_step(cuda, B, K, N, randomized, extra):
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\nConfig.randomized = %s\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
+                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.01\n%s' % (N, randomized, extra))
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(B, K, seed=950 + K, allow_multi_hit=K > 1, noise_boxes=0.2)
+    db = H.device_batch(b, cuda)
+    prev = db['init'][0:1] + 0.01
+    results = []
+    for fn in (train_boxpose.train_step, train_boxpose.train_step_one_call):
+        model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+        state = train_boxpose.create_train_state(variables)
+        rng, log = 11, []
+        for _ in range(3):
+            state, stats, rng, pose = fn(model, config, rng, state, db, 5e-4, 0.7, 6.5, prev)
+            log.append((stats, pose))
+        torch.cuda.synchronize()
+        results.append((state, log))
+    (s0, l0), (s1, l1) = results
+    _eq(s0.variables.flat, s1.variables.flat, 'parameters after 3 steps')
+    _eq(s0.m, s1.m, 'Adam m')
+    _eq(s0.v, s1.v, 'Adam v')
+    assert s0.step == s1.step == 3
+    for step, ((a, pa), (c, pc)) in enumerate(zip(l0, l1)):
+        _eq(pa, pc, 'pose')
+        for name in ('loss', 'losses', 'obj_losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses', 'tv_losses',
+                     'sampling_stats', 'offsets', 'offset_x', 'offset_y', 'offset_z', 'offset_yaw', 'psnr', 'psnrs', 'obj_psnr',
+                     'grad_norm', 'grad_abs_max', 'grad_norm_clipped'):
+            _eq(getattr(a, name), getattr(c, name), 'step %d: %s' % (step, name))
+        assert int(a.multi_hit_rays) == int(c.multi_hit_rays)
+        for wa, wc in zip(a.weights + a.samples, c.weights + c.samples):
+            _eq(wa, wc, 'step %d: logged weights / samples' % step)
+
+
+def test_loss_backward_gives_the_gradient_of_loss_and_grad(cuda):
+    B, K, N = 2048, 3, 64
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\nConfig.randomized = True\nConfig.rand_bkgd = False\n' % N)
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(B, K, seed=961)
+    db = H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+    state = train_boxpose.create_train_state(variables)
+    g = torch.Generator().manual_seed(2)
+    noise = dict(t_rand=torch.rand(B, N + 1, generator=g).to(cuda), u_rand=torch.rand(B, N + 1, generator=g).to(cuda))
+    flat0 = variables.flat.clone()
+    want, raw, _ = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, 10.0, db['init'][0:1], noise=noise)
+    got, st, ret = train_boxpose.train_step_one_call(model, config, 0, state, db, 5e-4, 3.0, 10.0, db['init'][0:1], noise=noise,
+                                                     update=False)
+    _eq(got, want, 'gradient')
+    _eq(variables.flat, flat0, 'durf_loss_backward leaves the parameters alone')
+    for lvl in range(2):
+        for i in range(7):
+            _eq(ret[lvl][i], raw['ret'][lvl][i], 'level %d output %d' % (lvl, i))
+
+
+def test_unsupported_configurations_are_refused(cuda):
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = 32\nMipNerfModel.no_pose_opt = False\nMipNerfModel.no_yaw_opt = False\n')
+    config = utils.configured(utils.Config)
+    db = H.device_batch(synthetic.make_batch(256, 1, seed=5), cuda)
+    model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+    with pytest.raises(NotImplementedError):
+        train_boxpose.train_step_one_call(model, config, 0, train_boxpose.create_train_state(variables), db, 5e-4, 3.0, 10.0,
+                                          db['init'][0:1])

@@ -202,3 +202,28 @@ def test_c2f_schedule():
     steps = (1000, 2000, 3000)
     got = [raygen.c2f_factor(i, steps) for i in (0, 1000, 1001, 2000, 2001, 3000, 3001, 10 ** 6)]
     assert got == [16, 16, 12, 12, 8, 8, 4, 4]          # c2f_obb_dataset.py:306-313 (inclusive upper bounds)
+
+
+def test_argument_structs_match_the_header(tmp_path):
+    """durf_forward_args / durf_train_args: the ctypes Structures of durf_amd/ops.py against the C definitions in
+    include/durf_hip.h, compiled here with gcc -- size and the offset of every field."""
+    import ctypes
+    import subprocess
+    from durf_amd import ops
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <stdint.h>', '#include "%s/include/durf_hip.h"' % root,
+             'int main(void) {']
+    for cname, cls in (('durf_forward_args', ops.ForwardArgs), ('durf_train_args', ops.TrainArgs)):
+        lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for name, _ in cls._fields_:
+            lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, name, cname, name))
+    lines += ['  return 0;', '}']
+    src = tmp_path / 'layout.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'layout'
+    subprocess.run(['gcc', str(src), '-o', str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in (('durf_forward_args', ops.ForwardArgs), ('durf_train_args', ops.TrainArgs)):
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for name, _ in cls._fields_:
+            assert int(got['%s.%s' % (cname, name)]) == getattr(cls, name).offset, (cname, name)
