@@ -114,7 +114,7 @@ class _AnyModule(types.ModuleType):
         return _Any()
 
 
-_DUMMIES = ('absl.app', 'flax.core', 'flax.metrics', 'flax.metrics.tensorboard', 'flax.training', 'flax.training.checkpoints',
+_DUMMIES = ('cv2', 'natsort', 'absl.app', 'flax.core', 'flax.metrics', 'flax.metrics.tensorboard', 'flax.training', 'flax.training.checkpoints',
             'matplotlib', 'matplotlib.pyplot', 'internal.obbpose_dataset', 'internal.c2f_obb_dataset', 'internal.vis')
 
 
@@ -189,6 +189,9 @@ def _install():
         if not name.startswith('_'):
             setattr(jnp, name, getattr(np, name))
     jnp.ndarray = np.ndarray
+    _ax = lambda a: tuple(a) if isinstance(a, list) else a            # jnp reductions accept a list of axes
+    jnp.mean = lambda x, axis=None, **k: np.mean(x, axis=_ax(axis), **k)
+    jnp.sum = lambda x, axis=None, **k: np.sum(x, axis=_ax(axis), **k)
     jnp.arange = lambda *a, **k: np.arange(*a, **k).view(_JArr)
     jnp.matmul = lambda a, b, precision=None: np.matmul(a, b)
     jnp.linalg = np.linalg
@@ -211,7 +214,11 @@ def _install():
             return (f(x + h * t) - f(x - h * t)) / (2 * h)
         return f(x), jvp
     jax.linearize = linearize
-    jax.vmap = lambda f, in_axes=0, out_axes=0: f
+    def vmap(f, in_axes=0, out_axes=0):
+        if in_axes == 0 and out_axes == 0:         # the hot path only maps functions that are vectorized already
+            return f
+        return lambda z: np.stack([f(np.take(z, i, axis=in_axes)) for i in range(z.shape[in_axes])], axis=out_axes)
+    jax.vmap = vmap
     import functools
     tu = types.ModuleType('jax.tree_util')
     tu.tree_map = tree_map
@@ -236,6 +243,8 @@ def _install():
     jnn = types.ModuleType('jax.nn')
     jnn.initializers = types.SimpleNamespace(glorot_uniform=lambda: None)
     jsp = types.ModuleType('jax.scipy')
+    import scipy.signal
+    jsp.signal = types.SimpleNamespace(convolve2d=lambda z, f, mode='full', precision=None: scipy.signal.convolve2d(z, f, mode=mode))
     jax.numpy, jax.lax, jax.random, jax.nn, jax.scipy = jnp, lax, random, jnn, jsp
     sys.modules['jax.tree_util'] = tu
 
@@ -284,7 +293,7 @@ def _drop_internal():
         del sys.modules[k]
 
 
-def load(modules=('math', 'mip', 'mip360', 'box_helpers', 'utils', 'obbpose_model'), train=False):
+def load(modules=('math', 'mip', 'mip360', 'box_helpers', 'utils', 'obbpose_model'), train=False, dataset=False):
     """-> namespace of the reference's modules, imported unmodified under the stand-ins"""
     global _saved
     assert available(), 'reference tree not present'
@@ -293,6 +302,10 @@ def load(modules=('math', 'mip', 'mip360', 'box_helpers', 'utils', 'obbpose_mode
     sys.path.insert(0, REF)
     _drop_internal()
     ns = types.SimpleNamespace(**{n: importlib.import_module('internal.' + n) for n in modules})
+    if dataset:    # internal/obbpose_dataset.py for real (cv2 / natsort: dummies; its file readers are not called)
+        for name in ('cv2', 'natsort'):
+            sys.modules[name] = _AnyModule(name)
+        ns.obbpose_dataset = importlib.import_module('internal.obbpose_dataset')
     if train:      # /root/reference/train_boxpose.py: train_step (:49-321); everything it imports beside the hot path is a dummy
         for name in _DUMMIES:
             sys.modules[name] = _AnyModule(name)
