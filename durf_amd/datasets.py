@@ -213,7 +213,11 @@ class Waymo:
 
     # -- iteration -------------------------------------------------------------------------------
     def _dev(self, a):
-        return torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device)
+        """device copy of a (static) table, made once: a per-step pageable upload would stop the host (raygen.IndexUploader)"""
+        cache = self.__dict__.setdefault('_dev_cache', {})
+        if id(a) not in cache:
+            cache[id(a)] = (a, torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.device))
+        return cache[id(a)][1]
 
     def _next_train(self):
         """:1551-1587: one timestep, batch_size pixel indices of its concatenated cameras (the SAME draw on every
@@ -223,7 +227,9 @@ class Waymo:
         td = self.ts_data[time_index]
         ray_indices = self.rng.randint(0, td.n_rays, (self.config.batch_size,))
         per = self.config.batch_size // self.world
-        mine = torch.as_tensor(ray_indices[self.rank * per:(self.rank + 1) * per].astype(np.int32), device=self.device)
+        if getattr(self, '_upload', None) is None:
+            self._upload = raygen.IndexUploader(self.device)
+        mine = self._upload(ray_indices[self.rank * per:(self.rank + 1) * per])
         rays, px, dp, sk = raygen.generate_batch(td, mine, self.near, self.far)
         ts = int(self.ts_values[time_index]) - 1
         return dict(rays=rays, pixels=px, depth=dp, sky=sk, init=self._dev(tb['init']), ext=self._dev(tb['ext'][ts]),

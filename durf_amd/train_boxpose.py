@@ -569,7 +569,9 @@ class SyntheticTimestepDataset:
         td = self.ts_data[ts]
         per = self.config.batch_size // self.world
         idx_all = self.rs.integers(0, td.n_rays, self.config.batch_size)                  # same draw on every rank
-        idx = torch.tensor(idx_all[self.rank * per:(self.rank + 1) * per], dtype=torch.int32, device=self.device)
+        if getattr(self, '_upload', None) is None:
+            self._upload = raygen.IndexUploader(self.device)                              # (no host stall per step)
+        idx = self._upload(idx_all[self.rank * per:(self.rank + 1) * per])
         rays, px, dp, sk = raygen.generate_batch(td, idx, self.config.near, self.config.far)
         return dict(rays=rays, pixels=px, depth=dp, sky=sk, init=self.init, ext=self.ext, ts=ts, target=self.target_all[ts])
 
