@@ -411,6 +411,12 @@ class MipNerfModel:
             trunk = ops.bkgd_const_trunk_f32(variables.mlp_flat('MLP_0'))
         variables._trunk_cache = (trunk, variables.flat._version)
 
+    def supports_one_call(self, variables, randomized=False):
+        """whether durf_forward (apply_one_call) covers this model's inference path"""
+        K = variables.layout.K
+        return (self.mlp_precision == 'bf16' and not (K and (not self.dynamics or self.object_precision() != 'bf16')) and
+                not (randomized and self.density_noise > 0) and variables.flat.device.type == 'cuda')
+
     def apply_one_call(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha, noise=None):
         """`apply` through ONE library call (durf_forward, csrc/forward.hip): the orchestration of `_forward(train=False)`
         done in C for hosts that are not Python; same arguments, same list of 10-tuples, bit-identical results
@@ -418,10 +424,9 @@ class MipNerfModel:
         self._check()
         lay = variables.layout
         K = lay.K
-        if self.mlp_precision != 'bf16' or (K and (not self.dynamics or self.object_precision() != 'bf16')):
-            raise NotImplementedError('durf_forward covers the bf16 inference path (dynamics=True, bf16 object MLPs)')
-        if randomized and self.density_noise > 0:
-            raise NotImplementedError('durf_forward applies no density noise')
+        if not self.supports_one_call(variables, randomized):
+            raise NotImplementedError('durf_forward covers the bf16 inference path (dynamics=True, bf16 object MLPs, no '
+                                      'density noise)')
         B, N = rays.origins.shape[0], self.num_samples
         dev = rays.origins.device
         if randomized and noise is None:

@@ -417,9 +417,12 @@ def make_schedules(config):
     return lr_fn, eps_fn, alpha_fn
 
 
-def make_render_fn(model, config, variables, one_call=False):
+def make_render_fn(model, config, variables, one_call=None):
     """render_eval_fn (train_boxpose.py:377-390): test-mode model.apply; the all-gather lives in render_image.
-    one_call: each chunk through the single C entry point durf_forward (MipNerfModel.apply_one_call; bit-identical)."""
+    one_call: each chunk through the single C entry point durf_forward (MipNerfModel.apply_one_call; bit-identical, a few
+    launches' worth of host work less per chunk); None = wherever that entry point covers the model."""
+    if one_call is None:
+        one_call = model.supports_one_call(variables)
     apply = model.apply_one_call if one_call else model.apply
 
     def render_fn(rng, batch):
