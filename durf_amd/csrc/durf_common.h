@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <cstdlib>
 #include <stdio.h>
 #include "../../include/durf_hip.h"
 
@@ -16,6 +17,15 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DURF_WAVE 64
 
 void durf_set_error(const char* fmt, ...);
+
+namespace durf {
+// A/B switch of the 128-sample (4-wave) blocks the fused forward / backward use for launches that would leave half the
+// chip idle (mlp_fwd.hip launch_mlp_fwd): DURF_HALF_BLOCKS=0 keeps 256-sample blocks everywhere.  Read once.
+inline bool half_blocks_enabled() {
+    static const bool on = [] { const char* e = getenv("DURF_HALF_BLOCKS"); return !(e && e[0] == '0'); }();
+    return on;
+}
+}  // namespace durf
 
 #define DURF_CHECK_LAUNCH(name)                                              \
     do {                                                                     \

@@ -33,11 +33,12 @@ struct BPipe {        // same protocol as WPipe (mlp_fwd.hip): asm LDS-DMA, coun
     unsigned lds0;
     char* lds;
     int slot_bytes, par, wave, lane;
+    int nw;              // waves of the workgroup (8, or 4: launch_mlp_bwd)
     int since;           // stores this wave issued after its last weight DMA (lower bound)
     __device__ __forceinline__ void skip(int chunks) { gnext += chunks * 1024u; }
     __device__ __forceinline__ void issue(int slot, int chunks) {
         const unsigned dst = lds0 + (unsigned)(slot * slot_bytes);
-        for (int c = wave; c < chunks; c += 8)
+        for (int c = wave; c < chunks; c += nw)
             lds_dma16_cached(rsrc, gnext + c * 1024u, lane * 16u, dst + c * 1024u);
         gnext += chunks * 1024u;
         since = 0;
@@ -171,7 +172,7 @@ __device__ __forceinline__ void run_enc_stage(BPipe& p, const bf16x8* in, f32x16
     }
 }
 
-template <int W, bool POSE>
+template <int W, bool POSE, int NWV = 8>
 __global__ void __launch_bounds__(512, 2)
 k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
           const int32_t* __restrict__ count, const char* __restrict__ wpack,
@@ -200,26 +201,26 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
         const size_t t = nrows_c + (size_t)(*tail_count);
         nrows = t < rows ? t : rows;
     }
-    if ((size_t)blockIdx.x * 256 >= nrows) return;
+    if ((size_t)blockIdx.x * (32 * NWV) >= nrows) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // stagger SIMD partners (see mlp_fwd.hip)
     const size_t ntile32 = rows >> 5;
-    const size_t nblk = (nrows + 255) / 256;
+    const size_t nblk = (nrows + 32 * NWV - 1) / (32 * NWV);
 
     BPipe p;
     constexpr int SLOT = 4 * (S::KW + 1);
     p.rsrc = make_rsrc(wpack);
     p.gnext = 0; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
     p.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    p.wave = wave; p.lane = lane;
+    p.wave = wave; p.lane = lane; p.nw = NWV;
     constexpr int GB0 = bgroup_tiles(S::CT, 1, SLOT) * 1;                 // all tiles of the rgb-head stage
     p.issue(0, GB0);
 
   // persistent workgroup (see mlp_fwd.hip): loop over this CU's 256-sample blocks
   for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const bool has_next = blk + gridDim.x < nblk;
-    const size_t tile32 = blk * 8 + wave;
+    const size_t tile32 = blk * NWV + wave;
     const size_t row = tile32 * 32 + (lane & 31);
     const bool valid = row < nrows;
     const bool tile_valid = tile32 * 32 < nrows;
@@ -1028,18 +1029,21 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
     DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
     if (rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const unsigned nblk = durf_cdiv(rows, 256);
-    dim3 grid(nblk < 256u ? nblk : 256u, K), block(512);     // persistent: at most one workgroup per CU and object
-#define LAUNCH_B(WW, PP)                                                                                   \
+    // (as launch_mlp_fwd: 128-sample blocks of 4 waves when 256-sample blocks would leave half the chip idle)
+    const bool half = width == 256 && K == 1 && !d_enc && durf_cdiv(rows, 256) <= 128 && durf::half_blocks_enabled();
+    const unsigned nblk = durf_cdiv(rows, half ? 128u : 256u);
+    dim3 grid(nblk < 256u ? nblk : 256u, K), block(half ? 256 : 512);     // persistent: at most one workgroup per CU and object
+#define LAUNCH_B(WW, PP, NWV)                                                                              \
     {                                                                                                      \
         constexpr int lds = 2 * 4 * (MlpSpec<WW>::KW + 1) * 1024;                                          \
-        (void)hipFuncSetAttribute((const void*)k_mlp_bwd<WW, PP>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((k_mlp_bwd<WW, PP>), grid, block, lds, s, rows, N, draw, ray_idx, count,         \
+        (void)hipFuncSetAttribute((const void*)k_mlp_bwd<WW, PP, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((k_mlp_bwd<WW, PP, NWV>), grid, block, lds, s, rows, N, draw, ray_idx, count,    \
                            (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out,  \
                            d_enc, st, tail_idx, tail_count, draw_ray_sum);                                 \
     }
-    if (width == 256) { if (d_enc) LAUNCH_B(256, true) else LAUNCH_B(256, false) }
-    else { if (d_enc) LAUNCH_B(128, true) else LAUNCH_B(128, false) }
+    if (half) LAUNCH_B(256, false, 4)
+    else if (width == 256) { if (d_enc) LAUNCH_B(256, true, 8) else LAUNCH_B(256, false, 8) }
+    else { if (d_enc) LAUNCH_B(128, true, 8) else LAUNCH_B(128, false, 8) }
 #undef LAUNCH_B
     DURF_CHECK_LAUNCH("durf_mlp_bwd");
     return 0;

@@ -60,10 +60,11 @@ struct WPipe {
     int slot_bytes;
     int par;             // slot that holds the tile about to be consumed
     int wave, lane;
+    int nw;              // waves of the workgroup (8; 4 for launches that would leave half the chip idle, launch_mlp_fwd)
     int since;           // vector-memory ops (stores) this wave issued after its last weight DMA (lower bound)
     __device__ __forceinline__ void issue(int slot, int chunks) {
         const unsigned dst = lds0 + (unsigned)(slot * slot_bytes);
-        for (int c = wave; c < chunks; c += 8)
+        for (int c = wave; c < chunks; c += nw)
             lds_dma16_cached(rsrc, gnext + c * 1024u, lane * 16u, dst + c * 1024u);
         gnext += chunks * 1024u;
         since = 0;
@@ -235,7 +236,7 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
 }
 
 
-template <int W, bool TRAIN>
+template <int W, bool TRAIN, int NWV = 8>
 __global__ void __launch_bounds__(512, 2)
 k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
           const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
@@ -269,21 +270,21 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         const size_t t = nrows_c + (size_t)(*tail_count);
         nrows = t < rows ? t : rows;
     }
-    if ((size_t)blockIdx.x * 256 >= nrows) return;           // whole workgroup idle
+    if ((size_t)blockIdx.x * (32 * NWV) >= nrows) return;    // whole workgroup idle
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Waves w and w+4 share a SIMD; static priority for the younger half staggers them so one
     // wave's epilogue can run under its partner's MFMAs.
     if (wave >= 4) __builtin_amdgcn_s_setprio(1);
     const size_t ntile32 = rows >> 5;
-    const size_t nblk = (nrows + 255) / 256;
+    const size_t nblk = (nrows + 32 * NWV - 1) / (32 * NWV);
 
     WPipe p;
     constexpr int SLOT = 4 * (S::KW + 1);            // chunks per LDS slot (two slots)
     p.rsrc = make_rsrc(wpack);
     p.gnext = 0; p.lds = smem; p.slot_bytes = SLOT * 1024; p.par = 0;
     p.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-    p.wave = wave; p.lane = lane;
+    p.wave = wave; p.lane = lane; p.nw = NWV;
     // prologue: first tile group of stage 0 -> slot 0
     constexpr int G0 = group_tiles(S::WT, S::KE + 1, SLOT) * (S::KE + 1);
     p.issue(0, G0);
@@ -293,7 +294,7 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
   // group + encoding fetch) behind the previous block's last stages.
   for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
     const bool has_next = blk + gridDim.x < nblk;
-    const size_t tile32 = blk * 8 + wave;
+    const size_t tile32 = blk * NWV + wave;
     const size_t row = tile32 * 32 + (lane & 31);
     const bool valid = row < nrows;
     const bool tile_valid = tile32 * 32 < nrows;
@@ -498,18 +499,23 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
     DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
     if (rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const unsigned nblk = durf_cdiv(rows, 256);
-    dim3 grid(nblk < 256u ? nblk : 256u, K), block(512);     // persistent: at most one workgroup per CU and object
-#define LAUNCH_F(WW, TR)                                                                          \
+    // A launch that fills at most half the chip with 256-sample blocks (8 waves) runs as 128-sample blocks (4 waves): twice the
+    // workgroups, each with half the dependent work, one per CU as before (cfg1: 128 -> 256 workgroups).
+    const bool half = width == 256 && K == 1 && durf_cdiv(rows, 256) <= 128 && durf::half_blocks_enabled();
+    const unsigned per = half ? 128u : 256u;
+    const unsigned nblk = durf_cdiv(rows, per);
+    dim3 grid(nblk < 256u ? nblk : 256u, K), block(half ? 256 : 512);     // persistent: at most one workgroup per CU and object
+#define LAUNCH_F(WW, TR, NWV)                                                                     \
     {                                                                                             \
         constexpr int lds = 2 * 4 * (MlpSpec<WW>::KW + 1) * 1024;                                 \
-        (void)hipFuncSetAttribute((const void*)k_mlp_fwd<WW, TR>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((k_mlp_fwd<WW, TR>), grid, block, lds, s, rows, N, (const bf16x8*)enc_tile, \
+        (void)hipFuncSetAttribute((const void*)k_mlp_fwd<WW, TR, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((k_mlp_fwd<WW, TR, NWV>), grid, block, lds, s, rows, N, (const bf16x8*)enc_tile, \
                            (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw,  \
                            (bf16x8*)stash, (uint4*)relu_mask, st, tail_idx, tail_count);           \
     }
-    if (width == 256) { if (stash) LAUNCH_F(256, true) else LAUNCH_F(256, false) }
-    else { if (stash) LAUNCH_F(128, true) else LAUNCH_F(128, false) }
+    if (half) { if (stash) LAUNCH_F(256, true, 4) else LAUNCH_F(256, false, 4) }
+    else if (width == 256) { if (stash) LAUNCH_F(256, true, 8) else LAUNCH_F(256, false, 8) }
+    else { if (stash) LAUNCH_F(128, true, 8) else LAUNCH_F(128, false, 8) }
 #undef LAUNCH_F
     DURF_CHECK_LAUNCH("durf_mlp_fwd");
     return 0;
