@@ -112,3 +112,25 @@ def test_c2f_levels_on_the_device(cuda):
             torch.testing.assert_close(getattr(got, name).cpu(), torch.tensor(flat), rtol=3e-5 if name == 'radii' else 2e-6,
                                        atol=1e-7, msg=lambda m: '%s at factor %d: %s' % (name, fac, m))
         assert torch.equal(px.cpu(), torch.tensor(np.concatenate([im.reshape(-1, 3) for im in levels[fac]['images']], 0)))
+
+
+def test_index_uploader_ring(cuda):
+    """raygen.IndexUploader: per-step pixel indices through a ring of pinned staging buffers with non_blocking copies --
+    every upload arrives intact although the slots are reused (more uploads than slots, growing and shrinking sizes, the GPU
+    kept busy in between so that the copies really are pending when the host moves on)."""
+    up = raygen.IndexUploader(cuda, slots=3)
+    rs = np.random.default_rng(3)
+    busy = torch.randn(2048, 2048, device=cuda)
+    sent, got = [], []
+    for i in range(12):
+        n = int(rs.integers(1, 9000))
+        idx = rs.integers(0, 1 << 30, n)
+        busy = busy @ busy * 1e-3                         # work queued ahead of the copy
+        sent.append(idx.astype(np.int32))
+        got.append(up(idx))
+    torch.cuda.synchronize()
+    for a, b in zip(sent, got):
+        assert b.dtype == torch.int32 and b.device.type == 'cuda'
+        np.testing.assert_array_equal(b.cpu().numpy(), a)
+    cpu = raygen.IndexUploader('cpu')
+    np.testing.assert_array_equal(cpu(sent[0]).numpy(), sent[0])
