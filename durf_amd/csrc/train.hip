@@ -1,7 +1,7 @@
 // durf_loss_backward / durf_train_step: value_and_grad(loss_fn) of train_step (train_boxpose.py:49-321) for one shard as ONE
 // C call -- the orchestration durf_amd/train_boxpose.py (loss_and_grad, train_step) and obbpose_model.py (_forward, train)
 // do in Python, for hosts that are not Python (durf_forward / durf_loss_backward / durf_clip_adam).  No kernel
-// of its own: the stage entry points of this library in the order the Python path issues them on ONE stream, every
+// of its own but a fill: the stage entry points of this library in the order the Python path issues them on ONE stream, every
 // intermediate carved out of a caller-owned workspace.  Scope: the benchmarked training configuration -- bf16 MLPs,
 // frozen box poses (no_pose_opt and no_yaw_opt), >= 2 levels, no density noise, no weight decay, fixed background colour.
 // Results are bit-identical to train_boxpose.train_step (tests/test_gpu_train_call.py).
@@ -22,6 +22,11 @@ struct Carver {
 };
 
 constexpr int ML = DURF_FORWARD_MAX_LEVELS;
+
+// (the one kernel of this file: hipMemsetAsync costs a few microseconds more than a fill launch between two kernels)
+__global__ void __launch_bounds__(256) k_zero(size_t n, float* __restrict__ p) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0f;
+}
 
 struct TrainWs {
     float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *draw, *part, *bpart, *opart, *obpart, *scratch;
@@ -173,7 +178,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
         }
     }
     // ---- weight gradients of every MLP over every level: the objects' split-K partials, the background's, one finalize ----
-    STEP((int)hipMemsetAsync(a->grad, 0, a->n_params * 4, hs));
+    hipLaunchKernelGGL(k_zero, dim3(512), dim3(256), 0, hs, a->n_params, a->grad);
     const void *enc[ML], *vt[ML], *stash[ML], *dz[ML], *dzo[ML], *ovt[ML];
     size_t seg_rows[ML];
     int per_ray[ML];
