@@ -4,9 +4,18 @@
 Build container only.  /root/reference/train_boxpose.py is imported unmodified under the numpy stand-ins of
 tests/ref_standin.py and its `train_step` (:49-321) runs on the reference's MipNerfModel (float64; PRNG draws replayed).
 Committed per case: the PRNG draws, a parameter checksum, every logged scalar of the reference's `loss_fn`, and the
-derivative of the reference's loss along seeded random directions (all of MLP_0, each BoxMLP, the step's box poses) by
-central differences of the reference's own `loss_fn` closure with `lax.stop_gradient` replayed
-(tests/test_reference_train_crosscheck.py explains the method and checks the oracle against the same runs).
+derivative of the reference's loss by central differences of the reference's own `loss_fn` closure with
+`lax.stop_gradient` replayed (tests/test_reference_train_crosscheck.py explains the method and checks the oracle against
+the same runs), along three families of directions:
+  * `derivatives`: seeded random directions, one per parameter group (all of MLP_0, each BoxMLP, the step's box poses);
+  * `grad_dir_derivatives`: per parameter group the direction g / |g| of the oracle's own gradient g restricted to the
+    group -- along it the reference's central difference IS the norm of the reference's gradient, so a gradient that is
+    zero, or scaled, or rotated away by more than the tolerance cannot reproduce it (the random directions alone cannot
+    tell: a dense Gaussian v over 594 308 entries makes tol * |g| * |v| hundreds of times the derivative);
+  * `layer_dir_derivatives`: the same per Dense kernel of MLP_0 (12 directions), which pins the split of the gradient
+    over the layers.
+The directions are not stored: a machine without /root/reference regenerates them from the oracle (float64 autograd on
+the committed seeds) and `grad_norms` checks that it got the same ones.
 tests/test_golden_ref_train.py checks the oracle (CPU) and the HIP path (GPU) against these vectors on machines that have
 no /root/reference.  A fixture is data -- seeds, draws, expected outputs -- no reference text.
     python tests/golden/make_ref_train_golden.py
@@ -28,6 +37,7 @@ from tests.ref_standin import Hooks, StopGrad, Uniform  # noqa: E402
 SCALARS = ('loss', 'losses', 'obj_losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses', 'tv_losses',
            'sampling_stats', 'offsets', 'offset_x', 'offset_y', 'offset_z', 'offset_yaw', 'weight_l2')
 STEPS = (1e-7, 1e-8, 1e-9)
+LAYER_STEPS = (1e-7, 1e-8)
 
 CASES = {
     # Waymo knobs, pose optimisation with the TV prior, box-weighted rgb loss, weight decay, stratified sampling
@@ -38,11 +48,17 @@ CASES = {
     'K1_frozen_det': dict(B=64, K=1, N=32, seed=312, alpha=10.0, eps=3.0,
                           config=dict(randomized=False, white_bkgd=True, disable_multiscale_loss=True),
                           model=dict(no_pose_opt=True, no_yaw_opt=True)),
-    # yaw only, static model (boxes select rays only), cylinder rays
+    # yaw only (positions frozen), dynamic model, cone rays: the yaw-only switch on a configuration the product runs
+    'K2_yaw_only': dict(B=64, K=2, N=32, seed=318, alpha=7.0, eps=0.2,
+                        config=dict(randomized=True, tv_loss_mult=1e-3),
+                        model=dict(no_pose_opt=True, no_yaw_opt=False)),
+    # yaw only, static model (boxes select rays only), cylinder rays: a knob combination the product rejects
+    # (MipNerfModel._check) -- pins the oracle only, see HIP_CASES
     'K2_yaw_only_static': dict(B=64, K=2, N=32, seed=313, alpha=10.0, eps=0.2,
                                config=dict(randomized=True, tv_loss_mult=1e-3),
                                model=dict(no_pose_opt=True, no_yaw_opt=False, dynamics=False, ray_shape='cylinder')),
 }
+HIP_CASES = ('K3_pose_opt_rand', 'K1_frozen_det', 'K2_yaw_only')        # the cases the HIP train step is held to
 
 
 class Optimizer:
@@ -136,6 +152,40 @@ def directions(params, b, seed):
     return out
 
 
+def groups(params):
+    return ['box_centers'] + [n for n in params if n != 'box_centers']
+
+
+def gradient_directions(params, grads):
+    """per parameter group: the gradient restricted to the group, normalised -> [(group, [v per leaf]), ...], norms.
+    `grads`: one tensor per leaf of R.params_leaves (the oracle's autograd gradient).  Along g / |g| the directional
+    derivative is |g|: what a zeroed, scaled or mis-directed gradient cannot reproduce."""
+    own = owners(params)
+    out, norms = [], []
+    for target in groups(params):
+        nrm = float(sum(float((g * g).sum()) for g, o in zip(grads, own) if o == target)) ** 0.5
+        vs = [(g / nrm) if (o == target and nrm > 0.0) else torch.zeros_like(g) for g, o in zip(grads, own)]
+        out.append((target, vs))
+        norms.append(nrm)
+    return out, norms
+
+
+def layer_directions(params, grads, group='MLP_0'):
+    """the same per Dense kernel of one MLP: [('MLP_0/Dense_3', [v per leaf]), ...], norms"""
+    own = owners(params)
+    first = own.index(group)
+    out, norms = [], []
+    for i in range(len(params[group])):
+        li = first + 2 * i                                 # leaves of an MLP: kernel, bias per Dense
+        nrm = float(grads[li].norm())
+        vs = [torch.zeros_like(g) for g in grads]
+        if nrm > 0.0:
+            vs[li] = grads[li] / nrm
+        out.append(('%s/Dense_%d' % (group, i), vs))
+        norms.append(nrm)
+    return out, norms
+
+
 def run_reference(ref, case, grad_tree=None, lr=5e-4):
     """the reference's train_step on the case -> (new_state, stats, pose, loss closure(tree, mode) -> float, inputs)"""
     c, b, ob, params, prev, noise, config, model_cfg = setup(case)
@@ -163,13 +213,15 @@ def run_reference(ref, case, grad_tree=None, lr=5e-4):
     return new_state, stats, pose, ref_loss, (c, b, ob, params, prev, noise, config, model_cfg, tree)
 
 
-def reference_derivatives(ref_loss, params, tree, dirs):
-    """central differences of the reference's loss along each direction, at every step size of STEPS: [groups, steps]"""
+def reference_derivatives(ref_loss, params, tree, dirs, steps=STEPS):
+    """central differences of the reference's loss along each direction, at every step size of `steps`: [groups, steps]"""
     leaves = R.params_leaves(params)
     ref_loss(tree, 'record')
-    out = np.zeros((len(dirs), len(STEPS)))
+    out = np.zeros((len(dirs), len(steps)))
     for gi, (_, vs) in enumerate(dirs):
-        for hi, h in enumerate(STEPS):
+        if all(float(v.abs().max()) == 0.0 for v in vs):      # a group no ray reaches: derivative 0, nothing to run
+            continue
+        for hi, h in enumerate(steps):
             plus = tree_of(params, [z + h * v for z, v in zip(leaves, vs)])
             minus = tree_of(params, [z - h * v for z, v in zip(leaves, vs)])
             out[gi, hi] = (ref_loss(plus, 'replay') - ref_loss(minus, 'replay')) / (2 * h)
@@ -187,12 +239,20 @@ def main():
             rec = {k: np.asarray(getattr(stats, k), dtype=np.float64) for k in SCALARS}
             rec['pose'] = np.asarray(pose, dtype=np.float64)
             rec['derivatives'] = reference_derivatives(ref_loss, params, tree, dirs)
+            _, grads = oracle(params, ob, config, model_cfg, c, prev, noise)
+            gdirs, gnorms = gradient_directions(params, grads)
+            ldirs, lnorms = layer_directions(params, grads)
+            rec['grad_norms'], rec['layer_grad_norms'] = np.array(gnorms), np.array(lnorms)
+            rec['grad_dir_derivatives'] = reference_derivatives(ref_loss, params, tree, gdirs)
+            rec['layer_dir_derivatives'] = reference_derivatives(ref_loss, params, tree, ldirs, LAYER_STEPS)
             flat = torch.cat([z.reshape(-1) for z in R.params_leaves(params)])
             rec['param_checksum'] = np.array([float(flat.sum()), float((flat * flat).sum())])
             rec['t_rand'], rec['u_rand'] = noise['t_rand'].numpy(), noise['u_rand'].numpy()
             path = os.path.join(gold, 'ref_train_' + case + '.npz')
             np.savez_compressed(path, **rec)
             print(case, '%.1f KB' % (os.path.getsize(path) / 1024), 'loss', float(rec['loss']), 'derivatives', rec['derivatives'][:, 1])
+            print('   |g| per group: oracle', rec['grad_norms'], 'reference', rec['grad_dir_derivatives'][:, 1])
+            print('   |g| per MLP_0 kernel: oracle', rec['layer_grad_norms'], 'reference', rec['layer_dir_derivatives'][:, 1])
     finally:
         ref_standin.unload()
 
