@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 N_LEVELS = 2
 MAC_BKGD, MAC_OBJ = 591872, 167552
 PEAK_BF16 = 2.5e15     # dense MFMA bf16 peak, MI355X_MICROARCH.md
+PEAK_F32 = 157.3e12    # fp32-input MFMA (v_mfma_f32_32x32x2_f32) = the fp32 vector rate, MI355X_MICROARCH.md
 PEAK_HBM = 8.0e12      # HBM3E spec peak (6.29e12 measured-achievable), MI355X_MICROARCH.md
 # algorithmic bytes per ray-level of the HBM-bound stages: derived from the workload's samples/ray in main()
 # (N = 128: encode 15 928 B with bf16 features; composite 3 108 B + 516 B for the next level's t_vals in the fused launch)
@@ -61,6 +62,10 @@ def parse_args():
     ap.add_argument('--config', default='cfg3', choices=sorted(WORKLOADS))
     ap.add_argument('--rays', type=int, default=0, help='rays per GPU (default: the workload\'s)')
     ap.add_argument('--objects', type=int, default=-1, help='override the number of dynamic boxes K')
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'],
+                    help="f32: the whole model in the reference's own arithmetic (MipNerfModel.mlp_precision = 'f32': every "
+                         'Dense layer on v_mfma_f32_32x32x2_f32, accurate-libm encodings; obbpose_model.py:326-327, '
+                         'internal/math.py:22-24) -- the roofline is then priced against the 157.3 TFLOP/s fp32-MFMA peak')
     ap.add_argument('--prewarm-events', type=int, default=512,
                     help='timing events recorded (and kept alive) before the warm-up: grows the HIP runtime\'s event pool there')
     ap.add_argument('--max-ahead', type=int, default=0, help='bound the number of steps the host may enqueue ahead of the GPU (0 = unbounded)')
@@ -119,10 +124,12 @@ def spawn_ranks(n):
     return rc
 
 
-def setup_workload(name, dev, rank=0, world=1, rays=0, objects=-1):
+def setup_workload(name, dev, rank=0, world=1, rays=0, objects=-1, precision='bf16'):
     """Config, model, train state and this rank's shard of the named workload (also used by tools/)."""
     from durf_amd import obbpose_model, synthetic, train_boxpose, utils
     gin, K_OBJ, far, wl_rays, extra, noise, alpha, label = WORKLOADS[name]
+    if precision != 'bf16':
+        extra = tuple(extra) + ('MipNerfModel.mlp_precision = "%s"' % precision,)
     if objects >= 0:
         K_OBJ = objects
     B = rays or wl_rays
@@ -371,13 +378,19 @@ def main():
     flush_c_stdio()       # RCCL's version banner (every rank, C stdio, otherwise flushed at exit -- after rank 0's JSON line)
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    if world > torch.cuda.device_count():
+    shared_gpu = os.environ.get('DURF_DIST_BACKEND') == 'gloo'      # tests: several gloo ranks on one device
+    if world > torch.cuda.device_count() and not shared_gpu:
         raise SystemExit('--gpus %d but only %d visible' % (world, torch.cuda.device_count()))
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
-    w = setup_workload(args.config, dev, rank, world, rays=args.rays, objects=args.objects)
+    w = setup_workload(args.config, dev, rank, world, rays=args.rays, objects=args.objects, precision=args.precision)
     config, model, state, batch, batch_np, prev = (w[k] for k in ('config', 'model', 'state', 'batch', 'batch_np', 'prev'))
+    f32 = args.precision == 'f32'
+    # the three background-MLP launches of a level by timer name, and the MFMA peak they are priced against
+    k_fwd, k_bwd, k_dw = ('mlp_fwd_f32_256', 'mlp_bwd_f32_256', 'mlp_dw_f32_256') if f32 else \
+        ('mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256')
+    peak = PEAK_F32 if f32 else PEAK_BF16
     B, K_OBJ, far, alpha, label, NS = w['B'], w['K'], w['far'], w['alpha'], w['label'], w['N']
     lr, eps = 5e-4, 3.0
 
@@ -402,8 +415,7 @@ def main():
     # timing events, none after this pre-warm even with --warmup 2).  With the timers switched on at the first timed step
     # and 5 warm-up steps, that stall used to sit in the timed region and cost every earlier figure of this repo 4-5 %.
     # `step_ms` in the JSON line (p50 / p90 / max / slow_steps) shows any such outlier.
-    ops.TIMED_NAMES = None if args.profile_ops else {'mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256', 'encode_bkgd',
-                                                     'composite_resample'}
+    ops.TIMED_NAMES = None if args.profile_ops else {k_fwd, k_bwd, k_dw, 'encode_bkgd', 'composite_resample'}
     ops.TIMERS = {}
     prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]    # kept alive to the end
     for e in prewarm:
@@ -456,8 +468,9 @@ def main():
         # Roofline.  MLP kernels: MFMA-bound by definition -- algorithmic FLOPs per launch
         # = 2 * 591 872 MAC * samples (one level; the dW launch covers both levels) / live HIP-event time /
         # 2.5 PFLOP/s.  Encode / composite: HBM-bound -- algorithmic bytes per ray-level / time / 8 TB/s.
-        mfma = {'mlp_fwd_256_train': 2.0 * MAC_BKGD * rows, 'mlp_bwd_256': 2.0 * MAC_BKGD * rows,
-                'mlp_dw_256': N_LEVELS * 2.0 * MAC_BKGD * rows}
+        # (the fp32 weight-gradient launch is per level, the bf16 one covers both levels)
+        mfma = {k_fwd: 2.0 * MAC_BKGD * rows, k_bwd: 2.0 * MAC_BKGD * rows,
+                k_dw: (1 if f32 else N_LEVELS) * 2.0 * MAC_BKGD * rows}
         # (the fused per-ray launch is latency-bound at 4096 rays, DESIGN.md 4: reported, not a tuning target)
         hbm = {'encode_bkgd': float(enc_bytes) * B, 'composite_resample': float(fused_bytes) * B}
         info = {}
@@ -465,7 +478,7 @@ def main():
             t = s / n
             if k in mfma:
                 info[k] = dict(us=t * 1e6, bound='mfma', achieved=mfma[k] / t / 1e12, unit='TFLOP/s',
-                               frac=mfma[k] / t / PEAK_BF16)
+                               frac=mfma[k] / t / peak)
             elif k in hbm:
                 info[k] = dict(us=t * 1e6, bound='hbm', achieved=hbm[k] / t / 1e9, unit='GB/s',
                                frac=hbm[k] / t / PEAK_HBM)
@@ -475,8 +488,11 @@ def main():
             dom = max(mlp, key=lambda k: info[k]['us'])      # the dominant kernel: longest launch
             d = info[dom]
             tr, src = pmc_traffic(int(_lib.lib().durf_version()), args.config, B, dom)
-            roof = dict(bound='mfma', kernel=dom, achieved=d['achieved'], peak=PEAK_BF16 / 1e12, unit='TFLOP/s',
+            roof = dict(bound='mfma', kernel=dom, achieved=d['achieved'], peak=peak / 1e12, unit='TFLOP/s',
                         frac=d['frac'], traffic=tr, traffic_source=src, launch_us=d['us'], all=info)
+            if not f32 and 'encode_bkgd' not in info and ops.FUSED_ENCODE:
+                # the background encode is no launch of its own any more: the forward computes its tiles' features itself
+                roof['encode_bkgd'] = 'fused into %s (durf_mlp_fwd_enc)' % k_fwd
             if tr:      # what the counter bytes say about the launch: its HBM rate as a fraction of the 8 TB/s peak
                 roof['traffic_frac_of_hbm_peak'] = tr / (d['us'] * 1e-6) / PEAK_HBM
             # end-to-end MFMA rate of the whole step (fwd + bwd-data + dW = 3 x fwd FLOPs, both levels, incl.
@@ -484,13 +500,13 @@ def main():
             step_s = dt / args.steps
             fl = 3 * N_LEVELS * 2.0 * (MAC_BKGD + hit * MAC_OBJ) * rows
             roof['step_mlp_tflops'] = fl / step_s / 1e12
-            roof['step_mlp_frac'] = fl / step_s / PEAK_BF16
+            roof['step_mlp_frac'] = fl / step_s / peak
             per_step = {k: totals[k][1] / args.steps for k in mlp}
             roof['non_mlp_ms_per_step'] = (step_s - sum(per_step.values())) * 1e3
             if totals_ss:
-                roof['single_stream'] = {k: dict(us=sv / nv * 1e6, frac=mfma[k] / (sv / nv) / PEAK_BF16)
+                roof['single_stream'] = {k: dict(us=sv / nv * 1e6, frac=mfma[k] / (sv / nv) / peak)
                                          for k, (nv, sv) in totals_ss.items() if k in mfma}
-            if not args.no_calibration:
+            if not args.no_calibration and not f32:
                 roof['board'] = board_calibration(dev, d['achieved'])
         if args.profile_ops:
             for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
@@ -499,9 +515,9 @@ def main():
         cb = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(batch_np, K_OBJ, NS, config)   # rank 0, N = 1 only
         out = dict(metric='train_rays_per_sec', value=B * world * args.steps / dt, unit='rays/s',
                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype='bf16', data='synthetic',
+                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.precision, data='synthetic',
                    config=dict(workload=label + ', %d samples/ray x 2 levels, 8x256 bkgd MLP + %d 8x128 object MLPs, '
-                                                'full train step' % (NS, K_OBJ),
+                                                'full train step%s' % (NS, K_OBJ, ' in exact fp32 (every Dense on fp32 MFMA)' if f32 else ''),
                                name=args.config, rays_per_gpu=B, global_batch=B * world, num_samples=NS,
                                num_levels=N_LEVELS, objects=K_OBJ, far=far, hit_fraction=hit, randomized=True,
                                pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world,
@@ -509,7 +525,8 @@ def main():
                                # object MLP launches on a side HIP stream (ops.py DURF_OVERLAP_OBJECTS): with '2' the timed
                                # background kernels' durations include what runs beside them
                                object_streams=(ops.overlap_mode(B * NS) if K_OBJ and model.object_precision() == 'bf16' else None),
-                               collective=('rccl all-reduce, world size %d%s' % (world, ' (forced)' if args.force_dist else ''))
+                               collective=('%s all-reduce, world size %d%s' % ('gloo' if shared_gpu else 'rccl', world,
+                                                                               ' (forced)' if args.force_dist else ''))
                                if (world > 1 or args.force_dist) else None),
                    loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,
                    # distribution of the individual steps' GPU time: ms_per_step is the mean over the timed region and

@@ -161,6 +161,8 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 // pointers by these strides (bytes, except idx in int32 elements and params/grads in floats).
 // Strides of 0 with gridDim.y == 1 are the plain per-MLP launches.
 struct FwdStrides { size_t enc, idx, wpack, raw, stash, mask; };
+// the background encoder's inputs, for the forward that encodes its own tiles (k_mlp_fwd<256, .., ENC>; durf_mlp_fwd_enc)
+struct EncIn { const float* t_vals; const float* origins_s; const float* dirs_s; const float* radii; const int32_t* hit; int K; int flags; };
 struct BwdStrides { size_t idx, wpack, mask, dz, dz_out, d_enc; };
 struct DwStrides { size_t enc, view, stash, dz_out, part, bpart; };      // stash stride also applies to dz
 
@@ -173,7 +175,7 @@ int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* i
 int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile, const void* view_bf16,
                    const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
                    void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx = nullptr,
-                   const int32_t* tail_count = nullptr);
+                   const int32_t* tail_count = nullptr, const EncIn* enc_in = nullptr);
 int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
                    const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
                    float* d_enc, int K, const BwdStrides& st, const int32_t* tail_idx = nullptr,

@@ -71,7 +71,7 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
 #define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)
     // ray setup + view encoding + level-0 sample positions (obbpose_model.py:99-131, mip.py:330-370): one launch
     STEP(durf_ray_prologue(stream, B, K, N, a->origins, a->directions, a->pose, a->ext, w.o_s, w.d_s, w.hit, a->zo, a->viewdirs,
-                           w.view, a->near, a->far, a->t_rand, a->lindisp, a->t_vals[0]));
+                           w.view, a->near, a->far, a->t_rand, a->lindisp, a->t_vals[0], nullptr, nullptr, 0));
     if (K > 0)      // per-object hit lists + the ray classes of the de-duplicated background evaluation: one launch
         STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
                               a->dyn_mask));
@@ -84,18 +84,14 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = a->t_vals[lvl];
         if (K > 0) {
-            STEP(durf_encode_bkgd(stream, B, N, t_vals, w.o_s, w.d_s, a->radii, w.hit, K, a->enc_flags, w.enc, nullptr, w.idx_cls,
-                                  w.count_cls));
-            STEP(durf_mlp_fwd(stream, 256, rows, N, w.enc, w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c, nullptr, nullptr,
+            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, w.hit, K, a->enc_flags, w.enc, w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c, nullptr, nullptr,
                               w.idx_cls + B, w.count_cls + 1));
             STEP(durf_expand_raw(stream, B, N, w.raw_c, w.count_cls, w.slot_cls, w.raw_b, nullptr));
             STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, a->radii, a->barf_w,
                                     a->enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), w.view, w.wf_obj, w.obj_enc,
                                     w.obj_raw, nullptr, nullptr, nullptr));
         } else {
-            STEP(durf_encode_bkgd(stream, B, N, t_vals, w.o_s, w.d_s, a->radii, nullptr, 0, a->enc_flags, w.enc, nullptr, nullptr,
-                                  nullptr));
-            STEP(durf_mlp_fwd(stream, 256, rows, N, w.enc, w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b, nullptr, nullptr, nullptr,
+            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, nullptr, 0, a->enc_flags, w.enc, w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b, nullptr, nullptr, nullptr,
                               nullptr));
         }
         STEP(durf_composite_fwd(stream, B, N, K, w.raw_b, raw_obj, w.slot_obj, t_vals, w.d_s, a->density_bias, a->bkgd_mode,

@@ -7,6 +7,7 @@
 // ds_read_b128 is conflict-free), double buffered per output M-tile, one barrier per tile.
 // MFMA-bound: 2*606 208 padded MAC per sample (591 872 algorithmic) for W=256.
 #include "mlp_pack.h"
+#include "enc_lane.h"
 
 // 16 bytes per lane, global -> LDS (lane-linear destination), as a BUFFER load: descriptor in
 // SGPRs, one constant per-lane VGPR offset (lane*16), the chunk offset in an SGPR.  The
@@ -236,13 +237,18 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
 }
 
 
-template <int W, bool TRAIN, int NWV = 8>
+// ENC (W = 256): the workgroup ENCODES its own tiles -- each lane computes its sample's 60 features from the ray data
+// (enc_lane.h, the body of k_encode_lane<false>: bit-identical features), keeps the half its MFMA fragment holds and
+// writes the tile to `enc`, where stage 5 (the skip connection) and the weight-gradient GEMMs of Dense_0 / Dense_5 read
+// it.  Replaces the durf_encode_bkgd launch in front of every forward: one launch, one 64 MB write + read and ~30 us of
+// launch gaps less per level at 4096 rays.
+template <int W, bool TRAIN, int NWV = 8, bool ENC = false>
 __global__ void __launch_bounds__(512, 2)
 k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
           const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
           const char* __restrict__ wpack, float* __restrict__ raw, bf16x8* __restrict__ stash,
           uint4* __restrict__ relu_mask, FwdStrides bs, const int32_t* __restrict__ tail_idx,
-          const int32_t* __restrict__ tail_count) {
+          const int32_t* __restrict__ tail_count, EncIn ei) {
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gridDim.y > 1) {                             // batched object MLPs: this workgroup's object slab
@@ -313,13 +319,33 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     };
     bf16x8 encf[S::KE];
     const char* enc_u = (const char*)enc + tile32 * (S::KE * 1024);      // wave-uniform
+    if constexpr (ENC) {
 #pragma unroll
-    for (int k = 0; k < S::KE; k++)
-        encf[k] = tile_valid ? (tail ? const_enc(k) : *(const bf16x8*)(enc_u + k * 1024 + lane * 16)) : zero8;
-    if (TRAIN && tail && tile_valid) {       // the weight-gradient GEMMs of Dense_0 / Dense_5 read the encoding tile
+        for (int k = 0; k < S::KE; k++) encf[k] = (tile_valid && tail) ? const_enc(k) : zero8;
+        if (tile_valid && !tail) {               // (a non-tail tile is whole: count * N and rows are multiples of 32)
+            const int j = (int)(row / (size_t)N), n = (int)(row % (size_t)N);
+            const int b = ray_idx ? ray_idx[j] : j;
+            const Gauss g = bkgd_sample_gaussian(b, n, N, ei.t_vals, ei.origins_s, ei.dirs_s, ei.radii, ei.hit, ei.K, ei.flags);
+            const bool hi = lane >= 32;          // this lane's fragment of k-step k: features [16 k + 8 hi, + 8) = vector q = 2 k + hi
+            lane_features<false>(g, BarfW{}, [&](auto q_, const bf16x8& o8) {
+                constexpr int q = decltype(q_)::value;
+                if (hi == (bool)(q & 1)) encf[q >> 1] = o8;
+            });
+        }
+        if (tile_valid && (TRAIN || !tail)) {    // stage 5 re-reads the tile; training: so do the weight-gradient GEMMs
 #pragma unroll
-        for (int k = 0; k < S::KE; k++) *(bf16x8*)(const_cast<char*>(enc_u) + k * 1024 + lane * 16) = encf[k];
-        p.since += S::KE;
+            for (int k = 0; k < S::KE; k++) *(bf16x8*)(const_cast<char*>(enc_u) + k * 1024 + lane * 16) = encf[k];
+            p.since += S::KE;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < S::KE; k++)
+            encf[k] = tile_valid ? (tail ? const_enc(k) : *(const bf16x8*)(enc_u + k * 1024 + lane * 16)) : zero8;
+        if (TRAIN && tail && tile_valid) {       // the weight-gradient GEMMs of Dense_0 / Dense_5 read the encoding tile
+#pragma unroll
+            for (int k = 0; k < S::KE; k++) *(bf16x8*)(const_cast<char*>(enc_u) + k * 1024 + lane * 16) = encf[k];
+            p.since += S::KE;
+        }
     }
     // jnp.maximum propagates NaN through every ReLU, v_max_f32 does not.  The only source of
     // non-finite values is the encoding of a garbage (multi-hit) ray, and one non-finite
@@ -380,9 +406,11 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         size_t ray = row / (size_t)N;
         if (tail) ray = valid ? (size_t)tail_idx[row - nrows_c] : 0;
         else if (ray_idx && valid) ray = (size_t)ray_idx[ray];
+        unsigned hi_v = (unsigned)lane >> 5;          // opaque: kept per block, not hoisted as a spilled 64-bit pointer
+        if (ENC) asm volatile("" : "+v"(hi_v));
 #pragma unroll
         for (int k = 0; k < S::KV; k++)
-            vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + (lane >> 5)] : zero8;
+            vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + hi_v] : zero8;
     }
     bf16x8 c[S::KC];
     run_stage<SLOT, S::KW, S::KV, S::CT, true, TRAIN, S::WT>(p, a, vf, c, S::KC + 1, ST(9), tile_valid, a, nullptr, nullptr, mcarry);
@@ -394,7 +422,13 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
 #pragma unroll
             for (int q = 4; q >= 1; q--) STREAM_STORE(ST(9) + (2 * S::CT - q) * 1024 + lane * 16, c[2 * S::CT - q]);
             p.since += 4;
-            if (MK(8)) *(uint4*)(MK(8) + lane * 16) = mcarry;
+            if (MK(8)) {
+                // (the lane offset is made opaque here: hoisted out of the block loop as a 64-bit per-lane pointer it is
+                // the one value the ENC instantiation spills, and a scratch reload waits for vmcnt(0) -- every store in flight)
+                unsigned lo = (unsigned)lane * 16u;
+                asm volatile("" : "+v"(lo));
+                *(uint4*)(MK(8) + lo) = mcarry;
+            }
         }
         const f32x16 acc = mma_tile<S::KC, 0>(slot, lane, c, nullptr);
         if (valid && lane < 32) {
@@ -454,6 +488,21 @@ int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_para
     return durf::launch_pack(stream, width, in_dim, 1, mlp_params, 0, wpack_fwd, wpack_bwd);
 }
 
+int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
+                     const float* radii, const int32_t* hit, int K, int enc_flags, void* enc_tile, const void* view_bf16,
+                     const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
+                     void* relu_mask, const int32_t* tail_idx, const int32_t* tail_count) {
+    DURF_REQUIRE((tail_idx == nullptr) == (tail_count == nullptr), "tail_idx and tail_count go together");
+    DURF_REQUIRE(tail_idx == nullptr || (count != nullptr && N % 32 == 0), "tail rows follow a compacted ray list");
+    DURF_REQUIRE((ray_idx == nullptr) == (count == nullptr), "ray_idx and count go together");
+    DURF_REQUIRE(t_vals && origins_s && dirs_s && radii && enc_tile, "ray data and the encoding tile buffer are required");
+    DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ && (K == 0 || hit != nullptr), "0 <= K <= DURF_MAX_OBJ, hit [B,K]");
+    DURF_REQUIRE(N > 0 && (count != nullptr ? N % 32 == 0 : rows % 32 == 0), "whole 32-sample tiles");
+    const EncIn ei{t_vals, origins_s, dirs_s, radii, hit, K, enc_flags};
+    return durf::launch_mlp_fwd(stream, 256, rows, N, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash,
+                                relu_mask, 1, FwdStrides{}, tail_idx, tail_count, &ei);
+}
+
 int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
                  const void* view_bf16, const int32_t* ray_idx, const int32_t* count,
                  const void* wpack_fwd, float* raw, void* stash, void* relu_mask,
@@ -493,8 +542,10 @@ int launch_pack(void* stream, int width, int in_dim, int K, const float* params,
 
 int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile, const void* view_bf16,
                    const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
-                   void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx, const int32_t* tail_count) {
+                   void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx, const int32_t* tail_count,
+                   const EncIn* enc_in) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
+    DURF_REQUIRE(enc_in == nullptr || (width == 256 && K == 1), "the self-encoding forward is the background MLP's");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
     if (rows == 0 || K <= 0) return 0;
@@ -505,17 +556,26 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
     const unsigned per = half ? 128u : 256u;
     const unsigned nblk = durf_cdiv(rows, per);
     dim3 grid(nblk < 256u ? nblk : 256u, K), block(half ? 256 : 512);     // persistent: at most one workgroup per CU and object
-#define LAUNCH_F(WW, TR, NWV)                                                                     \
+    const EncIn ei = enc_in ? *enc_in : EncIn{};
+#define LAUNCH_F(WW, TR, NWV, EN)                                                                 \
     {                                                                                             \
         constexpr int lds = 2 * 4 * (MlpSpec<WW>::KW + 1) * 1024;                                 \
-        (void)hipFuncSetAttribute((const void*)k_mlp_fwd<WW, TR, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
-        hipLaunchKernelGGL((k_mlp_fwd<WW, TR, NWV>), grid, block, lds, s, rows, N, (const bf16x8*)enc_tile, \
+        static bool attr_set = false;      /* once per instantiation (the attribute sticks to the function) */ \
+        if (!attr_set) {                                                                          \
+            (void)hipFuncSetAttribute((const void*)k_mlp_fwd<WW, TR, NWV, EN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+            attr_set = true;                                                                      \
+        }                                                                                         \
+        hipLaunchKernelGGL((k_mlp_fwd<WW, TR, NWV, EN>), grid, block, lds, s, rows, N, (const bf16x8*)enc_tile, \
                            (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw,  \
-                           (bf16x8*)stash, (uint4*)relu_mask, st, tail_idx, tail_count);           \
+                           (bf16x8*)stash, (uint4*)relu_mask, st, tail_idx, tail_count, ei);       \
     }
-    if (half) { if (stash) LAUNCH_F(256, true, 4) else LAUNCH_F(256, false, 4) }
-    else if (width == 256) { if (stash) LAUNCH_F(256, true, 8) else LAUNCH_F(256, false, 8) }
-    else { if (stash) LAUNCH_F(128, true, 8) else LAUNCH_F(128, false, 8) }
+    if (enc_in) {
+        if (half) { if (stash) LAUNCH_F(256, true, 4, true) else LAUNCH_F(256, false, 4, true) }
+        else { if (stash) LAUNCH_F(256, true, 8, true) else LAUNCH_F(256, false, 8, true) }
+    }
+    else if (half) { if (stash) LAUNCH_F(256, true, 4, false) else LAUNCH_F(256, false, 4, false) }
+    else if (width == 256) { if (stash) LAUNCH_F(256, true, 8, false) else LAUNCH_F(256, false, 8, false) }
+    else { if (stash) LAUNCH_F(128, true, 8, false) else LAUNCH_F(128, false, 8, false) }
 #undef LAUNCH_F
     DURF_CHECK_LAUNCH("durf_mlp_fwd");
     return 0;

@@ -107,8 +107,8 @@ extern "C" {
 
 int durf_poison_multi_hit(void* stream, size_t n, float* grad, const int32_t* cls_count, size_t box_floats, int K,
                           size_t mlp0_floats, size_t obj_floats) {
-    DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ && box_floats + mlp0_floats + (size_t)K * obj_floats == n,
-                 "flat layout: box_centers | MLP_0 | K object MLPs");
+    DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ && obj_floats > 0 && n <= box_floats + mlp0_floats + (size_t)K * obj_floats,
+                 "flat layout: box_centers | MLP_0 | K object MLPs (n: the whole buffer or a prefix of it)");
     hipLaunchKernelGGL(k_poison_multi_hit, dim3(32), dim3(256), 0, (hipStream_t)stream, n, grad, cls_count, box_floats, K,
                        mlp0_floats, obj_floats);
     DURF_CHECK_LAUNCH("durf_poison_multi_hit");

@@ -1,7 +1,7 @@
 // durf_loss_backward / durf_train_step: value_and_grad(loss_fn) of train_step (train_boxpose.py:49-321) for one shard as ONE
 // C call -- the orchestration durf_amd/train_boxpose.py (loss_and_grad, train_step) and obbpose_model.py (_forward, train)
 // do in Python, for hosts that are not Python (durf_forward / durf_loss_backward / durf_clip_adam).  No kernel
-// of its own but a fill: the stage entry points of this library in the order the Python path issues them on ONE stream, every
+// of its own: the stage entry points of this library in the order the Python path issues them on ONE stream, every
 // intermediate carved out of a caller-owned workspace.  Scope: the benchmarked training configuration -- bf16 MLPs,
 // frozen box poses (no_pose_opt and no_yaw_opt), >= 2 levels, no density noise, no weight decay, fixed background colour.
 // Results are bit-identical to train_boxpose.train_step (tests/test_gpu_train_call.py).
@@ -22,11 +22,6 @@ struct Carver {
 };
 
 constexpr int ML = DURF_FORWARD_MAX_LEVELS;
-
-// (the one kernel of this file: hipMemsetAsync costs a few microseconds more than a fill launch between two kernels)
-__global__ void __launch_bounds__(256) k_zero(size_t n, float* __restrict__ p) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0.0f;
-}
 
 struct TrainWs {
     float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *draw, *part, *bpart, *opart, *obpart, *scratch;
@@ -103,6 +98,11 @@ int check_args(const durf_train_args* a, void* workspace) {
                  (f.K == 0 || (f.obj_params == a->params + a->box_floats + a->mlp0_floats && f.obj_param_stride == a->obj_floats)),
                  "f.bkgd_params / f.obj_params point into params");
     DURF_REQUIRE(f.bkgd_mode == 0 || f.bkgd_mode == 1, "fixed background colour (grey or white)");
+    DURF_REQUIRE(a->params && a->grad && a->stats, "params, grad and stats buffers");
+    DURF_REQUIRE(((size_t)a->grad & 15) == 0, "grad aligned to 16 bytes");
+    for (int l = 0; l < f.num_levels; l++)
+        DURF_REQUIRE(f.t_vals[l] && f.weights[l] && f.rgb[l] && f.depth[l] && f.acc[l] && f.t_mids[l] && f.t_dists[l],
+                     "per-level output buffers (t_vals, rgb, depth, acc, weights, t_mids, t_dists)");
     return 0;
 }
 
@@ -116,7 +116,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
     int rc;
     // ---- forward (obbpose_model.py:68-261), activations stashed ----
     STEP(durf_ray_prologue(stream, B, K, N, f.origins, f.directions, f.pose, f.ext, w.o_s, w.d_s, w.hit, f.zo, f.viewdirs, w.view,
-                           f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0]));
+                           f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0], nullptr, a->grad, a->n_params));
     if (K > 0)
         STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
                               f.dyn_mask));
@@ -131,18 +131,14 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = f.t_vals[lvl];
         if (K > 0) {
-            STEP(durf_encode_bkgd(stream, B, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags, w.enc[lvl], nullptr, w.idx_cls,
-                                  w.count_cls));
-            STEP(durf_mlp_fwd(stream, 256, rows, N, w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c[lvl], w.stash[lvl],
+            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags, w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c[lvl], w.stash[lvl],
                               w.mask[lvl], w.idx_cls + B, w.count_cls + 1));
             STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], nullptr));
             STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, f.radii, f.barf_w, obj_flags,
                                     w.view, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
                                     lvl == 0 ? w.obj_view_tile : nullptr));
         } else {
-            STEP(durf_encode_bkgd(stream, B, N, t_vals, w.o_s, w.d_s, f.radii, nullptr, 0, f.enc_flags, w.enc[lvl], nullptr, nullptr,
-                                  nullptr));
-            STEP(durf_mlp_fwd(stream, 256, rows, N, w.enc[lvl], w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl],
+            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, nullptr, 0, f.enc_flags, w.enc[lvl], w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl],
                               w.mask[lvl], nullptr, nullptr));
         }
         if (lvl + 1 < L)        // composite + resample + the loss normalisers of this (level 0 only) and the next level: one launch
@@ -178,7 +174,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
         }
     }
     // ---- weight gradients of every MLP over every level: the objects' split-K partials, the background's, one finalize ----
-    hipLaunchKernelGGL(k_zero, dim3(512), dim3(256), 0, hs, a->n_params, a->grad);
+    // (the gradient buffer was zero filled by the prologue launch)
     const void *enc[ML], *vt[ML], *stash[ML], *dz[ML], *dzo[ML], *ovt[ML];
     size_t seg_rows[ML];
     int per_ray[ML];

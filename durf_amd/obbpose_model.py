@@ -187,9 +187,10 @@ class MipNerfModel:
 
     # -- forward -------------------------------------------------------------
     def _forward(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
-                 train=False, noise=None, loss_prep=None):
+                 train=False, noise=None, loss_prep=None, zero_fill=None):
         """loss_prep (training, num_levels >= 2): dict(lossmult, gt_depth, sky, eps, box_loss_mult, disable_multiscale,
-        norms [L,5]) -- the inputs of durf_loss_prep; the fused per-ray launches then fill `norms` for every level."""
+        norms [L,5]) -- the inputs of durf_loss_prep; the fused per-ray launches then fill `norms` for every level.
+        zero_fill: a flat fp32 tensor (the step's gradient buffer) the prologue launch zero fills on its way."""
         self._check()
         lay = variables.layout
         K, N = lay.K, self.num_samples
@@ -230,8 +231,11 @@ class MipNerfModel:
                 with torch.cuda.stream(tail_side):
                     trunk = ops.bkgd_const_trunk_f32(variables.mlp_flat('MLP_0'))
         # ray setup + view encoding + level-0 sample positions: one launch; both compactions: one launch
+        # (the launch also snapshots the poses: the outputs must not alias the parameters the optimizer updates in place)
+        pose_used = torch.empty_like(pose)
         o_s, d_s, hit, zo, view, t_vals0 = ops.ray_prologue(rays.origins, rays.directions, pose, ext, rays.viewdirs, near,
-                                                            far, N, noise['t_rand'] if randomized else None, self.lindisp)
+                                                            far, N, noise['t_rand'] if randomized else None, self.lindisp,
+                                                            pose_copy=pose_used, zero=zero_fill)
         if use_dd:
             (idx, count, slot), cls = ops.compact_all(hit, N)     # cls also counts the boxes each ray hits
         else:
@@ -263,7 +267,7 @@ class MipNerfModel:
         raw_tail = None
         ret = []
         t_vals = weights = None
-        box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
+        box_rot0 = pose_used[0, 3:] if K > 0 else torch.zeros(3, device=dev)
         if cls is not None:
             dyn_mask = cls[3].reshape(B, 1)
         elif K > 1:
@@ -316,7 +320,14 @@ class MipNerfModel:
                 stash_b = torch.empty(ops.mlp_stash_bytes(W_BKGD, rows), dtype=torch.uint8, device=dev) if train else None
                 mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
                 side = ops.on_side(dev, bool(Kb) and ops.overlap_forward(rows))          # the object MLPs run in the shadow of the background MLP
-                if dd is not None:
+                enc_kw = dict(contraction=self.contraction, disable_integration=self.disable_integration, cylinder=cyl)
+                if dd is not None and ops.FUSED_ENCODE:       # the forward encodes its own tiles (durf_mlp_fwd_enc)
+                    side.fork()
+                    raw_c, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit, view, packs['MLP_0'][0],
+                                                   ray_idx=dd['idx'][0], count=dd['count'][0:1], stash=stash_b,
+                                                   relu_mask=mask_b, tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
+                                                   **enc_kw)
+                elif dd is not None:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl,
                                                idx=dd['idx'][0], count=dd['count'][0:1])
@@ -324,10 +335,15 @@ class MipNerfModel:
                     raw_c = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], ray_idx=dd['idx'][0],
                                         count=dd['count'][0:1], stash=stash_b, relu_mask=mask_b,
                                         tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
+                if dd is not None:
                     if tail_side is not None:                # the fp32 hit-ray evaluation (side stream) must have landed
                         torch.cuda.current_stream().wait_stream(tail_side)
                         tail_side = None
                     raw_b = ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'], raw_tail=raw_tail)
+                elif ops.FUSED_ENCODE:
+                    side.fork()
+                    raw_b, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit if Kd else None, view,
+                                                   packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b, **enc_kw)
                 else:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl)
@@ -362,7 +378,7 @@ class MipNerfModel:
                 t_next = None
                 rgb, depth, acc, weights, t_mids, t_dists = ops.composite_fwd(
                     raw_b, raws, slot, t_vals, d_s, self.density_bias, bk)
-            ret.append((rgb, depth, acc, weights, t_vals, t_mids, t_dists, [pose[:, :3], box_rot0],
+            ret.append((rgb, depth, acc, weights, t_vals, t_mids, t_dists, [pose_used[:, :3], box_rot0],
                         dyn_mask, zo))
             if train:
                 ctx['levels'].append(dict(t_vals=t_vals, enc_b=enc_b, raw_b=raw_b, stash_b=stash_b,

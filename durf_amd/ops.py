@@ -69,11 +69,14 @@ def ray_setup(origins, dirs, pose, ext):
     return o_s, d_s, hit, zo
 
 
-def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, lindisp=False):
+def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, lindisp=False, pose_copy=None, zero=None):
     """ray_setup + view_enc (bf16) + sample_t as ONE launch (durf_ray_prologue)
-    -> origins_s[B,3], dirs_s[B,3], hit[B,K] int32, zo[B], view[B,32] bf16, t_vals[B,N+1]"""
+    -> origins_s[B,3], dirs_s[B,3], hit[B,K] int32, zo[B], view[B,32] bf16, t_vals[B,N+1]
+    pose_copy [K,6]: receives a snapshot of `pose`; zero: a contiguous fp32 tensor the launch zero fills (the gradient)"""
     B, K = origins.shape[0], pose.shape[0]
     dev = origins.device
+    if zero is not None:
+        assert zero.is_contiguous() and zero.dtype == torch.float32
     o_s = torch.empty(B, 3, device=dev)
     d_s = torch.empty(B, 3, device=dev)
     hit = torch.empty(B, K, dtype=torch.int32, device=dev)
@@ -83,7 +86,8 @@ def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, 
     _lib.check(_lib.lib().durf_ray_prologue(_stream(), B, K, N, _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
                                             _p(_f32(ext)), _p(o_s), _p(d_s), _p(hit), _p(zo), _p(_f32(viewdirs)), _p(view),
                                             _p(_f32(near)), _p(_f32(far)), _p(None if t_rand is None else _f32(t_rand)),
-                                            int(lindisp), _p(t)), 'durf_ray_prologue')
+                                            int(lindisp), _p(t), _p(pose_copy if K else None), _p(zero),
+                                            0 if zero is None else zero.numel()), 'durf_ray_prologue')
     return o_s, d_s, hit, zo, view, t
 
 
@@ -256,6 +260,30 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
                                            _p(relu_mask), _p(tail_idx), _p(tail_count)),
                    'durf_mlp_fwd')
     return raw
+
+
+# DURF_FUSED_ENCODE=0: the background encoding as its own launch in front of the forward (A/B switch; same results).
+FUSED_ENCODE = os.environ.get('DURF_FUSED_ENCODE', '1') != '0'
+
+
+def mlp_fwd_enc(rows, N, t_vals, origins_s, dirs_s, radii, hit, view_bf16, wpack_fwd, contraction=True,
+                disable_integration=False, cylinder=False, ray_idx=None, count=None, stash=None, raw=None, relu_mask=None,
+                tail_idx=None, tail_count=None):
+    """durf_mlp_fwd_enc: the background forward that encodes its own tiles (encode_bkgd + mlp_fwd(256) as one launch)
+    -> (raw, enc_tile); enc_tile is what encode_bkgd would have returned (the weight-gradient GEMMs read it)"""
+    dev = t_vals.device
+    K = 0 if hit is None else hit.shape[1]
+    if raw is None:
+        raw = torch.empty(rows, 4, device=dev)
+    enc_tile = torch.empty(tile_rows(rows), ENC_DIM, dtype=torch.bfloat16, device=dev)
+    flags = ((ENC_CONTRACT if contraction else 0) | (ENC_NO_INTEGRATION if disable_integration else 0) |
+             (ENC_CYLINDER if cylinder else 0))
+    with _Timed('mlp_fwd_256%s' % ('_train' if stash is not None else '')):
+        _lib.check(_lib.lib().durf_mlp_fwd_enc(_stream(), rows, N, _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
+                                               _p(_f32(radii)), _p(hit), K, flags, _p(enc_tile), _p(view_bf16),
+                                               _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash), _p(relu_mask),
+                                               _p(tail_idx), _p(tail_count)), 'durf_mlp_fwd_enc')
+    return raw, enc_tile
 
 
 # The K object MLPs touch ~10 % of the rays: their launches are small and latency-bound.  DURF_OVERLAP_OBJECTS issues the
@@ -691,9 +719,11 @@ def dw_finalize_all(rows_l, n_l, count_l, part, bpart, grad_bkgd, bkgd_params, o
                                                    _p(grad_bkgd), _p(_f32(bkgd_params)), *oa), 'durf_dw_finalize_all')
 
 
-def poison_multi_hit(grad, cls_count, box_floats, K, mlp0_floats, obj_floats):
-    """reference semantics of rays that hit two boxes (durf_poison_multi_hit): NaN into the gradient segments they touch"""
-    _lib.check(_lib.lib().durf_poison_multi_hit(_stream(), grad.numel(), _p(_f32(grad)), _p(cls_count), int(box_floats), int(K),
+def poison_multi_hit(grad, cls_count, box_floats, K, mlp0_floats, obj_floats, upto=None):
+    """reference semantics of rays that hit two boxes (durf_poison_multi_hit): NaN into the gradient segments they touch;
+    upto: only the first `upto` floats of the flat buffer are touched"""
+    n = grad.numel() if upto is None else int(upto)
+    _lib.check(_lib.lib().durf_poison_multi_hit(_stream(), n, _p(_f32(grad)), _p(cls_count), int(box_floats), int(K),
                                                 int(mlp0_floats), int(obj_floats)), 'durf_poison_multi_hit')
 
 

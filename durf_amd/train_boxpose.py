@@ -86,50 +86,84 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     # with >= 2 levels the forward's fused per-ray launches also compute the loss normalisers (durf_loss_prep's job)
     prep = dict(lossmult=lossmult, gt_depth=gt_depth, sky=sky, eps=float(eps), box_loss_mult=float(config.box_loss_mult),
                 disable_multiscale=config.disable_multiscale_loss, norms=norms) if L >= 2 else None
+    grad = torch.empty_like(variables.flat)         # zero filled by the forward's first launch (durf_ray_prologue)
     ret, ctx = model._forward(variables, rng, rays, batch['init'], batch['ext'], batch['ts'],
                               config.randomized, config.rand_bkgd, config.white_bkgd, alpha, train=True,
-                              noise=noise, loss_prep=prep)
+                              noise=noise, loss_prep=prep, zero_fill=grad)
     B, N, K = ctx['B'], ctx['N'], ctx['K']
     lay = variables.layout
     rows = B * N
     pixels = batch['pixels'][..., :3].contiguous()
     dyn = ret[0][8].reshape(-1).to(torch.int32).contiguous()
     bg = 0.0 if config.rand_bkgd else (1.0 if config.white_bkgd else 0.5)
-    grad = torch.zeros_like(variables.flat)
     f32 = model.mlp_precision == 'f32'
     obj_f32 = ctx['obj_f32']                    # object branch on the exact-fp32 kernels (MipNerfModel.object_precision)
     Kb = 0 if obj_f32 else K                    # objects on the bf16 kernels
     bufs = None if f32 else ops.dw_buffers(om.W_BKGD, dev)
     dzs = [None] * L                            # per-level (dz, dz_out) of the bkgd MLP, consumed by ONE dW launch
     dd = ctx.get('dedup')                        # de-duplicated background evaluation (obbpose_model._forward)
-    if f32:
-        view_tile = None
-    elif dd is not None:
-        view_tile = ops.expand_view(rows, N, ctx['view'], ray_idx=dd['idx'][0], count=dd['count'][0:1],
-                                    tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
-    else:
-        view_tile = ops.expand_view(rows, N, ctx['view'])
+    # Side stream (ops.overlap_mode; large batches only -- a fork / join is one more dependency in a latency-bound step): the
+    # object backward / weight gradients, and two things nothing on the critical path waits for: the view-direction tile
+    # (read by the weight-gradient launch only) and the loss kernels of the levels below the last -- stop_level_grad makes
+    # every level's loss gradient a function of the forward alone, so they run beside the last level's instead of between
+    # two persistent backward launches.
+    side = ops.on_side(dev, not f32 and ops.overlap_backward(rows))
+    main = torch.cuda.current_stream() if side.enabled else None
+    obj_side = side if Kb else ops.on_side(dev, False)
+
+    def make_view_tile():
+        if dd is not None:
+            return ops.expand_view(rows, N, ctx['view'], ray_idx=dd['idx'][0], count=dd['count'][0:1],
+                                   tail_idx=dd['idx'][1], tail_count=dd['count'][1:2])
+        return ops.expand_view(rows, N, ctx['view'])
+
     ray_sums = torch.empty(L, B, 4, device=dev) if dd is not None else None
     sums = torch.empty(L, ops.TERM_ROWS, device=dev)      # filled by the stats launch from the per-ray terms (ops.train_stats)
     terms = [None] * L
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
-    # side stream for the object backward / weight gradients (ops.overlap_mode)
-    side = ops.on_side(dev, bool(Kb) and not f32 and ops.overlap_backward(rows))
+
+    def level_loss(lvl):
+        lv = ctx['levels'][lvl]
+        out = (lv['rgb'], lv['depth'], lv['acc'], lv['weights'], lv['t_mids'], lv['t_dists']) if lv['deferred'] else None
+        return ops.loss_bwd(lv['raw_b'], lv['raws'], ctx['slot'], lv['t_vals'], ctx['d_s'], pixels, lossmult,
+                            gt_depth, sky, dyn, ctx['zo'], norms[lvl], float(eps),
+                            level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
+                            model.density_bias, config.disable_multiscale_loss, render_out=out,
+                            draw_ray_sum=None if dd is None else ray_sums[lvl], defer_sums=True)
+
+    draws, ready = [None] * L, [None] * L
+    view_tile = view_ready = None
+    if side.enabled:
+        side.fork()
+        with side:
+            view_tile = make_view_tile()
+            view_tile.record_stream(main)
+            view_ready = torch.cuda.Event()
+            view_ready.record(side.side)
+            if prep is not None:                  # (the fused forward filled every level's normalisers already)
+                for lvl in range(L - 1):
+                    draws[lvl], terms[lvl] = level_loss(lvl)
+                    draws[lvl].record_stream(main)
+                    terms[lvl].record_stream(main)
+                    ready[lvl] = torch.cuda.Event()
+                    ready[lvl].record(side.side)
+    elif not f32:
+        view_tile = make_view_tile()
     # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
     for lvl in reversed(range(L)):
         lv = ctx['levels'][lvl]
         if prep is None:
             ops.loss_prep(lv['t_vals'], lossmult, gt_depth, sky, dyn, ctx['zo'], float(eps),
                           float(config.box_loss_mult), lvl, config.disable_multiscale_loss, norm=norms[lvl])
-        norm = norms[lvl]
-        out = (lv['rgb'], lv['depth'], lv['acc'], lv['weights'], lv['t_mids'], lv['t_dists']) if lv['deferred'] else None
-        draw, terms[lvl] = ops.loss_bwd(lv['raw_b'], lv['raws'], ctx['slot'], lv['t_vals'], ctx['d_s'], pixels, lossmult,
-                                        gt_depth, sky, dyn, ctx['zo'], norm, float(eps),
-                                        level_multipliers(config, lvl, L), float(config.box_loss_mult), lvl, bg,
-                                        model.density_bias, config.disable_multiscale_loss, render_out=out,
-                                        draw_ray_sum=None if dd is None else ray_sums[lvl], defer_sums=True)
+        if draws[lvl] is None:
+            draw, terms[lvl] = level_loss(lvl)
+        else:
+            draw = draws[lvl]
+            main.wait_event(ready[lvl])
+        if obj_side.enabled:
+            draw.record_stream(obj_side.side)     # (read by the object backward on the side stream)
         if f32:                               # exact-fp32 parity instrument: per-MLP fp32 backward + weight gradients
             fl = lv['f32']
             off = lay.mlp_off['MLP_0']
@@ -146,7 +180,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                          rays.origins, rays.directions, pose_ts, alpha, pose_sums, precise=True)
         if f32:
             continue
-        side.fork()                          # the object backward runs in the shadow of the background backward
+        obj_side.fork()                      # the object backward runs in the shadow of the background backward
         if dd is not None:
             dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'], ray_idx=dd['idx'][0],
                                    count=dd['count'][0:1], tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
@@ -154,7 +188,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         else:
             dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
         if Kb:                                # all K object MLPs: one call (csrc/objects.hip)
-            with side:
+            with obj_side:
                 ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
                 if pose_opt:                            # d(loss)/d(box pose) through the object encoding, all K at once
                     ops.encode_obj_bwd_batch(K, ctx['idx'], ctx['count'], lv['slabs'].d_enc, lv['t_vals'],
@@ -162,19 +196,33 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                              pose_sums)
     levels = ctx['levels']
 
-    def poison():
+    def poison(upto=None):
         # rays that hit two boxes: the reference's gradient is NaN -> 0 for everything they touch (ops.poison_multi_hit);
         # on the local gradient, before whoever all-reduces it
         if dd is not None and lay.K > 1:
             ops.poison_multi_hit(grad, dd['count'], lay.box[1] - lay.box[0], lay.K, lay.mlp_size[om.W_BKGD],
-                                 lay.mlp_size[om.W_OBJ])
+                                 lay.mlp_size[om.W_OBJ], upto=upto)
+
+    flat = variables.flat
+    wd_c = 2.0 * config.weight_decay_mult / flat.numel()          # d/d theta of weight_decay_mult * mean(theta^2) (:73-75)
+    first_only = None                   # bucketed exchange: the objects' slice is FINAL (and in flight) once handed over
+
+    def hand_over_objects(o0, n):
+        # the slice leaves for its all-reduce: everything that belongs in it goes in first -- its weight-decay term (each
+        # rank adds its own once; clip + Adam divide the sum by the world size) and the multi-hit outcome -- and nothing
+        # after this line may write it (the collective reduces it in place)
+        nonlocal first_only
+        if config.weight_decay_mult != 0:
+            grad[o0:o0 + n] += wd_c * flat[o0:o0 + n]
+        poison()
+        first_only = o0
+        objects_ready(grad[o0:o0 + n])
 
     if obj_f32:                               # weight gradients of the K object MLPs over every level: one launch pair
         o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
         ops.objf32_dw_batch([lv['f32']['slabs32'] for lv in levels], ctx['count'], grad[o0:o0 + K * sz], sz)
         if objects_ready is not None:
-            poison()
-            objects_ready(grad[o0:o0 + K * sz])
+            hand_over_objects(o0, K * sz)
     if not f32:
         off = lay.mlp_off['MLP_0']
         g_b, p_b = grad[off:off + lay.mlp_size[om.W_BKGD]], variables.mlp_flat('MLP_0')
@@ -188,14 +236,15 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         if Kb and objects_ready is not None:           # bucketed all-reduce: the objects' gradients first, finalized on their own
             ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
                              grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
-            poison()
-            objects_ready(grad[o0:o0 + K * sz])
+            hand_over_objects(o0, K * sz)
         if merged:
             # The objects' split-K launch goes FIRST: the finalize launch then finds the background MLP's partials
             # (134 MB, the bulk) still in the 256 MB Infinity Cache -- behind the objects' 0.7 GB operand stream it
             # read them from HBM (k_dw_finalize 117 us instead of 2 x 37, rocprofv3)
             side.join()
             po, bo = ops.obj_dw_partials([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'])
+        if view_ready is not None:
+            main.wait_event(view_ready)          # (recorded at the start of the backward: long complete)
         ops.mlp_dw_levels(om.W_BKGD, *geo, enc_l, [view_tile] * L, stash_l, [d[0] for d in dzs], [d[1] for d in dzs], *bufs)
         if merged:                       # every MLP of the model is finalized by ONE pair of launches
             ops.dw_finalize_all(*geo, *bufs, g_b, p_b,
@@ -207,11 +256,13 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                     ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
                                      grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
     side.join()
-    flat = variables.flat
     weight_l2 = None
     if config.weight_decay_mult != 0:                                          # :73-75
         weight_l2 = config.weight_decay_mult * (flat * flat).sum() / flat.numel()
-        grad += (2.0 * config.weight_decay_mult / flat.numel()) * flat
+        if first_only is None:
+            grad += wd_c * flat
+        else:
+            grad[:first_only] += wd_c * flat[:first_only]
     if K > 0 and pose_opt:                      # no_pose_opt and no_yaw_opt: box_centers get no gradient (:100-104)
         g6 = torch.zeros(K, 6, device=dev)
         if pose_opt:
@@ -220,7 +271,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
         grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)[ctx['ts']] += g6
     pose = ret[0][7][0]
-    poison()
+    poison(upto=first_only)
     if dd is not None:
         multi = dd['multi_hit']
     else:
@@ -294,7 +345,7 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
         weight_l2=st['weight_l2'], psnr=st['psnrs'][-1], psnrs=st['psnrs'], obj_psnr=st['obj_psnrs'][-1],
         grad_norm=gs[0], grad_abs_max=gs[1], grad_norm_clipped=gs[3], multi_hit_rays=raw['multi_hit'])
     new_rng = (int(rng) + 1) if isinstance(rng, int) else rng
-    return new_state, stats, new_rng, pose.clone()
+    return new_state, stats, new_rng, pose              # (the prologue's snapshot: does not alias the updated parameters)
 
 
 def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, update=True):

@@ -88,11 +88,15 @@ int durf_compact_classes(void* stream, int B, int K, int N, const int32_t* hit, 
 int durf_compact_all(void* stream, int B, int K, int N, const int32_t* hit, int32_t* idx_obj, int32_t* count_obj,
                      int32_t* slot_obj, int32_t* idx_cls, int32_t* count_cls, int32_t* slot_cls, int32_t* dyn);
 /* The three preparations of a step that depend on the batch only, as ONE launch: durf_ray_setup, durf_view_enc (bf16
- * output) and durf_sample_t -- same kernels' code, same results. */
+ * output) and durf_sample_t -- same kernels' code, same results.  Two chores of a training step ride along (each a launch of
+ * its own otherwise): pose_copy [K,6] receives a snapshot of `pose` (train_step returns the poses it rendered with,
+ * train_boxpose.py:315, while the optimizer updates the parameters in place), and zero_buf[0..zero_count) -- the flat
+ * gradient buffer, 16-byte aligned -- is zero filled. */
 int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
                       const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
                       const float* viewdirs, void* view_bf16, const float* near, const float* far,
-                      const float* t_rand /* nullable */, int lindisp, float* t_vals);
+                      const float* t_rand /* nullable */, int lindisp, float* t_vals, float* pose_copy /* nullable */,
+                      float* zero_buf /* nullable */, size_t zero_count);
 
 /* mip.sample_along_rays t_vals (mip.py:353-368). t_rand nullable (randomized=False). */
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
@@ -138,6 +142,21 @@ int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_ti
                  *tail_count) hold ONE sample of ray tail_idx[i] each, evaluated on the constant encoding of a
                  zero-masked Gaussian ([0 x 30, 1 x 30]; enc_tile is not read for them) with that ray's view
                  direction; raw / stash / relu_mask rows follow the same numbering */);
+
+/* The background forward that ENCODES ITS OWN TILES: durf_encode_bkgd (bf16 tile output) + durf_mlp_fwd(width = 256) as
+ * ONE launch.  Every workgroup computes the 60 features of its 256 samples from the ray data at the head of the block
+ * (the body of the stand-alone encoder: bit-identical features, obbpose_model.py:205-210, mip.py:155-179,226-282,
+ * mip360.py:47-79), keeps them as its first MFMA operand and writes the tile to enc_tile -- an OUTPUT here, [rows,64]
+ * tile layout as durf_encode_bkgd writes it: the skip connection re-reads it, and in training the weight-gradient GEMMs
+ * of Dense_0 / Dense_5 do.  t_vals [B,N+1], origins_s / dirs_s [B,3], radii [B], hit [B,K] (nullable with K = 0: no
+ * object masking), enc_flags as durf_encode_bkgd's `contraction`; row r is sample r % N of ray r / N, or of ray
+ * ray_idx[r / N] when a compacted list is given (with count); everything else as durf_mlp_fwd.  raw / stash / relu_mask
+ * are bit-identical to the two separate calls'. */
+int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
+                     const float* radii, const int32_t* hit /* nullable */, int K, int enc_flags, void* enc_tile,
+                     const void* view_bf16, const int32_t* ray_idx /* nullable */, const int32_t* count /* nullable */,
+                     const void* wpack_fwd, float* raw, void* stash /* nullable */, void* relu_mask /* nullable */,
+                     const int32_t* tail_idx /* nullable */, const int32_t* tail_count /* nullable */);
 
 /* K8 merge + activations + volumetric_rendering (obbpose_model.py:232-254, mip.py:285-327).
  * raw_bkgd [B*N,4]; raw_obj[k] [count_k*N,4] compacted, slot from durf_compact_hits.
@@ -473,7 +492,9 @@ size_t durf_optim_scratch_floats(size_t n);
  * everything their path touches -> nan_to_num -> 0, train_boxpose.py:263): when cls_count[3] (durf_compact_classes) is
  * non-zero, the gradient segments of MLP_0 and of the boxes in cls_count[4] (their BoxMLP and their box_centers columns)
  * are set to NaN -- call it on the complete local gradient BEFORE the data-parallel all-reduce; durf_clip_adam scrubs.
- * Flat layout: box_centers (box_floats = T*K*6) | MLP_0 | K object MLPs of obj_floats each.  Exits at once otherwise. */
+ * Flat layout: box_centers (box_floats = T*K*6) | MLP_0 | K object MLPs of obj_floats each; n = the floats of grad this
+ * call covers: the whole buffer, or a PREFIX of it (e.g. box_centers | MLP_0 when the objects' slice was poisoned earlier
+ * and is already being all-reduced).  Exits at once when no ray hits two boxes. */
 int durf_poison_multi_hit(void* stream, size_t n, float* grad, const int32_t* cls_count, size_t box_floats, int K,
                           size_t mlp0_floats, size_t obj_floats);
 int durf_clip_adam(void* stream, size_t n, float* params, float* m, float* v, float* grad, float inv_world,

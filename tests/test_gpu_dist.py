@@ -161,7 +161,7 @@ def test_train_step_through_rccl_world_size_one(cuda, tmp_path, pose_opt):
         assert got['losses'] == base['losses'], tag
 
 
-def _bucket_worker(rank, world, port, out_dir, bucket):
+def _bucket_worker(rank, world, port, out_dir, bucket, weight_decay=0.0, multi_hit=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), DURF_DIST_BACKEND='gloo', DURF_BUCKET_ALLREDUCE='1' if bucket else '0')
     sys.path.insert(0, ROOT)
@@ -170,27 +170,67 @@ def _bucket_worker(rank, world, port, out_dir, bucket):
     r, w, local = train_boxpose.init_distributed()
     dev = torch.device('cuda', local)
     wl = bench.setup_workload('cfg3', dev, r, w, rays=256)
+    wl['config'].weight_decay_mult = weight_decay
+    if multi_hit:                               # the first ray's box hits copied from two rays that hit different boxes:
+        from durf_amd import synthetic          # a batch with rays that hit two boxes (poisoned gradient segments)
+        bn = synthetic.make_batch(256 * w, wl['K'], far=wl['far'], seed=synthetic.SEED, noise_boxes=0.0, allow_multi_hit=True,
+                                  hit_range=(0.2, 0.4))
+        full = synthetic.device_batch(bn, dev)
+        wl['batch'] = train_boxpose.shard_batch(full, r, w)
+        wl['prev'] = full['init'][0:1]
     state, rng = wl['state'], 1000 * r
     for i in range(2):
         state, stats, rng, _ = train_boxpose.train_step(wl['model'], wl['config'], rng, state, wl['batch'], 5e-4, 3.0,
                                                         wl['alpha'], wl['prev'], reduce_stats=False)
     torch.cuda.synchronize()
     if r == 0:
-        torch.save(state.variables.flat.cpu(), os.path.join(out_dir, 'bucket_%d.pt' % bucket))
+        torch.save(dict(flat=state.variables.flat.cpu(), multi=int(stats.multi_hit_rays)),
+                   os.path.join(out_dir, 'bucket_%d.pt' % bucket))
     import torch.distributed as dist
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_bucketed_allreduce_gives_the_same_parameters(cuda, tmp_path):
+@pytest.mark.parametrize('weight_decay,multi_hit', [(0.0, False), (1e-2, False), (1e-2, True)])
+def test_bucketed_allreduce_gives_the_same_parameters(cuda, tmp_path, weight_decay, multi_hit):
     """two ranks (gloo): objects' gradient slice all-reduced ahead of [box_centers | MLP_0] == one all-reduce of the
-    flat buffer, bit for bit (same element-wise sums, same kernels)"""
+    flat buffer, bit for bit (same element-wise sums, same kernels) -- also with weight decay (the slice must carry its
+    own term before it leaves, and nothing may write it afterwards) and with rays that hit two boxes (the poisoned
+    segments)"""
     for bucket in (0, 1):
         s = socket.socket()
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
         s.close()
-        mp.spawn(_bucket_worker, args=(2, port, str(tmp_path), bucket), nprocs=2, join=True)
+        mp.spawn(_bucket_worker, args=(2, port, str(tmp_path), bucket, weight_decay, multi_hit), nprocs=2, join=True)
     a = torch.load(os.path.join(str(tmp_path), 'bucket_0.pt'))
     b = torch.load(os.path.join(str(tmp_path), 'bucket_1.pt'))
-    assert torch.equal(a, b)
+    assert torch.equal(a['flat'], b['flat'])
+    assert (a['multi'] > 0) == multi_hit
+
+
+def test_bench_gpus_2_end_to_end_on_one_gpu(cuda):
+    """`python bench.py --gpus 2` as the driver starts it, with the two ranks sharing the one GPU of this box over gloo
+    (DURF_DIST_BACKEND=gloo; RCCL needs a GPU per rank): the launcher, the file-store rendezvous, distinct shards, the
+    gradient all-reduce inside the timed steps, max-over-ranks timing, and ONE JSON line -- the last line of stdout --
+    whose fields say what ran.  No scaling number is read off this run."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['DURF_DIST_BACKEND'] = 'gloo'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+                        '--rays', '512', '--no-calibration'], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       timeout=900)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.strip()]
+    out = json.loads(lines[-1])                                 # the result is the LAST line of stdout
+    assert sum(ln.startswith('{"metric"') for ln in lines) == 1  # and rank 0 alone prints it
+    assert out['metric'] == 'train_rays_per_sec' and out['unit'] == 'rays/s' and out['higher_is_better'] is True
+    assert out['n_gpus'] == 2 and out['steps'] == 4 and out['warmup'] == 2 and out['scaling'] == 'weak'
+    c = out['config']
+    assert c['rays_per_gpu'] == 512 and c['global_batch'] == 1024 and c['parallelism'] == 'dp2' and c['name'] == 'cfg3'
+    assert c['collective'] == 'gloo all-reduce, world size 2'
+    assert out['cpu_baseline'] is None                          # rank 0 at N = 1 only
+    assert abs(out['value'] - 1024 * 4 / (out['ms_per_step'] * 4e-3)) <= 1e-6 * out['value']    # whole-job rays / max-over-ranks time
+    r = out['roofline']
+    assert r['kernel'].startswith('mlp_') and 0.0 < r['frac'] < 1.0 and out['loss'] == out['loss']

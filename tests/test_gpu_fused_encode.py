@@ -1,0 +1,124 @@
+"""durf_mlp_fwd_enc: the background forward that encodes its own tiles (csrc/mlp_fwd.hip k_mlp_fwd<256, .., ENC>,
+csrc/enc_lane.h) against the two launches it replaces (durf_encode_bkgd + durf_mlp_fwd; ops.FUSED_ENCODE = False).
+One encoder body serves both, so EVERYTHING must be bit-identical: the encoding tile the weight-gradient GEMMs read, the
+raw outputs, the activation stash, the ReLU masks, every rendered quantity of both levels, and a training step's gradient
+(reference: obbpose_model.py:205-210, mip.py:155-179,226-282, mip360.py:47-79)."""
+import pytest
+import torch
+
+from durf_amd import obbpose_model, ops, synthetic, train_boxpose, utils
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(cuda, B, K, N, seed, extra=''):
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
+                    'Config.randomized = True\nConfig.rand_bkgd = False\n' % N + extra)
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(B, K, seed=seed, hit_range=(0.2, 0.4))
+    db = H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(seed, db, device=cuda)
+    g = torch.Generator().manual_seed(seed)
+    for name in variables.layout.mlp_names():
+        for i in range(12):
+            bias = variables['params'][name]['Dense_%d' % i]['bias']
+            bias.copy_(((torch.rand(bias.shape, generator=g) - 0.5) * 0.1).to(cuda))
+    noise = dict(t_rand=torch.rand(B, N + 1, generator=g).to(cuda), u_rand=torch.rand(B, N + 1, generator=g).to(cuda))
+    return config, b, db, model, variables, noise
+
+
+def _same(a, c, what):
+    assert a.shape == c.shape and a.dtype == c.dtype, what
+    if a.dtype.is_floating_point:
+        a, c = a.float(), c.float()
+        ok = (a == c) | (torch.isnan(a) & torch.isnan(c))
+    else:
+        ok = a == c
+    assert bool(ok.all()), '%s: %d of %d entries differ' % (what, int((~ok).sum()), ok.numel())
+
+
+def _both(fn):
+    out = {}
+    for on in (True, False):
+        ops.FUSED_ENCODE = on
+        try:
+            out[on] = fn()
+        finally:
+            ops.FUSED_ENCODE = True
+    return out[True], out[False]
+
+
+# (rays, boxes, samples): whole 256-sample blocks; 128-sample blocks of 4 waves (small launches); K = 0 (no compaction,
+# no tail rows); ragged ray counts; the metric's own samples per ray
+SHAPES = [(512, 3, 64), (96, 1, 32), (300, 0, 32), (517, 3, 64), (256, 8, 32), (1024, 3, 128)]
+
+
+@pytest.mark.parametrize('B,K,N', SHAPES)
+@pytest.mark.parametrize('train', [False, True])
+def test_forward_is_bit_identical_to_the_separate_launches(cuda, B, K, N, train):
+    config, b, db, model, variables, noise = _setup(cuda, B, K, N, 31 + K)
+
+    def run():
+        return model._forward(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], True, False, False, 10.0,
+                              train=train, noise=noise,
+                              loss_prep=None)
+    (ret_f, ctx_f), (ret_s, ctx_s) = _both(run)
+    for lvl in range(model.num_levels):
+        for i, nm in enumerate(['rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists']):
+            _same(ret_f[lvl][i], ret_s[lvl][i], '%s level %d' % (nm, lvl))
+        if train:
+            lf, ls = ctx_f['levels'][lvl], ctx_s['levels'][lvl]
+            _same(lf['raw_b'], ls['raw_b'], 'raw level %d' % lvl)
+            dd = ctx_f.get('dedup')
+            # the rows the kernels own: all of them, or the compacted rows + the tail rows of a de-duplicated batch
+            nrows = B * N if dd is None else int(dd['count'][0]) * N + int(dd['count'][1])
+            nt = (nrows + 31) // 32
+            enc_f = lf['enc_b'].view(torch.int16).reshape(-1, 4 * 512)[:nt]
+            enc_s = ls['enc_b'].view(torch.int16).reshape(-1, 4 * 512)[:nt]
+            if dd is not None and nrows % 32:          # a partial last (tail) tile: lanes beyond the tail hold whatever
+                enc_f, enc_s = enc_f[:-1], enc_s[:-1]  # (checked through the outputs above)
+            _same(enc_f, enc_s, 'encoding tile level %d' % lvl)
+            whole = nrows // 32
+            kb = ops.mlp_stash_bytes(obbpose_model.W_BKGD, 32) // 1024        # KB per 32-row tile, all regions
+            nt_all = lf['stash_b'].numel() // (kb * 1024)
+            for j in range(10):                                               # region j: [k-steps][tiles][1 KB]
+                ks = 8 if j == 9 else 16
+                if j == 8:
+                    continue                                                  # the linear bottleneck is not stashed
+                off = 16 * j * nt_all * 1024
+                a = lf['stash_b'][off:off + ks * nt_all * 1024].reshape(nt_all, ks * 1024)[:whole]
+                c = ls['stash_b'][off:off + ks * nt_all * 1024].reshape(nt_all, ks * 1024)[:whole]
+                _same(a, c, 'stash region %d level %d' % (j, lvl))
+            ma = lf['mask_b'].reshape(9, -1, 1024)[:, :whole]
+            mc = ls['mask_b'].reshape(9, -1, 1024)[:, :whole]
+            _same(ma, mc, 'ReLU masks level %d' % lvl)
+
+
+@pytest.mark.parametrize('B,K,N', [(512, 3, 64), (300, 0, 32)])
+def test_a_training_step_is_bit_identical(cuda, B, K, N):
+    config, b, db, model, variables, noise = _setup(cuda, B, K, N, 41 + K)
+    prev = db['init'][0:1]
+
+    def run():
+        g, raw, _ = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, 10.0, prev, noise=noise)
+        return g.clone(), torch.stack([t.clone() for t in raw['terms']])
+    (g_f, t_f), (g_s, t_s) = _both(run)
+    _same(g_f, g_s, 'gradient')
+    _same(t_f, t_s, 'per-ray loss terms')
+
+
+@pytest.mark.parametrize('extra', ['MipNerfModel.ray_shape = "cylinder"\n', 'MipNerfModel.disable_integration = True\n',
+                                   'MipNerfModel.contraction = False\n', 'MipNerfModel.dynamics = False\n'])
+def test_encoder_knobs(cuda, extra):
+    config, b, db, model, variables, noise = _setup(cuda, 256, 2, 32, 51, extra)
+
+    def run():
+        return model.apply(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], randomized=True, rand_bkgd=False,
+                           white_bkgd=False, alpha=10.0, noise=noise)
+    ret_f, ret_s = _both(run)
+    for lvl in range(model.num_levels):
+        for i, nm in enumerate(['rgb', 'depth', 'acc', 'weights', 't_vals']):
+            _same(ret_f[lvl][i], ret_s[lvl][i], '%s level %d (%s)' % (nm, lvl, extra.strip()))
