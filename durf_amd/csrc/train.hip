@@ -2,9 +2,10 @@
 // C call -- the orchestration durf_amd/train_boxpose.py (loss_and_grad, train_step) and obbpose_model.py (_forward, train)
 // do in Python, for hosts that are not Python (durf_forward / durf_loss_backward / durf_clip_adam).  No kernel
 // of its own: the stage entry points of this library in the order the Python path issues them on ONE stream, every
-// intermediate carved out of a caller-owned workspace.  Scope: the benchmarked training configuration -- bf16 MLPs,
-// frozen box poses (no_pose_opt and no_yaw_opt), >= 2 levels, no density noise, no weight decay, fixed background colour.
-// Results are bit-identical to train_boxpose.train_step (tests/test_gpu_train_call.py).
+// intermediate carved out of a caller-owned workspace.  Scope: every BASELINE.json training configuration -- bf16 background
+// MLP; object MLPs on the bf16 kernels (frozen poses: cfg2 / cfg3 / cfg5) or, with obj_fp32, on the exact-fp32 kernels with
+// the box-pose gradient behind them (cfg4: want_pos / want_rot, the TV prior); >= 2 levels, no density noise, no weight
+// decay, fixed background colour.  Results are bit-identical to train_boxpose.train_step (tests/test_gpu_train_call.py).
 #include "durf_common.h"
 #include "../../include/durf_hip.h"
 
@@ -22,6 +23,17 @@ struct Carver {
 };
 
 constexpr int ML = DURF_FORWARD_MAX_LEVELS;
+constexpr int OBJ32_NSPLIT = 8;        // ops.objf32_dw_batch's default: same split-K partial order as the Python path
+
+// (the one kernel of this file) TV prior on the box positions (train_boxpose.py:136,219) added to this timestep's rows of the
+// gradient: g[k, 0:3] += c * (pose[k, 0:3] - prev[k, 0:3]), in the operation order of the Python path's tensor expression
+__global__ void k_tv_rows(int K, const float* __restrict__ pose, const float* __restrict__ prev, float c, float* __restrict__ g) {
+    const int i = threadIdx.x, k = i / 3, q = i % 3;
+    if (k >= K) return;
+    const float t = pose[k * 6 + q] - prev[k * 6 + q];
+    const float t2 = c * t;
+    g[k * 6 + q] = g[k * 6 + q] + t2;
+}
 
 struct TrainWs {
     float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *draw, *part, *bpart, *opart, *obpart, *scratch;
@@ -30,10 +42,15 @@ struct TrainWs {
     void *view, *wf_bkgd, *wb_bkgd, *wf_obj, *wb_obj, *view_tile, *obj_view_tile;
     void *enc[ML], *stash[ML], *mask[ML], *dz[ML], *dz_out[ML];
     void *obj_enc[ML], *obj_stash[ML], *obj_mask[ML], *obj_dz[ML], *obj_dz_out[ML];
+    // object branch on the exact-fp32 kernels (obj_fp32): view features, the background's fp32 evaluation of the box-hit
+    // rays, weight streams, per-level records, the pose sums
+    float *view27, *trunk, *raw_tail, *obj_ws, *dw32_scratch, *pose_sums, *pose_scratch;
+    float *act32[ML], *dz32[ML], *d_enc32[ML];
     size_t total;
 };
 
-TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params) {
+TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params, int flags = 0) {
+    const bool f32o = K > 0 && (flags & DURF_TRAIN_OBJ_FP32) != 0, pose = f32o && (flags & DURF_TRAIN_POSE_OPT) != 0;
     Carver c{(char*)workspace, 0};
     TrainWs w{};
     const size_t rows = (size_t)B * N, Kc = K > 0 ? K : 1, trows = (rows + 31) / 32 * 32;
@@ -72,14 +89,28 @@ TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params) {
         w.mask[l] = c.take(durf_mlp_mask_bytes(rows));
         w.dz[l] = c.take(durf_mlp_stash_bytes(256, rows));
         w.dz_out[l] = c.take(trows * 16 * 2);
-        if (K > 0) {
+        if (K > 0 && !f32o) {
             w.obj_enc[l] = c.take((size_t)K * durf_obj_enc_stride(B, N));
             w.obj_raw[l] = (float*)c.take((size_t)K * rows * 4 * 4);
             w.obj_stash[l] = c.take((size_t)K * durf_mlp_stash_bytes(128, rows));
             w.obj_mask[l] = c.take((size_t)K * durf_mlp_mask_bytes(rows));
             w.obj_dz[l] = c.take((size_t)K * durf_mlp_stash_bytes(128, rows));
             w.obj_dz_out[l] = c.take((size_t)K * durf_obj_dzout_stride(B, N));
+        } else if (f32o) {
+            w.obj_raw[l] = (float*)c.take((size_t)K * rows * 4 * 4);
+            w.act32[l] = (float*)c.take((size_t)K * durf_objf32_act_stride(B, N) * 4);
+            w.dz32[l] = (float*)c.take((size_t)K * durf_objf32_dz_stride(B, N) * 4);
+            w.d_enc32[l] = (float*)c.take(pose ? (size_t)K * rows * 64 * 4 : 0);
         }
+    }
+    if (f32o) {
+        w.view27 = (float*)c.take((size_t)B * 27 * 4);
+        w.trunk = (float*)c.take(264 * 4);
+        w.raw_tail = (float*)c.take((size_t)B * 4 * 4);
+        w.obj_ws = (float*)c.take((size_t)K * durf_mlp_f32_wstream_floats(128) * 4);
+        w.dw32_scratch = (float*)c.take((size_t)K * durf_mlp_f32_dw_scratch_floats(128, 63, OBJ32_NSPLIT) * 4);
+        w.pose_sums = (float*)c.take((size_t)K * 21 * 4);
+        w.pose_scratch = (float*)c.take(pose ? (size_t)K * 21 * B * 4 : 0);
     }
     w.total = (c.off + 255) & ~(size_t)255;
     return w;
@@ -98,6 +129,14 @@ int check_args(const durf_train_args* a, void* workspace) {
                  (f.K == 0 || (f.obj_params == a->params + a->box_floats + a->mlp0_floats && f.obj_param_stride == a->obj_floats)),
                  "f.bkgd_params / f.obj_params point into params");
     DURF_REQUIRE(f.bkgd_mode == 0 || f.bkgd_mode == 1, "fixed background colour (grey or white)");
+    DURF_REQUIRE((a->flags & ~(DURF_TRAIN_OBJ_FP32 | DURF_TRAIN_POSE_OPT)) == 0, "unknown flags");
+    if (a->flags & DURF_TRAIN_POSE_OPT) {
+        DURF_REQUIRE(f.K > 0 && (a->flags & DURF_TRAIN_OBJ_FP32), "box-pose optimisation runs behind the fp32 object branch");
+        DURF_REQUIRE(a->want_pos || a->want_rot, "pose optimisation without a pose gradient to compute");
+        DURF_REQUIRE(f.pose >= a->params && f.pose + (size_t)f.K * 6 <= a->params + a->box_floats,
+                     "f.pose must be this timestep's rows of box_centers inside params (their gradient goes to the same rows of grad)");
+        DURF_REQUIRE(a->prev6 != nullptr || a->tv_loss_mult == 0.0f, "the TV prior needs prev6");
+    }
     DURF_REQUIRE(a->params && a->grad && a->stats, "params, grad and stats buffers");
     DURF_REQUIRE(((size_t)a->grad & 15) == 0, "grad aligned to 16 bytes");
     for (int l = 0; l < f.num_levels; l++)
@@ -122,8 +161,20 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
                               f.dyn_mask));
     else
         STEP((int)hipMemsetAsync(f.dyn_mask, 0, (size_t)B * 4, hs));
-    STEP(durf_pack_weights_all(stream, f.bkgd_params, 60, w.wf_bkgd, w.wb_bkgd, K, f.obj_params, f.obj_param_stride, 63, w.wf_obj,
+    const bool f32o = K > 0 && (a->flags & DURF_TRAIN_OBJ_FP32), pose_opt = f32o && (a->flags & DURF_TRAIN_POSE_OPT);
+    const int Kb = f32o ? 0 : K;                          // objects on the bf16 kernels
+    STEP(durf_pack_weights_all(stream, f.bkgd_params, 60, w.wf_bkgd, w.wb_bkgd, Kb, f.obj_params, f.obj_param_stride, 63, w.wf_obj,
                                w.wb_obj));
+    if (f32o) {
+        // the object branch in exact fp32 (MipNerfModel.object_precision, obbpose_model._forward): fp32 view features and
+        // weight streams, and the background MLP's ONE evaluation of every box-hit ray redone in fp32 -- the constant
+        // trunk once, the view layer + rgb head per ray (the Python path runs these beside the prologue on a side stream)
+        STEP(durf_view_enc(stream, B, f.viewdirs, nullptr, w.view27));
+        STEP(durf_mlp_f32_pack(stream, 128, 63, K, f.obj_params, f.obj_param_stride, w.obj_ws));
+        STEP(durf_bkgd_const_trunk_f32(stream, f.bkgd_params, w.trunk));
+        STEP(durf_bkgd_hit_rays_f32(stream, B, w.view27, f.bkgd_params, w.idx_cls + B, w.count_cls + 1, w.trunk, w.raw_tail));
+        if (pose_opt) STEP((int)hipMemsetAsync(w.pose_sums, 0, (size_t)K * 21 * 4, hs));
+    }
     const float* raw_obj[ML][DURF_MAX_OBJ];
     for (int l = 0; l < L; l++)
         for (int k = 0; k < K; k++) raw_obj[l][k] = w.obj_raw[l] + (size_t)k * rows * 4;
@@ -133,10 +184,15 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
         if (K > 0) {
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags, w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c[lvl], w.stash[lvl],
                               w.mask[lvl], w.idx_cls + B, w.count_cls + 1));
-            STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], nullptr));
-            STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, f.radii, f.barf_w, obj_flags,
-                                    w.view, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
-                                    lvl == 0 ? w.obj_view_tile : nullptr));
+            STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], f32o ? w.raw_tail : nullptr));
+            if (f32o)
+                STEP(durf_objf32_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, nullptr, w.view27, f.obj_params,
+                                           f.obj_param_stride, w.obj_ws, w.obj_raw[lvl], w.act32[lvl], t_vals, w.o_s, w.d_s,
+                                           f.radii, f.barf_w, obj_flags));
+            else
+                STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, f.radii, f.barf_w, obj_flags,
+                                        w.view, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
+                                        lvl == 0 ? w.obj_view_tile : nullptr));
         } else {
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, nullptr, 0, f.enc_flags, w.enc[lvl], w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl],
                               w.mask[lvl], nullptr, nullptr));
@@ -163,11 +219,19 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
                            a->box_loss_mult, lvl, a->disable_multiscale, a->bg, f.density_bias, w.draw, w.terms[lvl], nullptr,
                            last ? f.rgb[lvl] : nullptr, last ? f.depth[lvl] : nullptr, last ? f.acc[lvl] : nullptr,
                            last ? f.weights[lvl] : nullptr, last ? f.t_mids[lvl] : nullptr, last ? f.t_dists[lvl] : nullptr, rs));
+        if (f32o) {       // the object branch in fp32: backward (+ d(enc) -> the 21 pose sums per object), all K at once
+            STEP(durf_objf32_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw, f.obj_params, f.obj_param_stride, w.obj_ws,
+                                       w.act32[lvl], w.dz32[lvl], pose_opt ? w.d_enc32[lvl] : nullptr));
+            if (pose_opt)
+                STEP(durf_encode_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.d_enc32[lvl], f.t_vals[lvl], w.o_s, w.d_s,
+                                               f.radii, f.origins, f.directions, f.pose, f.barf_w, w.pose_scratch, w.pose_sums, 1));
+        }
         if (K > 0) {
             STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw, w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
                               nullptr, w.idx_cls + B, w.count_cls + 1, rs));
-            STEP(durf_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw, w.wb_obj, w.obj_mask[lvl], w.obj_dz[lvl],
-                                    w.obj_dz_out[lvl], nullptr));
+            if (!f32o)
+                STEP(durf_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw, w.wb_obj, w.obj_mask[lvl], w.obj_dz[lvl],
+                                        w.obj_dz_out[lvl], nullptr));
         } else {
             STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw, nullptr, nullptr, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl], nullptr,
                               nullptr, nullptr, nullptr));
@@ -185,17 +249,29 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
         per_ray[l] = K > 0 ? 1 : N;                           // de-duplicated: one segment of count_cls[2] valid rows
         seg_count[l] = K > 0 ? w.count_cls + 2 : nullptr;
     }
-    if (K > 0) {
+    float* g_bkgd = a->grad + a->box_floats;
+    float* g_obj = g_bkgd + a->mlp0_floats;
+    if (f32o) {                 // fp32 object branch: its own weight-gradient launch pair over every level
+        const float *act[ML], *dz32[ML];
+        for (int l = 0; l < L; l++) { act[l] = w.act32[l]; dz32[l] = w.dz32[l]; }
+        STEP(durf_objf32_dw_batch(stream, K, B, N, w.count_obj, L, act, dz32, OBJ32_NSPLIT, w.dw32_scratch, g_obj, a->obj_floats));
+    } else if (K > 0) {
         for (int l = 0; l < L; l++) { enc[l] = w.obj_enc[l]; stash[l] = w.obj_stash[l]; dz[l] = w.obj_dz[l]; dzo[l] = w.obj_dz_out[l]; }
         STEP(durf_obj_dw_partials(stream, K, B, N, w.count_obj, L, enc, ovt, stash, dz, dzo, w.opart, w.obpart));
     }
     for (int l = 0; l < L; l++) { enc[l] = w.enc[l]; stash[l] = w.stash[l]; dz[l] = w.dz[l]; dzo[l] = w.dz_out[l]; }
     STEP(durf_mlp_dw_levels(stream, 256, L, seg_rows, per_ray, seg_count, enc, vt, stash, dz, dzo, w.part, w.bpart));
-    float* g_bkgd = a->grad + a->box_floats;
-    float* g_obj = g_bkgd + a->mlp0_floats;
-    STEP(durf_dw_finalize_all(stream, 60, L, seg_rows, per_ray, seg_count, w.part, w.bpart, g_bkgd, f.bkgd_params, K, K ? B : 0,
-                              K ? N : 0, K ? w.count_obj : nullptr, K ? L : 1, 63, K ? w.opart : nullptr, K ? w.obpart : nullptr,
-                              K ? g_obj : nullptr, K ? a->obj_floats : 0, K ? f.obj_params : nullptr));
+    STEP(durf_dw_finalize_all(stream, 60, L, seg_rows, per_ray, seg_count, w.part, w.bpart, g_bkgd, f.bkgd_params, Kb, Kb ? B : 0,
+                              Kb ? N : 0, Kb ? w.count_obj : nullptr, Kb ? L : 1, 63, Kb ? w.opart : nullptr, Kb ? w.obpart : nullptr,
+                              Kb ? g_obj : nullptr, Kb ? a->obj_floats : 0, Kb ? f.obj_params : nullptr));
+    if (pose_opt) {             // d(loss)/d(box_centers[ts]) (obbpose_model.py:99-131) + the TV prior, into this timestep's rows
+        float* g_rows = a->grad + (f.pose - a->params);
+        STEP(durf_pose_finish(stream, K, f.pose, w.pose_sums, a->want_pos, a->want_rot, g_rows));
+        if (a->want_pos && a->tv_loss_mult != 0.0f) {
+            const float c = (float)((double)a->tv_loss_mult * (1.0 + 0.1 * (double)(L - 1)) * 2.0);
+            hipLaunchKernelGGL(k_tv_rows, dim3(1), dim3(64), 0, hs, K, f.pose, a->prev6, c, g_rows);
+        }
+    }
     if (K > 1)                  // rays that hit two boxes: the reference's NaN -> zero update (durf_poison_multi_hit)
         STEP(durf_poison_multi_hit(stream, a->n_params, a->grad, w.count_cls, a->box_floats, K, a->mlp0_floats, a->obj_floats));
     // ---- the logged scalars (utils.Stats), one launch ----
@@ -214,18 +290,21 @@ extern "C" {
 size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params) {
     return carve(nullptr, B, N, K, num_levels, n_params).total;
 }
+size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, size_t n_params, int flags) {
+    return carve(nullptr, B, N, K, num_levels, n_params, flags).total;
+}
 
 int durf_loss_backward(void* stream, const durf_train_args* a, void* workspace) {
     int rc = check_args(a, workspace);
     if (rc != 0) return rc;
-    return loss_backward(stream, a, carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params));
+    return loss_backward(stream, a, carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params, a->flags));
 }
 
 int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
     int rc = check_args(a, workspace);
     if (rc != 0) return rc;
     DURF_REQUIRE(a->adam_m && a->adam_v && a->grad_stats, "Adam moments and grad_stats");
-    const TrainWs w = carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params);
+    const TrainWs w = carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params, a->flags);
     STEP(loss_backward(stream, a, w));
     return durf_clip_adam(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, 1.0f, a->max_val, a->max_norm, a->lr, a->step,
                           w.scratch, a->grad_stats);

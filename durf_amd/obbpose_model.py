@@ -224,7 +224,7 @@ class MipNerfModel:
             tail_side = ops.side_stream(dev)
             cached = getattr(variables, '_trunk_cache', None)
             variables._trunk_cache = None
-            if cached is not None and cached[1] == variables.flat._version:
+            if cached is not None and cached[1] == (variables.flat._version, ops.param_generation(variables.flat)):
                 trunk = cached[0]
             else:
                 tail_side.wait_stream(torch.cuda.current_stream())
@@ -321,6 +321,21 @@ class MipNerfModel:
                 mask_b = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev) if train else None
                 side = ops.on_side(dev, bool(Kb) and ops.overlap_forward(rows))          # the object MLPs run in the shadow of the background MLP
                 enc_kw = dict(contraction=self.contraction, disable_integration=self.disable_integration, cylinder=cyl)
+                slabs = None
+                obj_first = bool(Kb) and side.enabled and ops.OBJECTS_FIRST
+
+                def launch_objects():                    # all K object MLPs of this level: one call (csrc/objects.hip)
+                    with side:
+                        ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
+                                          view_tile=view_tiles_obj if lvl == 0 else None,
+                                          disable_integration=self.disable_integration, cylinder=cyl)
+                if Kb:
+                    slabs = ops.ObjSlabs(Kd, B, N, dev, train)      # allocated on the main stream, filled on the side one
+                if obj_first:
+                    # issued BEFORE the persistent background forward takes every CU: the object launches (one latency-
+                    # bound round of ~100 workgroups) then run at its start instead of in its tail
+                    side.fork()
+                    launch_objects()
                 if dd is not None and ops.FUSED_ENCODE:       # the forward encodes its own tiles (durf_mlp_fwd_enc)
                     side.fork()
                     raw_c, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit, view, packs['MLP_0'][0],
@@ -349,16 +364,12 @@ class MipNerfModel:
                                                disable_integration=self.disable_integration, cylinder=cyl)
                     side.fork()
                     raw_b = ops.mlp_fwd(W_BKGD, rows, N, enc_b, view, packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b)
-                slabs = None
                 if obj_f32:                              # object branch in exact fp32 (object_precision)
                     lvd = self._objects_f32(obj_flat, lay.mlp_size[W_OBJ], ctx['obj_ws'], train, t_vals, o_s, d_s, radii, Kd, cyl,
                                             view27, idx, count, alpha, B, N)
-                if Kb:                                   # all K object MLPs of this level: one call (csrc/objects.hip)
-                    slabs = ops.ObjSlabs(Kd, B, N, dev, train)      # allocated on the main stream, filled on the side one
-                    with side:
-                        ops.obj_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view, packs['obj'][0],
-                                          view_tile=view_tiles_obj if lvl == 0 else None,
-                                          disable_integration=self.disable_integration, cylinder=cyl)
+                if Kb:
+                    if not obj_first:
+                        launch_objects()
                     side.join()
                 raws = slabs.raws() if Kb else (lvd['raws'] if obj_f32 else [])
             if randomized and self.density_noise > 0:    # :236-240 (added once to the merged raw density)
@@ -415,7 +426,8 @@ class MipNerfModel:
         parameters alone, one workgroup reading 2.4 MB of cold weights -- is started NOW on the side stream, where it
         overlaps the step's tail and the next step's small per-ray launches instead of the persistent MLP kernels (beside
         those it waits for a CU and delays the workgroup that finally shares it: measured +40 us on the forward).
-        Used once, and only if the parameters have not been touched through torch since (tensor version counter)."""
+        Used once, and only if the parameters have not been touched since: through torch (tensor version counter) or
+        through this library's in-place updates, which torch does not see (ops.param_generation)."""
         lay = variables.layout
         if self.mlp_precision != 'bf16' or not self.dynamics or lay.K == 0 or self.object_precision() != 'f32':
             return
@@ -425,7 +437,7 @@ class MipNerfModel:
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             trunk = ops.bkgd_const_trunk_f32(variables.mlp_flat('MLP_0'))
-        variables._trunk_cache = (trunk, variables.flat._version)
+        variables._trunk_cache = (trunk, (variables.flat._version, ops.param_generation(variables.flat)))
 
     def supports_one_call(self, variables, randomized=False):
         """whether durf_forward (apply_one_call) covers this model's inference path"""

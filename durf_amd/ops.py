@@ -325,6 +325,8 @@ def overlap_dw(rows):
 
 
 MERGE_FINALIZE = os.environ.get('DURF_MERGE_FINALIZE', '1') != '0'    # A/B switch: one finalize launch pair for all MLPs
+# side-stream forward: issue the object launches BEFORE the persistent background forward (A/B switch)
+OBJECTS_FIRST = os.environ.get('DURF_OBJECTS_FIRST', '0') != '0'
 _SIDE = {}
 
 
@@ -727,9 +729,29 @@ def poison_multi_hit(grad, cls_count, box_floats, K, mlp0_floats, obj_floats, up
                                                 int(mlp0_floats), int(obj_floats)), 'durf_poison_multi_hit')
 
 
+# Parameter updates go through ctypes data pointers, which torch's tensor version counters do not see.  Whatever caches a
+# function of the parameters (MipNerfModel.prefetch_const_trunk) keys it on this generation count instead: every
+# in-place update issued from this module bumps the count of the flat buffer it wrote.
+_PARAM_GENERATION = {}
+
+
+def param_generation(params):
+    return _PARAM_GENERATION.get((params.data_ptr(), params.numel()), 0)
+
+
+def _bump_generation(params):
+    key = (params.data_ptr(), params.numel())
+    _PARAM_GENERATION[key] = _PARAM_GENERATION.get(key, 0) + 1
+    if len(_PARAM_GENERATION) > 256:                 # (buffers come and go in tests; the table need not grow with them)
+        for k in list(_PARAM_GENERATION)[:128]:
+            if k != key:
+                del _PARAM_GENERATION[k]
+
+
 def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):
     """In-place Adam step on the flat buffers; returns stats[4] (grad_norm, grad_abs_max,
     clip multiplier, grad_norm_clipped) as a device tensor."""
+    _bump_generation(params)
     n = params.numel()
     dev = params.device
     scratch = torch.empty(int(_lib.lib().durf_optim_scratch_floats(n)), device=dev)
@@ -941,7 +963,11 @@ class TrainArgs(C.Structure):
                  ('level_mults', (C.c_float * 6) * FORWARD_MAX_LEVELS), ('stat_mults', C.c_float * 6), ('params', C.c_void_p)] +
                 [(n, C.c_size_t) for n in ('n_params', 'box_floats', 'mlp0_floats', 'obj_floats')] +
                 [(n, C.c_void_p) for n in ('grad', 'stats', 'adam_m', 'adam_v')] +
-                [('lr', C.c_float), ('max_val', C.c_float), ('max_norm', C.c_float), ('step', C.c_int), ('grad_stats', C.c_void_p)])
+                [('lr', C.c_float), ('max_val', C.c_float), ('max_norm', C.c_float), ('step', C.c_int), ('grad_stats', C.c_void_p),
+                 ('flags', C.c_int), ('want_pos', C.c_int), ('want_rot', C.c_int), ('tv_loss_mult', C.c_float)])
+
+
+TRAIN_OBJ_FP32, TRAIN_POSE_OPT = 1, 2          # durf_train_args.flags
 
 
 def _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
@@ -987,9 +1013,14 @@ def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, 
 def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_floats, N, num_levels, alpha, enc_flags,
                lossmult, pixels, gt_depth, sky, target6, prev6, eps, box_loss_mult, bg, disable_multiscale, level_mults,
                stat_mults, lr, max_val, max_norm, step, lindisp=False, bkgd_mode=BKGD_GREY, density_bias=-1.0,
-               resample_padding=0.01, t_rand=None, u_rand=None, update=True):
+               resample_padding=0.01, t_rand=None, u_rand=None, update=True, obj_fp32=False, want_pos=False, want_rot=False,
+               tv_loss_mult=0.0):
     """One shard's training step as ONE library call (durf_train_step; update=False: durf_loss_backward, parameters
-    untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None)"""
+    untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None).
+    obj_fp32: the object branch on the exact-fp32 kernels; want_pos / want_rot: box-pose optimisation behind it (`pose` must
+    then be a view of this timestep's rows of box_centers inside params_flat)"""
+    if update:
+        _bump_generation(params_flat)
     B, K = rays.origins.shape[0], pose.shape[0]
     dev = rays.origins.device
     L = _lib.lib()
@@ -1016,7 +1047,11 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
     a.grad, a.stats, a.grad_stats = _p(grad), _p(stats), _p(gstats)
     a.adam_m, a.adam_v = _p(_f32(m)), _p(_f32(v))
     a.lr, a.max_val, a.max_norm, a.step = float(lr), float(max_val), float(max_norm), int(step)
-    ws = torch.empty(int(L.durf_train_workspace_bytes(B, N, K, num_levels, params_flat.numel())), dtype=torch.uint8, device=dev)
+    pose_opt = bool(K) and (want_pos or want_rot)
+    a.flags = (TRAIN_OBJ_FP32 if (K and (obj_fp32 or pose_opt)) else 0) | (TRAIN_POSE_OPT if pose_opt else 0)
+    a.want_pos, a.want_rot, a.tv_loss_mult = int(bool(want_pos)), int(bool(want_rot)), float(tv_loss_mult)
+    ws = torch.empty(int(L.durf_train_workspace_bytes_flags(B, N, K, num_levels, params_flat.numel(), a.flags)), dtype=torch.uint8,
+                     device=dev)
     assert ws.data_ptr() % 256 == 0
     with _Timed('train_call'):
         fn = L.durf_train_step if update else L.durf_loss_backward

@@ -196,11 +196,17 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                              pose_sums)
     levels = ctx['levels']
 
+    # the ray classes' counts (multi-hit rays, the boxes they hit): from the de-duplicated forward, or -- with the A/B
+    # switch DURF_DEDUP_HIT_RAYS=0, where the forward does not classify -- from a classification of their own, so that
+    # the switch stays result-neutral for batches with rays that hit two boxes
+    cls_count = dd['count'] if dd is not None else (
+        ops.compact_classes(ctx['hit'], N)[1] if (lay.K > 1 and K > 0 and not f32) else None)
+
     def poison(upto=None):
         # rays that hit two boxes: the reference's gradient is NaN -> 0 for everything they touch (ops.poison_multi_hit);
         # on the local gradient, before whoever all-reduces it
-        if dd is not None and lay.K > 1:
-            ops.poison_multi_hit(grad, dd['count'], lay.box[1] - lay.box[0], lay.K, lay.mlp_size[om.W_BKGD],
+        if cls_count is not None and lay.K > 1:
+            ops.poison_multi_hit(grad, cls_count, lay.box[1] - lay.box[0], lay.K, lay.mlp_size[om.W_BKGD],
                                  lay.mlp_size[om.W_OBJ], upto=upto)
 
     flat = variables.flat
@@ -348,20 +354,25 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     return new_state, stats, new_rng, pose              # (the prologue's snapshot: does not alias the updated parameters)
 
 
-def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, update=True):
+def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, update=True, reduce_stats=True):
     """`train_step` through ONE library call (durf_train_step, csrc/train.hip): the orchestration of loss_and_grad /
     train_step done in C for hosts that are not Python; same arguments, same (new_state, stats, rng, pose), bit-identical
-    results (tests/test_gpu_train_call.py).  Scope of the C entry point: bf16 MLPs, frozen box poses, >= 2 levels, no density
-    noise, no weight decay, fixed background colour, one device.  update=False: gradient and scalars only
-    (durf_loss_backward) -> (grad, stats buffer views, per-level outputs)."""
+    results (tests/test_gpu_train_call.py).  Scope of the C entry point: every BASELINE.json training configuration on one
+    device -- bf16 background MLP, the object branch in bf16 (frozen poses) or in fp32 with box-pose optimisation behind it
+    (cfg4), >= 2 levels, no density noise, no weight decay, fixed background colour.  update=False: gradient and scalars
+    only (durf_loss_backward) -> (grad, stats buffer views, per-level outputs).  reduce_stats is accepted (and has nothing
+    to do on one device) so that this function can be handed to train_loop as its step_fn."""
     model._check()
     variables = state.variables
     lay = variables.layout
     K, L, N = lay.K, model.num_levels, model.num_samples
-    if (model.mlp_precision != 'bf16' or not (model.no_pose_opt and model.no_yaw_opt) or (K and not model.dynamics) or L < 2 or
+    if (model.mlp_precision != 'bf16' or (K and not model.dynamics) or L < 2 or
             config.weight_decay_mult != 0 or config.rand_bkgd or (config.randomized and model.density_noise > 0) or
             _dist() is not None):
-        raise NotImplementedError('durf_train_step covers the single-device bf16 step with frozen box poses (see csrc/train.hip)')
+        raise NotImplementedError('durf_train_step covers the single-device step with a bf16 background MLP, >= 2 levels, no '
+                                  'density noise / weight decay / random background (see csrc/train.hip)')
+    pose_opt = bool(K) and not (model.no_pose_opt and model.no_yaw_opt)
+    obj_fp32 = bool(K) and model.object_precision() == 'f32'
     rays = batch['rays']
     B = rays.origins.shape[0]
     dev = variables.flat.device
@@ -369,7 +380,9 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         u = torch.rand(2, B, N + 1, device=dev, generator=om._make_generator(rng, dev))
         noise = dict(t_rand=u[0], u_rand=u[1])
     ts = int(batch['ts'])
-    pose = variables['params']['box_centers'][ts].contiguous()
+    pose = variables['params']['box_centers'][ts]          # a view of the parameters: the pose gradient goes to the same rows
+    assert pose.is_contiguous()
+    pose_used = pose.clone()                               # what the step renders with (the update below is in place)
     flags = ((ops.ENC_CONTRACT if model.contraction else 0) | (ops.ENC_NO_INTEGRATION if model.disable_integration else 0) |
              (ops.ENC_CYLINDER if model.ray_shape == 'cylinder' else 0))
     outs, dyn, zo, grad, out, gs = ops.train_call(
@@ -381,9 +394,10 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         config.grad_max_norm, state.step, lindisp=model.lindisp, bkgd_mode=ops.BKGD_WHITE if config.white_bkgd else ops.BKGD_GREY,
         density_bias=model.density_bias, resample_padding=model.resample_padding,
         t_rand=noise['t_rand'] if config.randomized else None, u_rand=noise['u_rand'] if config.randomized else None,
-        update=update)
-    box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
-    ret = [tuple(o) + ([pose[:, :3], box_rot0], dyn, zo) for o in outs]
+        update=update, obj_fp32=obj_fp32, want_pos=pose_opt and not model.no_pose_opt, want_rot=pose_opt and not model.no_yaw_opt,
+        tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0)
+    box_rot0 = pose_used[0, 3:] if K > 0 else torch.zeros(3, device=dev)
+    ret = [tuple(o) + ([pose_used[:, :3], box_rot0], dyn, zo) for o in outs]
     st = ops.stats_views(out, L)
     if not update:
         return grad, st, ret
@@ -398,7 +412,7 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         grad_norm=gs[0], grad_abs_max=gs[1], grad_norm_clipped=gs[3],
         multi_hit_rays=(dyn > 1).sum() if K > 1 else torch.zeros((), dtype=torch.int64, device=dev))
     new_rng = (int(rng) + 1) if isinstance(rng, int) else rng
-    return TrainState(variables, state.m, state.v, state.step + 1), stats, new_rng, pose_out.clone()
+    return TrainState(variables, state.m, state.v, state.step + 1), stats, new_rng, pose_out
 
 
 # ---------------------------------------------------------------------------
@@ -535,9 +549,10 @@ def train_loop(model, config, state, dataset, test_dataset=None, train_dir=None,
                 # the reference's stats_trace holds pmean'd stats of EVERY step (train_boxpose.py:255,440); here only
                 # the logging step's were all-reduced, so average the window's loss / psnr over the ranks now -- one
                 # small collective per print_every steps (the gradient norm is global already: it is taken after pmean)
+                # (the logging step's own entry is already a mean over the ranks -- averaging equal values again is exact)
                 lp = torch.stack([losses, psnrs])
                 d_.all_reduce(lp)
-                losses, psnrs = lp[0] / world, lp[1] / world
+                losses, psnrs = lp[0] / d_.get_world_size(), lp[1] / d_.get_world_size()
             steps_per_sec = len(trace) / max(time.time() - t_loop, 1e-9)
             rec = dict(loss=float(stats.loss), avg_loss=float(losses.mean()), avg_psnr=float(psnrs.mean()),
                        max_grad_norm=float(gn.max()), lr=lr, eps=eps, alpha=alpha,

@@ -127,6 +127,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_train_workspace_bytes.restype = u64
     L.durf_train_workspace_bytes.argtypes = [i32, i32, i32, i32, u64]
     #   (B, N, K, num_levels, n_params)
+    L.durf_train_workspace_bytes_flags.restype = u64
+    L.durf_train_workspace_bytes_flags.argtypes = [i32, i32, i32, i32, u64, i32]
+    #   (B, N, K, num_levels, n_params, flags)
     L.durf_loss_backward.restype = i32
     L.durf_loss_backward.argtypes = [vp, vp, vp]
     #   (stream, args, workspace)

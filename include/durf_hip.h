@@ -336,11 +336,19 @@ int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
  * (durf_poison_multi_hit) and the logged scalars -- in the order durf_amd/train_boxpose.py issues them, on `stream`,
  * bit-identical to that path.  A data-parallel host all-reduces `grad` (and `stats` when it logs) and calls
  * durf_clip_adam (lax.pmean, train_boxpose.py:253-255); durf_train_step = durf_loss_backward + durf_clip_adam with
- * inv_world = 1 for a single device.  Scope: the benchmarked configuration -- bf16 MLPs, frozen box poses (no_pose_opt
- * and no_yaw_opt: box_centers get a zero gradient), >= 2 levels, no density noise, no weight decay, fixed background
- * colour (f.bkgd_mode 0 / 1, bg = 0.5 / 1.0).  `f` carries the rays, boxes, draws and -- as outputs -- each level's
- * rendered values; f.bkgd_params / f.obj_params must point into `params`.  workspace:
- * durf_train_workspace_bytes(B, N, K, num_levels, n_params) bytes, 256-byte aligned. */
+ * inv_world = 1 for a single device.  Scope: every BASELINE.json training configuration -- bf16 background MLP; the K
+ * object MLPs on the bf16 kernels with frozen box poses (flags = 0: box_centers get a zero gradient; cfg2 / cfg3 / cfg5),
+ * or on the exact-fp32 kernels (DURF_TRAIN_OBJ_FP32: MipNerfModel.object_precision() == 'f32' -- the box-hit rays'
+ * object MLPs, their encodings and the background MLP's one evaluation of those rays in fp32) with, under
+ * DURF_TRAIN_POSE_OPT, the box-pose gradient behind them (cfg4: obbpose_model.py:99-131; want_pos = !no_pose_opt,
+ * want_rot = !no_yaw_opt, the TV prior tv_loss_mult of train_boxpose.py:136,219 on the positions; f.pose must then be this
+ * timestep's rows of box_centers INSIDE params: their gradient lands in the same rows of grad); >= 2 levels, no density
+ * noise, no weight decay, fixed background colour (f.bkgd_mode 0 / 1, bg = 0.5 / 1.0).  `f` carries the rays, boxes,
+ * draws and -- as outputs -- each level's rendered values; f.bkgd_params / f.obj_params must point into `params`.
+ * workspace: durf_train_workspace_bytes_flags(B, N, K, num_levels, n_params, flags) bytes, 256-byte aligned
+ * (durf_train_workspace_bytes = flags 0). */
+#define DURF_TRAIN_OBJ_FP32 1
+#define DURF_TRAIN_POSE_OPT 2
 typedef struct durf_train_args {
     durf_forward_args f;
     const float *lossmult, *pixels, *gt_depth, *sky;     /* Rays.lossmult [B], batch pixels [B,3], depth [B], sky [B] */
@@ -357,8 +365,12 @@ typedef struct durf_train_args {
     float lr, max_val, max_norm;                          /*   learning rate, Config.grad_max_val, Config.grad_max_norm */
     int step;                                             /*   optimizer step count (0 for the first update) */
     float* grad_stats;                                    /*   [4] out: grad_norm, grad_abs_max, clip multiplier, grad_norm_clipped */
+    int flags;                                            /* DURF_TRAIN_OBJ_FP32 | DURF_TRAIN_POSE_OPT (0: the bf16 object branch, frozen poses) */
+    int want_pos, want_rot;                               /* DURF_TRAIN_POSE_OPT: !no_pose_opt, !no_yaw_opt (obbpose_model.py:100-104) */
+    float tv_loss_mult;                                   /*   Config.tv_loss_mult (position prior against prev6) */
 } durf_train_args;
 size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params);
+size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, size_t n_params, int flags);
 int durf_loss_backward(void* stream, const durf_train_args* args, void* workspace);
 int durf_train_step(void* stream, const durf_train_args* args, void* workspace);
 

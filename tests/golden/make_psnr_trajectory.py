@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates tests/golden/psnr_trajectory_N128.npz: the fp32 CPU oracle's training trajectory on the procedural
-scene of tests/psnr_experiment.py at the metric's 128 samples/ray x 2 levels, with the batches it consumed, so that
+scene of tests/scripts/psnr_experiment.py at the metric's 128 samples/ray x 2 levels, with the batches it consumed, so that
 `pytest -m gpu` (tests/test_gpu_psnr.py) can train the HIP path on the SAME batches from the SAME parameters and
 assert |delta PSNR| <= 0.1 dB (BASELINE.json north_star) without running the oracle on the GPU box.
 
@@ -20,7 +20,7 @@ sys.path.insert(0, ROOT)
 from durf_amd import math as dmath, obbpose_model, utils  # noqa: E402
 from oracle import durf_ref as R  # noqa: E402
 from tests import helpers as H  # noqa: E402
-from tests import psnr_experiment as P  # noqa: E402
+from tests.scripts import psnr_experiment as P  # noqa: E402
 
 N, STEPS, BATCH, NBATCH, NTEST, SEED = 128, 240, 256, 8, 1024, 7
 EVAL_AT = (40, 80, 120, 160, 200, 240)

@@ -1,6 +1,6 @@
 """Debug aid: per-layer relative errors of the HIP weight gradients vs the bf16-emulating oracle."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from durf_amd import ops
 from oracle import durf_ref as R

@@ -1,7 +1,7 @@
 """Max / mean abs error of the production (bf16, hardware sin/exp) encode path against the oracle, for contracted and
 uncontracted coordinates -- run by hand when the encode arithmetic changes:  python tests/encode_error.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from durf_amd import ops
 from oracle import durf_ref as R

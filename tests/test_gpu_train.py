@@ -583,6 +583,16 @@ def test_a_ray_that_hits_two_boxes_poisons_the_step_like_the_reference(cuda):
         else:
             assert float((moved_ref[sl] > 0).float().mean()) < 0.25, name + ': NaN reaches most of a hit box in the oracle'
             assert float(moved[sl].max()) == 0.0, name + ': zero gradient for the whole box here'
+    # the A/B switch DURF_DEDUP_HIT_RAYS=0 (every ray through the full background path) must not change the outcome
+    variables.flat.copy_(flat0)
+    ops.DEDUP_HIT_RAYS = False
+    try:
+        st2 = train_boxpose.create_train_state(variables)
+        st2, stats2, _, _ = train_boxpose.train_step(model, config, 0, st2, db, 5e-4, 3.0, 10.0, db['init'][0:1])
+    finally:
+        ops.DEDUP_HIT_RAYS = True
+    moved2 = (st2.variables.flat - flat0).abs().cpu()
+    assert torch.equal(moved2 == 0, moved == 0), 'the same segments stay put without the de-duplicated forward'
 
 
 @pytest.mark.parametrize('pose_opt', [False, True])
@@ -614,3 +624,30 @@ def test_side_stream_modes_give_the_same_parameters(cuda, monkeypatch, pose_opt)
             assert torch.equal(a, b), 'mode %s differs from the single-stream step' % mode
     monkeypatch.setattr(ops, '_MODE', 'auto')
     assert ops.overlap_mode(2048 * 128) == '2' and ops.overlap_mode(2048 * 128 - 1) == '0'
+
+
+def test_the_prefetched_trunk_is_dropped_when_the_parameters_change_behind_torch(cuda):
+    """MipNerfModel.prefetch_const_trunk caches a function of the parameters for the next pose-optimisation step.  Every
+    parameter update of this library goes through raw pointers (durf_clip_adam, durf_train_step) that torch's version
+    counter does not see: an update issued between the prefetch and the next forward must invalidate the cache
+    (ops.param_generation)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    wl = bench.setup_workload('cfg4', cuda, rays=256)
+    model, config, state, batch, prev = wl['model'], wl['config'], wl['state'], wl['batch'], wl['prev']
+    assert model.object_precision() == 'f32'
+    state, _, _, _ = train_boxpose.train_step(model, config, 0, state, batch, 5e-4, 3.0, wl['alpha'], prev)   # prefetches
+    v = state.variables
+    assert getattr(v, '_trunk_cache', None) is not None
+    # a second optimizer update that no forward has seen: a large step along a fixed direction
+    g = torch.full_like(v.flat, 0.05)
+    ops.clip_adam(v.flat, state.m, state.v, g, 1.0, 1.0, 0.0, 1e-2, state.step)
+    noise = dict(t_rand=torch.rand(256, model.num_samples + 1, device=cuda), u_rand=torch.rand(256, model.num_samples + 1, device=cuda))
+    run = lambda: model.apply(v, 0, batch['rays'], batch['init'], batch['ext'], batch['ts'], randomized=True, rand_bkgd=False,
+                              white_bkgd=False, alpha=wl['alpha'], noise=noise)
+    got = run()                       # must recompute the trunk from the CURRENT parameters
+    v._trunk_cache = None
+    want = run()
+    for lvl in range(2):
+        assert torch.equal(torch.nan_to_num(got[lvl][0]), torch.nan_to_num(want[lvl][0]))

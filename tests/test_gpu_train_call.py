@@ -16,18 +16,28 @@ def _eq(a, b, what):
     assert torch.allclose(a, b, rtol=0, atol=0, equal_nan=True), what
 
 
+POSE = 'MipNerfModel.no_pose_opt = False\nMipNerfModel.no_yaw_opt = False\n'
+
+
 @pytest.mark.parametrize('B,K,N,randomized,extra', [
     (4096, 3, 128, True, ''),                                            # the benchmarked shape (cfg3)
     (1000, 1, 64, True, 'Config.white_bkgd = True\nConfig.box_loss_mult = 2\n'),
     (777, 0, 32, False, 'Config.disable_multiscale_loss = True\n'),      # static model, ragged ray count
     (640, 8, 32, True, 'MipNerfModel.ray_shape = "cylinder"\nMipNerfModel.disable_integration = True\n'),
     (512, 2, 32, False, 'MipNerfModel.num_levels = 3\n'),
+    # box-pose optimisation (BASELINE cfg4): the object branch and the hit rays' background evaluation in fp32, the pose
+    # gradient + TV prior into this timestep's rows of box_centers, the poses moving from step to step
+    (1024, 3, 128, True, POSE),                                          # cfg4's per-rank shape
+    (600, 2, 32, True, 'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = False\n'),     # yaw only: no TV term
+    (512, 1, 32, False, POSE + 'Config.tv_loss_mult = 0.0\nConfig.white_bkgd = True\n'),
+    (512, 3, 32, True, 'MipNerfModel.obj_precision = "f32"\n'),          # fp32 object branch, frozen poses
 ])
 def test_one_call_train_step_is_bit_identical_to_train_step(cuda, B, K, N, randomized, extra):
     utils.clear_gin()
-    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
-                    'MipNerfModel.no_yaw_opt = True\nConfig.randomized = %s\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
-                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.01\n%s' % (N, randomized, extra))
+    base = ('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
+            'MipNerfModel.no_yaw_opt = True\nConfig.randomized = %s\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
+            'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.01\n' % (N, randomized))
+    utils.parse_gin(base + extra)
     config = utils.configured(utils.Config)
     b = synthetic.make_batch(B, K, seed=950 + K, allow_multi_hit=K > 1, noise_boxes=0.2)
     db = H.device_batch(b, cuda)
