@@ -390,52 +390,131 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                 }
             __syncthreads();
         };
-        static_for<0, TOTAL>([&](auto g_) {
-            constexpr int g = decltype(g_)::value;
-            constexpr int i = Sc::layer_of(g), c = Sc::chunk_of(g), l = Sc::layer(i), C = Sc::cols(i);
-            const float* xin = (i & 1) ? xb : xa;
-            float* xout = (i & 1) ? xa : xb;
-            if constexpr (g + 1 < TOTAL) chunk_commit<Sc::cols(Sc::layer_of(g + 1)), KC, NT, PFV>(pf[(g + 1) % D], wbuf + ((g + 1) & 1) * CB, tid);
-            if constexpr (g + D < TOTAL) chunk_issue<Sc::cols(Sc::layer_of(g + D)), KC, NT, PFV>(pf[(g + D) % D], rs, (unsigned)(Sc::chunk_off(g + D) * 4), tid);
-            if constexpr (c == 0) {                                    // the bias is the initial accumulator
+        if constexpr (W == 128) {
+            static_for<0, TOTAL>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                constexpr int i = Sc::layer_of(g), c = Sc::chunk_of(g), l = Sc::layer(i), C = Sc::cols(i);
+                const float* xin = (i & 1) ? xb : xa;
+                float* xout = (i & 1) ? xa : xb;
+                if constexpr (g + 1 < TOTAL) chunk_commit<Sc::cols(Sc::layer_of(g + 1)), KC, NT, PFV>(pf[(g + 1) % D], wbuf + ((g + 1) & 1) * CB, tid);
+                if constexpr (g + D < TOTAL) chunk_issue<Sc::cols(Sc::layer_of(g + D)), KC, NT, PFV>(pf[(g + D) % D], rs, (unsigned)(Sc::chunk_off(g + D) * 4), tid);
+                if constexpr (c == 0) {                                    // the bias is the initial accumulator
+    #pragma unroll
+                    for (int r = 0; r < 16; r++) acc[0][r] = cst[i * W + ((32 * wave + c_row(r, hi)) & (W - 1))];
+                }
+                chunk_mma<C, KC, Cf::NW, 1>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
+                if constexpr (c == Sc::nchunk(i) - 1) {
+                    // this wave's output tile -> the next Dense's input (LDS) and its record (global)
+                    constexpr int lrec = l == 7 ? 8 : (l == 9 ? 10 : l + 1);    // h7 is x8 (density head and bottleneck); bottleneck -> x10
+                    if (wave < C / 32) {
+    #pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int o = 32 * wave + c_row(r, hi);
+                            float v = acc[0][r];
+                            if (l != 9) v = (v != v) ? v : fmaxf(v, 0.0f);     // jnp.maximum(x, 0) propagates NaN; fmaxf would drop it
+                            xout[o * F32_XS + n] = v;
+                            if (TRAIN) rec_store_t<S.L[lrec].x_off>(ra, lane_off, r, v);
+                        }
+                    }
+                    if constexpr (l == 4) {                                 // x5 = [h4, enc]   (obbpose_model.py:333-334)
+                        for (int idx = tid; idx < 64 * 32; idx += NT) {
+                            const int f = idx >> 5, nn = idx & 31;
+                            const float v = encs[f * F32_XS + nn];
+                            xout[(W + f) * F32_XS + nn] = v;
+                            if (TRAIN && f < in_dim) rec_store(ra, S.L[5].x_off + W + f, nn, v);
+                        }
+                    }
+                    if constexpr (l == 9) {                                 // x10 = [bottleneck, view]   (:339, :346-347)
+                        for (int idx = tid; idx < 32 * 32; idx += NT) {
+                            const int f = idx >> 5, nn = idx & 31;
+                            const float v = vws[f * F32_XS + nn];
+                            xout[(W + f) * F32_XS + nn] = v;
+                            if (TRAIN && f < 27) rec_store(ra, S.L[10].x_off + W + f, nn, v);
+                        }
+                    }
+                }
+                __syncthreads();
+                if constexpr (c == Sc::nchunk(i) - 1 && l == 7) head(w8s, xout, W, 1, dens3);           // density head on h7
+                if constexpr (c == Sc::nchunk(i) - 1 && l == 10) head(w11s, xout, 128, 3, rgb);         // rgb head on hc
+            });
+        } else {
+            // W = 256: the same schedule with the chunks of a layer walked by a RUNTIME loop (pairs of chunks: the LDS
+            // buffer and the prefetch register set alternate), the last pair of every layer peeled for the hand-over to
+            // the next layer.  Fully unrolled (as for W = 128, whose 35-50 KB fit) the pass is 154 chunk bodies = 170 KB
+            // of straight-line code, three times the 64 KB instruction cache two CUs share: the kernel ran at 1.4 TFLOP/s,
+            // 1 % of the fp32 MFMA rate, waiting for instructions (tools/time_f32_bkgd.py).
+            static_assert(W == 128 || D == 2, "the pairwise walk assumes two prefetch register sets");
+            static_for<0, Sc::NL>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, l = Sc::layer(i), C = Sc::cols(i), NCH = Sc::nchunk(i);
+                constexpr bool has_next = i + 1 < Sc::NL;
+                constexpr int CN = Sc::cols(has_next ? i + 1 : i);                   // the next layer's chunk width
+                constexpr int G0 = TOTAL - [] { int t = 0; for (int j = i; j < Sc::NL; j++) t += Sc::nchunk(j); return t; }();
+                static_assert(NCH % 2 == 0 && G0 % 2 == 0, "whole pairs of chunks per layer");
+                constexpr unsigned OFF0 = (unsigned)(Sc::chunk_off(G0) * 4), OFFN = (unsigned)(Sc::chunk_off(G0 + NCH) * 4);
+                const float* xin = (i & 1) ? xb : xa;
+                float* xout = (i & 1) ? xa : xb;
 #pragma unroll
-                for (int r = 0; r < 16; r++) acc[0][r] = cst[i * W + ((32 * wave + c_row(r, hi)) & (W - 1))];
-            }
-            chunk_mma<C, KC, Cf::NW, 1>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
-            if constexpr (c == Sc::nchunk(i) - 1) {
-                // this wave's output tile -> the next Dense's input (LDS) and its record (global)
-                constexpr int lrec = l == 7 ? 8 : (l == 9 ? 10 : l + 1);    // h7 is x8 (density head and bottleneck); bottleneck -> x10
-                if (wave < C / 32) {
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int o = 32 * wave + c_row(r, hi);
-                        float v = acc[0][r];
-                        if (l != 9) v = (v != v) ? v : fmaxf(v, 0.0f);     // jnp.maximum(x, 0) propagates NaN; fmaxf would drop it
-                        xout[o * F32_XS + n] = v;
-                        if (TRAIN) rec_store_t<S.L[lrec].x_off>(ra, lane_off, r, v);
-                    }
+                for (int r = 0; r < 16; r++) acc[0][r] = cst[i * W + ((32 * wave + c_row(r, hi)) & (W - 1))];     // bias
+                // chunk c (parity PAR) of this layer: commit chunk c + 1, issue chunk c + 2, multiply
+                auto same_layer_step = [&](auto par_, int c) {
+                    constexpr int PAR = decltype(par_)::value;
+                    chunk_commit<C, KC, NT, PFV>(pf[PAR ^ 1], wbuf + (PAR ^ 1) * CB, tid);
+                    chunk_issue<C, KC, NT, PFV>(pf[PAR], rs, OFF0 + (unsigned)((c + 2) * KC * C * 4), tid);
+                    chunk_mma<C, KC, Cf::NW, 1>(wbuf + PAR * CB, xin + c * KC * F32_XS, wave, lane, acc);
+                    __syncthreads();
+                };
+#pragma unroll 1
+                for (int c = 0; c < NCH - 2; c += 2) {
+                    same_layer_step(std::integral_constant<int, 0>{}, c);
+                    same_layer_step(std::integral_constant<int, 1>{}, c + 1);
                 }
-                if constexpr (l == 4) {                                 // x5 = [h4, enc]   (obbpose_model.py:333-334)
-                    for (int idx = tid; idx < 64 * 32; idx += NT) {
-                        const int f = idx >> 5, nn = idx & 31;
-                        const float v = encs[f * F32_XS + nn];
-                        xout[(W + f) * F32_XS + nn] = v;
-                        if (TRAIN && f < in_dim) rec_store(ra, S.L[5].x_off + W + f, nn, v);
-                    }
+                // chunk NCH - 2: commit NCH - 1, issue the next layer's chunk 0
+                chunk_commit<C, KC, NT, PFV>(pf[1], wbuf + CB, tid);
+                if constexpr (has_next) chunk_issue<CN, KC, NT, PFV>(pf[0], rs, OFFN, tid);
+                chunk_mma<C, KC, Cf::NW, 1>(wbuf, xin + (NCH - 2) * KC * F32_XS, wave, lane, acc);
+                __syncthreads();
+                // chunk NCH - 1: commit the next layer's chunk 0, issue its chunk 1, multiply, hand the tile over
+                if constexpr (has_next) {
+                    chunk_commit<CN, KC, NT, PFV>(pf[0], wbuf, tid);
+                    chunk_issue<CN, KC, NT, PFV>(pf[1], rs, OFFN + (unsigned)(KC * CN * 4), tid);
                 }
-                if constexpr (l == 9) {                                 // x10 = [bottleneck, view]   (:339, :346-347)
-                    for (int idx = tid; idx < 32 * 32; idx += NT) {
-                        const int f = idx >> 5, nn = idx & 31;
-                        const float v = vws[f * F32_XS + nn];
-                        xout[(W + f) * F32_XS + nn] = v;
-                        if (TRAIN && f < 27) rec_store(ra, S.L[10].x_off + W + f, nn, v);
+                chunk_mma<C, KC, Cf::NW, 1>(wbuf + CB, xin + (NCH - 1) * KC * F32_XS, wave, lane, acc);
+                {
+                    // this wave's output tile -> the next Dense's input (LDS) and its record (global)
+                    constexpr int lrec = l == 7 ? 8 : (l == 9 ? 10 : l + 1);    // h7 is x8 (density head and bottleneck); bottleneck -> x10
+                    if (wave < C / 32) {
+    #pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int o = 32 * wave + c_row(r, hi);
+                            float v = acc[0][r];
+                            if (l != 9) v = (v != v) ? v : fmaxf(v, 0.0f);     // jnp.maximum(x, 0) propagates NaN; fmaxf would drop it
+                            xout[o * F32_XS + n] = v;
+                            if (TRAIN) rec_store_t<S.L[lrec].x_off>(ra, lane_off, r, v);
+                        }
                     }
+                    if constexpr (l == 4) {                                 // x5 = [h4, enc]   (obbpose_model.py:333-334)
+                        for (int idx = tid; idx < 64 * 32; idx += NT) {
+                            const int f = idx >> 5, nn = idx & 31;
+                            const float v = encs[f * F32_XS + nn];
+                            xout[(W + f) * F32_XS + nn] = v;
+                            if (TRAIN && f < in_dim) rec_store(ra, S.L[5].x_off + W + f, nn, v);
+                        }
+                    }
+                    if constexpr (l == 9) {                                 // x10 = [bottleneck, view]   (:339, :346-347)
+                        for (int idx = tid; idx < 32 * 32; idx += NT) {
+                            const int f = idx >> 5, nn = idx & 31;
+                            const float v = vws[f * F32_XS + nn];
+                            xout[(W + f) * F32_XS + nn] = v;
+                            if (TRAIN && f < 27) rec_store(ra, S.L[10].x_off + W + f, nn, v);
+                        }
+                    }
+            
                 }
-            }
-            __syncthreads();
-            if constexpr (c == Sc::nchunk(i) - 1 && l == 7) head(w8s, xout, W, 1, dens3);           // density head on h7
-            if constexpr (c == Sc::nchunk(i) - 1 && l == 10) head(w11s, xout, 128, 3, rgb);         // rgb head on hc
-        });
+                __syncthreads();
+                if constexpr (l == 7) head(w8s, xout, W, 1, dens3);           // density head on h7
+                if constexpr (l == 10) head(w11s, xout, 128, 3, rgb);         // rgb head on hc
+            });
+        }
         if (tid < 32 && row0 + tid < nrows) {
             const f32x4 o = {rgb[0], rgb[1], rgb[2], dens3[0]};
             *(f32x4*)(raw + (row0 + tid) * 4) = o;
@@ -518,14 +597,67 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
         f32x16 acc[2];
         float hm[16];                      // the producer's ReLU outputs at this lane's 16 positions: fetched at the first
                                            // chunk of a layer, applied in its epilogue (a round trip hidden behind the MFMAs)
-        static_for<0, TOTAL>([&](auto g_) {
-            constexpr int g = decltype(g_)::value;
-            constexpr int i = Sc::layer_of(g), c = Sc::chunk_of(g), l = Sc::layer(i), C = Sc::cols(i);
-            const float* xin = (i & 1) ? xb : xa;
-            float* xout = (i & 1) ? xa : xb;
-            if constexpr (g + 1 < TOTAL) chunk_commit<Sc::cols(Sc::layer_of(g + 1)), KC, NT, PFV>(pf[(g + 1) % D], wbuf + ((g + 1) & 1) * CB, tid);
-            if constexpr (g + D < TOTAL) chunk_issue<Sc::cols(Sc::layer_of(g + D)), KC, NT, PFV>(pf[(g + D) % D], rs, (unsigned)(Sc::chunk_off(g + D) * 4), tid);
-            if constexpr (c == 0) {
+        if constexpr (W == 128) {
+            static_for<0, TOTAL>([&](auto g_) {
+                constexpr int g = decltype(g_)::value;
+                constexpr int i = Sc::layer_of(g), c = Sc::chunk_of(g), l = Sc::layer(i), C = Sc::cols(i);
+                const float* xin = (i & 1) ? xb : xa;
+                float* xout = (i & 1) ? xa : xb;
+                if constexpr (g + 1 < TOTAL) chunk_commit<Sc::cols(Sc::layer_of(g + 1)), KC, NT, PFV>(pf[(g + 1) % D], wbuf + ((g + 1) & 1) * CB, tid);
+                if constexpr (g + D < TOTAL) chunk_issue<Sc::cols(Sc::layer_of(g + D)), KC, NT, PFV>(pf[(g + D) % D], rs, (unsigned)(Sc::chunk_off(g + D) * 4), tid);
+                if constexpr (c == 0) {
+    #pragma unroll
+                    for (int r = 0; r < 16; r++) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
+                    if constexpr (l != 0 && l != 10) {
+                        constexpr int h_off = S.L[l == 9 ? 8 : l].x_off;
+    #pragma unroll
+                        for (int r = 0; r < 16; r++) hm[r] = rec_load_t<h_off>(ra, lane_off, r);
+                    }
+                }
+                chunk_mma<C, KC, Cf::NW, 2>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
+                if constexpr (c == Sc::nchunk(i) - 1) {
+                    if constexpr (l != 0) {
+                        // d x_l (its first W features) -> dz of the Dense that produced them, masked by that Dense's ReLU output
+                        // (the record x_l itself; the bottleneck, Dense_9, is linear; h7 = x8 also feeds the density head)
+                        constexpr int lp = l == 10 ? 9 : (l == 9 ? 7 : l - 1);                  // the producer
+                        constexpr bool relu = l != 10;
+    #pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int k = 32 * wave + c_row(r, hi);
+                            float v = acc[0][r];
+                            if (l == 9) v += w8s[k] * gsm[3 * 32 + n];
+                            if (relu) v = hm[r] > 0.0f ? v : 0.0f;
+                            xout[k * F32_XS + n] = v;
+                            rec_store_t<S.L[lp].dz_off>(rz, lane_off, r, v);
+                        }
+                        if constexpr (l == 5) {            // skip connection: output tiles W/32 and W/32 + 1 are d enc
+                            if (wave < 2) {
+    #pragma unroll
+                                for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] = acc[1][r];
+                            }
+                        }
+                    } else {                               // Dense_0: d enc += W0 dz0
+                        if (wave < 2) {
+    #pragma unroll
+                            for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] += acc[0][r];
+                        }
+                    }
+                }
+                __syncthreads();
+            });
+        } else {
+            // W = 256: a runtime loop over the chunk pairs of every layer, the last pair peeled (see k_mlp_fwd_f32: the fully
+            // unrolled pass does not fit the instruction cache)
+            static_assert(W == 128 || D == 2, "the pairwise walk assumes two prefetch register sets");
+            static_for<0, Sc::NL>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, l = Sc::layer(i), C = Sc::cols(i), NCH = Sc::nchunk(i);
+                constexpr bool has_next = i + 1 < Sc::NL;
+                constexpr int CN = Sc::cols(has_next ? i + 1 : i);
+                constexpr int G0 = TOTAL - [] { int t = 0; for (int j = i; j < Sc::NL; j++) t += Sc::nchunk(j); return t; }();
+                static_assert(NCH % 2 == 0 && G0 % 2 == 0, "whole pairs of chunks per layer");
+                constexpr unsigned OFF0 = (unsigned)(Sc::chunk_off(G0) * 4), OFFN = (unsigned)(Sc::chunk_off(G0 + NCH) * 4);
+                const float* xin = (i & 1) ? xb : xa;
+                float* xout = (i & 1) ? xa : xb;
 #pragma unroll
                 for (int r = 0; r < 16; r++) { acc[0][r] = 0.0f; acc[1][r] = 0.0f; }
                 if constexpr (l != 0 && l != 10) {
@@ -533,38 +665,60 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
 #pragma unroll
                     for (int r = 0; r < 16; r++) hm[r] = rec_load_t<h_off>(ra, lane_off, r);
                 }
-            }
-            chunk_mma<C, KC, Cf::NW, 2>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
-            if constexpr (c == Sc::nchunk(i) - 1) {
-                if constexpr (l != 0) {
-                    // d x_l (its first W features) -> dz of the Dense that produced them, masked by that Dense's ReLU output
-                    // (the record x_l itself; the bottleneck, Dense_9, is linear; h7 = x8 also feeds the density head)
-                    constexpr int lp = l == 10 ? 9 : (l == 9 ? 7 : l - 1);                  // the producer
-                    constexpr bool relu = l != 10;
-#pragma unroll
-                    for (int r = 0; r < 16; r++) {
-                        const int k = 32 * wave + c_row(r, hi);
-                        float v = acc[0][r];
-                        if (l == 9) v += w8s[k] * gsm[3 * 32 + n];
-                        if (relu) v = hm[r] > 0.0f ? v : 0.0f;
-                        xout[k * F32_XS + n] = v;
-                        rec_store_t<S.L[lp].dz_off>(rz, lane_off, r, v);
-                    }
-                    if constexpr (l == 5) {            // skip connection: output tiles W/32 and W/32 + 1 are d enc
+            
+                auto same_layer_step = [&](auto par_, int c) {
+                    constexpr int PAR = decltype(par_)::value;
+                    chunk_commit<C, KC, NT, PFV>(pf[PAR ^ 1], wbuf + (PAR ^ 1) * CB, tid);
+                    chunk_issue<C, KC, NT, PFV>(pf[PAR], rs, OFF0 + (unsigned)((c + 2) * KC * C * 4), tid);
+                    chunk_mma<C, KC, Cf::NW, 2>(wbuf + PAR * CB, xin + c * KC * F32_XS, wave, lane, acc);
+                    __syncthreads();
+                };
+#pragma unroll 1
+                for (int c = 0; c < NCH - 2; c += 2) {
+                    same_layer_step(std::integral_constant<int, 0>{}, c);
+                    same_layer_step(std::integral_constant<int, 1>{}, c + 1);
+                }
+                chunk_commit<C, KC, NT, PFV>(pf[1], wbuf + CB, tid);
+                if constexpr (has_next) chunk_issue<CN, KC, NT, PFV>(pf[0], rs, OFFN, tid);
+                chunk_mma<C, KC, Cf::NW, 2>(wbuf, xin + (NCH - 2) * KC * F32_XS, wave, lane, acc);
+                __syncthreads();
+                if constexpr (has_next) {
+                    chunk_commit<CN, KC, NT, PFV>(pf[0], wbuf, tid);
+                    chunk_issue<CN, KC, NT, PFV>(pf[1], rs, OFFN + (unsigned)(KC * CN * 4), tid);
+                }
+                chunk_mma<C, KC, Cf::NW, 2>(wbuf + CB, xin + (NCH - 1) * KC * F32_XS, wave, lane, acc);
+                {
+                    if constexpr (l != 0) {
+                        // d x_l (its first W features) -> dz of the Dense that produced them, masked by that Dense's ReLU output
+                        // (the record x_l itself; the bottleneck, Dense_9, is linear; h7 = x8 also feeds the density head)
+                        constexpr int lp = l == 10 ? 9 : (l == 9 ? 7 : l - 1);                  // the producer
+                        constexpr bool relu = l != 10;
+    #pragma unroll
+                        for (int r = 0; r < 16; r++) {
+                            const int k = 32 * wave + c_row(r, hi);
+                            float v = acc[0][r];
+                            if (l == 9) v += w8s[k] * gsm[3 * 32 + n];
+                            if (relu) v = hm[r] > 0.0f ? v : 0.0f;
+                            xout[k * F32_XS + n] = v;
+                            rec_store_t<S.L[lp].dz_off>(rz, lane_off, r, v);
+                        }
+                        if constexpr (l == 5) {            // skip connection: output tiles W/32 and W/32 + 1 are d enc
+                            if (wave < 2) {
+    #pragma unroll
+                                for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] = acc[1][r];
+                            }
+                        }
+                    } else {                               // Dense_0: d enc += W0 dz0
                         if (wave < 2) {
-#pragma unroll
-                            for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] = acc[1][r];
+    #pragma unroll
+                            for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] += acc[0][r];
                         }
                     }
-                } else {                               // Dense_0: d enc += W0 dz0
-                    if (wave < 2) {
-#pragma unroll
-                        for (int r = 0; r < 16; r++) denc[(32 * wave + c_row(r, hi)) * F32_XS + n] += acc[0][r];
-                    }
+            
                 }
-            }
-            __syncthreads();
-        });
+                __syncthreads();
+            });
+        }
         if (d_enc) {
             for (int idx = tid; idx < 32 * 64; idx += NT) {
                 const int nn = idx >> 6, k = idx & 63;

@@ -325,8 +325,10 @@ def overlap_dw(rows):
 
 
 MERGE_FINALIZE = os.environ.get('DURF_MERGE_FINALIZE', '1') != '0'    # A/B switch: one finalize launch pair for all MLPs
-# side-stream forward: issue the object launches BEFORE the persistent background forward (A/B switch)
-OBJECTS_FIRST = os.environ.get('DURF_OBJECTS_FIRST', '0') != '0'
+# side-stream forward: issue the object launches BEFORE the persistent background forward, which takes every CU: they then
+# run at its start instead of in its tail (round 4, three interleaved runs on one box at cfg3: 956.2-958.0 -> 961.2-962.9 k
+# rays/s; DURF_OBJECTS_FIRST=0 is the A/B switch)
+OBJECTS_FIRST = os.environ.get('DURF_OBJECTS_FIRST', '1') != '0'
 _SIDE = {}
 
 
