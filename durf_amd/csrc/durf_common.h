@@ -162,7 +162,13 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 // Strides of 0 with gridDim.y == 1 are the plain per-MLP launches.
 struct FwdStrides { size_t enc, idx, wpack, raw, stash, mask; };
 // the background encoder's inputs, for the forward that encodes its own tiles (k_mlp_fwd<256, .., ENC>; durf_mlp_fwd_enc)
-struct EncIn { const float* t_vals; const float* origins_s; const float* dirs_s; const float* radii; const int32_t* hit; int K; int flags; };
+// (obj: the object form -- no hit masking, no contraction, the coordinates prepended and the BARF weights w, mip.py:182-223;
+// view_tile, nullable: the launch also writes the per-sample view-direction tile [rows,32] the weight-gradient GEMM of
+// Dense_10 reads (durf_expand_view's output; view_stride bytes apart for batched objects))
+struct EncIn {
+    const float* t_vals; const float* origins_s; const float* dirs_s; const float* radii; const int32_t* hit; int K; int flags;
+    int obj; float w[10]; void* view_tile; size_t view_stride;
+};
 struct BwdStrides { size_t idx, wpack, mask, dz, dz_out, d_enc; };
 struct DwStrides { size_t enc, view, stash, dz_out, part, bpart; };      // stash stride also applies to dz
 

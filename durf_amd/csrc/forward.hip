@@ -85,14 +85,14 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
         float* t_vals = a->t_vals[lvl];
         if (K > 0) {
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, w.hit, K, a->enc_flags, w.enc, w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c, nullptr, nullptr,
-                              w.idx_cls + B, w.count_cls + 1));
+                              w.idx_cls + B, w.count_cls + 1, nullptr));
             STEP(durf_expand_raw(stream, B, N, w.raw_c, w.count_cls, w.slot_cls, w.raw_b, nullptr));
             STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, a->radii, a->barf_w,
                                     a->enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), w.view, w.wf_obj, w.obj_enc,
                                     w.obj_raw, nullptr, nullptr, nullptr));
         } else {
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, nullptr, 0, a->enc_flags, w.enc, w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b, nullptr, nullptr, nullptr,
-                              nullptr));
+                              nullptr, nullptr));
         }
         STEP(durf_composite_fwd(stream, B, N, K, w.raw_b, raw_obj, w.slot_obj, t_vals, w.d_s, a->density_bias, a->bkgd_mode,
                                 a->rgb[lvl], a->depth[lvl], a->acc[lvl], a->weights[lvl], a->t_mids[lvl], a->t_dists[lvl]));

@@ -258,6 +258,7 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         count += k;
         wpack += k * bs.wpack;
         raw = (float*)((char*)raw + k * bs.raw);
+        if (ENC && ei.view_tile) ei.view_tile = (char*)ei.view_tile + k * ei.view_stride;
         if (TRAIN) {
             stash = (bf16x8*)((char*)stash + k * bs.stash);
             relu_mask = (uint4*)((char*)relu_mask + k * bs.mask);
@@ -325,12 +326,25 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         if (tile_valid && !tail) {               // (a non-tail tile is whole: count * N and rows are multiples of 32)
             const int j = (int)(row / (size_t)N), n = (int)(row % (size_t)N);
             const int b = ray_idx ? ray_idx[j] : j;
-            const Gauss g = bkgd_sample_gaussian(b, n, N, ei.t_vals, ei.origins_s, ei.dirs_s, ei.radii, ei.hit, ei.K, ei.flags);
             const bool hi = lane >= 32;          // this lane's fragment of k-step k: features [16 k + 8 hi, + 8) = vector q = 2 k + hi
-            lane_features<false>(g, BarfW{}, [&](auto q_, const bf16x8& o8) {
+            auto keep = [&](auto q_, const bf16x8& o8) {
                 constexpr int q = decltype(q_)::value;
                 if (hi == (bool)(q & 1)) encf[q >> 1] = o8;
-            });
+            };
+            if constexpr (W == 128) {            // object MLP: k_encode_lane<true>'s Gaussian (object frame, no masking, no contraction)
+                const float t0 = ei.t_vals[(size_t)b * (N + 1) + n], t1 = ei.t_vals[(size_t)b * (N + 1) + n + 1];
+                float o[3] = {ei.origins_s[b * 3], ei.origins_s[b * 3 + 1], ei.origins_s[b * 3 + 2]};
+                float d[3] = {ei.dirs_s[b * 3], ei.dirs_s[b * 3 + 1], ei.dirs_s[b * 3 + 2]};
+                Gauss g = frustum_gaussian(t0, t1, o, d, ei.radii[b], (ei.flags & DURF_ENC_CYLINDER) != 0);
+                if (ei.flags & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
+                BarfW bw;
+#pragma unroll
+                for (int i = 0; i < 10; i++) bw.w[i] = ei.w[i];
+                lane_features<true>(g, bw, keep);
+            } else {
+                const Gauss g = bkgd_sample_gaussian(b, n, N, ei.t_vals, ei.origins_s, ei.dirs_s, ei.radii, ei.hit, ei.K, ei.flags);
+                lane_features<false>(g, BarfW{}, keep);
+            }
         }
         if (tile_valid && (TRAIN || !tail)) {    // stage 5 re-reads the tile; training: so do the weight-gradient GEMMs
 #pragma unroll
@@ -411,6 +425,13 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
 #pragma unroll
         for (int k = 0; k < S::KV; k++)
             vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + hi_v] : zero8;
+        if constexpr (ENC) {     // the view-direction tile of the weight-gradient GEMM: this fragment IS its tile layout
+            if (TRAIN && ei.view_tile && tile_valid) {
+#pragma unroll
+                for (int k = 0; k < S::KV; k++) *(bf16x8*)((char*)ei.view_tile + (tile32 * S::KV + k) * 1024 + lane * 16) = vf[k];
+                p.since += S::KV;
+            }
+        }
     }
     bf16x8 c[S::KC];
     run_stage<SLOT, S::KW, S::KV, S::CT, true, TRAIN, S::WT>(p, a, vf, c, S::KC + 1, ST(9), tile_valid, a, nullptr, nullptr, mcarry);
@@ -491,14 +512,17 @@ int durf_pack_weights(void* stream, int width, int in_dim, const float* mlp_para
 int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
                      const float* radii, const int32_t* hit, int K, int enc_flags, void* enc_tile, const void* view_bf16,
                      const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
-                     void* relu_mask, const int32_t* tail_idx, const int32_t* tail_count) {
+                     void* relu_mask, const int32_t* tail_idx, const int32_t* tail_count, void* view_tile) {
     DURF_REQUIRE((tail_idx == nullptr) == (tail_count == nullptr), "tail_idx and tail_count go together");
     DURF_REQUIRE(tail_idx == nullptr || (count != nullptr && N % 32 == 0), "tail rows follow a compacted ray list");
     DURF_REQUIRE((ray_idx == nullptr) == (count == nullptr), "ray_idx and count go together");
+    DURF_REQUIRE(view_tile == nullptr || stash != nullptr, "the view-direction tile is a training output");
     DURF_REQUIRE(t_vals && origins_s && dirs_s && radii && enc_tile, "ray data and the encoding tile buffer are required");
     DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ && (K == 0 || hit != nullptr), "0 <= K <= DURF_MAX_OBJ, hit [B,K]");
     DURF_REQUIRE(N > 0 && (count != nullptr ? N % 32 == 0 : rows % 32 == 0), "whole 32-sample tiles");
-    const EncIn ei{t_vals, origins_s, dirs_s, radii, hit, K, enc_flags};
+    EncIn ei{};
+    ei.t_vals = t_vals; ei.origins_s = origins_s; ei.dirs_s = dirs_s; ei.radii = radii; ei.hit = hit; ei.K = K; ei.flags = enc_flags;
+    ei.view_tile = view_tile;
     return durf::launch_mlp_fwd(stream, 256, rows, N, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash,
                                 relu_mask, 1, FwdStrides{}, tail_idx, tail_count, &ei);
 }
@@ -545,7 +569,8 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
                    void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx, const int32_t* tail_count,
                    const EncIn* enc_in) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
-    DURF_REQUIRE(enc_in == nullptr || (width == 256 && K == 1), "the self-encoding forward is the background MLP's");
+    DURF_REQUIRE(enc_in == nullptr || (width == 256 && K == 1 && !enc_in->obj) || (width == 128 && enc_in->obj && ray_idx && count),
+                 "the self-encoding forward: the background MLP, or the object MLPs on their compacted ray lists");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
     if (rows == 0 || K <= 0) return 0;
@@ -569,7 +594,8 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
                            (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw,  \
                            (bf16x8*)stash, (uint4*)relu_mask, st, tail_idx, tail_count, ei);       \
     }
-    if (enc_in) {
+    if (enc_in && width == 128) { if (stash) LAUNCH_F(128, true, 8, true) else LAUNCH_F(128, false, 8, true) }
+    else if (enc_in) {
         if (half) { if (stash) LAUNCH_F(256, true, 4, true) else LAUNCH_F(256, false, 4, true) }
         else { if (stash) LAUNCH_F(256, true, 8, true) else LAUNCH_F(256, false, 8, true) }
     }

@@ -3,6 +3,7 @@
 // behind the host (K = 8: 16 objects x levels x ~10 launches).  Here every kernel of the per-object path
 // runs once with the object index in blockIdx.y (k_dw_finalize: blockIdx.z) over [K, ...] slabs whose
 // strides are documented in include/durf_hip.h, so all objects' workgroups are resident together.
+#include <stdlib.h>
 #include "durf_common.h"
 #include "mlp_spec.h"
 
@@ -29,15 +30,29 @@ int durf_obj_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, co
     FwdStrides st;
     st.enc = durf_obj_enc_stride(B, N); st.idx = (size_t)B; st.wpack = durf_wpack_fwd_bytes(DURF_W_OBJ);
     st.raw = rows * 4 * sizeof(float); st.stash = durf_mlp_stash_bytes(DURF_W_OBJ, rows); st.mask = durf_mlp_mask_bytes(rows);
-    int rc = durf::launch_encode_obj(stream, K, B, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags, enc,
-                                     st.enc, nullptr);
-    if (rc) return rc;
-    rc = durf::launch_mlp_fwd(stream, DURF_W_OBJ, rows, N, enc, view_bf16, idx, count, wpack_fwd, raw, stash, relu_mask,
-                              K, st);
-    if (rc) return rc;
-    if (view_tile)
-        rc = durf::launch_expand_view(stream, rows, N, view_bf16, idx, count, view_tile, K, (size_t)B,
-                                      durf_obj_view_stride(B, N));
+    // ONE launch: the forward encodes its own tiles (enc_lane.h: k_encode_lane<true>'s body, bit-identical) and, in
+    // training, writes the view-direction tile from the fragment it holds for the view layer (durf_expand_view's output).
+    // DURF_OBJ_SEPARATE_ENCODE=1 keeps the three launches (A/B switch; same results).
+    static const bool separate = [] { const char* e = getenv("DURF_OBJ_SEPARATE_ENCODE"); return e && e[0] != '0'; }();
+    int rc;
+    if (separate) {
+        rc = durf::launch_encode_obj(stream, K, B, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags, enc, st.enc, nullptr);
+        if (rc) return rc;
+        rc = durf::launch_mlp_fwd(stream, DURF_W_OBJ, rows, N, enc, view_bf16, idx, count, wpack_fwd, raw, stash, relu_mask, K, st);
+        if (rc) return rc;
+        if (view_tile)
+            rc = durf::launch_expand_view(stream, rows, N, view_bf16, idx, count, view_tile, K, (size_t)B, durf_obj_view_stride(B, N));
+        return rc;
+    }
+    EncIn ei{};
+    ei.t_vals = t_vals; ei.origins_s = origins_s; ei.dirs_s = dirs_s; ei.radii = radii;
+    ei.flags = flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER); ei.obj = 1;
+    for (int i = 0; i < 10; i++) ei.w[i] = barf_w[i];
+    ei.view_tile = stash ? view_tile : nullptr; ei.view_stride = durf_obj_view_stride(B, N);
+    rc = durf::launch_mlp_fwd(stream, DURF_W_OBJ, rows, N, enc, view_bf16, idx, count, wpack_fwd, raw, stash, relu_mask, K, st,
+                              nullptr, nullptr, &ei);
+    if (rc == 0 && view_tile && !stash)        // (inference callers that still ask for the tile)
+        rc = durf::launch_expand_view(stream, rows, N, view_bf16, idx, count, view_tile, K, (size_t)B, durf_obj_view_stride(B, N));
     return rc;
 }
 

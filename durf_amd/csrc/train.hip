@@ -183,7 +183,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
         float* t_vals = f.t_vals[lvl];
         if (K > 0) {
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags, w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c[lvl], w.stash[lvl],
-                              w.mask[lvl], w.idx_cls + B, w.count_cls + 1));
+                              w.mask[lvl], w.idx_cls + B, w.count_cls + 1, lvl == 0 ? w.view_tile : nullptr));
             STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], f32o ? w.raw_tail : nullptr));
             if (f32o)
                 STEP(durf_objf32_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, nullptr, w.view27, f.obj_params,
@@ -195,7 +195,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
                                         lvl == 0 ? w.obj_view_tile : nullptr));
         } else {
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, nullptr, 0, f.enc_flags, w.enc[lvl], w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl],
-                              w.mask[lvl], nullptr, nullptr));
+                              w.mask[lvl], nullptr, nullptr, lvl == 0 ? w.view_tile : nullptr));
         }
         if (lvl + 1 < L)        // composite + resample + the loss normalisers of this (level 0 only) and the next level: one launch
             STEP(durf_composite_resample(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, t_vals, w.d_s, f.density_bias,
@@ -207,10 +207,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
         // (the last level launches no composite: durf_loss_bwd recomputes it and fills its rendered outputs)
     }
     // ---- losses + backward (train_boxpose.py:67-252), last level first ----
-    if (K > 0)
-        STEP(durf_expand_view(stream, rows, N, w.view, w.idx_cls, w.count_cls, w.view_tile, w.idx_cls + B, w.count_cls + 1));
-    else
-        STEP(durf_expand_view(stream, rows, N, w.view, nullptr, nullptr, w.view_tile, nullptr, nullptr));
+    // (the view-direction tile of the weight-gradient launch was written by the level-0 forward)
     for (int lvl = L - 1; lvl >= 0; lvl--) {
         const bool last = lvl == L - 1;
         float* rs = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;

@@ -336,12 +336,15 @@ class MipNerfModel:
                     # bound round of ~100 workgroups) then run at its start instead of in its tail
                     side.fork()
                     launch_objects()
+                vt = None
+                if train and lvl == 0 and ops.FUSED_ENCODE:   # ... and writes the view-direction tile of the weight-gradient launch
+                    vt = ctx['view_tile'] = torch.empty(ops.tile_rows(rows), ops.VIEW_DIM, dtype=torch.bfloat16, device=dev)
                 if dd is not None and ops.FUSED_ENCODE:       # the forward encodes its own tiles (durf_mlp_fwd_enc)
                     side.fork()
                     raw_c, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit, view, packs['MLP_0'][0],
                                                    ray_idx=dd['idx'][0], count=dd['count'][0:1], stash=stash_b,
                                                    relu_mask=mask_b, tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
-                                                   **enc_kw)
+                                                   view_tile=vt, **enc_kw)
                 elif dd is not None:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl,
@@ -358,7 +361,7 @@ class MipNerfModel:
                 elif ops.FUSED_ENCODE:
                     side.fork()
                     raw_b, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit if Kd else None, view,
-                                                   packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b, **enc_kw)
+                                                   packs['MLP_0'][0], stash=stash_b, relu_mask=mask_b, view_tile=vt, **enc_kw)
                 else:
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit if Kd else None, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl)

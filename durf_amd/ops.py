@@ -268,9 +268,10 @@ FUSED_ENCODE = os.environ.get('DURF_FUSED_ENCODE', '1') != '0'
 
 def mlp_fwd_enc(rows, N, t_vals, origins_s, dirs_s, radii, hit, view_bf16, wpack_fwd, contraction=True,
                 disable_integration=False, cylinder=False, ray_idx=None, count=None, stash=None, raw=None, relu_mask=None,
-                tail_idx=None, tail_count=None):
+                tail_idx=None, tail_count=None, view_tile=None):
     """durf_mlp_fwd_enc: the background forward that encodes its own tiles (encode_bkgd + mlp_fwd(256) as one launch)
-    -> (raw, enc_tile); enc_tile is what encode_bkgd would have returned (the weight-gradient GEMMs read it)"""
+    -> (raw, enc_tile); enc_tile is what encode_bkgd would have returned (the weight-gradient GEMMs read it).
+    view_tile (training): a [tile_rows, 32] bf16 buffer the launch fills with expand_view's output"""
     dev = t_vals.device
     K = 0 if hit is None else hit.shape[1]
     if raw is None:
@@ -282,7 +283,7 @@ def mlp_fwd_enc(rows, N, t_vals, origins_s, dirs_s, radii, hit, view_bf16, wpack
         _lib.check(_lib.lib().durf_mlp_fwd_enc(_stream(), rows, N, _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
                                                _p(_f32(radii)), _p(hit), K, flags, _p(enc_tile), _p(view_bf16),
                                                _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash), _p(relu_mask),
-                                               _p(tail_idx), _p(tail_count)), 'durf_mlp_fwd_enc')
+                                               _p(tail_idx), _p(tail_count), _p(view_tile)), 'durf_mlp_fwd_enc')
     return raw, enc_tile
 
 

@@ -134,14 +134,15 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                             draw_ray_sum=None if dd is None else ray_sums[lvl], defer_sums=True)
 
     draws, ready = [None] * L, [None] * L
-    view_tile = view_ready = None
+    view_tile, view_ready = ctx.get('view_tile'), None       # (written by the level-0 forward when it encodes its own tiles)
     if side.enabled:
         side.fork()
         with side:
-            view_tile = make_view_tile()
-            view_tile.record_stream(main)
-            view_ready = torch.cuda.Event()
-            view_ready.record(side.side)
+            if view_tile is None:
+                view_tile = make_view_tile()
+                view_tile.record_stream(main)
+                view_ready = torch.cuda.Event()
+                view_ready.record(side.side)
             if prep is not None:                  # (the fused forward filled every level's normalisers already)
                 for lvl in range(L - 1):
                     draws[lvl], terms[lvl] = level_loss(lvl)
@@ -149,7 +150,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                     terms[lvl].record_stream(main)
                     ready[lvl] = torch.cuda.Event()
                     ready[lvl].record(side.side)
-    elif not f32:
+    elif not f32 and view_tile is None:
         view_tile = make_view_tile()
     # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
     for lvl in reversed(range(L)):

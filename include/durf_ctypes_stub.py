@@ -68,8 +68,8 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_fwd.argtypes = [vp, i32, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, width, rows, N, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash, relu_mask, tail_idx, tail_count)
     L.durf_mlp_fwd_enc.restype = i32
-    L.durf_mlp_fwd_enc.argtypes = [vp, u64, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
-    #   (stream, rows, N, t_vals, origins_s, dirs_s, radii, hit, K, enc_flags, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash, relu_mask, tail_idx, tail_count)
+    L.durf_mlp_fwd_enc.argtypes = [vp, u64, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    #   (stream, rows, N, t_vals, origins_s, dirs_s, radii, hit, K, enc_flags, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash, relu_mask, tail_idx, tail_count, view_tile)
     L.durf_composite_fwd.restype = i32
     L.durf_composite_fwd.argtypes = [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp]
     #   (stream, B, N, K, raw_bkgd, raw_obj, slot, t_vals, dirs_s, density_bias, bkgd_mode, rgb, depth, acc, weights, t_mids, t_dists)

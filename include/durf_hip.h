@@ -151,12 +151,15 @@ int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_ti
  * of Dense_0 / Dense_5 do.  t_vals [B,N+1], origins_s / dirs_s [B,3], radii [B], hit [B,K] (nullable with K = 0: no
  * object masking), enc_flags as durf_encode_bkgd's `contraction`; row r is sample r % N of ray r / N, or of ray
  * ray_idx[r / N] when a compacted list is given (with count); everything else as durf_mlp_fwd.  raw / stash / relu_mask
- * are bit-identical to the two separate calls'. */
+ * are bit-identical to the two separate calls'.  view_tile (nullable, training): the launch also writes the per-sample
+ * view-direction tile [rows,32] that durf_expand_view would (the fragment each lane holds for the view layer IS its tile
+ * layout) -- one launch less per step. */
 int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
                      const float* radii, const int32_t* hit /* nullable */, int K, int enc_flags, void* enc_tile,
                      const void* view_bf16, const int32_t* ray_idx /* nullable */, const int32_t* count /* nullable */,
                      const void* wpack_fwd, float* raw, void* stash /* nullable */, void* relu_mask /* nullable */,
-                     const int32_t* tail_idx /* nullable */, const int32_t* tail_count /* nullable */);
+                     const int32_t* tail_idx /* nullable */, const int32_t* tail_count /* nullable */,
+                     void* view_tile /* nullable */);
 
 /* K8 merge + activations + volumetric_rendering (obbpose_model.py:232-254, mip.py:285-327).
  * raw_bkgd [B*N,4]; raw_obj[k] [count_k*N,4] compacted, slot from durf_compact_hits.

@@ -122,3 +122,70 @@ def test_encoder_knobs(cuda, extra):
     for lvl in range(model.num_levels):
         for i, nm in enumerate(['rgb', 'depth', 'acc', 'weights', 't_vals']):
             _same(ret_f[lvl][i], ret_s[lvl][i], '%s level %d (%s)' % (nm, lvl, extra.strip()))
+
+
+@pytest.mark.parametrize('B,K,N', [(512, 3, 64), (300, 1, 32), (256, 8, 32)])
+def test_the_object_forward_encodes_its_own_tiles_like_the_separate_launches(cuda, B, K, N):
+    """durf_obj_fwd_batch is ONE launch since round 4 (k_mlp_fwd<128, .., ENC>: the object encoder's body at the head of
+    every block, the view-direction tile written from the view layer's fragment).  Against the separate entry points it
+    replaces -- durf_encode_obj, durf_mlp_fwd(128), durf_expand_view, object by object -- every valid byte must be equal:
+    encoding tile, raw, stash, masks, view tile (reference: mip.py:182-223, obbpose_model.py:167-201)."""
+    config, b, db, model, variables, noise = _setup(cuda, B, K, N, 61 + K)
+    ret, ctx = model._forward(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], True, False, False, 6.5,
+                              train=True, noise=noise, loss_prep=None)
+    rays = db['rays']
+    radii = rays.radii.reshape(-1).contiguous()
+    rows = B * N
+    L = ops._lib.lib()
+    wf_stride = int(L.durf_wpack_fwd_bytes(obbpose_model.W_OBJ))
+    enc_stride, view_stride = int(L.durf_obj_enc_stride(B, N)), int(L.durf_obj_view_stride(B, N))
+    st_stride, mk_stride = ops.mlp_stash_bytes(obbpose_model.W_OBJ, rows), ops.mlp_mask_bytes(rows)
+    total = 0
+    for lvl in range(model.num_levels):
+        lv = ctx['levels'][lvl]
+        slabs = lv['slabs']
+        for k in range(K):
+            cnt = int(ctx['count'][k])
+            total += cnt
+            if cnt == 0:
+                continue
+            idx_k, count_k = ctx['idx'][k].contiguous(), ctx['count'][k:k + 1]
+            enc_t, _ = ops.encode_obj(B, idx_k, count_k, lv['t_vals'], ctx['o_s'], ctx['d_s'], radii, 6.5)
+            stash = torch.empty(st_stride, dtype=torch.uint8, device=cuda)
+            mask = torch.empty(mk_stride, dtype=torch.uint8, device=cuda)
+            wf = ctx['packs']['obj'][0][k * wf_stride:(k + 1) * wf_stride]
+            raw = ops.mlp_fwd(obbpose_model.W_OBJ, rows, N, enc_t, ctx['view'], wf, ray_idx=idx_k, count=count_k, stash=stash,
+                              relu_mask=mask)
+            nt = cnt * N // 32                                        # whole 32-row tiles (N is a multiple of 32)
+            _same(slabs.enc[k * enc_stride:(k + 1) * enc_stride].view(torch.int16).reshape(-1, 2048)[:nt],
+                  enc_t.view(torch.int16).reshape(-1, 2048)[:nt], 'object %d level %d: encoding tile' % (k, lvl))
+            _same(slabs.raw[k][:cnt * N], raw[:cnt * N], 'object %d level %d: raw' % (k, lvl))
+            kb = st_stride // ((rows + 31) // 32 * 1024)
+            assert kb * ((rows + 31) // 32) * 1024 == st_stride
+            nt_all = (rows + 31) // 32
+            got_s, want_s = slabs.stash[k * st_stride:(k + 1) * st_stride], stash
+            for j in range(10):
+                if j == 8:
+                    continue
+                ks = 8                                                 # W = 128: 8 k-steps per region (the view layer too)
+                off = 8 * j * nt_all * 1024
+                _same(got_s[off:off + ks * nt_all * 1024].reshape(nt_all, ks * 1024)[:nt],
+                      want_s[off:off + ks * nt_all * 1024].reshape(nt_all, ks * 1024)[:nt], 'object %d level %d: stash %d' % (k, lvl, j))
+            _same(slabs.mask[k * mk_stride:(k + 1) * mk_stride].reshape(9, -1, 1024)[:, :nt],
+                  mask.reshape(9, -1, 1024)[:, :nt], 'object %d level %d: masks' % (k, lvl))
+            if lvl == 0:
+                vt = ops.expand_view(rows, N, ctx['view'], ray_idx=idx_k, count=count_k)
+                got_v = ctx['view_tiles_obj'][k * view_stride:(k + 1) * view_stride].view(torch.int16).reshape(-1, 1024)[:nt]
+                _same(got_v, vt.view(torch.int16).reshape(-1, 1024)[:nt], 'object %d: view tile' % k)
+    assert total > 0, 'the batch must contain box-hit rays'
+    # ... and the background's view tile, written by its level-0 forward
+    dd = ctx['dedup'] if K else None
+    if dd is not None:
+        want = ops.expand_view(rows, N, ctx['view'], ray_idx=dd['idx'][0], count=dd['count'][0:1], tail_idx=dd['idx'][1],
+                               tail_count=dd['count'][1:2])
+        nrows = int(dd['count'][0]) * N + int(dd['count'][1])
+    else:
+        want, nrows = ops.expand_view(rows, N, ctx['view']), rows
+    ntv = (nrows + 31) // 32
+    _same(ctx['view_tile'].view(torch.int16).reshape(-1, 1024)[:ntv], want.view(torch.int16).reshape(-1, 1024)[:ntv],
+          'background view tile')

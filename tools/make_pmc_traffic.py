@@ -9,7 +9,7 @@ import os
 import re
 import sys
 
-KERNELS = {'mlp_fwd_256_train': r'k_mlp_fwd<256, true>', 'mlp_bwd_256': r'k_mlp_bwdILi256|k_mlp_bwd<256',
+KERNELS = {'mlp_fwd_256_train': r'k_mlp_fwd<256, true[,>]', 'mlp_bwd_256': r'k_mlp_bwdILi256|k_mlp_bwd<256',
            'mlp_dw_256': r'k_dw_all<256>', 'encode_bkgd': r'k_encode_lane<false>|k_encode_oct<false>',
            'composite_resample': r'k_composite_resample'}
 
