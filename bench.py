@@ -411,7 +411,7 @@ def main():
     rng = 1000 * rank                                  # stratified-sampling noise differs per rank
     # The warm-up runs exactly what the timed region runs, the live HIP-event timers included, after --prewarm-events
     # timing events have been recorded and parked: when the number of live timing events of a process first passes
-    # ~100, the HIP runtime stalls the stream ONCE for ~40 ms (it grows a pool; tools/stall_probe.py: no stall without
+    # ~100, the HIP runtime stalls the stream ONCE for ~40 ms (it grows a pool; tools/experiments/stall_probe.py: no stall without
     # timing events, none after this pre-warm even with --warmup 2).  With the timers switched on at the first timed step
     # and 5 warm-up steps, that stall used to sit in the timed region and cost every earlier figure of this repo 4-5 %.
     # `step_ms` in the JSON line (p50 / p90 / max / slow_steps) shows any such outlier.

@@ -889,7 +889,7 @@ static DwPlan dw_plan(int width) {
     // splits per job in proportion to its bytes per sample, summing EXACTLY to total_wgs (largest
     // remainder): with one resident workgroup per CU, n x 256 workgroups are n full rounds; two
     // stragglers from plain rounding (1026) cost another round (measured).  W = 256: two rounds -- round 2's
-    // sweep at cfg3 (tools/sweep_dw_wgs.sh): 256 1507 us, 384 1617, 512 1445-1460, 640 1600, 768 1451-1459,
+    // sweep at cfg3 (tools/experiments/sweep_dw_wgs.sh): 256 1507 us, 384 1617, 512 1445-1460, 640 1600, 768 1451-1459,
     // 1024 1464-1495, 1280 1490, 1536 1508; fewer workgroups also mean fewer fp32 partials to write and re-read
     // (268 -> 134 MB).  W = 128 (objects; the grid is total_wgs x K and a sparsely hit object leaves most of its
     // workgroups without tiles -- an early-exit workgroup still costs its dispatch): 256 per object (1024 -> 256: the

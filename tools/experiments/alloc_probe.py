@@ -1,7 +1,7 @@
 """Which training steps make the caching allocator go to the driver (hipMalloc / hipFree), and what do they cost?
 python tools/alloc_probe.py [cfg]"""
 import gc, os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from durf_amd import train_boxpose

@@ -1,6 +1,6 @@
 """Run only the fused MLP forward (inference + training variants) at cfg2 size -- for PMC passes."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from durf_amd import ops
 dev = torch.device('cuda:0')

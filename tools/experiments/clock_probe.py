@@ -1,7 +1,7 @@
 """Is the fused MLP power/clock-limited?  Times the training forward / backward on random and on all-zero operands, and
 samples rocm-smi clocks and power while a kernel loops (tools/clock_probe.py, run on the GPU box)."""
 import os, subprocess, sys, threading, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from durf_amd import ops
 dev = torch.device('cuda:0')

@@ -3,7 +3,7 @@ every launch: keep the process tiny).   python tools/encode_only.py [rays] [laun
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 import bench

@@ -1,7 +1,7 @@
 """How long does the host need to ENQUEUE one training step (ctypes launches + torch allocations), against the GPU's step
 time?  If the two are close, the short per-ray kernels run host-bound.   python tools/host_issue_time.py [cfg]"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from durf_amd import train_boxpose

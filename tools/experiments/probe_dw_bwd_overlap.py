@@ -4,7 +4,7 @@ so they cannot share a CU)?  Streams with CU masks (hipExtStreamCreateWithCUMask
 buffers (4096 rays x 128 samples), wall time from a common start event to the later of the two finishing.
     python tools/probe_dw_bwd_overlap.py         (kill criterion: >= 2 % of a 4.3 ms step = 86 us saved vs back to back)"""
 import ctypes, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from durf_amd import ops
 

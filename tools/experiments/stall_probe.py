@@ -1,7 +1,7 @@
 """Where does the one-off ~40 ms step of a fresh process come from?  Times the first 16 steps (GPU events) after different
 pre-treatments:  python tools/stall_probe.py none|launches|events|both|sync"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 from durf_amd import train_boxpose, ops

@@ -3,7 +3,7 @@ bench batch: python tools/time_encode.py [rays] [launches]"""
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 
 from durf_amd import ops, synthetic

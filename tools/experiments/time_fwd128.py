@@ -1,7 +1,7 @@
 """Times one launch of the object MLP forward (W = 128) at 72, 1 and 8 blocks: the latency of a single 12-layer block.
     python tools/time_fwd128.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from durf_amd import ops
 dev = torch.device('cuda:0')

@@ -1,7 +1,7 @@
 """How the persistent fused MLP kernels scale with the number of 256-sample blocks (rounds of 256 workgroups):
 python tools/time_mlp_rounds.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from durf_amd import ops
 

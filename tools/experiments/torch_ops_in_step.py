@@ -1,6 +1,6 @@
 """Which torch (aten) operators launch kernels inside one training step?  python tools/torch_ops_in_step.py [cfg]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 import bench
