@@ -150,6 +150,15 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
     }
 }
 
+// Workgroup barrier of the M-split kernels: this wave's LDS writes have landed (lgkmcnt), then the raw barrier.  __syncthreads()
+// also waits for vmcnt(0) -- every global store and every prefetched weight load the wave has in flight -- which made each of
+// the 11-13 stages of a tile pay a full HBM round trip (k_mlp_fwd_ms 46 -> 2x us at K = 8).  Nothing the other waves read
+// through LDS depends on global memory traffic.
+__device__ __forceinline__ void ms_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
 // 16-byte store of a streamed-once tensor (activation stash, dz): non-temporal, so the stream does
 // not compete with the packed weights for L2 (measured on the fused forward / backward: nt 784 / 643 us,
 // plain 826 / 700, sc1 816 / 747, sc0 sc1 807 / 745)
@@ -178,6 +187,7 @@ int launch_pack(void* stream, int width, int in_dim, int K, const float* params,
 int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* idx, const int32_t* count,
                       const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
                       const float* barf_w, int flags, void* out_tile, size_t out_stride, float* out_f32);
+bool obj_msplit(size_t rows);
 int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile, const void* view_bf16,
                    const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
                    void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx = nullptr,

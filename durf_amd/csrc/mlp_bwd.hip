@@ -300,6 +300,190 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
   }
 }
 
+// ---------------------------------------------------------------------------
+// M-split backward for the object MLPs (W = 128): the counterpart of k_mlp_fwd_ms (mlp_fwd.hip).  A workgroup is 4 waves x
+// 64 samples; wave w owns input-feature tile w of every stage, gradients are exchanged through LDS as the next stage's B
+// fragments, the transposed weight tiles come straight from L2, one barrier per stage.  Same MFMA instruction, operands and
+// k order per output as k_mlp_bwd<128, false>: dz / dz_out are BIT-identical.  (The box-pose variant -- d(enc) -- stays on
+// k_mlp_bwd<128, true>.)
+// ---------------------------------------------------------------------------
+namespace msb {
+using S = MlpSpec<128>;
+using B_ = BwdSpec<128>;
+constexpr int NT = 2;
+constexpr int X_BYTES = NT * S::KW * 1024;
+constexpr int OFF_X = 0;                               // two gradient fragment buffers [tile][k-step][lane][16 B]
+constexpr int OFF_G = 2 * X_BYTES;                     // head-gradient fragments [tile][2: rgb, density][lane][16 B]
+constexpr int LDS_BYTES = OFF_G + NT * 2 * 1024;
+}  // namespace msb
+
+__global__ void __launch_bounds__(256)
+k_mlp_bwd_ms(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
+             const int32_t* __restrict__ count, const char* __restrict__ wpack, const uint4* __restrict__ relu_mask,
+             bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out, BwdStrides bs) {
+    using S = msb::S;
+    using BS = msb::B_;
+    constexpr int NT = msb::NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    {
+        const size_t k = blockIdx.x;       // object FASTEST in the grid: the workgroups that find no pair (the hit count
+                                            // lives on the device) are dispatched after every working one, not in front of the next object's
+        ray_idx += k * bs.idx;
+        count += k;
+        wpack += k * bs.wpack;
+        relu_mask = (const uint4*)((const char*)relu_mask + k * bs.mask);
+        dz = (bf16x8*)((char*)dz + k * bs.dz);
+        dz_out = (bf16x8*)((char*)dz_out + k * bs.dz_out);
+    }
+    const size_t c = (size_t)(*count) * (size_t)N;
+    const size_t nrows = c < rows ? c : rows;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31;
+    const size_t ntile32 = rows >> 5;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    char* const X0 = smem + msb::OFF_X;
+    char* const G = smem + msb::OFF_G;
+
+    for (size_t pair = blockIdx.y; pair * (32 * NT) < nrows; pair += gridDim.y) {
+        const size_t t32[NT] = {pair * NT, pair * NT + 1};
+        const bool tv[NT] = {true, t32[1] * 32 < nrows};
+        ms_barrier();
+        // head gradients (fp32 [*,4]: d raw_rgb[3], d raw_density), gathered by ray: waves 0 / 1 build tile 0 / 1's fragments
+        if (wave < NT) {
+            const int t = wave;
+            f32x4 dr = {0.f, 0.f, 0.f, 0.f};
+            if (tv[t] && lane < 32) {
+                const size_t row = t32[t] * 32 + n;
+                const size_t src = (size_t)ray_idx[row / (size_t)N] * (size_t)N + row % (size_t)N;
+                dr = *(const f32x4*)(draw + src * 4);
+            }
+            bf16x8 g10 = zero8, gd = zero8, gout = zero8;
+            if (lane < 32) {
+                g10[0] = (__bf16)dr[0]; g10[1] = (__bf16)dr[1]; g10[2] = (__bf16)dr[2];
+                gd[0] = (__bf16)dr[3];
+                gout = g10; gout[3] = gd[0];
+            }
+            *(bf16x8*)(G + (t * 2 + 0) * 1024 + lane * 16) = g10;
+            *(bf16x8*)(G + (t * 2 + 1) * 1024 + lane * 16) = gd;
+            if (tv[t]) dz_out[t32[t] * 64 + lane] = gout;         // [rows,16] tile: slots 0-2 rgb, 3 density
+        }
+        f32x16 acc[NT];
+        // Weights of (backward stage b, this wave's tile): requested ONE STAGE AHEAD into one of two alternating register sets
+        struct WSet { bf16x8 A[S::KW + 1]; };
+        auto load_w = [&](auto b_, WSet& w) {
+            constexpr int b = decltype(b_)::value, T = BS::n_ks(b);
+            const char* wt = wpack + (size_t)(BS::chunk_base(b) + wave * T) * 1024;
+            asm volatile("" : "+s"(wt));               // (see k_mlp_fwd_ms: keeps later stages' weight loads below the barriers)
+#pragma unroll
+            for (int k = 0; k < T; k++) w.A[k] = *(const bf16x8*)(wt + k * 1024 + lane * 16);
+        };
+        // this wave's tile of backward stage b: NX k-steps from Xin, then NG head-gradient fragments (g: 0 rgb, 1 density)
+        unsigned mword[NT] = {0u, 0u};                 // this stage's ReLU flags (requested before its MFMAs, used in its epilogue)
+        auto load_mask = [&](int jm) {
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+                mword[t] = tv[t] ? ((const unsigned*)((const char*)relu_mask + ((size_t)jm * ntile32 + t32[t]) * 1024 + lane * 16))[wave >> 1] : 0u;
+        };
+        auto stage_mma = [&](auto b_, const WSet& w, auto nx_, auto ng_, int g, const char* Xin) {
+            constexpr int b = decltype(b_)::value, NX = decltype(nx_)::value, NG = decltype(ng_)::value, T = NX + NG;
+            static_assert(T == BS::n_ks(b), "k-steps of the backward stage");
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < T; k++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const char* src = k < NX ? Xin + (t * S::KW + k) * 1024 : G + (t * 2 + g) * 1024;
+                    const bf16x8 bv = *(const bf16x8*)(src + lane * 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], bv, acc[t], 0, 0, 0);
+                }
+            }
+        };
+        // mask with the forward's ReLU flags of stash region jm (this wave's tile: word wave / 2, parity wave % 2), hand the
+        // fragments over, store dz region jd (jd < 0: not stored -- the linear bottleneck's gradient)
+        auto hand_over = [&](auto mask_, int /*jm*/, int jd, char* Xout) {
+            constexpr bool MASK = decltype(mask_)::value;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const unsigned word = MASK ? mword[t] : 0u;
+                bf16x8 o0, o1;
+                if (wave & 1) bpack_tile<MASK>(acc[t], word, 1, o0, o1);
+                else bpack_tile<MASK>(acc[t], word, 0, o0, o1);
+                *(bf16x8*)(Xout + (t * S::KW + 2 * wave) * 1024 + lane * 16) = o0;
+                *(bf16x8*)(Xout + (t * S::KW + 2 * wave + 1) * 1024 + lane * 16) = o1;
+                if (jd >= 0 && tv[t]) {
+                    char* dd = (char*)dz + ((size_t)S::stash_ks_before(jd) * ntile32 + t32[t] * S::stash_ks(jd)) * 1024;
+                    STREAM_STORE(dd + (2 * wave) * 1024 + lane * 16, o0);
+                    STREAM_STORE(dd + (2 * wave + 1) * 1024 + lane * 16, o1);
+                }
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using I1 = std::integral_constant<int, 1>;
+        using IW = std::integral_constant<int, S::KW>;
+        char* Xa = X0;
+        char* Xb = X0 + msb::X_BYTES;
+        WSet w0, w1;
+        load_w(std::integral_constant<int, 0>{}, w0);
+        ms_barrier();                               // head-gradient fragments in place
+        // bwd of stage 10 (rgb head): d rgb -> d A9, masked by A9 (mask region 8) -> dz region 9
+        load_w(std::integral_constant<int, 1>{}, w1);
+        load_mask(8);
+        stage_mma(std::integral_constant<int, 0>{}, w0, I0{}, I1{}, 0, Xa);
+        hand_over(std::true_type{}, 8, 9, Xa);
+        ms_barrier();
+        // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear; not stored)
+        load_w(std::integral_constant<int, 2>{}, w0);
+        stage_mma(std::integral_constant<int, 1>{}, w1, std::integral_constant<int, S::KC>{}, I0{}, 0, Xa);
+        hand_over(std::false_type{}, 0, -1, Xb);
+        ms_barrier();
+        // bwd of stage 8 (bottleneck + density head): -> d A7 (mask region 7, dz region 7)
+        load_w(std::integral_constant<int, 3>{}, w1);
+        load_mask(7);
+        stage_mma(std::integral_constant<int, 2>{}, w0, IW{}, I1{}, 1, Xb);
+        hand_over(std::true_type{}, 7, 7, Xa);
+        ms_barrier();
+        // bwd of stages 7, 6, 5 (trunk rows) -> d Z6, d Z5, d Z4
+        load_w(std::integral_constant<int, 4>{}, w0);
+        load_mask(6);
+        stage_mma(std::integral_constant<int, 3>{}, w1, IW{}, I0{}, 0, Xa);
+        hand_over(std::true_type{}, 6, 6, Xb);
+        ms_barrier();
+        load_w(std::integral_constant<int, 5>{}, w1);
+        load_mask(5);
+        stage_mma(std::integral_constant<int, 4>{}, w0, IW{}, I0{}, 0, Xb);
+        hand_over(std::true_type{}, 5, 5, Xa);
+        ms_barrier();
+        load_w(std::integral_constant<int, 7>{}, w0);
+        load_mask(4);
+        stage_mma(std::integral_constant<int, 5>{}, w1, IW{}, I0{}, 0, Xa);
+        hand_over(std::true_type{}, 4, 4, Xb);
+        ms_barrier();
+        // bwd of stages 4..1 -> d Z3 .. d Z0
+        load_w(std::integral_constant<int, 8>{}, w1);
+        load_mask(3);
+        stage_mma(std::integral_constant<int, 7>{}, w0, IW{}, I0{}, 0, Xb);
+        hand_over(std::true_type{}, 3, 3, Xa);
+        ms_barrier();
+        load_w(std::integral_constant<int, 9>{}, w0);
+        load_mask(2);
+        stage_mma(std::integral_constant<int, 8>{}, w1, IW{}, I0{}, 0, Xa);
+        hand_over(std::true_type{}, 2, 2, Xb);
+        ms_barrier();
+        load_w(std::integral_constant<int, 10>{}, w1);
+        load_mask(1);
+        stage_mma(std::integral_constant<int, 9>{}, w0, IW{}, I0{}, 0, Xb);
+        hand_over(std::true_type{}, 1, 1, Xa);
+        ms_barrier();
+        load_mask(0);
+        stage_mma(std::integral_constant<int, 10>{}, w1, IW{}, I0{}, 0, Xa);
+        hand_over(std::true_type{}, 0, 0, Xb);
+    }
+}
+
 // view-direction features expanded per sample into tile layout [rows, 32] (dW of Dense_10)
 __global__ void __launch_bounds__(256)
 k_expand_view(size_t rows, int N, const bf16x8* __restrict__ view, const int32_t* __restrict__ ray_idx,
@@ -406,9 +590,15 @@ struct DwArgs {
 #ifndef DW_MIN_TPS
 #define DW_MIN_TPS 48
 #endif
+// A launch with few tiles altogether (the objects of a 512-ray batch: ~150 tiles) is bound by the tiles a workgroup walks IN
+// SEQUENCE (~1 us each), not by its partials: the floor then drops to 1/16 of the tiles, at least 8 (k_dw_all<128> 56 -> 2x us
+// at cfg3's gin-literal 512 rays; unchanged from 768 tiles per MLP up, i.e. at 4096 rays).
 __host__ __device__ inline size_t dw_tiles_per_split(size_t nt_all, int nsplit) {
     const size_t even = (nt_all + nsplit - 1) / nsplit;
-    return even > DW_MIN_TPS ? even : DW_MIN_TPS;
+    size_t floor_ = DW_MIN_TPS;
+    const size_t small = (nt_all + 15) / 16;
+    if (small < floor_) floor_ = small < 8 ? 8 : small;
+    return even > floor_ ? even : floor_;
 }
 
 // valid 32-sample tiles of level l (object `obj` of a batched launch): the last tile of a level whose row count is
@@ -1029,6 +1219,16 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
     DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
     if (rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    // the object MLPs (W = 128 on compacted ray lists, no d(enc)): the M-split kernel (k_mlp_bwd_ms; DURF_OBJ_MSPLIT=0: A/B switch)
+    {
+        if (width == 128 && ray_idx && count && !d_enc && !tail_idx && obj_msplit(rows)) {
+            const unsigned pairs = durf_cdiv(rows, 64);          // (small batches only, <= 128 workgroups per object: launch_mlp_fwd)
+            hipLaunchKernelGGL(k_mlp_bwd_ms, dim3(K, pairs < 128u ? pairs : 128u), dim3(256), msb::LDS_BYTES, s, rows, N, draw, ray_idx,
+                               count, (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out, st);
+            DURF_CHECK_LAUNCH("durf_mlp_bwd (M-split)");
+            return 0;
+        }
+    }
     // (as launch_mlp_fwd: 128-sample blocks of 4 waves when 256-sample blocks would leave half the chip idle)
     const bool half = width == 256 && K == 1 && !d_enc && durf_cdiv(rows, 256) <= 128 && durf::half_blocks_enabled();
     const unsigned nblk = durf_cdiv(rows, half ? 128u : 256u);

@@ -6,6 +6,7 @@
 // global_load_lds (one 1 KB chunk per wave-instruction, lane-linear = fragment order, so
 // ds_read_b128 is conflict-free), double buffered per output M-tile, one barrier per tile.
 // MFMA-bound: 2*606 208 padded MAC per sample (591 872 algorithmic) for W=256.
+#include <stdlib.h>
 #include "mlp_pack.h"
 #include "enc_lane.h"
 
@@ -464,6 +465,290 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
 }
 
 // ---------------------------------------------------------------------------
+// M-split forward for the object MLPs (W = 128): latency per tile instead of work per wave.
+//
+// k_mlp_fwd gives every wave 32 samples and ALL output tiles of a layer: a block is a chain of 11 stages x 32 MFMAs per
+// wave behind a workgroup barrier and a weight DMA each, ~2.3 us per stage whatever the occupancy -- and the object launches
+// of a step are one round of a few dozen such blocks, i.e. pure latency (25-45 us per launch at the reference's 512-ray
+// batch and at K = 8).  Here a workgroup is 4 waves x 64 samples (two 32-sample MFMA tiles); wave w owns output tile w of
+// every layer, so a stage is 8-12 k-steps x 2 independent accumulators per wave.  Activations are exchanged through LDS
+// as the very fragments the next stage's MFMAs read (the C-layout of tile w IS k-steps 2w, 2w+1 of the next B operand:
+// mlp_spec.h), weights come straight from L2 (each wave reads only its own tile's 9-13 KB per stage: no LDS staging, no
+// DMA waits), one barrier per stage.  Same MFMA instruction, same operands, same k order per output as k_mlp_fwd<128>:
+// raw, encoding tile, stash, masks and view tile are BIT-identical (tests/test_gpu_fused_encode.py).
+// ---------------------------------------------------------------------------
+namespace ms {
+using S = MlpSpec<128>;
+constexpr int NT = 2;                                  // 32-sample tiles per workgroup
+constexpr int X_BYTES = NT * S::KW * 1024;             // one activation fragment buffer: [tile][k-step][lane][16 B]
+constexpr int OFF_X = 0;                               // two of them (written by stage s, read by stage s + 1)
+constexpr int OFF_E = 2 * X_BYTES;                     // encoding fragments [tile][KE][lane][16 B] (natural order)
+constexpr int OFF_V = OFF_E + NT * S::KE * 1024;       // view fragments     [tile][KV][lane][16 B]
+constexpr int OFF_M = OFF_V + NT * S::KV * 1024;       // ReLU-flag pieces   [2][tile][wave][lane] u32
+constexpr int LDS_BYTES = OFF_M + 2 * NT * 4 * 64 * 4;
+}  // namespace ms
+
+template <bool TRAIN>
+__global__ void __launch_bounds__(256)      // one wave per SIMD: the register file is this workgroup's (latency, not occupancy)
+k_mlp_fwd_ms(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
+             const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count, const char* __restrict__ wpack,
+             float* __restrict__ raw, bf16x8* __restrict__ stash, uint4* __restrict__ relu_mask, FwdStrides bs, EncIn ei) {
+    using S = ms::S;
+    constexpr int NT = ms::NT;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    {
+        const size_t k = blockIdx.x;       // object FASTEST in the grid: the workgroups that find no pair (the hit count
+                                            // lives on the device) are dispatched after every working one, not in front of the next object's                   // object slab (0 for a single MLP)
+        enc = (const bf16x8*)((const char*)enc + k * bs.enc);
+        ray_idx += k * bs.idx;
+        count += k;
+        wpack += k * bs.wpack;
+        raw = (float*)((char*)raw + k * bs.raw);
+        if (ei.view_tile) ei.view_tile = (char*)ei.view_tile + k * ei.view_stride;
+        if (TRAIN) {
+            stash = (bf16x8*)((char*)stash + k * bs.stash);
+            relu_mask = (uint4*)((char*)relu_mask + k * bs.mask);
+        }
+    }
+    const size_t c = (size_t)(*count) * (size_t)N;
+    const size_t nrows = c < rows ? c : rows;          // a multiple of 32 (N % 32 == 0)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n = lane & 31, hi = lane >> 5;
+    const size_t ntile32 = rows >> 5;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    char* const X0 = smem + ms::OFF_X;
+    char* const E = smem + ms::OFF_E;
+    char* const V = smem + ms::OFF_V;
+    unsigned* const M = (unsigned*)(smem + ms::OFF_M);
+
+    for (size_t pair = blockIdx.y; pair * (32 * NT) < nrows; pair += gridDim.y) {
+        const size_t t32[NT] = {pair * NT, pair * NT + 1};
+        const bool tv[NT] = {true, t32[1] * 32 < nrows};
+        ms_barrier();                               // the previous pair is done with the LDS
+        // ---- inputs: the tiles' encodings (computed here or read), view directions ----
+        if (ei.obj) {
+            if (wave == 0) {                           // lane = sample: 64 lanes = both tiles; the stand-alone encoder's body
+                const int t = lane >> 5;
+                const size_t row = t32[t] * 32 + n;
+                if (tv[t]) {
+                    const int j = (int)(row / (size_t)N), nn = (int)(row % (size_t)N);
+                    const int b = ray_idx[j];
+                    const float t0 = ei.t_vals[(size_t)b * (N + 1) + nn], t1 = ei.t_vals[(size_t)b * (N + 1) + nn + 1];
+                    float o[3] = {ei.origins_s[b * 3], ei.origins_s[b * 3 + 1], ei.origins_s[b * 3 + 2]};
+                    float d[3] = {ei.dirs_s[b * 3], ei.dirs_s[b * 3 + 1], ei.dirs_s[b * 3 + 2]};
+                    Gauss g = frustum_gaussian(t0, t1, o, d, ei.radii[b], (ei.flags & DURF_ENC_CYLINDER) != 0);
+                    if (ei.flags & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
+                    BarfW bw;
+#pragma unroll
+                    for (int i = 0; i < 10; i++) bw.w[i] = ei.w[i];
+                    char* const eg = (char*)enc + t32[t] * (S::KE * 1024);
+                    lane_features<true>(g, bw, [&](auto q_, const bf16x8& o8) {
+                        constexpr int q = decltype(q_)::value;             // features [8 q, 8 q + 8): k-step q / 2, half q % 2
+                        const int off = (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16;
+                        *(bf16x8*)(E + t * (S::KE * 1024) + off) = o8;
+                        *(bf16x8*)(eg + off) = o8;      // the encoding tile the weight-gradient GEMMs of Dense_0 / Dense_5 read
+                    });
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 8; q++) *(bf16x8*)(E + t * (S::KE * 1024) + (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16) = zero8;
+                }
+            }
+        } else {
+            for (int ch = wave; ch < NT * S::KE; ch += 4) {                // chunk = (tile, k-step)
+                const int t = ch / S::KE, k = ch % S::KE;
+                *(bf16x8*)(E + ch * 1024 + lane * 16) =
+                    tv[t] ? *(const bf16x8*)((const char*)enc + t32[t] * (S::KE * 1024) + k * 1024 + lane * 16) : zero8;
+            }
+        }
+        if (wave >= 2) {                               // waves 2, 3: the view-direction fragments of tile 0, 1
+            const int t = wave - 2;
+            const size_t row = t32[t] * 32 + n;
+            size_t ray = 0;
+            if (tv[t]) ray = (size_t)ray_idx[row / (size_t)N];
+#pragma unroll
+            for (int k = 0; k < S::KV; k++) {
+                const bf16x8 v = tv[t] ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + hi] : zero8;
+                *(bf16x8*)(V + (t * S::KV + k) * 1024 + lane * 16) = v;
+                if (TRAIN && ei.view_tile && tv[t]) *(bf16x8*)((char*)ei.view_tile + (t32[t] * S::KV + k) * 1024 + lane * 16) = v;
+            }
+        }
+
+        // ---- one stage: this wave's output tile `mo` of forward stage s for both sample tiles ----
+        // B operands: NX k-steps from the activation buffer Xin, then NE from the encoding, then NV from the view fragments
+        f32x16 acc[NT];
+        // Weights of (stage s, output tile mo): T A-fragments + the 16 bias values of this lane, straight from L2 into registers.
+        // They are requested ONE STAGE AHEAD (two register sets, alternating), so a stage never waits for its own loads.
+        struct WSet { bf16x8 A[S::KW + S::KE]; f32x4 b[4]; };
+        auto load_w = [&](auto s_, int mo, WSet& w) {
+            constexpr int s = decltype(s_)::value, T = S::n_ks(s);
+            const char* wt = wpack + (size_t)(S::stage_chunk_base(s) + mo * S::tile_chunks(s)) * 1024;     // wave-uniform
+            // (opaque: the stream is read-only, so hipcc would otherwise hoist EVERY later stage's loads above the barriers in
+            // between -- the inference instantiation needed all 512 registers and still spilled)
+            asm volatile("" : "+s"(wt));
+#pragma unroll
+            for (int k = 0; k < T; k++) w.A[k] = *(const bf16x8*)(wt + k * 1024 + lane * 16);
+            const f32x4* bp = (const f32x4*)(wt + T * 1024 + hi * 64);     // the bias rows: the initial accumulators
+#pragma unroll
+            for (int g = 0; g < 4; g++) w.b[g] = bp[g];
+        };
+        auto stage_mma = [&](auto s_, const WSet& w, auto nx_, auto ne_, auto nv_, const char* Xin) {
+            constexpr int s = decltype(s_)::value, NX = decltype(nx_)::value, NE = decltype(ne_)::value, NV = decltype(nv_)::value;
+            constexpr int T = NX + NE + NV;
+            static_assert(T == S::n_ks(s), "k-steps of the stage");
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) { acc[t][4 * g] = w.b[g][0]; acc[t][4 * g + 1] = w.b[g][1]; acc[t][4 * g + 2] = w.b[g][2]; acc[t][4 * g + 3] = w.b[g][3]; }
+            }
+#pragma unroll
+            for (int k = 0; k < T; k++) {
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const char* src = k < NX ? Xin + (t * S::KW + k) * 1024
+                                             : (k < NX + NE ? E + (t * S::KE + (k - NX)) * 1024 : V + (t * S::KV + (k - NX - NE)) * 1024);
+                    const bf16x8 b = *(const bf16x8*)(src + lane * 16);
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], b, acc[t], 0, 0, 0);
+                }
+            }
+        };
+        // epilogue of a stashed ReLU stage: fragments 2 mo, 2 mo + 1 of the next stage's input, the stash, the flag pieces
+        auto hand_over = [&](auto relu_, int mo, char* Xout, int jstash, unsigned* Mbuf) {
+            constexpr bool RELU = decltype(relu_)::value;
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                bf16x8 o0, o1;
+                const unsigned bits = pack_tile<RELU, TRAIN && RELU>(acc[t], o0, o1);
+                *(bf16x8*)(Xout + (t * S::KW + 2 * mo) * 1024 + lane * 16) = o0;
+                *(bf16x8*)(Xout + (t * S::KW + 2 * mo + 1) * 1024 + lane * 16) = o1;
+                if (TRAIN && RELU && tv[t]) {
+                    char* sd = (char*)stash + ((size_t)S::stash_ks_before(jstash) * ntile32 + t32[t] * S::stash_ks(jstash)) * 1024;
+                    STREAM_STORE(sd + (2 * mo) * 1024 + lane * 16, o0);
+                    STREAM_STORE(sd + (2 * mo + 1) * 1024 + lane * 16, o1);
+                    Mbuf[(t * 4 + mo) * 64 + lane] = bits << (8 * (mo & 1));
+                }
+            }
+        };
+        // waves 0 / 1 assemble the previous stage's flags of tile 0 / 1 into k_mlp_fwd's layout (one uint4 per lane: words
+        // 0, 1 = tile pairs (0,1), (2,3)) -- after the barrier that made every wave's piece visible
+        auto flush_mask = [&](int jmask, const unsigned* Mbuf) {
+            if (TRAIN && wave < NT && tv[wave]) {
+                const unsigned* m = Mbuf + (wave * 4) * 64 + lane;
+                const uint4 w4 = make_uint4(m[0] | m[64], m[128] | m[192], 0u, 0u);
+                *(uint4*)((char*)relu_mask + ((size_t)jmask * ntile32 + t32[wave]) * 1024 + lane * 16) = w4;
+            }
+        };
+        using I0 = std::integral_constant<int, 0>;
+        char* Xa = X0;
+        char* Xb = X0 + ms::X_BYTES;
+        unsigned* Ma = M;
+        unsigned* Mb = M + NT * 4 * 64;
+        WSet w0, w1, wd;                               // two alternating weight sets + wave 0's density-head tile
+        load_w(std::integral_constant<int, 0>{}, wave, w0);
+        ms_barrier();                               // encodings and view fragments are in place
+        using IE = std::integral_constant<int, S::KE>;
+        using IW = std::integral_constant<int, S::KW>;
+        auto swap = [&]() { char* tx = Xa; Xa = Xb; Xb = tx; unsigned* tm = Ma; Ma = Mb; Mb = tm; };
+        // stage 0: enc -> Xa
+        load_w(std::integral_constant<int, 1>{}, wave, w1);
+        stage_mma(std::integral_constant<int, 0>{}, w0, I0{}, IE{}, I0{}, Xa);
+        hand_over(std::true_type{}, wave, Xa, 0, Ma);
+        ms_barrier();
+        // stages 1-4 (the next stage's weights are requested before this stage's MFMAs)
+        flush_mask(0, Ma);
+        load_w(std::integral_constant<int, 2>{}, wave, w0);
+        stage_mma(std::integral_constant<int, 1>{}, w1, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::true_type{}, wave, Xb, 1, Mb);
+        ms_barrier();
+        swap();
+        flush_mask(1, Ma);
+        load_w(std::integral_constant<int, 3>{}, wave, w1);
+        stage_mma(std::integral_constant<int, 2>{}, w0, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::true_type{}, wave, Xb, 2, Mb);
+        ms_barrier();
+        swap();
+        flush_mask(2, Ma);
+        load_w(std::integral_constant<int, 4>{}, wave, w0);
+        stage_mma(std::integral_constant<int, 3>{}, w1, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::true_type{}, wave, Xb, 3, Mb);
+        ms_barrier();
+        swap();
+        flush_mask(3, Ma);
+        load_w(std::integral_constant<int, 5>{}, wave, w1);
+        stage_mma(std::integral_constant<int, 4>{}, w0, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::true_type{}, wave, Xb, 4, Mb);
+        ms_barrier();
+        swap();
+        // stage 5: [h4, enc] (obbpose_model.py:333-334)
+        flush_mask(4, Ma);
+        load_w(std::integral_constant<int, 6>{}, wave, w0);
+        stage_mma(std::integral_constant<int, 5>{}, w1, IW{}, IE{}, I0{}, Xa);
+        hand_over(std::true_type{}, wave, Xb, 5, Mb);
+        ms_barrier();
+        swap();
+        // stages 6, 7
+        flush_mask(5, Ma);
+        load_w(std::integral_constant<int, 7>{}, wave, w1);
+        if (wave == 0) load_w(std::integral_constant<int, 8>{}, S::WT, wd);       // the density head's tile, two stages ahead
+        stage_mma(std::integral_constant<int, 6>{}, w0, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::true_type{}, wave, Xb, 6, Mb);
+        ms_barrier();
+        swap();
+        flush_mask(6, Ma);
+        load_w(std::integral_constant<int, 8>{}, wave, w0);
+        stage_mma(std::integral_constant<int, 7>{}, w1, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::true_type{}, wave, Xb, 7, Mb);
+        ms_barrier();
+        swap();
+        // stage 8: h7 -> bottleneck (linear, tile `wave`) and, wave 0, the density head (tile WT)
+        flush_mask(7, Ma);
+        load_w(std::integral_constant<int, 9>{}, wave, w1);
+        float dens[NT] = {0.0f, 0.0f};
+        if (wave == 0) {
+            stage_mma(std::integral_constant<int, 8>{}, wd, IW{}, I0{}, I0{}, Xa);
+#pragma unroll
+            for (int t = 0; t < NT; t++) dens[t] = acc[t][0];
+        }
+        stage_mma(std::integral_constant<int, 8>{}, w0, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::false_type{}, wave, Xb, 8, Mb);
+        ms_barrier();
+        { char* tx = Xa; Xa = Xb; Xb = tx; }
+        // stage 9: [bottleneck, view] -> hc (128, relu); its flags go to mask region 8
+        if (wave == 0) load_w(std::integral_constant<int, 10>{}, 0, w0);
+        stage_mma(std::integral_constant<int, 9>{}, w1, IW{}, I0{}, std::integral_constant<int, S::KV>{}, Xa);
+        hand_over(std::true_type{}, wave, Xb, 9, Mb);
+        ms_barrier();
+        flush_mask(8, Mb);
+        // stage 10: hc -> rgb (wave 0), raw = (rgb, density)
+        if (wave == 0) {
+            // jnp.maximum propagates NaN, v_max_f32 does not: a non-finite encoding poisons the sample's output (as k_mlp_fwd:
+            // the lane's 8 features of each k-step, then the sample's other half)
+            bool bad[NT] = {false, false};
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int k = 0; k < S::KE; k++) {
+                    const bf16x8 e8 = *(const bf16x8*)(E + (t * S::KE + k) * 1024 + lane * 16);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) bad[t] |= !(fabsf((float)e8[e]) <= 3.0e38f);
+                }
+#pragma unroll
+            for (int t = 0; t < NT; t++) bad[t] |= (__shfl_xor((int)bad[t], 32, 64) != 0);
+            stage_mma(std::integral_constant<int, 10>{}, w0, std::integral_constant<int, S::KC>{}, I0{}, I0{}, Xb);
+            if (lane < 32) {
+                const float qn = __builtin_nanf("");
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    if (!tv[t]) continue;
+                    const f32x4 o = {bad[t] ? qn : acc[t][0], bad[t] ? qn : acc[t][1], bad[t] ? qn : acc[t][2], bad[t] ? qn : dens[t]};
+                    *(f32x4*)(raw + (t32[t] * 32 + n) * 4) = o;
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 extern "C" {
 
 size_t durf_mlp_param_count(int width, int in_dim) { return durf_layer_offset(width, in_dim, 12, 0); }
@@ -541,6 +826,13 @@ int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_ti
 
 namespace durf {
 
+static bool msplit_enabled() {           // read per call: tests toggle it
+    const char* e = getenv("DURF_OBJ_MSPLIT");
+    return !(e && e[0] == '0');
+}
+// whether launch_mlp_fwd / launch_mlp_bwd take the M-split kernels for a W = 128 launch on compacted ray lists of `rows` rows
+bool obj_msplit(size_t rows) { return rows < (size_t)2048 * 128 && msplit_enabled(); }
+
 int pack_bwd_launch(void* stream, int width, int in_dim, int K, const float* params, size_t param_stride, void* wpack_bwd);
 
 // fp32 flax params -> bf16 fragment streams for K MLPs laid out `param_stride` floats apart
@@ -569,7 +861,7 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
                    void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx, const int32_t* tail_count,
                    const EncIn* enc_in) {
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
-    DURF_REQUIRE(enc_in == nullptr || (width == 256 && K == 1 && !enc_in->obj) || (width == 128 && enc_in->obj && ray_idx && count),
+    DURF_REQUIRE(enc_in == nullptr || (width == 256 && K == 1 && !enc_in->obj) || (width == 128 && ray_idx && count && (enc_in->obj || obj_msplit(rows))),
                  "the self-encoding forward: the background MLP, or the object MLPs on their compacted ray lists");
     DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
     DURF_REQUIRE(K == 1 || (ray_idx && count), "batched launches are for compacted object rays");
@@ -582,6 +874,25 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
     const unsigned nblk = durf_cdiv(rows, per);
     dim3 grid(nblk < 256u ? nblk : 256u, K), block(half ? 256 : 512);     // persistent: at most one workgroup per CU and object
     const EncIn ei = enc_in ? *enc_in : EncIn{};
+    // The object MLPs (W = 128 on compacted ray lists): the M-split kernel -- 4 waves x 64 samples, one output tile per wave --
+    // whose launch is a few microseconds of latency instead of one 11-stage round of 256-sample blocks.  DURF_OBJ_MSPLIT=0
+    // keeps k_mlp_fwd<128> (A/B switch; bit-identical results).
+    // Small batches only (below ops.OVERLAP_MIN_ROWS = 2048 x 128 sample rows): there the object launches sit on the critical
+    // path; above, they run on a side stream in the shadow of the persistent background kernels, where a launch that spreads
+    // over every CU only delays those (measured at cfg3: 4.26 -> 4.42 ms per step).  At most 128 workgroups per object walk the
+    // 64-sample pairs: the hit count lives on the device and an early-exit workgroup still costs its dispatch.
+    if (width == 128 && ray_idx && count && obj_msplit(rows)) {
+        const unsigned pairs = durf_cdiv(rows, 64);
+        dim3 g(K, pairs < 128u ? pairs : 128u), b(256);
+        if (stash)
+            hipLaunchKernelGGL((k_mlp_fwd_ms<true>), g, b, ms::LDS_BYTES, s, rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16,
+                               ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei);
+        else
+            hipLaunchKernelGGL((k_mlp_fwd_ms<false>), g, b, ms::LDS_BYTES, s, rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16,
+                               ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei);
+        DURF_CHECK_LAUNCH("durf_mlp_fwd (M-split)");
+        return 0;
+    }
 #define LAUNCH_F(WW, TR, NWV, EN)                                                                 \
     {                                                                                             \
         constexpr int lds = 2 * 4 * (MlpSpec<WW>::KW + 1) * 1024;                                 \

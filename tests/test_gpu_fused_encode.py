@@ -3,6 +3,8 @@ csrc/enc_lane.h) against the two launches it replaces (durf_encode_bkgd + durf_m
 One encoder body serves both, so EVERYTHING must be bit-identical: the encoding tile the weight-gradient GEMMs read, the
 raw outputs, the activation stash, the ReLU masks, every rendered quantity of both levels, and a training step's gradient
 (reference: obbpose_model.py:205-210, mip.py:155-179,226-282, mip360.py:47-79)."""
+import os
+
 import pytest
 import torch
 
@@ -126,8 +128,9 @@ def test_encoder_knobs(cuda, extra):
 
 @pytest.mark.parametrize('B,K,N', [(512, 3, 64), (300, 1, 32), (256, 8, 32)])
 def test_the_object_forward_encodes_its_own_tiles_like_the_separate_launches(cuda, B, K, N):
-    """durf_obj_fwd_batch is ONE launch since round 4 (k_mlp_fwd<128, .., ENC>: the object encoder's body at the head of
-    every block, the view-direction tile written from the view layer's fragment).  Against the separate entry points it
+    """durf_obj_fwd_batch is ONE launch since round 4, on the M-split kernel (k_mlp_fwd_ms: 4 waves x 64 samples, one output
+    tile per wave, the object encoder's body at its head, the view-direction tile written from the view fragments).  Against the
+    sample-split kernel and the separate entry points it
     replaces -- durf_encode_obj, durf_mlp_fwd(128), durf_expand_view, object by object -- every valid byte must be equal:
     encoding tile, raw, stash, masks, view tile (reference: mip.py:182-223, obbpose_model.py:167-201)."""
     config, b, db, model, variables, noise = _setup(cuda, B, K, N, 61 + K)
@@ -154,8 +157,13 @@ def test_the_object_forward_encodes_its_own_tiles_like_the_separate_launches(cud
             stash = torch.empty(st_stride, dtype=torch.uint8, device=cuda)
             mask = torch.empty(mk_stride, dtype=torch.uint8, device=cuda)
             wf = ctx['packs']['obj'][0][k * wf_stride:(k + 1) * wf_stride]
-            raw = ops.mlp_fwd(obbpose_model.W_OBJ, rows, N, enc_t, ctx['view'], wf, ray_idx=idx_k, count=count_k, stash=stash,
-                              relu_mask=mask)
+            # the reference side on the sample-split kernel k_mlp_fwd<128> (the batched launch above ran the M-split kernel)
+            os.environ['DURF_OBJ_MSPLIT'] = '0'
+            try:
+                raw = ops.mlp_fwd(obbpose_model.W_OBJ, rows, N, enc_t, ctx['view'], wf, ray_idx=idx_k, count=count_k, stash=stash,
+                                  relu_mask=mask)
+            finally:
+                del os.environ['DURF_OBJ_MSPLIT']
             nt = cnt * N // 32                                        # whole 32-row tiles (N is a multiple of 32)
             _same(slabs.enc[k * enc_stride:(k + 1) * enc_stride].view(torch.int16).reshape(-1, 2048)[:nt],
                   enc_t.view(torch.int16).reshape(-1, 2048)[:nt], 'object %d level %d: encoding tile' % (k, lvl))
@@ -189,3 +197,51 @@ def test_the_object_forward_encodes_its_own_tiles_like_the_separate_launches(cud
     ntv = (nrows + 31) // 32
     _same(ctx['view_tile'].view(torch.int16).reshape(-1, 1024)[:ntv], want.view(torch.int16).reshape(-1, 1024)[:ntv],
           'background view tile')
+
+
+@pytest.mark.parametrize('B,K,N', [(512, 3, 64), (300, 1, 32), (256, 8, 32), (1024, 3, 128)])
+def test_msplit_object_kernels_give_the_sample_split_kernels_results_bit_for_bit(cuda, B, K, N):
+    """k_mlp_fwd_ms / k_mlp_bwd_ms (4 waves x 64 samples, one tile per wave; the object launches since round 4) against
+    k_mlp_fwd<128> / k_mlp_bwd<128> (DURF_OBJ_MSPLIT=0): same MFMA instruction, operands and k order per output, so a whole
+    training step's gradient, per-ray loss terms and every object buffer (raw, stash, masks, dz, dz_out) must be equal."""
+    config, b, db, model, variables, noise = _setup(cuda, B, K, N, 71 + K)
+    prev = db['init'][0:1]
+    out = {}
+    for ms in ('1', '0'):
+        os.environ['DURF_OBJ_MSPLIT'] = ms
+        try:
+            g, raw, _ = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, 10.0, prev, noise=noise)
+            torch.cuda.synchronize()
+            lv = raw['ctx']['levels']
+            cnt = [int(x) for x in raw['ctx']['count']]
+            out[ms] = (g.clone(), torch.stack([t.clone() for t in raw['terms']]),
+                       [(l['slabs'].raw.clone(), l['slabs'].stash.clone(), l['slabs'].mask.clone(), l['slabs'].dz.clone(),
+                         l['slabs'].dz_out.clone()) for l in lv], cnt)
+        finally:
+            del os.environ['DURF_OBJ_MSPLIT']
+    (g1, t1, s1, cnt), (g0, t0, s0, _) = out['1'], out['0']
+    assert sum(cnt) > 0
+    _same(g1, g0, 'gradient')
+    _same(t1, t0, 'per-ray loss terms')
+    rows = B * N
+    nt_all = (rows + 31) // 32
+    st_stride, mk_stride = ops.mlp_stash_bytes(obbpose_model.W_OBJ, rows), ops.mlp_mask_bytes(rows)
+    dzo_stride = int(ops._lib.lib().durf_obj_dzout_stride(B, N))
+    for lvl, (a, c) in enumerate(zip(s1, s0)):
+        for k in range(K):
+            nt = cnt[k] * N // 32
+            if nt == 0:
+                continue
+            _same(a[0][k][:cnt[k] * N], c[0][k][:cnt[k] * N], 'raw, object %d level %d' % (k, lvl))
+            for which, name in ((1, 'stash'), (3, 'dz')):
+                ga, gc = a[which][k * st_stride:(k + 1) * st_stride], c[which][k * st_stride:(k + 1) * st_stride]
+                for j in range(10):
+                    if j == 8:
+                        continue
+                    off = 8 * j * nt_all * 1024
+                    _same(ga[off:off + 8 * nt_all * 1024].reshape(nt_all, 8192)[:nt],
+                          gc[off:off + 8 * nt_all * 1024].reshape(nt_all, 8192)[:nt], '%s region %d, object %d level %d' % (name, j, k, lvl))
+            _same(a[2][k * mk_stride:(k + 1) * mk_stride].reshape(9, -1, 1024)[:, :nt],
+                  c[2][k * mk_stride:(k + 1) * mk_stride].reshape(9, -1, 1024)[:, :nt], 'masks, object %d level %d' % (k, lvl))
+            _same(a[4][k * dzo_stride:(k + 1) * dzo_stride].reshape(-1, 1024)[:nt],
+                  c[4][k * dzo_stride:(k + 1) * dzo_stride].reshape(-1, 1024)[:nt], 'dz_out, object %d level %d' % (k, lvl))
