@@ -21,7 +21,7 @@ struct Carver {                      // 256-byte aligned sub-buffers of the work
 };
 
 struct FwdWs {
-    float *o_s, *d_s, *raw_c, *raw_b, *obj_raw, *t_scratch;
+    float *o_s, *d_s, *raw_b, *obj_raw, *t_scratch;
     int32_t *hit, *idx_obj, *count_obj, *slot_obj, *idx_cls, *count_cls, *slot_cls;
     void *view, *wf_bkgd, *wf_obj, *enc, *obj_enc;
     size_t total;
@@ -44,7 +44,6 @@ FwdWs carve(void* workspace, int B, int N, int K) {
     w.wf_bkgd = c.take(durf_wpack_fwd_bytes(256));
     w.wf_obj = c.take(Kc * durf_wpack_fwd_bytes(128));
     w.enc = c.take(((rows + 31) / 32 * 32) * 64 * 2);
-    w.raw_c = (float*)c.take(rows * 4 * 4);
     w.raw_b = (float*)c.take(rows * 4 * 4);
     w.obj_enc = c.take(K > 0 ? (size_t)K * durf_obj_enc_stride(B, N) : 0);
     w.obj_raw = (float*)c.take(K > 0 ? (size_t)K * rows * 4 * 4 : 0);
@@ -84,9 +83,8 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = a->t_vals[lvl];
         if (K > 0) {
-            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, w.hit, K, a->enc_flags, w.enc, w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c, nullptr, nullptr,
-                              w.idx_cls + B, w.count_cls + 1, nullptr));
-            STEP(durf_expand_raw(stream, B, N, w.raw_c, w.count_cls, w.slot_cls, w.raw_b, nullptr));
+            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, w.hit, K, a->enc_flags | DURF_FWD_RAW_FULL, w.enc, w.view, w.idx_cls, w.count_cls,
+                                  w.wf_bkgd, w.raw_b, nullptr, nullptr, w.idx_cls + B, w.count_cls + 1, nullptr));
             STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, a->radii, a->barf_w,
                                     a->enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), w.view, w.wf_obj, w.obj_enc,
                                     w.obj_raw, nullptr, nullptr, nullptr));

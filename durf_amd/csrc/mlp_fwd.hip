@@ -421,8 +421,9 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         size_t ray = row / (size_t)N;
         if (tail) ray = valid ? (size_t)tail_idx[row - nrows_c] : 0;
         else if (ray_idx && valid) ray = (size_t)ray_idx[ray];
-        unsigned hi_v = (unsigned)lane >> 5;          // opaque: kept per block, not hoisted as a spilled 64-bit pointer
-        if (ENC) asm volatile("" : "+v"(hi_v));
+        unsigned hi_v = (unsigned)lane;               // opaque: kept per block, not hoisted as a spilled 64-bit pointer
+        if (ENC) asm volatile("" : "+v"(hi_v));       // (the lane itself: `lane >> 5` would be hoisted and spilled too)
+        hi_v >>= 5;
 #pragma unroll
         for (int k = 0; k < S::KV; k++)
             vf[k] = valid ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + hi_v] : zero8;
@@ -453,10 +454,42 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
             }
         }
         const f32x16 acc = mma_tile<S::KC, 0>(slot, lane, c, nullptr);
-        if (valid && lane < 32) {
-            const float qn = __builtin_nanf("");
-            const f32x4 o = {poison ? qn : acc[0], poison ? qn : acc[1], poison ? qn : acc[2], poison ? qn : dens};
-            *(f32x4*)(raw + row * 4) = o;
+        const float qn = __builtin_nanf("");
+        const f32x4 o = {poison ? qn : acc[0], poison ? qn : acc[1], poison ? qn : acc[2], poison ? qn : dens};
+        bool scattered = false;
+        if constexpr (ENC) scattered = (ei.flags & DURF_FWD_RAW_FULL) != 0 && ray_idx != nullptr;
+        if (!scattered) {
+            if (valid && lane < 32) *(f32x4*)(raw + row * 4) = o;
+        } else if (!tail) {
+            // de-duplicated batch, raw straight in the full [B*N,4] layout (what durf_expand_raw would make of the compacted
+            // rows): a tile's 32 samples are consecutive samples of ONE ray (N % 32 == 0) -- ray and first sample are
+            // wave-uniform (scalar unit), the store stays one 512 B run
+            const unsigned row0 = __builtin_amdgcn_readfirstlane((unsigned)(tile32 * 32));
+            unsigned Nu = (unsigned)N;
+            asm volatile("" : "+s"(Nu));         // (a division of its own: sharing the hoisted reciprocal of N costs a spill)
+            const unsigned j = row0 / Nu;
+            const unsigned b = (unsigned)ray_idx[tile_valid ? j : 0u];
+            unsigned l31 = (unsigned)lane;
+            asm volatile("" : "+v"(l31));        // (not a hoisted, spilled per-lane pointer: see MK(8) above)
+            l31 &= 31u;
+            if (valid && lane < 32) *(f32x4*)(raw + ((size_t)(b * Nu + (row0 - j * Nu)) + l31) * 4) = o;
+        } else if (tile_valid) {
+            // a box-hit ray's ONE evaluation is the background's raw at every sample of that ray: broadcast it
+            unsigned l64 = (unsigned)lane;
+            asm volatile("" : "+v"(l64));
+            const unsigned l31 = l64 & 31u;
+            const unsigned ti = __builtin_amdgcn_readfirstlane((unsigned)(tile32 * 32 - nrows_c));
+            const int rr = (valid && lane < 32) ? tail_idx[ti + l31] : -1;
+#pragma unroll 1
+            for (int r = 0; r < 32; r++) {
+                const int ray = __builtin_amdgcn_readlane(rr, r);
+                if (ray < 0) break;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o[e]), r));
+                float* dst = raw + (size_t)((unsigned)ray * (unsigned)N) * 4;
+                for (unsigned n = l64; n < (unsigned)N; n += 64) *(f32x4*)(dst + (size_t)n * 4) = v;
+            }
         }
     }
 #undef ST
@@ -805,6 +838,7 @@ int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, cons
     DURF_REQUIRE(t_vals && origins_s && dirs_s && radii && enc_tile, "ray data and the encoding tile buffer are required");
     DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ && (K == 0 || hit != nullptr), "0 <= K <= DURF_MAX_OBJ, hit [B,K]");
     DURF_REQUIRE(N > 0 && (count != nullptr ? N % 32 == 0 : rows % 32 == 0), "whole 32-sample tiles");
+    DURF_REQUIRE(!(enc_flags & DURF_FWD_RAW_FULL) || rows < ((size_t)1 << 32), "DURF_FWD_RAW_FULL: 32-bit row numbers");
     EncIn ei{};
     ei.t_vals = t_vals; ei.origins_s = origins_s; ei.dirs_s = dirs_s; ei.radii = radii; ei.hit = hit; ei.K = K; ei.flags = enc_flags;
     ei.view_tile = view_tile;

@@ -182,9 +182,12 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = f.t_vals[lvl];
         if (K > 0) {
-            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags, w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_c[lvl], w.stash[lvl],
-                              w.mask[lvl], w.idx_cls + B, w.count_cls + 1, lvl == 0 ? w.view_tile : nullptr));
-            STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], f32o ? w.raw_tail : nullptr));
+            // (bf16 objects: the forward writes raw in the full layout itself, DURF_FWD_RAW_FULL; fp32 objects: the box-hit
+            // rays' rows come from k_bkgd_hit_rays' fp32 evaluation instead, through durf_expand_raw)
+            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags | (f32o ? 0 : DURF_FWD_RAW_FULL),
+                                  w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, f32o ? w.raw_c[lvl] : w.raw_b[lvl], w.stash[lvl],
+                                  w.mask[lvl], w.idx_cls + B, w.count_cls + 1, lvl == 0 ? w.view_tile : nullptr));
+            if (f32o) STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], w.raw_tail));
             if (f32o)
                 STEP(durf_objf32_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, nullptr, w.view27, f.obj_params,
                                            f.obj_param_stride, w.obj_ws, w.obj_raw[lvl], w.act32[lvl], t_vals, w.o_s, w.d_s,

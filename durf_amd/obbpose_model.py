@@ -341,11 +341,14 @@ class MipNerfModel:
                     vt = ctx['view_tile'] = torch.empty(ops.tile_rows(rows), ops.VIEW_DIM, dtype=torch.bfloat16, device=dev)
                 if dd is not None and ops.FUSED_ENCODE:       # the forward encodes its own tiles (durf_mlp_fwd_enc)
                     side.fork()
+                    # (raw straight in the full layout unless the box-hit rays' rows come from the fp32 evaluation, raw_tail)
+                    scatter = raw_tail is None and ops.FWD_SCATTER_RAW
                     raw_c, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit, view, packs['MLP_0'][0],
                                                    ray_idx=dd['idx'][0], count=dd['count'][0:1], stash=stash_b,
                                                    relu_mask=mask_b, tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
-                                                   view_tile=vt, **enc_kw)
+                                                   view_tile=vt, raw_full=scatter, **enc_kw)
                 elif dd is not None:
+                    scatter = False
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,
                                                disable_integration=self.disable_integration, cylinder=cyl,
                                                idx=dd['idx'][0], count=dd['count'][0:1])
@@ -357,7 +360,7 @@ class MipNerfModel:
                     if tail_side is not None:                # the fp32 hit-ray evaluation (side stream) must have landed
                         torch.cuda.current_stream().wait_stream(tail_side)
                         tail_side = None
-                    raw_b = ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'], raw_tail=raw_tail)
+                    raw_b = raw_c if scatter else ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'], raw_tail=raw_tail)
                 elif ops.FUSED_ENCODE:
                     side.fork()
                     raw_b, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit if Kd else None, view,

@@ -37,6 +37,7 @@ extern "C" {
 #define DURF_ENC_CONTRACT 1        /* MipNerfModel.contraction (mip360.new_space) */
 #define DURF_ENC_NO_INTEGRATION 2  /* MipNerfModel.disable_integration: PE instead of IPE (covariances zeroed) */
 #define DURF_ENC_CYLINDER 4        /* MipNerfModel.ray_shape == 'cylinder' (mip.cylinder_to_gaussian) */
+#define DURF_FWD_RAW_FULL 8        /* durf_mlp_fwd_enc only (not an encoder flag): see there */
 #define DURF_ENC_DIM 64      /* 60 (bkgd IPE) / 63 (object IPE) features padded to 64 */
 #define DURF_VIEW_DIM 32     /* 27 view-direction features padded to 32 */
 
@@ -153,7 +154,10 @@ int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_ti
  * ray_idx[r / N] when a compacted list is given (with count); everything else as durf_mlp_fwd.  raw / stash / relu_mask
  * are bit-identical to the two separate calls'.  view_tile (nullable, training): the launch also writes the per-sample
  * view-direction tile [rows,32] that durf_expand_view would (the fragment each lane holds for the view layer IS its tile
- * layout) -- one launch less per step. */
+ * layout) -- one launch less per step.  enc_flags | DURF_FWD_RAW_FULL with a compacted list + tail (a de-duplicated batch,
+ * N % 32 == 0): raw is written in the FULL [B*N,4] layout -- row ray_idx[j]*N + n for the compacted rows, and the one
+ * evaluation of tail ray tail_idx[i] at all N samples of that ray -- i.e. exactly what durf_expand_raw makes of the compacted
+ * raw (bit-identical), which then is not called: one launch less per level. */
 int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
                      const float* radii, const int32_t* hit /* nullable */, int K, int enc_flags, void* enc_tile,
                      const void* view_bf16, const int32_t* ray_idx /* nullable */, const int32_t* count /* nullable */,

@@ -100,9 +100,10 @@ def test_hip_path_reproduces_the_reference_outputs(cuda, case, precision):
     for lvl in range(2):
         if precision == 'f32':       # SURVEY.md 8c F32_EXACT (level 1 sits on positions resampled from fp32 weights)
             t = 1e-5 if lvl == 0 else (2e-4 if c['model'].get('disable_integration') else 5e-5)
-            tol = dict(rgb=t, acc=t, weights=t, distance=1e-4 * FAR, t_vals=1e-4 * FAR)
-        else:
-            tol = dict(rgb=2e-2, acc=2e-2, weights=2e-2, distance=2e-2 * FAR, t_vals=2e-2 * FAR)
+            tol = dict(rgb=t, acc=t, weights=t, distance=5e-4, t_vals=5e-4)      # scene units; measured <= 6.6e-5 / 6.0e-5
+        else:                        # 2e-2 on colours; the distances in scene units (far = 40) at 3-4 x the
+            # measured maxima over the six fixtures (distance 3.4e-2, t_vals 1.1e-2: level 1 resamples from bf16 weights)
+            tol = dict(rgb=2e-2, acc=2e-2, weights=2e-2, distance=0.1, t_vals=0.05)
         meas = {}
         for i, nm in enumerate(G.NAMES):
             got, want = ret[lvl][i].double().cpu().numpy(), gold['l%d_%s' % (lvl, nm)]

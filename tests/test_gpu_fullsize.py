@@ -241,3 +241,81 @@ def test_loss_terms_at_the_metric_shape_against_the_oracle(cuda):
     for k in ('losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses'):
         torch.testing.assert_close(getattr(stats, k).cpu(), S[k], rtol=5e-3, atol=1e-7, msg=lambda m: k + ': ' + m)
     assert int((ret[0][8] > 0).sum()) > 100, 'box-hit rays take part'
+
+
+@pytest.mark.parametrize('pose_opt,alpha', [(False, 10.0), (True, 3.3)])
+def test_gradients_at_the_reference_batch_and_128_samples_against_the_oracle(cuda, pose_opt, alpha):
+    """The reference's own batch (configs/waymo.gin:17: 512 rays) at the metric's 128 samples per ray x 2 levels, K = 3, Waymo
+    loss terms, stratified sampling: the HIP training step's GRADIENT straight against the autograd of the plain fp32
+    restatement on the CPU (no bf16 emulation on the oracle's side, ~30 s), in both precisions of the product: the exact-fp32
+    kernels 2e-3 norm-wise per MLP, the bf16 production path 5e-2; with box-pose optimisation on (cfg4: alpha 3.3, box noise
+    0.5, TV prior) the pose gradient per object, position and rotation, 5e-2 in both (the box-hit rays run in fp32).  The MLP
+    weights are bf16-representable, so both precisions and the oracle evaluate the same network (as in the test above).  This
+    is the largest shape the oracle's autograd graph fits in a test; the 1024- and 4096-ray shapes are tied to it through the
+    exact-fp32 instrument (test_per_rank_shapes_of_cfg5_and_cfg4) and the loss terms
+    (test_loss_terms_at_the_metric_shape_against_the_oracle)."""
+    from oracle import durf_ref as R
+    B, K = 512, 3
+    tv = 1e-2 if pose_opt else 0.0
+    b = synthetic.make_batch(B, K, seed=205, far=40.0, noise_boxes=0.5 if pose_opt else 0.0, redraw_noisy_multi_hit=True)
+    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    g = torch.Generator().manual_seed(21)
+    noise_c = dict(t_rand=torch.rand(B, N + 1, generator=g), u_rand=torch.rand(B, N + 1, generator=g))
+    noise_d = {k: v.to(cuda) for k, v in noise_c.items()}
+    prev_c, prev_d = ob['init'][0:1] + 0.01, db['init'][0:1] + 0.01
+    flat0, grads = None, {}
+    for prec in ('f32', 'bf16'):
+        utils.clear_gin()
+        utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = %s\n'
+                        'MipNerfModel.no_yaw_opt = %s\nMipNerfModel.mlp_precision = %r\nConfig.randomized = True\n'
+                        'Config.rand_bkgd = False\nConfig.grad_max_norm = 1.0\nConfig.grad_max_val = 0.1\n'
+                        'Config.tv_loss_mult = %g\n' % (N, not pose_opt, not pose_opt, prec, tv))
+        config = utils.configured(utils.Config)
+        model, variables = obbpose_model.construct_mipnerf(9, db, device=cuda)
+        lay = variables.layout
+        if flat0 is None:
+            for name in lay.mlp_names():
+                for i in range(12):
+                    bias = variables['params'][name]['Dense_%d' % i]['bias']
+                    bias.copy_(((torch.rand(bias.shape, generator=g) - 0.5) * 0.1).to(cuda))
+            w = variables.flat[lay.box[1]:]
+            w.copy_(w.to(torch.bfloat16).float())
+            flat0 = variables.flat.clone()
+            params = H.oracle_params_from_variables(variables)
+        else:
+            variables.flat.copy_(flat0)
+        grad, raw, _ = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, alpha, prev_d, noise=noise_d)
+        torch.cuda.synchronize()
+        grads[prec] = grad.cpu()
+    ocfg = dict(R.CONFIG_DEFAULTS, randomized=True, tv_loss_mult=tv)
+    mcfg = dict(num_samples=N, density_noise=0.0, no_pose_opt=not pose_opt, no_yaw_opt=not pose_opt)
+    leaves = [z.detach().clone().requires_grad_(True) for z in R.params_leaves(params)]
+    loss, S, _ = R.loss_fn(R.set_leaves(params, leaves), ob, ocfg, mcfg, 3.0, alpha, prev_c, noise=noise_c)
+    assert torch.isfinite(loss), 'the batch must not contain rays that hit two boxes'
+    og = torch.autograd.grad(loss, leaves, allow_unused=True)
+    og = torch.cat([(torch.zeros_like(z) if gr is None else gr).reshape(-1) for gr, z in zip(og, leaves)])
+    ts = b['ts']
+    want = og[lay.box[0]:lay.box[1]].view(lay.T, K, 6)
+    for prec, tol in (('f32', 2e-3), ('bf16', 5e-2)):
+        grad, report = grads[prec], []
+        assert og.numel() == grad.numel()
+        for name in lay.mlp_names():
+            w, _ = lay.mlp_dims(name)
+            sl = slice(lay.mlp_off[name], lay.mlp_off[name] + lay.mlp_size[w])
+            if float(og[sl].norm()) > 0:
+                r = _rel(grad[sl], og[sl])
+                report.append('%s %.2e' % (name, r))
+                assert r < tol, '%s (%s): gradient rel err %g' % (name, prec, r)
+        got = grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)
+        if pose_opt:
+            assert float(want[ts].abs().max()) > 0
+            for k in range(K):
+                if float(want[ts, k].abs().max()) == 0.0:
+                    continue
+                rp, rr = _rel(got[ts, k, :3], want[ts, k, :3]), _rel(got[ts, k, 3:], want[ts, k, 3:])
+                report.append('pose %d %.2e / %.2e' % (k, rp, rr))
+                assert rp < 5e-2 and rr < 5e-2, 'object %d (%s): position rel err %g, rotation rel err %g' % (k, prec, rp, rr)
+        else:
+            assert float(got.abs().max()) == 0.0 and float(want.abs().max()) == 0.0
+        print('512 rays x 128 samples x 2 levels, pose_opt=%s, %s: gradient rel err vs the fp32 oracle: %s'
+              % (pose_opt, prec, ', '.join(report)))

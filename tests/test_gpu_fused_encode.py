@@ -245,3 +245,28 @@ def test_msplit_object_kernels_give_the_sample_split_kernels_results_bit_for_bit
                   c[2][k * mk_stride:(k + 1) * mk_stride].reshape(9, -1, 1024)[:, :nt], 'masks, object %d level %d' % (k, lvl))
             _same(a[4][k * dzo_stride:(k + 1) * dzo_stride].reshape(-1, 1024)[:nt],
                   c[4][k * dzo_stride:(k + 1) * dzo_stride].reshape(-1, 1024)[:nt], 'dz_out, object %d level %d' % (k, lvl))
+
+
+@pytest.mark.parametrize('B,K,N', [(512, 3, 64), (96, 1, 32), (517, 3, 64), (256, 8, 32), (1024, 3, 128)])
+def test_the_forward_writes_the_full_raw_layout_like_expand_raw(cuda, B, K, N):
+    """DURF_FWD_RAW_FULL: a de-duplicated forward writes raw straight into the [B*N,4] layout (its compacted rows at their
+    rays' rows, the one evaluation of a box-hit ray at all N samples of that ray) -- bit for bit what durf_expand_raw makes of
+    the compacted rows (ops.FWD_SCATTER_RAW = False), training and inference variant of the kernel."""
+    config, b, db, model, variables, noise = _setup(cuda, B, K, N, 71 + K)
+    for train in (True, False):
+        out = {}
+        for on in (True, False):
+            ops.FWD_SCATTER_RAW = on
+            try:
+                ret, ctx = model._forward(variables, 0, db['rays'], db['init'], db['ext'], b['ts'], True, False, False, 10.0,
+                                          train=train, noise=noise, loss_prep=None)
+                torch.cuda.synchronize()
+            finally:
+                ops.FWD_SCATTER_RAW = True
+            out[on] = (ret, ctx)
+        assert out[True][1].get('dedup') is not None or not train, 'the batch must take the de-duplicated path'
+        for lvl in range(model.num_levels):
+            for i, nm in enumerate(['rgb', 'depth', 'acc', 'weights', 't_vals']):
+                _same(out[True][0][lvl][i], out[False][0][lvl][i], '%s level %d' % (nm, lvl))
+            if train:
+                _same(out[True][1]['levels'][lvl]['raw_b'], out[False][1]['levels'][lvl]['raw_b'], 'raw level %d' % lvl)
