@@ -66,6 +66,9 @@ def parse_args():
                     help="f32: the whole model in the reference's own arithmetic (MipNerfModel.mlp_precision = 'f32': every "
                          'Dense layer on v_mfma_f32_32x32x2_f32, accurate-libm encodings; obbpose_model.py:326-327, '
                          'internal/math.py:22-24) -- the roofline is then priced against the 157.3 TFLOP/s fp32-MFMA peak')
+    ap.add_argument('--time-every', type=int, default=0,
+                    help='record the roofline HIP events on every n-th timed step only (0: min(8, steps / 5); 1: every step, '
+                         'as up to round 3 -- each record costs the stream 3-6 us on either side of the launch it brackets)')
     ap.add_argument('--prewarm-events', type=int, default=512,
                     help='timing events recorded (and kept alive) before the warm-up: grows the HIP runtime\'s event pool there')
     ap.add_argument('--max-ahead', type=int, default=0, help='bound the number of steps the host may enqueue ahead of the GPU (0 = unbounded)')
@@ -420,7 +423,13 @@ def main():
     prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]    # kept alive to the end
     for e in prewarm:
         e.record()
+    # Only every `every`-th step carries the event records (--time-every; default min(8, steps / 5)): a record makes the
+    # stream wait for the marker's signal on either side of the launch it brackets -- 3-6 us each, 50-70 us per step with the
+    # seven timed launches, 1.5 % of a 4096-ray step and 9 % of a 512-ray step (profiles/r04_event_overhead.txt).  The
+    # averages are over the sampled launches, all inside the timed region.
+    every = 1 if args.profile_ops else (args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 5)))
     for i in range(args.warmup):
+        ops.TIMERS_ACTIVE = i % every == 0
         state, stats, rng, _ = step(state, rng, i)
     sync()
     flush_c_stdio()       # (the communicator, and with it the banner, is created lazily by the first collective)
@@ -430,7 +439,10 @@ def main():
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]     # per-step GPU timestamps (diagnostic)
     t0 = time.perf_counter()
     marks[0].record()
+    sampled = 0
     for i in range(args.steps):
+        ops.TIMERS_ACTIVE = i % every == 0
+        sampled += int(ops.TIMERS_ACTIVE)
         state, stats, rng, _ = step(state, rng, i + 1)
         marks[i + 1].record()
         if args.max_ahead > 0 and i + 1 > args.max_ahead:
@@ -445,6 +457,7 @@ def main():
     dt = float(tt)
     totals = ops.timer_totals()
     ops.TIMERS = None
+    ops.TIMERS_ACTIVE = True
     # With the object launches on a side stream the timed background kernels share the chip with them for part of their
     # run, and their live durations say so.  A short extra pass on ONE stream (outside the timed region; every rank takes
     # part, the step holds the collective) gives the same kernels' undisturbed durations: `roofline.single_stream`.
@@ -501,7 +514,8 @@ def main():
             fl = 3 * N_LEVELS * 2.0 * (MAC_BKGD + hit * MAC_OBJ) * rows
             roof['step_mlp_tflops'] = fl / step_s / 1e12
             roof['step_mlp_frac'] = fl / step_s / peak
-            per_step = {k: totals[k][1] / args.steps for k in mlp}
+            per_step = {k: totals[k][1] / sampled for k in mlp}
+            roof['timed_steps'] = '%d of %d (every %d)' % (sampled, args.steps, every)
             roof['non_mlp_ms_per_step'] = (step_s - sum(per_step.values())) * 1e3
             if totals_ss:
                 roof['single_stream'] = {k: dict(us=sv / nv * 1e6, frac=mfma[k] / (sv / nv) / peak)
@@ -510,7 +524,7 @@ def main():
                 roof['board'] = board_calibration(dev, d['achieved'])
         if args.profile_ops:
             for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
-                print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / args.steps),
+                print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / sampled),
                       file=sys.stderr)
         cb = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(batch_np, K_OBJ, NS, config)   # rank 0, N = 1 only
         out = dict(metric='train_rays_per_sec', value=B * world * args.steps / dt, unit='rays/s',

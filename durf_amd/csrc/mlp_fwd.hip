@@ -455,7 +455,8 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         }
         const f32x16 acc = mma_tile<S::KC, 0>(slot, lane, c, nullptr);
         const float qn = __builtin_nanf("");
-        const f32x4 o = {poison ? qn : acc[0], poison ? qn : acc[1], poison ? qn : acc[2], poison ? qn : dens};
+        const float o0 = poison ? qn : acc[0], o1 = poison ? qn : acc[1], o2 = poison ? qn : acc[2], o3 = poison ? qn : dens;
+        const f32x4 o = {o0, o1, o2, o3};
         bool scattered = false;
         if constexpr (ENC) scattered = (ei.flags & DURF_FWD_RAW_FULL) != 0 && ray_idx != nullptr;
         if (!scattered) {
@@ -484,9 +485,11 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
             for (int r = 0; r < 32; r++) {
                 const int ray = __builtin_amdgcn_readlane(rr, r);
                 if (ray < 0) break;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o[e]), r));
+                const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o0), r));
+                const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o1), r));
+                const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o2), r));
+                const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, o3), r));
+                const f32x4 v = {v0, v1, v2, v3};
                 float* dst = raw + (size_t)((unsigned)ray * (unsigned)N) * 4;
                 for (unsigned n = l64; n < (unsigned)N; n += 64) *(f32x4*)(dst + (size_t)n * 4) = v;
             }

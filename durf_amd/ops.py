@@ -21,6 +21,8 @@ def _stream():
 # roofline measurement).  TIMERS = None disables it (default: zero overhead).
 TIMERS = None
 TIMED_NAMES = None       # optional set of op names to time (None: every wrapped op)
+TIMERS_ACTIVE = True     # bench.py samples: an event record stalls the stream for ~3-6 us on either side of the launch it
+                         # brackets (the next packet waits for the marker's signal), so only every n-th step is timed
 
 
 class _Timed:
@@ -28,7 +30,7 @@ class _Timed:
         self.name = name
 
     def __enter__(self):
-        self.on = TIMERS is not None and (TIMED_NAMES is None or self.name in TIMED_NAMES)
+        self.on = TIMERS is not None and TIMERS_ACTIVE and (TIMED_NAMES is None or self.name in TIMED_NAMES)
         if self.on:
             self.e0 = torch.cuda.Event(enable_timing=True)
             self.e1 = torch.cuda.Event(enable_timing=True)
