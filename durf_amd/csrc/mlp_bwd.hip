@@ -954,16 +954,17 @@ __device__ __forceinline__ size_t frag_index(int W, int i, int j, int NI) {
 // One workgroup per 32 x 32 output tile (LDS-staged operands: P is gathered from fragment order once per tile):
 //   tiles [0, nA):        dK9[i, o]  = sum_j P[i, j] K10[o, j]                    (W/32 x W/32 tiles, K = 128)
 //   tiles [nA, nA + nC):  dK10[o, j] = sum_i K9[i, o] P[i, j] + b9[o] db10[j]     (W/32 x 4 tiles,    K = W)
-//   tile nA + nC:         db9[o]     = sum_j db10[j] K10[o, j]
+//   (tiles [0, W/32) also:  db9[o]   = sum_j db10[j] K10[o, j])
 __global__ void __launch_bounds__(256)
 k_bottleneck_grads(FinArgs A) {
     __shared__ float sa[32][257];        // rows of the first operand, K (<= 256) values each
     __shared__ float sb[32][257];        // rows of the second operand
+    __shared__ float sdb[128];           // db10 (first row of tiles: db9)
     const int cls = (int)blockIdx.y < A.m[0].count ? 0 : 1;       // blockIdx.y: MLP, classes as in k_dw_finalize
     const FinMlp& M = A.m[cls];
     const size_t obj = blockIdx.y - (cls ? A.m[0].count : 0);
     const int W = M.W, in_dim = M.in_dim, NI = M.NI10;
-    if ((int)blockIdx.x >= (W / 32) * (W / 32) + (W / 32) * 4 + 1) return;      // the grid is sized for the wider class
+    if ((int)blockIdx.x >= (W / 32) * (W / 32) + (W / 32) * 4) return;          // the grid is sized for the wider class
     const float* part10 = M.part + M.jobs.part_off[10] + obj * M.part_stride;
     const float* bpart10 = M.bpart + M.jobs.bpart_off[10] + obj * M.bpart_stride;
     const float* params = M.params + obj * M.param_stride;
@@ -994,6 +995,7 @@ k_bottleneck_grads(FinArgs A) {
                 sb[r][j] = bf16r(vb[u]);
             }
         }
+        if (i0 == 0 && tid < 128) sdb[tid] = bpart10[cperm_slot(tid)];
         __syncthreads();
         float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};        // four independent chains, LDS reads batched 8 k-values at a time
 #pragma unroll 8
@@ -1004,6 +1006,15 @@ k_bottleneck_grads(FinArgs A) {
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) grad[off9 + (size_t)(i0 + ty + 8 * q) * W + o0 + tx] = s4[q];
+        // db9[o] = sum_j db10[j] K10[o, j]: one more row of this product, carried by the first row of tiles (the rows of K10
+        // are already in LDS).  (Until round 4 a workgroup of its own walked K10 with 8 dependent rounds of strided loads:
+        // ~20 us on cold weights -- the long pole of the launch.)
+        if (i0 == 0 && ty == 0) {
+            float s = 0.0f;
+#pragma unroll 8
+            for (int j = 0; j < 128; j++) s += sdb[j] * sb[tx][j];
+            grad[off9 + (size_t)W * W + o0 + tx] = s;
+        }
     } else if (t < nA + nC) {
         const int u = t - nA, o0 = (u / 4) * 32, j0 = (u % 4) * 32;
 #pragma unroll 1
@@ -1035,20 +1046,6 @@ k_bottleneck_grads(FinArgs A) {
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) grad[off10 + (size_t)(o0 + ty + 8 * q) * 128 + j0 + tx] = s4[q];
-    } else {
-        if (tid < 128) sa[0][tid] = bpart10[cperm_slot(tid)];
-        __syncthreads();
-        for (int o = tid; o < W; o += 256) {
-            float s = 0.0f;
-            for (int j0 = 0; j0 < 128; j0 += 16) {
-                float v[16];
-#pragma unroll
-                for (int u = 0; u < 16; u++) v[u] = K10[(size_t)o * 128 + j0 + u];
-#pragma unroll
-                for (int u = 0; u < 16; u++) s += sa[0][j0 + u] * bf16r(v[u]);
-            }
-            grad[off9 + (size_t)W * W + o] = s;
-        }
     }
 }
 
@@ -1058,7 +1055,9 @@ struct DwPlan {
     size_t part_off[12], bpart_off[12], part_total, bpart_total;
     int max_split;
 };
-static DwPlan dw_plan(int width) {
+// total_rows: the sample rows (all levels) the launch is sized for -- a host-side number both the launch and its finalize
+// know; 0 = the largest plan (buffer sizes)
+static DwPlan dw_plan(int width, size_t total_rows = 0) {
     DwPlan P;
     const int KW = width / 16;
     int cost = 0, wcost[12];
@@ -1087,7 +1086,14 @@ static DwPlan dw_plan(int width) {
     static const int env_wgs = getenv("DURF_DW_WGS") ? atoi(getenv("DURF_DW_WGS")) : 0;
     static const int env_wgs_obj = getenv("DURF_DW_WGS_OBJ") ? atoi(getenv("DURF_DW_WGS_OBJ")) : 0;
     const int env_w = width == 256 ? env_wgs : env_wgs_obj;
-    const int total_wgs = env_w > 0 ? env_w : (width == 256 ? 512 : 256);
+    // Round 4, small batches: every workgroup writes its fp32 partial tile whatever its share of the samples -- 134 MB per
+    // launch with 512 workgroups, written here and read again by k_dw_finalize: ~50 us per step that do not shrink with
+    // the batch.  ONE round of 256 workgroups halves that; the longer k loop per workgroup costs less than it saves below
+    // ~3000 rays x 128 samples x 2 levels (step, k rays/s, 512 vs 256 workgroups: 512 rays 688-693 -> 714-728, cfg1
+    // 1125-1136 -> 1185-1192, cfg5 761-783 -> 783-811, 1024 rays 810 -> 829, 2048 rays 921 -> 941, 4096 rays 966 -> 957;
+    // 128 / 192 / 320 / 384 are worse everywhere: partial rounds).
+    const bool small = total_rows > 0 && total_rows < (size_t)3072 * 256;
+    const int total_wgs = env_w > 0 ? env_w : (width == 256 ? (small ? 256 : 512) : 256);
     int base[12], given = 0;
     for (int j = 0; j < 12; j++) {
         base[j] = total_wgs * wcost[j] / cost;
@@ -1284,7 +1290,7 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
     }
     if (total_rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const DwPlan P = dw_plan(width);
+    const DwPlan P = dw_plan(width, total_rows);
     const int KW = width / 16;
     auto region = [&](const void* base, int j, int l) { return (const char*)base + ((size_t)j * KW * (lv.rows[l] >> 5)) * 1024; };
     DwArgs a;
@@ -1350,7 +1356,9 @@ static int fin_class(FinMlp& M, int width, int in_dim, const DwLevels& lv, const
     DURF_REQUIRE(mlp_params != nullptr, "the bottleneck gradients need the MLP's parameters");
     DURF_REQUIRE(width == 256 || width == 128, "width must be 256 or 128");
     const int W = width, KW = W / 16;
-    const DwPlan P = dw_plan(width);
+    size_t total_rows = 0;
+    for (int l = 0; l < lv.nlevels; l++) total_rows += lv.rows[l];
+    const DwPlan P = dw_plan(width, total_rows);
     M.W = W; M.in_dim = in_dim; M.count = K; M.NI10 = P.NI[10];
     M.part = part; M.bpart = bpart; M.grad = grad_mlp; M.params = mlp_params;
     M.part_stride = part_stride; M.bpart_stride = bpart_stride; M.grad_stride = grad_stride; M.param_stride = param_stride;
@@ -1370,7 +1378,7 @@ static int fin_class(FinMlp& M, int width, int in_dim, const DwLevels& lv, const
         const int el = J.MO * J.NI * 1024 + J.MO * 32;
         if (el > *max_el) *max_el = el;
     }
-    const int ntiles = (W / 32) * (W / 32) + (W / 32) * 4 + 1;
+    const int ntiles = (W / 32) * (W / 32) + (W / 32) * 4;
     if (ntiles > *max_tiles) *max_tiles = ntiles;
     return 0;
 }
