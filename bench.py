@@ -296,20 +296,27 @@ def eval_main(args):
     prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]
     for e in prewarm:
         e.record()
-    for _ in range(max(args.warmup, 2)):
+    # (the event records on every `every`-th image only: see run_train)
+    every = args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 5))
+    for i in range(max(args.warmup, 2)):
+        ops.TIMERS_ACTIVE = i % every == 0
         render()
     torch.cuda.synchronize()
     ops.TIMERS = {}
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     e0.record()
-    for _ in range(args.steps):
+    sampled = 0
+    for i in range(args.steps):
+        ops.TIMERS_ACTIVE = i % every == 0
+        sampled += int(ops.TIMERS_ACTIVE)
         rgb, dist_, acc = render()
     e1.record()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     totals = ops.timer_totals()
     ops.TIMERS = None
+    ops.TIMERS_ACTIVE = True
     NS = w['N']
     nchunks = (H * W + args.chunk - 1) // args.chunk
     if args.one_call:                                    # the kernels are launched from C: only the whole call is timed
@@ -321,20 +328,20 @@ def eval_main(args):
                    config=dict(workload=w['label'] + ', render_image, every chunk of %d rays ONE durf_forward call' % args.chunk,
                                name=args.config, mode='eval', one_call=True, image=[H, W], chunk=args.chunk, num_samples=NS,
                                objects=w['K']),
-                   roofline=dict(bound='mfma', kernel='durf_forward (whole chunk)', achieved=fl / (sec / args.steps) / 1e12,
-                                 peak=PEAK_BF16 / 1e12, unit='TFLOP/s', frac=fl / (sec / args.steps) / PEAK_BF16, traffic=None,
+                   roofline=dict(bound='mfma', kernel='durf_forward (whole chunk)', achieved=fl / (sec / sampled) / 1e12,
+                                 peak=PEAK_BF16 / 1e12, unit='TFLOP/s', frac=fl / (sec / sampled) / PEAK_BF16, traffic=None,
                                  launch_us=sec / n * 1e6), cpu_baseline=None)
         print(json.dumps(out))
         return
     n, sec = totals['mlp_fwd_256']
     rows = H * W * NS                                    # per level, all chunks of one image
-    per_image = sec / args.steps                         # the background forward of both levels, all chunks
+    per_image = sec / sampled                         # the background forward of both levels, all chunks
     fl = N_LEVELS * 2.0 * MAC_BKGD * rows
-    busy = sum(s_ for _, s_ in totals.values()) / args.steps
+    busy = sum(s_ for _, s_ in totals.values()) / sampled
     roof = dict(bound='mfma', kernel='mlp_fwd_256 (inference)', achieved=fl / per_image / 1e12, peak=PEAK_BF16 / 1e12,
                 unit='TFLOP/s', frac=fl / per_image / PEAK_BF16, traffic=None, launch_us=sec / n * 1e6,
-                launches_per_image=n // args.steps,
-                timed_kernels_ms_per_image={k: v[1] / args.steps * 1e3 for k, v in totals.items()},
+                launches_per_image=n // sampled, timed_images='%d of %d (every %d)' % (sampled, args.steps, every),
+                timed_kernels_ms_per_image={k: v[1] / sampled * 1e3 for k, v in totals.items()},
                 # GPU time of an image outside the three timed kernels (object MLPs, per-ray launches, idle gaps)
                 other_ms_per_image=(e0.elapsed_time(e1) / args.steps) - busy * 1e3)
     out = dict(metric='eval_rays_per_sec', value=H * W * args.steps / dt, unit='rays/s', n_gpus=1, steps=args.steps,

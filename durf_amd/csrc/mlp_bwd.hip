@@ -1093,7 +1093,7 @@ static DwPlan dw_plan(int width, size_t total_rows = 0) {
     // 1125-1136 -> 1185-1192, cfg5 761-783 -> 783-811, 1024 rays 810 -> 829, 2048 rays 921 -> 941, 4096 rays 966 -> 957;
     // 128 / 192 / 320 / 384 are worse everywhere: partial rounds).
     const bool small = total_rows > 0 && total_rows < (size_t)3072 * 256;
-    const int total_wgs = env_w > 0 ? env_w : (width == 256 ? (small ? 256 : 512) : 256);
+    const int total_wgs = env_w > 0 ? env_w : (width == 256 ? (small ? 256 : 512) : (small ? 128 : 256));     // (objects, small: 512 rays 706 -> 711, cfg5 776 -> 783)
     int base[12], given = 0;
     for (int j = 0; j < 12; j++) {
         base[j] = total_wgs * wcost[j] / cost;

@@ -824,6 +824,138 @@ k_mlp_dw_f32(F32Spec S, F32TileTab T, F32DwArgs a, int nsplit, size_t params, fl
     }
 }
 
+// The same sums with a 2 x 2 block of output tiles per workgroup (round 4): a wave's 32-sample tile feeds 64 MFMAs from
+// 8 + 8 float4 per lane instead of 16 from 4 + 4 -- every record strip is read by half as many workgroups (the launch above
+// re-reads the records 4-5 x and runs at ~40 % of its MFMA time: one tile of prefetch hides ~0.4 us of compute per load
+// round trip, this one 1.7 us).  Tiles are dealt to (split, wave) exactly as above and the four waves' accumulators are
+// summed in the same order, so every partial is BIT-identical to k_mlp_dw_f32's.  Blocks of a layer: ceil(k tiles / 2) x
+// ceil(column tiles / 2), k-block major; the absent half of an edge block is skipped (wave-uniform).
+struct F32BlockTab { int base[13]; };
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_mlp_dw_f32_b2(F32Spec S, F32BlockTab T, F32DwArgs a, int nsplit, size_t params, float* __restrict__ part) {
+    __shared__ float red[4][3][16][64];
+    __shared__ float redb[2][3][32];
+    const int t = blockIdx.x, sp = blockIdx.y;
+    int l = 11;
+    while (l > 0 && t < T.base[l]) l--;
+    const F32Layer Ly = S.L[l];
+    const int ntk = (Ly.fi + 31) / 32, ntm = (Ly.fo + 31) / 32;
+    const int nbm = (ntm + 1) / 2;
+    const int kb = (t - T.base[l]) / nbm, mb = (t - T.base[l]) % nbm;
+    const int ki0 = 2 * kb, mj0 = 2 * mb;
+    const bool k1 = ki0 + 1 < ntk, m1 = mj0 + 1 < ntm;          // wave-uniform: the block's second k / column tile exists
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, kk = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+        for (int y = 0; y < 2; y++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[x][y][r] = 0.0f;
+    int kq[2], mq[2], krow[2], mrow[2];
+#pragma unroll
+    for (int x = 0; x < 2; x++) {
+        kq[x] = 32 * (ki0 + x) + i; mq[x] = 32 * (mj0 + x) + i;
+        krow[x] = Ly.x_off + (kq[x] < Ly.fi ? kq[x] : 0);       // clamped: rows >= fi are padding
+        mrow[x] = Ly.dz_off + (mq[x] < Ly.fo ? mq[x] : 0);
+    }
+    float bsum[2] = {0.0f, 0.0f};
+    for (int sgi = 0; sgi < a.nseg; sgi++) {
+        const F32DwSeg sg = a.seg[sgi];
+        const size_t nrows = f32_rows(sg.rows, sg.N, sg.count ? sg.count + blockIdx.z : nullptr);
+        const size_t ntile = (nrows + 31) / 32;
+        const float* act = sg.act + blockIdx.z * a.act_stride;
+        const float* dz = sg.dz + blockIdx.z * a.dz_stride;
+        const size_t step = (size_t)nsplit * 4;
+        size_t tl = (size_t)sp * 4 + wave;
+        f32x4 av[2][4], bv[2][4], an[2][4], bn[2][4];
+        auto load = [&](size_t t_, f32x4 (&a_)[2][4], f32x4 (&b_)[2][4]) {
+#pragma unroll
+            for (int x = 0; x < 2; x++) {
+                const float* xa = act + (t_ * S.act + krow[x]) * 32 + 16 * kk;
+                const float* za = dz + (t_ * S.dz + mrow[x]) * 32 + 16 * kk;
+#pragma unroll
+                for (int q = 0; q < 4; q++) { a_[x][q] = *(const f32x4*)(xa + 4 * q); b_[x][q] = *(const f32x4*)(za + 4 * q); }
+            }
+        };
+        // padding rows (k >= fi, m >= fo: edge blocks only) and the samples beyond the count (last tile only) enter as zeros:
+        // masked IN PLACE once per tile and only where they occur (wave-uniform tests), not with four selects per MFMA
+        const bool edge = 32 * (ki0 + 2) > Ly.fi || 32 * (mj0 + 2) > Ly.fo;
+        auto mask_tile = [&](size_t t_, f32x4 (&a_)[2][4], f32x4 (&b_)[2][4]) {
+            const bool ragged = (t_ + 1) * 32 > nrows;
+            if (!edge && !ragged) return;
+            const size_t s0 = t_ * 32 + 16 * kk;
+#pragma unroll
+            for (int x = 0; x < 2; x++)
+#pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const bool ok = s0 + j < nrows;
+                    a_[x][j >> 2][j & 3] = (ok && kq[x] < Ly.fi) ? a_[x][j >> 2][j & 3] : 0.0f;
+                    b_[x][j >> 2][j & 3] = (ok && mq[x] < Ly.fo) ? b_[x][j >> 2][j & 3] : 0.0f;
+                }
+        };
+        auto tile_mma = [&](const f32x4 (&a_)[2][4], const f32x4 (&b_)[2][4]) {
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const float x0 = a_[0][j >> 2][j & 3], x1 = a_[1][j >> 2][j & 3];
+                const float z0 = b_[0][j >> 2][j & 3], z1 = b_[1][j >> 2][j & 3];
+                bsum[0] += z0; bsum[1] += z1;
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, z0, acc[0][0], 0, 0, 0);
+                if (m1) acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x0, z1, acc[0][1], 0, 0, 0);
+                if (k1) acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, z0, acc[1][0], 0, 0, 0);
+                if (k1 && m1) acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(x1, z1, acc[1][1], 0, 0, 0);
+            }
+        };
+        // two tiles per trip, ping-pong between the operand sets (no register copies)
+        if (tl < ntile) load(tl, av, bv);
+        while (tl < ntile) {
+            if (tl + step < ntile) load(tl + step, an, bn);
+            mask_tile(tl, av, bv);
+            tile_mma(av, bv);
+            tl += step;
+            if (tl >= ntile) break;
+            if (tl + step < ntile) load(tl + step, av, bv);
+            mask_tile(tl, an, bn);
+            tile_mma(an, bn);
+            tl += step;
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; x++) bsum[x] += __shfl_xor(bsum[x], 32, 64);          // the two sample halves of column m
+    if (wave > 0) {
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+            for (int y = 0; y < 2; y++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) red[2 * x + y][wave - 1][r][lane] = acc[x][y][r];
+        if (lane < 32) { redb[0][wave - 1][lane] = bsum[0]; redb[1][wave - 1][lane] = bsum[1]; }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* pp = part + blockIdx.z * a.part_stride + (size_t)sp * params + Ly.w_off;
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+            for (int y = 0; y < 2; y++) {
+                if ((x && !k1) || (y && !m1)) continue;
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const float v = ((acc[x][y][r] + red[2 * x + y][0][r][lane]) + red[2 * x + y][1][r][lane]) + red[2 * x + y][2][r][lane];
+                    const int kr = 32 * (ki0 + x) + c_row(r, kk);
+                    if (kr < Ly.fi && mq[y] < Ly.fo) pp[(size_t)kr * Ly.fo + mq[y]] = v;
+                }
+            }
+        if (ki0 == 0 && lane < 32) {
+#pragma unroll
+            for (int y = 0; y < 2; y++)
+                if ((!y || m1) && mq[y] < Ly.fo)
+                    pp[(size_t)Ly.fi * Ly.fo + mq[y]] = ((bsum[y] + redb[y][0][lane]) + redb[y][1][lane]) + redb[y][2][lane];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_dw_f32_reduce(size_t params, int nsplit, const float* __restrict__ part, size_t part_stride, float* __restrict__ grad,
                 size_t grad_stride, int accumulate) {
@@ -938,6 +1070,35 @@ F32TileTab tile_table(const F32Spec& S) {
     return T;
 }
 
+F32BlockTab block_table(const F32Spec& S) {
+    F32BlockTab T;
+    int nb = 0;
+    for (int l = 0; l < 12; l++) {
+        T.base[l] = nb;
+        nb += (((S.L[l].fi + 31) / 32 + 1) / 2) * (((S.L[l].fo + 31) / 32 + 1) / 2);
+    }
+    T.base[12] = nb;
+    return T;
+}
+// The 2 x 2 blocks pay where a wave has many sample tiles to walk: the W = 256 instrument / --precision f32 (8.52 -> 8.05 ms
+// per launch at 4096 rays).  On the K object MLPs of a pose-optimisation step (cfg4: ~5 tiles per wave, 42 blocks x 8 splits
+// x K workgroups at occupancy 2 instead of 172 x 8 x K at 4) they LOSE: 87 -> 101-103 us (tools/time_objf32.py), cfg4
+// 636 -> 629 k rays/s -- the sixth layout of that launch measured slower than one tile per workgroup (review item 6).
+// DURF_F32_DW_B2 = 0 / 1 forces one or the other (A/B switch; bit-identical partials).
+bool dw_b2_enabled(bool wide) {
+    const char* e = getenv("DURF_F32_DW_B2");
+    return e ? e[0] != '0' : wide;
+}
+void launch_dw_f32(hipStream_t s, const F32Spec& S, const F32DwArgs& a, int nsplit, int K, size_t params, float* scratch) {
+    if (dw_b2_enabled(S.W == 256)) {
+        const F32BlockTab T = block_table(S);
+        hipLaunchKernelGGL(k_mlp_dw_f32_b2, dim3(T.base[12], nsplit, K), dim3(256), 0, s, S, T, a, nsplit, params, scratch);
+    } else {
+        const F32TileTab T = tile_table(S);
+        hipLaunchKernelGGL(k_mlp_dw_f32, dim3(T.base[12], nsplit, K), dim3(256), 0, s, S, T, a, nsplit, params, scratch);
+    }
+}
+
 template <int W, int IN, bool TRAIN, bool ENC>
 void launch_fwd_k(hipStream_t s, dim3 grid, size_t rows, int N, const float* enc, const float* view27, const int32_t* ray_idx,
                   const int32_t* count, const float* P, const float* ws, float* raw, float* act, const F32FwdBatch& bs,
@@ -1036,12 +1197,11 @@ int durf_mlp_dw_f32(void* stream, int width, int in_dim, size_t rows, int N, con
     DURF_REQUIRE(nsplit >= 1 && nsplit <= 1024, "1 <= nsplit <= 1024");
     const F32Spec S = f32_spec(width, in_dim);
     const size_t params = durf_layer_offset(width, in_dim, 12, 0);
-    const F32TileTab T = tile_table(S);
     F32DwArgs a{};
     a.nseg = 1;
     a.seg[0] = F32DwSeg{act, dz, count, rows, N};
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_mlp_dw_f32, dim3(T.base[12], nsplit, 1), dim3(256), 0, s, S, T, a, nsplit, params, scratch);
+    launch_dw_f32(s, S, a, nsplit, 1, params, scratch);
     hipLaunchKernelGGL(k_dw_f32_reduce, dim3(durf_cdiv(params, 256), 1), dim3(256), 0, s, params, nsplit, scratch, (size_t)0,
                        grad_mlp, (size_t)0, 0);
     DURF_CHECK_LAUNCH("durf_mlp_dw_f32");
@@ -1108,14 +1268,13 @@ int durf_objf32_dw_batch(void* stream, int K, int B, int N, const int32_t* count
     if (B <= 0) return 0;
     const F32Spec S = f32_spec(DURF_W_OBJ, 63);
     const size_t params = durf_layer_offset(DURF_W_OBJ, 63, 12, 0);
-    const F32TileTab T = tile_table(S);
     F32DwArgs a{};
     a.nseg = nlevels;
     for (int l = 0; l < nlevels; l++) a.seg[l] = F32DwSeg{act[l], dz[l], count, (size_t)B * N, N};
     a.act_stride = durf_objf32_act_stride(B, N); a.dz_stride = durf_objf32_dz_stride(B, N);
     a.part_stride = (size_t)nsplit * params;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_mlp_dw_f32, dim3(T.base[12], nsplit, K), dim3(256), 0, s, S, T, a, nsplit, params, scratch);
+    launch_dw_f32(s, S, a, nsplit, K, params, scratch);
     hipLaunchKernelGGL(k_dw_f32_reduce, dim3(durf_cdiv(params, 256), K), dim3(256), 0, s, params, nsplit, scratch,
                        a.part_stride, grad_obj, grad_stride, 0);
     DURF_CHECK_LAUNCH("durf_objf32_dw_batch");

@@ -909,7 +909,11 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
     const bool half = width == 256 && K == 1 && durf_cdiv(rows, 256) <= 128 && durf::half_blocks_enabled();
     const unsigned per = half ? 128u : 256u;
     const unsigned nblk = durf_cdiv(rows, per);
-    dim3 grid(nblk < 256u ? nblk : 256u, K), block(half ? 256 : 512);     // persistent: at most one workgroup per CU and object
+    // persistent: at most one workgroup per CU and object -- less DURF_FWD_RESERVE_CUS(n) CUs the caller wants left to a
+    // launch on another stream (a persistent grid on every CU starves it until its own tail)
+    unsigned wgs = 256u;
+    if (enc_in && K == 1) { const unsigned r = ((unsigned)enc_in->flags >> 8) & 0x7fu; wgs -= r; }
+    dim3 grid(nblk < wgs ? nblk : wgs, K), block(half ? 256 : 512);
     const EncIn ei = enc_in ? *enc_in : EncIn{};
     // The object MLPs (W = 128 on compacted ray lists): the M-split kernel -- 4 waves x 64 samples, one output tile per wave --
     // whose launch is a few microseconds of latency instead of one 11-stage round of 256-sample blocks.  DURF_OBJ_MSPLIT=0

@@ -346,7 +346,8 @@ class MipNerfModel:
                     raw_c, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit, view, packs['MLP_0'][0],
                                                    ray_idx=dd['idx'][0], count=dd['count'][0:1], stash=stash_b,
                                                    relu_mask=mask_b, tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
-                                                   view_tile=vt, raw_full=scatter, **enc_kw)
+                                                   view_tile=vt, raw_full=scatter,
+                                                   reserve_cus=ops.FWD_RESERVE_CUS if tail_side is not None else 0, **enc_kw)
                 elif dd is not None:
                     scatter = False
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,

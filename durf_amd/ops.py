@@ -269,22 +269,28 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
 FUSED_ENCODE = os.environ.get('DURF_FUSED_ENCODE', '1') != '0'
 # DURF_FWD_SCATTER_RAW=0: a de-duplicated forward writes compacted raw rows and expand_raw makes the full layout (A/B switch)
 FWD_SCATTER_RAW = os.environ.get('DURF_FWD_SCATTER_RAW', '1') != '0'
+# CUs the level-0 background forward of a pose-optimisation step leaves to the fp32 evaluation of the box-hit rays queued on
+# the side stream (k_bkgd_hit_rays: beside a persistent grid on all 256 CUs it runs 160-180 us instead of 40 and the main
+# stream waits for it).  Measured at cfg4 with 16: 636 -> 625 k rays/s (and 629 -> 623 with the 2 x 2 fp32 weight-gradient
+# kernel): the forward loses more than the join gains -- off by default, the knob stays for other shapes.
+FWD_RESERVE_CUS = int(os.environ.get('DURF_FWD_RESERVE_CUS', '0'))
 
 
 def mlp_fwd_enc(rows, N, t_vals, origins_s, dirs_s, radii, hit, view_bf16, wpack_fwd, contraction=True,
                 disable_integration=False, cylinder=False, ray_idx=None, count=None, stash=None, raw=None, relu_mask=None,
-                tail_idx=None, tail_count=None, view_tile=None, raw_full=False):
+                tail_idx=None, tail_count=None, view_tile=None, raw_full=False, reserve_cus=0):
     """durf_mlp_fwd_enc: the background forward that encodes its own tiles (encode_bkgd + mlp_fwd(256) as one launch)
     -> (raw, enc_tile); enc_tile is what encode_bkgd would have returned (the weight-gradient GEMMs read it).
     view_tile (training): a [tile_rows, 32] bf16 buffer the launch fills with expand_view's output; raw_full (with
-    ray_idx / tail_idx): raw comes back in the full [B*N,4] layout -- expand_raw's output, without that launch"""
+    ray_idx / tail_idx): raw comes back in the full [B*N,4] layout -- expand_raw's output, without that launch;
+    reserve_cus: the persistent grid leaves that many CUs to a launch queued on another stream"""
     dev = t_vals.device
     K = 0 if hit is None else hit.shape[1]
     if raw is None:
         raw = torch.empty(rows, 4, device=dev)
     enc_tile = torch.empty(tile_rows(rows), ENC_DIM, dtype=torch.bfloat16, device=dev)
     flags = ((ENC_CONTRACT if contraction else 0) | (ENC_NO_INTEGRATION if disable_integration else 0) |
-             (ENC_CYLINDER if cylinder else 0) | (FWD_RAW_FULL if raw_full else 0))
+             (ENC_CYLINDER if cylinder else 0) | (FWD_RAW_FULL if raw_full else 0) | ((int(reserve_cus) & 0x7f) << 8))
     with _Timed('mlp_fwd_256%s' % ('_train' if stash is not None else '')):
         _lib.check(_lib.lib().durf_mlp_fwd_enc(_stream(), rows, N, _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
                                                _p(_f32(radii)), _p(hit), K, flags, _p(enc_tile), _p(view_bf16),

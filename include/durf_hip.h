@@ -38,6 +38,7 @@ extern "C" {
 #define DURF_ENC_NO_INTEGRATION 2  /* MipNerfModel.disable_integration: PE instead of IPE (covariances zeroed) */
 #define DURF_ENC_CYLINDER 4        /* MipNerfModel.ray_shape == 'cylinder' (mip.cylinder_to_gaussian) */
 #define DURF_FWD_RAW_FULL 8        /* durf_mlp_fwd_enc only (not an encoder flag): see there */
+#define DURF_FWD_RESERVE_CUS(n) (((n) & 0x7f) << 8)   /* durf_mlp_fwd_enc only: launch on 256 - n CUs (n <= 127), see there */
 #define DURF_ENC_DIM 64      /* 60 (bkgd IPE) / 63 (object IPE) features padded to 64 */
 #define DURF_VIEW_DIM 32     /* 27 view-direction features padded to 32 */
 
@@ -157,7 +158,9 @@ int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_ti
  * layout) -- one launch less per step.  enc_flags | DURF_FWD_RAW_FULL with a compacted list + tail (a de-duplicated batch,
  * N % 32 == 0): raw is written in the FULL [B*N,4] layout -- row ray_idx[j]*N + n for the compacted rows, and the one
  * evaluation of tail ray tail_idx[i] at all N samples of that ray -- i.e. exactly what durf_expand_raw makes of the compacted
- * raw (bit-identical), which then is not called: one launch less per level. */
+ * raw (bit-identical), which then is not called: one launch less per level.  enc_flags | DURF_FWD_RESERVE_CUS(n): the
+ * persistent grid takes 256 - n workgroups, leaving n CUs to a small launch the caller has queued on another stream (the fp32
+ * evaluation of the box-hit rays of a pose-optimisation step), which otherwise waits for the tail of this one. */
 int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
                      const float* radii, const int32_t* hit /* nullable */, int K, int enc_flags, void* enc_tile,
                      const void* view_bf16, const int32_t* ray_idx /* nullable */, const int32_t* count /* nullable */,
