@@ -86,10 +86,15 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     # with >= 2 levels the forward's fused per-ray launches also compute the loss normalisers (durf_loss_prep's job)
     prep = dict(lossmult=lossmult, gt_depth=gt_depth, sky=sky, eps=float(eps), box_loss_mult=float(config.box_loss_mult),
                 disable_multiscale=config.disable_multiscale_loss, norms=norms) if L >= 2 else None
-    grad = torch.empty_like(variables.flat)         # zero filled by the forward's first launch (durf_ray_prologue)
+    # zero filled by the forward's first launch (durf_ray_prologue): the gradient and, behind it, the pose sums of a
+    # pose-optimisation step (one buffer: no fill launch of their own)
+    n_par = variables.flat.numel()
+    n_sums = 21 * max(int(variables.layout.K), 1) if (pose_opt and variables.layout.K) else 0
+    zbuf = torch.empty(n_par + n_sums, device=variables.flat.device)
+    grad = zbuf[:n_par]
     ret, ctx = model._forward(variables, rng, rays, batch['init'], batch['ext'], batch['ts'],
                               config.randomized, config.rand_bkgd, config.white_bkgd, alpha, train=True,
-                              noise=noise, loss_prep=prep, zero_fill=grad)
+                              noise=noise, loss_prep=prep, zero_fill=zbuf)
     B, N, K = ctx['B'], ctx['N'], ctx['K']
     lay = variables.layout
     rows = B * N
@@ -122,7 +127,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     terms = [None] * L
     radii = rays.radii.reshape(-1).contiguous()
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
-    pose_sums = torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None
+    pose_sums = zbuf[n_par:].view(-1, 21) if n_sums else (torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None)
 
     def level_loss(lvl):
         lv = ctx['levels'][lvl]
@@ -271,12 +276,15 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         else:
             grad[:first_only] += wd_c * flat[:first_only]
     if K > 0 and pose_opt:                      # no_pose_opt and no_yaw_opt: box_centers get no gradient (:100-104)
-        g6 = torch.zeros(K, 6, device=dev)
-        if pose_opt:
-            ops.pose_finish(pose_ts, pose_sums, not model.no_pose_opt, not model.no_yaw_opt, g6)
+        # (k_pose_finish ADDS: straight into this timestep's rows of the zero-filled gradient when they are a view)
+        g_ts = grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)
+        direct = not torch.is_tensor(ctx['ts'])          # an integer timestep: the rows are a view
+        g6 = g_ts[ctx['ts']] if direct else torch.zeros(K, 6, device=dev)
+        ops.pose_finish(pose_ts, pose_sums, not model.no_pose_opt, not model.no_yaw_opt, g6)
         if not model.no_pose_opt and config.tv_loss_mult != 0:               # :136,:219
             g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
-        grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)[ctx['ts']] += g6
+        if not direct:
+            g_ts[ctx['ts']] += g6
     pose = ret[0][7][0]
     poison(upto=first_only)
     if dd is not None:
