@@ -318,25 +318,13 @@ constexpr int LDS_BYTES = OFF_G + NT * 2 * 1024;
 }  // namespace msb
 
 __global__ void __launch_bounds__(256)
-k_mlp_bwd_ms(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
-             const int32_t* __restrict__ count, const char* __restrict__ wpack, const uint4* __restrict__ relu_mask,
-             bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out, BwdStrides bs) {
+k_mlp_bwd_ms(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx_g,
+             const int32_t* __restrict__ count_g, const char* __restrict__ wpack_g, const uint4* __restrict__ relu_mask_g,
+             bf16x8* __restrict__ dz_g, bf16x8* __restrict__ dz_out_g, BwdStrides bs, int nobj) {
     using S = msb::S;
     using BS = msb::B_;
     constexpr int NT = msb::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    {
-        const size_t k = blockIdx.x;       // object FASTEST in the grid: the workgroups that find no pair (the hit count
-                                            // lives on the device) are dispatched after every working one, not in front of the next object's
-        ray_idx += k * bs.idx;
-        count += k;
-        wpack += k * bs.wpack;
-        relu_mask = (const uint4*)((const char*)relu_mask + k * bs.mask);
-        dz = (bf16x8*)((char*)dz + k * bs.dz);
-        dz_out = (bf16x8*)((char*)dz_out + k * bs.dz_out);
-    }
-    const size_t c = (size_t)(*count) * (size_t)N;
-    const size_t nrows = c < rows ? c : rows;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31;
@@ -344,8 +332,29 @@ k_mlp_bwd_ms(size_t rows, int N, const float* __restrict__ draw, const int32_t* 
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     char* const X0 = smem + msb::OFF_X;
     char* const G = smem + msb::OFF_G;
+    // (object, pair) items dealt to a 1-D grid by the device-side hit counts: see k_mlp_fwd_ms
+    auto pairs_of = [&](int k) -> size_t {
+        const size_t c = (size_t)count_g[k] * (size_t)N;
+        return ((c < rows ? c : rows) + 32 * NT - 1) / (32 * NT);
+    };
+    size_t total = 0;
+    for (int k = 0; k < nobj; k++) total += pairs_of(k);
 
-    for (size_t pair = blockIdx.y; pair * (32 * NT) < nrows; pair += gridDim.y) {
+    for (size_t item = blockIdx.x; item < total; item += gridDim.x) {
+        size_t k = 0, pair = item;
+        for (;; k++) {
+            const size_t np = pairs_of((int)k);
+            if (pair < np) break;
+            pair -= np;
+        }
+        k = (size_t)__builtin_amdgcn_readfirstlane((unsigned)k);
+        const int32_t* __restrict__ ray_idx = ray_idx_g + k * bs.idx;
+        const char* __restrict__ wpack = wpack_g + k * bs.wpack;
+        const uint4* __restrict__ relu_mask = (const uint4*)((const char*)relu_mask_g + k * bs.mask);
+        bf16x8* __restrict__ dz = (bf16x8*)((char*)dz_g + k * bs.dz);
+        bf16x8* __restrict__ dz_out = (bf16x8*)((char*)dz_out_g + k * bs.dz_out);
+        const size_t c = (size_t)count_g[k] * (size_t)N;
+        const size_t nrows = c < rows ? c : rows;
         const size_t t32[NT] = {pair * NT, pair * NT + 1};
         const bool tv[NT] = {true, t32[1] * 32 < nrows};
         ms_barrier();
@@ -1228,9 +1237,9 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
     // the object MLPs (W = 128 on compacted ray lists, no d(enc)): the M-split kernel (k_mlp_bwd_ms; DURF_OBJ_MSPLIT=0: A/B switch)
     {
         if (width == 128 && ray_idx && count && !d_enc && !tail_idx && obj_msplit(rows)) {
-            const unsigned pairs = durf_cdiv(rows, 64);          // (small batches only, <= 128 workgroups per object: launch_mlp_fwd)
-            hipLaunchKernelGGL(k_mlp_bwd_ms, dim3(K, pairs < 128u ? pairs : 128u), dim3(256), msb::LDS_BYTES, s, rows, N, draw, ray_idx,
-                               count, (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out, st);
+            const size_t items = (size_t)K * durf_cdiv(rows, 64);       // (small batches only; one round of workgroups: launch_mlp_fwd)
+            hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, s, rows, N, draw, ray_idx,
+                               count, (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out, st, K);
             DURF_CHECK_LAUNCH("durf_mlp_bwd (M-split)");
             return 0;
         }

@@ -526,28 +526,13 @@ constexpr int LDS_BYTES = OFF_M + 2 * NT * 4 * 64 * 4;
 
 template <bool TRAIN>
 __global__ void __launch_bounds__(256)      // one wave per SIMD: the register file is this workgroup's (latency, not occupancy)
-k_mlp_fwd_ms(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
-             const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count, const char* __restrict__ wpack,
-             float* __restrict__ raw, bf16x8* __restrict__ stash, uint4* __restrict__ relu_mask, FwdStrides bs, EncIn ei) {
+k_mlp_fwd_ms(size_t rows, int N, const bf16x8* __restrict__ enc_g, const bf16x8* __restrict__ view,
+             const int32_t* __restrict__ ray_idx_g, const int32_t* __restrict__ count_g, const char* __restrict__ wpack_g,
+             float* __restrict__ raw_g, bf16x8* __restrict__ stash_g, uint4* __restrict__ relu_mask_g, FwdStrides bs, EncIn ei_g,
+             int nobj) {
     using S = ms::S;
     constexpr int NT = ms::NT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    {
-        const size_t k = blockIdx.x;       // object FASTEST in the grid: the workgroups that find no pair (the hit count
-                                            // lives on the device) are dispatched after every working one, not in front of the next object's                   // object slab (0 for a single MLP)
-        enc = (const bf16x8*)((const char*)enc + k * bs.enc);
-        ray_idx += k * bs.idx;
-        count += k;
-        wpack += k * bs.wpack;
-        raw = (float*)((char*)raw + k * bs.raw);
-        if (ei.view_tile) ei.view_tile = (char*)ei.view_tile + k * ei.view_stride;
-        if (TRAIN) {
-            stash = (bf16x8*)((char*)stash + k * bs.stash);
-            relu_mask = (uint4*)((char*)relu_mask + k * bs.mask);
-        }
-    }
-    const size_t c = (size_t)(*count) * (size_t)N;
-    const size_t nrows = c < rows ? c : rows;          // a multiple of 32 (N % 32 == 0)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = lane & 31, hi = lane >> 5;
@@ -557,8 +542,37 @@ k_mlp_fwd_ms(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* _
     char* const E = smem + ms::OFF_E;
     char* const V = smem + ms::OFF_V;
     unsigned* const M = (unsigned*)(smem + ms::OFF_M);
+    // The work items are (object, pair of 32-sample tiles); the hit counts live on the device.  A 1-D grid deals them in
+    // order -- object 0's pairs, object 1's, ... -- so the workgroups that find work are exactly the first sum(pairs) of the
+    // grid.  (With a (object, pair) grid the first 256 workgroups dispatched covered only pairs < 256 / K of every object: at
+    // K = 8 an object with more than 32 pairs waited for a second round of CUs although fewer than 256 workgroups had work --
+    // 47 us a launch for 26 us of work.)
+    auto pairs_of = [&](int k) -> size_t {
+        const size_t c = (size_t)count_g[k] * (size_t)N;
+        return ((c < rows ? c : rows) + 32 * NT - 1) / (32 * NT);
+    };
+    size_t total = 0;
+    for (int k = 0; k < nobj; k++) total += pairs_of(k);
 
-    for (size_t pair = blockIdx.y; pair * (32 * NT) < nrows; pair += gridDim.y) {
+    for (size_t item = blockIdx.x; item < total; item += gridDim.x) {
+        size_t k = 0, pair = item;
+        for (;; k++) {
+            const size_t np = pairs_of((int)k);
+            if (pair < np) break;
+            pair -= np;
+        }
+        k = (size_t)__builtin_amdgcn_readfirstlane((unsigned)k);
+        // this object's slabs (0 strides for a single MLP)
+        const bf16x8* __restrict__ enc = (const bf16x8*)((const char*)enc_g + k * bs.enc);
+        const int32_t* __restrict__ ray_idx = ray_idx_g + k * bs.idx;
+        const char* __restrict__ wpack = wpack_g + k * bs.wpack;
+        float* __restrict__ raw = (float*)((char*)raw_g + k * bs.raw);
+        EncIn ei = ei_g;
+        if (ei.view_tile) ei.view_tile = (char*)ei.view_tile + k * ei.view_stride;
+        bf16x8* __restrict__ stash = TRAIN ? (bf16x8*)((char*)stash_g + k * bs.stash) : nullptr;
+        uint4* __restrict__ relu_mask = TRAIN ? (uint4*)((char*)relu_mask_g + k * bs.mask) : nullptr;
+        const size_t c = (size_t)count_g[k] * (size_t)N;
+        const size_t nrows = c < rows ? c : rows;          // a multiple of 32 (N % 32 == 0)
         const size_t t32[NT] = {pair * NT, pair * NT + 1};
         const bool tv[NT] = {true, t32[1] * 32 < nrows};
         ms_barrier();                               // the previous pair is done with the LDS
@@ -923,14 +937,14 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
     // over every CU only delays those (measured at cfg3: 4.26 -> 4.42 ms per step).  At most 128 workgroups per object walk the
     // 64-sample pairs: the hit count lives on the device and an early-exit workgroup still costs its dispatch.
     if (width == 128 && ray_idx && count && obj_msplit(rows)) {
-        const unsigned pairs = durf_cdiv(rows, 64);
-        dim3 g(K, pairs < 128u ? pairs : 128u), b(256);
+        const size_t items = (size_t)K * durf_cdiv(rows, 64);           // capacity; the counts decide (see the kernel)
+        dim3 g((unsigned)(items < 256 ? items : 256)), b(256);         // one workgroup per CU at most: one round
         if (stash)
             hipLaunchKernelGGL((k_mlp_fwd_ms<true>), g, b, ms::LDS_BYTES, s, rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16,
-                               ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei);
+                               ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei, K);
         else
             hipLaunchKernelGGL((k_mlp_fwd_ms<false>), g, b, ms::LDS_BYTES, s, rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16,
-                               ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei);
+                               ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei, K);
         DURF_CHECK_LAUNCH("durf_mlp_fwd (M-split)");
         return 0;
     }
