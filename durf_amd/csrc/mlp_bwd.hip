@@ -889,24 +889,29 @@ k_dw_finalize(FinArgs A) {
     durf_layer_shape(W, in_dim, job.layer, &fi, &fo);
     const int nfrag = job.MO * job.NI * 1024;
     const int nb = job.MO * 32;
-    // One thread per element, all of its partials with 16 independent loads in flight, summed in split order
-    // (deterministic).  A block covers 256 consecutive elements: with 64 per block and the partials dealt to 4 waves the
-    // launch was bound by the dispatch of its ~30 000 tiny blocks whenever a job has few partials (small batches, objects).
-    const int idx = xblk * 256 + (int)threadIdx.x;
-    if (idx >= nfrag + nb) return;
-    float s = 0.0f;
+    // One thread per FOUR consecutive elements (one float4 per partial), 8 partials in flight, each element summed in split
+    // order (deterministic, the same sums as one element per thread).  A block covers 1024 elements: the launch is bound by
+    // the dispatch of its blocks whenever a job has few partials (small batches, objects -- with 256 elements per block 7500
+    // blocks at K = 8, 32 us; with 64 per block and the partials dealt to 4 waves, round 2, ~30 000).
+    const int idx0 = (xblk * 256 + (int)threadIdx.x) * 4;
+    if (idx0 >= nfrag + nb) return;
+    f32x4 s4 = {0.0f, 0.0f, 0.0f, 0.0f};
     {
-        const float* p0 = idx < nfrag ? part + idx : bpart + (idx - nfrag);
-        const size_t stride = idx < nfrag ? (size_t)nfrag : (size_t)nb;
-        for (int p = 0; p < nparts; p += 16) {
-            float v[16];
+        const float* p0 = idx0 < nfrag ? part + idx0 : bpart + (idx0 - nfrag);
+        const size_t stride = idx0 < nfrag ? (size_t)nfrag : (size_t)nb;
+        for (int p = 0; p < nparts; p += 8) {
+            f32x4 v[8];
 #pragma unroll
-            for (int u = 0; u < 16; u++) v[u] = (p + u < nparts) ? p0[(size_t)(p + u) * stride] : 0.0f;
+            for (int u = 0; u < 8; u++) v[u] = (p + u < nparts) ? *(const f32x4*)(p0 + (size_t)(p + u) * stride) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-            for (int u = 0; u < 16; u++)
-                if (p + u < nparts) s += v[u];
+            for (int u = 0; u < 8; u++)
+                if (p + u < nparts) { s4[0] += v[u][0]; s4[1] += v[u][1]; s4[2] += v[u][2]; s4[3] += v[u][3]; }
         }
     }
+#pragma unroll
+  for (int e4 = 0; e4 < 4; e4++) {
+    const int idx = idx0 + e4;
+    const float s = s4[e4];
     if (idx < nfrag) {
         const int r = idx & 15, lane = (idx >> 4) & 63, t = idx >> 10;
         const int ni = t % job.NI, mo = t / job.NI;
@@ -939,6 +944,7 @@ k_dw_finalize(FinArgs A) {
             if (job.layer == 10) const_cast<float*>(bpart)[idx - nfrag] = s;     // db10, kept for k_bottleneck_grads
         }
     }
+  }
 }
 
 // The bottleneck Dense_9 is LINEAR (obbpose_model.py:339: no activation between it and the view layer), so neither its
@@ -1402,7 +1408,7 @@ static int launch_fin(void* stream, FinArgs& A, int max_el, int max_tiles) {
         for (int j = 0; j < 12; j++) {
             A.job_blk[c][j] = b;
             if (A.m[c].count > 0 && A.m[c].jobs.nparts[j] > 0)          // (the bottleneck layer has no job of its own)
-                b += durf_cdiv(A.m[c].jobs.j[j].MO * A.m[c].jobs.j[j].NI * 1024 + A.m[c].jobs.j[j].MO * 32, 256);
+                b += durf_cdiv(A.m[c].jobs.j[j].MO * A.m[c].jobs.j[j].NI * 1024 + A.m[c].jobs.j[j].MO * 32, 1024);
         }
         A.job_blk[c][12] = b > 0 ? b : 1;
         total += A.m[c].count * b;
