@@ -199,7 +199,9 @@ def test_the_object_forward_encodes_its_own_tiles_like_the_separate_launches(cud
           'background view tile')
 
 
-@pytest.mark.parametrize('B,K,N', [(512, 3, 64), (300, 1, 32), (256, 8, 32), (1024, 3, 128)])
+# ((1024, 8, 128): ~600 (object, pair) items for the 256 workgroups of the M-split grid -- several items per workgroup, of
+# different objects; (640, 5, 64): a ragged last pair per object)
+@pytest.mark.parametrize('B,K,N', [(512, 3, 64), (300, 1, 32), (256, 8, 32), (1024, 3, 128), (1024, 8, 128), (640, 5, 64)])
 def test_msplit_object_kernels_give_the_sample_split_kernels_results_bit_for_bit(cuda, B, K, N):
     """k_mlp_fwd_ms / k_mlp_bwd_ms (4 waves x 64 samples, one tile per wave; the object launches since round 4) against
     k_mlp_fwd<128> / k_mlp_bwd<128> (DURF_OBJ_MSPLIT=0): same MFMA instruction, operands and k order per output, so a whole
