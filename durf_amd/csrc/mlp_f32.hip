@@ -1012,16 +1012,20 @@ k_bkgd_const_trunk(F32Spec S, const float* __restrict__ P, float* __restrict__ o
 }
 
 #define HITRAYS_PER_WG 4
-__global__ void __launch_bounds__(128)
+// 512 threads: 128 outputs of the view layer x 4 groups that split its 283 inputs (k = g, g + 4, ...: one 128-float row of
+// the kernel per load, coalesced), partial sums joined in a fixed order through LDS.  (Until round 4: 128 threads, each
+// walking all 283 rows -- 36 rounds of 8 dependent-latency loads, 40 us standalone; this form: ~10 us.)
+__global__ void __launch_bounds__(512)
 k_bkgd_hit_rays(F32Spec S, const float* __restrict__ P, const float* __restrict__ trunk, const float* __restrict__ view27,
                 const int32_t* __restrict__ idx, const int32_t* __restrict__ count, float* __restrict__ raw_tail) {
     __shared__ float x10[HITRAYS_PER_WG][288];
     __shared__ float hc[HITRAYS_PER_WG][128];
+    __shared__ float part[3][HITRAYS_PER_WG][128];
     const int n = *count;
     const int j0 = blockIdx.x * HITRAYS_PER_WG;
     if (j0 >= n) return;
-    const int tid = threadIdx.x;
-    for (int i = tid; i < HITRAYS_PER_WG * 283; i += 128) {
+    const int tid = threadIdx.x, o = tid & 127, g = tid >> 7;
+    for (int i = tid; i < HITRAYS_PER_WG * 283; i += 512) {
         const int r = i / 283, f = i - r * 283;
         float v = 0.0f;
         if (j0 + r < n) v = f < 256 ? trunk[f] : view27[(size_t)idx[j0 + r] * 27 + (f - 256)];
@@ -1031,15 +1035,26 @@ k_bkgd_hit_rays(F32Spec S, const float* __restrict__ P, const float* __restrict_
     const float* W10 = P + S.L[10].w_off;
     float acc[HITRAYS_PER_WG];
 #pragma unroll
-    for (int r = 0; r < HITRAYS_PER_WG; r++) acc[r] = W10[283 * 128 + tid];
+    for (int r = 0; r < HITRAYS_PER_WG; r++) acc[r] = 0.0f;
 #pragma unroll 8
-    for (int k = 0; k < 283; k++) {
-        const float w = W10[k * 128 + tid];
+    for (int k = g; k < 283; k += 4) {
+        const float w = W10[k * 128 + o];
 #pragma unroll
         for (int r = 0; r < HITRAYS_PER_WG; r++) acc[r] = fmaf(w, x10[r][k], acc[r]);
     }
+    if (g > 0) {
 #pragma unroll
-    for (int r = 0; r < HITRAYS_PER_WG; r++) { const float v = acc[r]; hc[r][tid] = (v != v) ? v : fmaxf(v, 0.0f); }
+        for (int r = 0; r < HITRAYS_PER_WG; r++) part[g - 1][r][o] = acc[r];
+    }
+    __syncthreads();
+    if (g == 0) {
+        const float b = W10[283 * 128 + o];
+#pragma unroll
+        for (int r = 0; r < HITRAYS_PER_WG; r++) {
+            const float v = (((b + acc[r]) + part[0][r][o]) + part[1][r][o]) + part[2][r][o];
+            hc[r][o] = (v != v) ? v : fmaxf(v, 0.0f);
+        }
+    }
     __syncthreads();
     if (tid < HITRAYS_PER_WG * 4) {
         const int r = tid >> 2, c = tid & 3;
@@ -1220,7 +1235,7 @@ int durf_bkgd_hit_rays_f32(void* stream, int B, const float* view27, const float
     if (B <= 0) return 0;
     const F32Spec S = f32_spec(DURF_W_BKGD, 60);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_bkgd_hit_rays, dim3(durf_cdiv(B, HITRAYS_PER_WG)), dim3(128), 0, s, S, bkgd_params, trunk, view27, idx,
+    hipLaunchKernelGGL(k_bkgd_hit_rays, dim3(durf_cdiv(B, HITRAYS_PER_WG)), dim3(512), 0, s, S, bkgd_params, trunk, view27, idx,
                        count, raw_tail);
     DURF_CHECK_LAUNCH("durf_bkgd_hit_rays_f32");
     return 0;

@@ -292,7 +292,8 @@ class MipNerfModel:
         if cls is not None:
             dd = dict(idx=cls[0], count=cls[1], slot=cls[2], nrows=cls[1][2:3], multi_hit=cls[1][3])
             ctx['dedup'] = dd
-        if obj_f32:
+        hit_rays_late = obj_f32 and ops.HIT_RAYS_AFTER_FORWARD
+        if obj_f32 and not hit_rays_late:
             # ... and the view layer + rgb head per box-hit ray on top of it (same input at both levels: once per step)
             tail_side.wait_stream(torch.cuda.current_stream())           # ray classes, view27
             with torch.cuda.stream(tail_side):
@@ -342,7 +343,7 @@ class MipNerfModel:
                 if dd is not None and ops.FUSED_ENCODE:       # the forward encodes its own tiles (durf_mlp_fwd_enc)
                     side.fork()
                     # (raw straight in the full layout unless the box-hit rays' rows come from the fp32 evaluation, raw_tail)
-                    scatter = raw_tail is None and ops.FWD_SCATTER_RAW
+                    scatter = not obj_f32 and ops.FWD_SCATTER_RAW
                     raw_c, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit, view, packs['MLP_0'][0],
                                                    ray_idx=dd['idx'][0], count=dd['count'][0:1], stash=stash_b,
                                                    relu_mask=mask_b, tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
@@ -361,6 +362,12 @@ class MipNerfModel:
                     if tail_side is not None:                # the fp32 hit-ray evaluation (side stream) must have landed
                         torch.cuda.current_stream().wait_stream(tail_side)
                         tail_side = None
+                    if hit_rays_late and lvl == 0:
+                        # the view layer + rgb head per box-hit ray (same input at both levels: once per step), HERE, on
+                        # the main stream behind the level-0 forward: beside that persistent launch it found no CU until its
+                        # tail and the main stream waited for it (160-180 us instead of 40; ~10 us now that it has the chip)
+                        raw_tail = ops.bkgd_hit_rays_f32(B, view27, variables.mlp_flat('MLP_0'), dd['idx'][1],
+                                                         dd['count'][1:2], trunk=trunk)
                     raw_b = raw_c if scatter else ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'], raw_tail=raw_tail)
                 elif ops.FUSED_ENCODE:
                     side.fork()

@@ -274,6 +274,8 @@ FWD_SCATTER_RAW = os.environ.get('DURF_FWD_SCATTER_RAW', '1') != '0'
 # stream waits for it).  Measured at cfg4 with 16: 636 -> 625 k rays/s (and 629 -> 623 with the 2 x 2 fp32 weight-gradient
 # kernel): the forward loses more than the join gains -- off by default, the knob stays for other shapes.
 FWD_RESERVE_CUS = int(os.environ.get('DURF_FWD_RESERVE_CUS', '0'))
+# DURF_HIT_RAYS_AFTER_FORWARD=0: that launch on the side stream beside the level-0 forward, as up to round 3 (A/B switch)
+HIT_RAYS_AFTER_FORWARD = os.environ.get('DURF_HIT_RAYS_AFTER_FORWARD', '1') != '0'
 
 
 def mlp_fwd_enc(rows, N, t_vals, origins_s, dirs_s, radii, hit, view_bf16, wpack_fwd, contraction=True,

@@ -67,7 +67,12 @@ def test_pose_trajectory_follows_the_oracle(cuda):
         print('%s: oracle moved %s\n      HIP - oracle %s\n      final loss %.4f (oracle %.4f)' % (
             precision, np.array2string(np.round(moved, 4), max_line_width=400), np.array2string(np.round(apart[precision], 4), max_line_width=400),
             loss[-10:].mean(), p['oracle_loss'][-10:].mean()))
-        assert abs(loss[-10:].mean() - p['oracle_loss'][-10:].mean()) < 0.05 * p['oracle_loss'][-10:].mean()
+        # the loss LEVEL at the end: medians over the last 30 steps (the series has single-step spikes of 1.5-4 x -- the oracle's
+        # own last 40 steps hold 0.716, 0.277 and 0.252 among values around 0.19 -- and which step spikes is as chaotic as the
+        # trajectory: a mean over 10 steps is at the mercy of one of them)
+        med, omed = float(np.median(loss[-30:])), float(np.median(p['oracle_loss'][-30:]))
+        print('      median of the last 30 losses %.4f (oracle %.4f)' % (med, omed))
+        assert abs(med - omed) < 0.05 * omed          # measured: f32 0.8 %, bf16 2.0 %
     # early on (steps 10-40, before the optimisation has amplified anything) the exact-fp32 path IS the oracle and the
     # bf16 path is within a fifth of the distance travelled
     assert (apart['f32'][1:5] <= 0.05 * moved[1:5] + 4e-4).all(), (apart['f32'], moved)
