@@ -1306,6 +1306,10 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
     if (total_rows == 0 || K <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     const DwPlan P = dw_plan(width, total_rows);
+    {   // the caller sized the partial buffers with durf_dw_part_floats / durf_dw_bpart_floats = the largest plan
+        const DwPlan big = dw_plan(width);
+        DURF_REQUIRE(P.part_total <= big.part_total && P.bpart_total <= big.bpart_total, "split plan exceeds the partial buffers");
+    }
     const int KW = width / 16;
     auto region = [&](const void* base, int j, int l) { return (const char*)base + ((size_t)j * KW * (lv.rows[l] >> 5)) * 1024; };
     DwArgs a;
