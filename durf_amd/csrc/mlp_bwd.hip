@@ -972,8 +972,10 @@ __device__ __forceinline__ size_t frag_index(int W, int i, int j, int NI) {
 //   (tiles [0, W/32) also:  db9[o]   = sum_j db10[j] K10[o, j])
 __global__ void __launch_bounds__(256)
 k_bottleneck_grads(FinArgs A) {
-    __shared__ float sa[32][257];        // rows of the first operand, K (<= 256) values each
-    __shared__ float sb[32][257];        // rows of the second operand
+    // (row stride 260 floats: 16-byte aligned rows, so the products read four k values per LDS instruction -- the launch's
+    // compute phase was 5 ds_read_b32 per multiply-add group, ~1300 LDS instructions per wave at K = 256)
+    __shared__ __attribute__((aligned(16))) float sa[32][260];        // rows of the first operand, K (<= 256) values each
+    __shared__ __attribute__((aligned(16))) float sb[32][260];        // rows of the second operand
     __shared__ float sdb[128];           // db10 (first row of tiles: db9)
     const int cls = (int)blockIdx.y < A.m[0].count ? 0 : 1;       // blockIdx.y: MLP, classes as in k_dw_finalize
     const FinMlp& M = A.m[cls];
@@ -993,19 +995,19 @@ k_bottleneck_grads(FinArgs A) {
     const int tx = tid & 31, ty = tid >> 5;          // output (row = ty + 8 q, col = tx), q = 0..3
     if (t < nA) {
         const int i0 = (t / wt) * 32, o0 = (t % wt) * 32;
-        // (operand gathers: 8 independent loads per thread in flight -- one at a time the tile was a chain of L2 round trips)
-#pragma unroll 1
-        for (int e0 = tid; e0 < 32 * 128; e0 += 8 * 256) {
-            float va[8], vb[8];
+        // (operand gathers: ALL of a thread's 16 + 16 loads in flight at once -- P was summed a moment ago on other XCDs, every
+        // round of loads is a trip past this XCD's L2; one at a time the tile was a chain of them, 8 + 8 at a time two)
+        {
+            float va[16], vb[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int e = e0 + 256 * u, r = e >> 7, j = e & 127;
+            for (int u = 0; u < 16; u++) {
+                const int e = tid + 256 * u, r = e >> 7, j = e & 127;
                 va[u] = part10[frag_index(W, i0 + r, j, NI)];
                 vb[u] = K10[(size_t)(o0 + r) * 128 + j];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int e = e0 + 256 * u, r = e >> 7, j = e & 127;
+            for (int u = 0; u < 16; u++) {
+                const int e = tid + 256 * u, r = e >> 7, j = e & 127;
                 sa[r][j] = va[u];
                 sb[r][j] = bf16r(vb[u]);
             }
@@ -1013,11 +1015,16 @@ k_bottleneck_grads(FinArgs A) {
         if (i0 == 0 && tid < 128) sdb[tid] = bpart10[cperm_slot(tid)];
         __syncthreads();
         float s4[4] = {0.0f, 0.0f, 0.0f, 0.0f};        // four independent chains, LDS reads batched 8 k-values at a time
-#pragma unroll 8
-        for (int j = 0; j < 128; j++) {
-            const float b = sb[tx][j];
+#pragma unroll 2
+        for (int j = 0; j < 128; j += 4) {
+            const f32x4 b = *(const f32x4*)&sb[tx][j];
+            f32x4 a4[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) s4[q] += sa[ty + 8 * q][j] * b;
+            for (int q = 0; q < 4; q++) a4[q] = *(const f32x4*)&sa[ty + 8 * q][j];
+#pragma unroll
+            for (int e = 0; e < 4; e++)          // (k ascending per chain, as one value at a time)
+#pragma unroll
+                for (int q = 0; q < 4; q++) s4[q] += a4[q][e] * b[e];
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) grad[off9 + (size_t)(i0 + ty + 8 * q) * W + o0 + tx] = s4[q];
@@ -1026,24 +1033,29 @@ k_bottleneck_grads(FinArgs A) {
         // ~20 us on cold weights -- the long pole of the launch.)
         if (i0 == 0 && ty == 0) {
             float s = 0.0f;
-#pragma unroll 8
-            for (int j = 0; j < 128; j++) s += sdb[j] * sb[tx][j];
+#pragma unroll 2
+            for (int j = 0; j < 128; j += 4) {
+                const f32x4 b = *(const f32x4*)&sb[tx][j];
+#pragma unroll
+                for (int e = 0; e < 4; e++) s += sdb[j + e] * b[e];
+            }
             grad[off9 + (size_t)W * W + o0 + tx] = s;
         }
     } else if (t < nA + nC) {
         const int u = t - nA, o0 = (u / 4) * 32, j0 = (u % 4) * 32;
+        const int wsh = W == 256 ? 8 : 7;                           // W is 128 or 256
 #pragma unroll 1
-        for (int e0 = tid; e0 < 32 * W; e0 += 8 * 256) {           // 32 W is a multiple of 2048 for W = 128, 256
-            float va[8], vb[8];
+        for (int e0 = tid; e0 < 32 * W; e0 += 16 * 256) {          // 32 W = 4096 or 8192: one or two rounds of 16 + 16 loads
+            float va[16], vb[16];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int e = e0 + 256 * u, r = e / W, i = e % W;
+            for (int u = 0; u < 16; u++) {
+                const int e = e0 + 256 * u, r = e >> wsh, i = e & (W - 1);
                 va[u] = K9[(size_t)i * W + o0 + r];                    // K9^T rows: output feature o0 + r
                 vb[u] = part10[frag_index(W, i, j0 + r, NI)];          // P^T rows: dz10 feature j0 + r
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
-                const int e = e0 + 256 * u, r = e / W, i = e % W;
+            for (int u = 0; u < 16; u++) {
+                const int e = e0 + 256 * u, r = e >> wsh, i = e & (W - 1);
                 sa[r][i] = bf16r(va[u]);
                 sb[r][i] = vb[u];
             }
@@ -1053,11 +1065,16 @@ k_bottleneck_grads(FinArgs A) {
         const float db = bpart10[cperm_slot(j0 + tx)];
 #pragma unroll
         for (int q = 0; q < 4; q++) s4[q] = b9[o0 + ty + 8 * q] * db;
-#pragma unroll 8
-        for (int i = 0; i < W; i++) {
-            const float b = sb[tx][i];
+#pragma unroll 2
+        for (int i = 0; i < W; i += 4) {
+            const f32x4 b = *(const f32x4*)&sb[tx][i];
+            f32x4 a4[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) s4[q] += sa[ty + 8 * q][i] * b;
+            for (int q = 0; q < 4; q++) a4[q] = *(const f32x4*)&sa[ty + 8 * q][i];
+#pragma unroll
+            for (int e = 0; e < 4; e++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) s4[q] += a4[q][e] * b[e];
         }
 #pragma unroll
         for (int q = 0; q < 4; q++) grad[off10 + (size_t)(o0 + ty + 8 * q) * 128 + j0 + tx] = s4[q];
