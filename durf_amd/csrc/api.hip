@@ -13,5 +13,5 @@ void durf_set_error(const char* fmt, ...) {
 
 extern "C" {
 const char* durf_last_error(void) { return g_err; }
-int durf_version(void) { return 24; }      // bump with every kernel change: bench.py quotes PMC traffic per version
+int durf_version(void) { return 25; }      // bump with every kernel change: bench.py quotes PMC traffic per version
 }

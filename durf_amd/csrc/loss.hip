@@ -284,6 +284,16 @@ k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __res
     __shared__ float s_sum[DURF_MAX_LEVELS * LT_ROWS];
     __shared__ float s_w[14][16];
     const bool reduce_here = (mode & 1) && terms.p[0] != nullptr;
+    // the small inputs of thread 0's assembly below, fetched by many threads at once and under the reduction's loads (thread 0
+    // alone walked them as a chain of dependent round trips)
+    __shared__ float s_norm[DURF_MAX_LEVELS * 5], s_pose[DURF_MAX_OBJ * 6], s_prev[DURF_MAX_OBJ * 6], s_tgt[DURF_MAX_OBJ * 6],
+        s_tv[DURF_MAX_LEVELS * 2];
+    if (mode & 1) {
+        const int t = threadIdx.x;
+        if (t < L * 5) s_norm[t] = norms[t];
+        if (t >= 64 && t < 64 + K * 6) { s_pose[t - 64] = pose6[t - 64]; s_prev[t - 64] = prev6[t - 64]; s_tgt[t - 64] = target6[t - 64]; }
+        if (t >= 128 && t < 128 + 2 * L) s_tv[t - 128] = tv.p[(t - 128) >> 1][((t - 128) & 1) ? N : 0];
+    }
     if (reduce_here) {
         const int nrow = L * LT_ROWS;
         for (int r0 = 0; r0 < nrow; r0 += 14) {
@@ -295,7 +305,21 @@ k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __res
                 p[r] = terms.p[row / LT_ROWS] + (size_t)(row % LT_ROWS) * B;
                 v[r] = 0.0f;
             }
-            for (int i = threadIdx.x; i < B; i += 1024) {
+            // (four strides of the batch per trip: 56 loads in flight, added in the same order -- one stride at a time a
+            // 4096-ray batch was four round trips to memory in sequence)
+            int i = threadIdx.x;
+            for (; i + 3 * 1024 < B; i += 4 * 1024) {
+                float x[4][14];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int r = 0; r < 14; r++) x[u][r] = p[r][i + u * 1024];
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int r = 0; r < 14; r++) v[r] += x[u][r];
+            }
+            for (; i < B; i += 1024) {
 #pragma unroll
                 for (int r = 0; r < 14; r++) v[r] += p[r][i];
             }
@@ -315,9 +339,11 @@ k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __res
             __syncthreads();
         }
     }
+    __syncthreads();
     if (threadIdx.x != 0) return;
     float* rows = out + 1;
     if (mode & 1) {
+        const float* pose6 = s_pose; const float* prev6 = s_prev; const float* target6 = s_tgt; const float* norms = s_norm;
         float sq_prev = 0.f, sq_t = 0.f, sx = 0.f, sy = 0.f, sz = 0.f, syaw = 0.f;
         for (int k = 0; k < K; k++) {
             for (int j = 0; j < 3; j++) {
@@ -346,8 +372,8 @@ k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __res
             loss += (last ? 1.0f : m.coarse) * v[0] + (last ? 10.0f : 1.0f) * m.sky * v[5]
                   + (last ? 1.0f : 0.1f) * (m.depth * v[2] + m.near * v[3] + m.empty * v[4] + m.tv * (K > 0 ? sq_prev : 0.0f))
                   + 0.000001f * v[6];
-            out[1 + 15 * L + 2 * l] = tv.p[l][0];
-            out[1 + 15 * L + 2 * l + 1] = tv.p[l][N];
+            out[1 + 15 * L + 2 * l] = s_tv[2 * l];
+            out[1 + 15 * L + 2 * l + 1] = s_tv[2 * l + 1];
         }
         out[0] = loss;
         out[1 + 17 * L] = wl2;
