@@ -416,7 +416,13 @@ int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, c
                       int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count) {
     DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
     DURF_REQUIRE(zero_buf == nullptr || ((size_t)zero_buf & 15) == 0, "zero_buf aligned to 16 bytes");
-    if (B <= 0) return 0;
+    if (B <= 0) {       // an empty shard still owes its caller the zero-filled gradient (it is all-reduced and fed to clip + Adam)
+        if (zero_buf && zero_count) {
+            DURF_REQUIRE(hipMemsetAsync(zero_buf, 0, zero_count * sizeof(float), (hipStream_t)stream) == hipSuccess,
+                         "zero fill of an empty shard's gradient");
+        }
+        return 0;
+    }
     // the grid covers the largest of the three index spaces (rays, view-encoding features, sample positions)
     const size_t items = std::max((size_t)B * (N + 1), (size_t)B * DURF_VIEW_DIM);
     hipLaunchKernelGGL(k_ray_prologue, dim3(durf_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, B,

@@ -366,6 +366,8 @@ class MipNerfModel:
                         # the view layer + rgb head per box-hit ray (same input at both levels: once per step), HERE, on
                         # the main stream behind the level-0 forward: beside that persistent launch it found no CU until its
                         # tail and the main stream waited for it (160-180 us instead of 40; ~10 us now that it has the chip)
+                        if trunk is not None:
+                            trunk.record_stream(torch.cuda.current_stream())      # (produced on the side stream's pool)
                         raw_tail = ops.bkgd_hit_rays_f32(B, view27, variables.mlp_flat('MLP_0'), dd['idx'][1],
                                                          dd['count'][1:2], trunk=trunk)
                     raw_b = raw_c if scatter else ops.expand_raw(B, N, raw_c, dd['slot'], dd['count'], raw_tail=raw_tail)

@@ -1065,7 +1065,9 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
     a.adam_m, a.adam_v = _p(_f32(m)), _p(_f32(v))
     a.lr, a.max_val, a.max_norm, a.step = float(lr), float(max_val), float(max_norm), int(step)
     pose_opt = bool(K) and (want_pos or want_rot)
-    a.flags = (TRAIN_OBJ_FP32 if (K and (obj_fp32 or pose_opt)) else 0) | (TRAIN_POSE_OPT if pose_opt else 0)
+    if pose_opt and not obj_fp32:
+        raise NotImplementedError('durf_train_step: DURF_TRAIN_POSE_OPT needs DURF_TRAIN_OBJ_FP32 (csrc/train.hip)')
+    a.flags = (TRAIN_OBJ_FP32 if (K and obj_fp32) else 0) | (TRAIN_POSE_OPT if pose_opt else 0)
     a.want_pos, a.want_rot, a.tv_loss_mult = int(bool(want_pos)), int(bool(want_rot)), float(tv_loss_mult)
     ws = torch.empty(int(L.durf_train_workspace_bytes_flags(B, N, K, num_levels, params_flat.numel(), a.flags)), dtype=torch.uint8,
                      device=dev)

@@ -10,6 +10,7 @@ weights/samples tensors, which nothing downstream needs).
 """
 import dataclasses
 import math
+import struct
 from typing import Any
 
 import torch
@@ -246,6 +247,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         o0, sz = (lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]) if Kb else (0, 0)
         merged = Kb and not ops.overlap_dw(rows) and ops.MERGE_FINALIZE and objects_ready is None
         if Kb and objects_ready is not None:           # bucketed all-reduce: the objects' gradients first, finalized on their own
+            obj_side.join()                            # (the object backward may still be writing dz on the side stream)
             ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
                              grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
             hand_over_objects(o0, K * sz)
@@ -282,7 +284,10 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         g6 = g_ts[ctx['ts']] if direct else torch.zeros(K, 6, device=dev)
         ops.pose_finish(pose_ts, pose_sums, not model.no_pose_opt, not model.no_yaw_opt, g6)
         if not model.no_pose_opt and config.tv_loss_mult != 0:               # :136,:219
-            g6[:, :3] += (config.tv_loss_mult * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
+            # (the multiplier enters as the fp32 value the C entry point's `float tv_loss_mult` field carries, widened for
+            # the product and rounded once: csrc/train.hip computes the same constant, bit for bit, for any multiplier)
+            tv_f32 = struct.unpack('f', struct.pack('f', config.tv_loss_mult))[0]
+            g6[:, :3] += (tv_f32 * (1.0 + 0.1 * (L - 1)) * 2.0) * (pose_ts[:, :3] - prev[0, :, :3])
         if not direct:
             g_ts[ctx['ts']] += g6
     pose = ret[0][7][0]
@@ -382,6 +387,11 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
                                   'density noise / weight decay / random background (see csrc/train.hip)')
     pose_opt = bool(K) and not (model.no_pose_opt and model.no_yaw_opt)
     obj_fp32 = bool(K) and model.object_precision() == 'f32'
+    if pose_opt and not obj_fp32:
+        # (train_step runs this combination -- obj_precision='bf16' forced under pose optimisation -- on the bf16 object
+        # kernels; the C entry point only has the fp32 hit-ray branch behind the pose gradient)
+        raise NotImplementedError("durf_train_step optimises box poses with the hit rays in fp32 only "
+                                  "(MipNerfModel.obj_precision = 'auto' or 'f32')")
     rays = batch['rays']
     B = rays.origins.shape[0]
     dev = variables.flat.device

@@ -161,9 +161,11 @@ def test_train_step_through_rccl_world_size_one(cuda, tmp_path, pose_opt):
         assert got['losses'] == base['losses'], tag
 
 
-def _bucket_worker(rank, world, port, out_dir, bucket, weight_decay=0.0, multi_hit=False):
+def _bucket_worker(rank, world, port, out_dir, bucket, weight_decay=0.0, multi_hit=False, side_streams=False):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank), DURF_DIST_BACKEND='gloo', DURF_BUCKET_ALLREDUCE='1' if bucket else '0')
+    if side_streams:        # the object backward on the side stream (what batches >= 2048 rays do by themselves): the
+        os.environ['DURF_OVERLAP_OBJECTS'] = '2'       # objects' weight-gradient launch has to join it first
     sys.path.insert(0, ROOT)
     import bench
     from durf_amd import train_boxpose
@@ -191,18 +193,20 @@ def _bucket_worker(rank, world, port, out_dir, bucket, weight_decay=0.0, multi_h
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('weight_decay,multi_hit', [(0.0, False), (1e-2, False), (1e-2, True)])
-def test_bucketed_allreduce_gives_the_same_parameters(cuda, tmp_path, weight_decay, multi_hit):
+@pytest.mark.parametrize('weight_decay,multi_hit,side_streams',
+                         [(0.0, False, False), (1e-2, False, False), (1e-2, True, False), (1e-2, True, True)])
+def test_bucketed_allreduce_gives_the_same_parameters(cuda, tmp_path, weight_decay, multi_hit, side_streams):
     """two ranks (gloo): objects' gradient slice all-reduced ahead of [box_centers | MLP_0] == one all-reduce of the
     flat buffer, bit for bit (same element-wise sums, same kernels) -- also with weight decay (the slice must carry its
     own term before it leaves, and nothing may write it afterwards) and with rays that hit two boxes (the poisoned
-    segments)"""
+    segments), and with the object launches on the side stream (round-4 advice: the bucketed branch issued the objects'
+    weight gradients on the main stream without joining the side stream's object backward)"""
     for bucket in (0, 1):
         s = socket.socket()
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
         s.close()
-        mp.spawn(_bucket_worker, args=(2, port, str(tmp_path), bucket, weight_decay, multi_hit), nprocs=2, join=True)
+        mp.spawn(_bucket_worker, args=(2, port, str(tmp_path), bucket, weight_decay, multi_hit, side_streams), nprocs=2, join=True)
     a = torch.load(os.path.join(str(tmp_path), 'bucket_0.pt'))
     b = torch.load(os.path.join(str(tmp_path), 'bucket_1.pt'))
     assert torch.equal(a['flat'], b['flat'])
