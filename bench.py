@@ -74,6 +74,8 @@ def parse_args():
     ap.add_argument('--max-ahead', type=int, default=0, help='bound the number of steps the host may enqueue ahead of the GPU (0 = unbounded)')
     ap.add_argument('--no-calibration', action='store_true', help='skip the vendor-GEMM board calibration line')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-workloads', action='store_true',
+                    help='skip the short passes over the other BASELINE.json configurations (`workloads` in the JSON line)')
     ap.add_argument('--profile-ops', action='store_true', help='print the per-op time table to stderr')
     ap.add_argument('--main-priority', type=int, default=0,
                     help='experiment: run the step loop on a stream of this priority (-1 = high), so that side-stream work '
@@ -215,22 +217,6 @@ def cpu_baseline(batch_np, K_OBJ, n_samples, config, seconds_budget=15.0):
                                                                                         cfg['randomized'], dt))
 
 
-def pmc_traffic(lib_version, workload, rays, kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC passes (not measurable live).  Only
-    quoted when the passes were collected on THIS library version, workload and shard size."""
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
-        try:
-            with open(path) as f:
-                tr = json.load(f)
-        except (OSError, ValueError):
-            continue
-        if (tr.get('lib_version') == lib_version and tr.get('workload') == workload and
-                tr.get('rays_per_gpu') == rays and kernel in tr):
-            return tr[kernel]['total_bytes'], '%s: %s' % (os.path.basename(path), tr.get('source', ''))
-    return None, None
-
-
 def selftest_launch(args):
     """CPU/gloo: rendezvous, contiguous shard of the global synthetic batch, one all-reduce of a flat
     fp32 buffer the size of the gradient, barrier, max-over-ranks timing -- the plumbing of the real
@@ -369,34 +355,42 @@ def flush_c_stdio():
         pass
 
 
-def main():
-    args = parse_args()
-    if args.mode == 'eval':
-        raise SystemExit(eval_main(args))
-    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
-        raise SystemExit(spawn_ranks(args.gpus))        # parent: spawns and waits; no GPU call in this process
-    if args.selftest_launch:
-        raise SystemExit(selftest_launch(args))
+# algorithmic HBM bytes per sample of the three background-MLP launches (what each kernel has to write / read
+# once -- bf16 stash of 8 ReLU layers + view layer + masks + encoding tile; dz of the same layers; both operands of 10 GEMMs)
+BYTES_FWD, BYTES_BWD, BYTES_DW = 4640 + 128, 4384, 9088
+# MACs per sample the weight-gradient LAUNCH executes: Dense_9 and the bottleneck rows of Dense_10 come from k_bottleneck_grads
+MAC_DW_LAUNCH = MAC_BKGD - 256 * 256 - 256 * 128
+HBM_ACHIEVABLE = 6.29e12     # float4 copy, MI355X_MICROARCH.md
 
-    if args.force_dist:
-        os.environ['DURF_FORCE_DIST'] = '1'
+
+def pmc_entry(lib_version, workload, rays, kernel):
+    """{total_bytes, mfma_busy_cycles, source} of `kernel` from the committed PMC passes of THIS library version / workload /
+    shard size (profiles/r*_pmc_traffic.json, tools/make_pmc_traffic.py), or None"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic.json')), reverse=True):
+        try:
+            with open(path) as f:
+                tr = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if (tr.get('lib_version') == lib_version and tr.get('workload') == workload and
+                tr.get('rays_per_gpu') == rays and kernel in tr):
+            return dict(tr[kernel], source='%s: %s' % (os.path.basename(path), tr.get('source', '')))
+    return None
+
+
+def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-1, precision='bf16', light=False):
+    """Warm-up + timed region of one training workload on this rank; rank 0 returns the result dict (the JSON line's keys),
+    the other ranks None.  light: one of the extra `workloads` passes -- no CPU baseline, board calibration or single-stream
+    pass."""
     import torch
     import torch.distributed as dist
-    from durf_amd import _lib, obbpose_model, ops, synthetic, train_boxpose, utils
+    from durf_amd import _lib, ops, train_boxpose
 
-    rank, world, local = train_boxpose.init_distributed()
-    flush_c_stdio()       # RCCL's version banner (every rank, C stdio, otherwise flushed at exit -- after rank 0's JSON line)
-    if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     shared_gpu = os.environ.get('DURF_DIST_BACKEND') == 'gloo'      # tests: several gloo ranks on one device
-    if world > torch.cuda.device_count() and not shared_gpu:
-        raise SystemExit('--gpus %d but only %d visible' % (world, torch.cuda.device_count()))
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
-
-    w = setup_workload(args.config, dev, rank, world, rays=args.rays, objects=args.objects, precision=args.precision)
+    w = setup_workload(cfg_name, dev, rank, world, rays=rays, objects=objects, precision=precision)
     config, model, state, batch, batch_np, prev = (w[k] for k in ('config', 'model', 'state', 'batch', 'batch_np', 'prev'))
-    f32 = args.precision == 'f32'
+    f32 = precision == 'f32'
     # the three background-MLP launches of a level by timer name, and the MFMA peak they are priced against
     k_fwd, k_bwd, k_dw = ('mlp_fwd_f32_256', 'mlp_bwd_f32_256', 'mlp_dw_f32_256') if f32 else \
         ('mlp_fwd_256_train', 'mlp_bwd_256', 'mlp_dw_256')
@@ -414,28 +408,21 @@ def main():
         return train_boxpose.train_step(model, config, rng, state, batch, lr, eps, alpha, prev,
                                         reduce_stats=(i % config.print_every == 0))
 
-    if args.main_priority != 0:
-        main_stream = torch.cuda.Stream(device=dev, priority=args.main_priority)
-        main_stream.wait_stream(torch.cuda.current_stream())
-        torch.cuda.set_stream(main_stream)
     rng = 1000 * rank                                  # stratified-sampling noise differs per rank
     # The warm-up runs exactly what the timed region runs, the live HIP-event timers included, after --prewarm-events
-    # timing events have been recorded and parked: when the number of live timing events of a process first passes
+    # timing events have been recorded and parked (main): when the number of live timing events of a process first passes
     # ~100, the HIP runtime stalls the stream ONCE for ~40 ms (it grows a pool; tools/experiments/stall_probe.py: no stall without
-    # timing events, none after this pre-warm even with --warmup 2).  With the timers switched on at the first timed step
-    # and 5 warm-up steps, that stall used to sit in the timed region and cost every earlier figure of this repo 4-5 %.
-    # `step_ms` in the JSON line (p50 / p90 / max / slow_steps) shows any such outlier.
-    ops.TIMED_NAMES = None if args.profile_ops else {k_fwd, k_bwd, k_dw, 'encode_bkgd', 'composite_resample'}
+    # timing events, none after this pre-warm even with --warmup 2).  `step_ms` in the JSON line (p50 / p90 / max /
+    # slow_steps) shows any such outlier.
+    profile_ops = args.profile_ops and not light
+    ops.TIMED_NAMES = None if profile_ops else {k_fwd, k_bwd, k_dw, 'encode_bkgd', 'composite_resample'}
     ops.TIMERS = {}
-    prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]    # kept alive to the end
-    for e in prewarm:
-        e.record()
     # Only every `every`-th step carries the event records (--time-every; default min(8, steps / 5)): a record makes the
     # stream wait for the marker's signal on either side of the launch it brackets -- 3-6 us each, 50-70 us per step with the
     # seven timed launches, 1.5 % of a 4096-ray step and 9 % of a 512-ray step (profiles/r04_event_overhead.txt).  The
     # averages are over the sampled launches, all inside the timed region.
-    every = 1 if args.profile_ops else (args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 5)))
-    for i in range(args.warmup):
+    every = 1 if profile_ops else (args.time_every if args.time_every > 0 else max(1, min(8, steps // 5)))
+    for i in range(warmup):
         ops.TIMERS_ACTIVE = i % every == 0
         state, stats, rng, _ = step(state, rng, i)
     sync()
@@ -445,16 +432,16 @@ def main():
     ops.TIMERS = {}                                    # drop the warm-up's records
     # GPU timestamps (diagnostic: `step_ms`) after every `group`-th step -- a record between two steps costs the stream
     # 5-11 us like any other (0.3 % of a 4096-ray step, 1.5 % of a 512-ray one), so the outlier check works on groups of steps
-    group = 1 if (args.max_ahead > 0 or args.steps < 16) else 4
+    group = 1 if (args.max_ahead > 0 or steps < 16) else 4
     marks = {0: torch.cuda.Event(enable_timing=True)}
     t0 = time.perf_counter()
     marks[0].record()
     sampled = 0
-    for i in range(args.steps):
+    for i in range(steps):
         ops.TIMERS_ACTIVE = i % every == 0
         sampled += int(ops.TIMERS_ACTIVE)
         state, stats, rng, _ = step(state, rng, i + 1)
-        if (i + 1) % group == 0 or i + 1 == args.steps:
+        if (i + 1) % group == 0 or i + 1 == steps:
             marks[i + 1] = torch.cuda.Event(enable_timing=True)
             marks[i + 1].record()
         if args.max_ahead > 0 and i + 1 > args.max_ahead:
@@ -475,95 +462,201 @@ def main():
     # run, and their live durations say so.  A short extra pass on ONE stream (outside the timed region; every rank takes
     # part, the step holds the collective) gives the same kernels' undisturbed durations: `roofline.single_stream`.
     totals_ss = None
-    if K_OBJ and model.object_precision() == 'bf16' and ops.overlap_mode(B * NS) != '0' and not args.profile_ops:
+    if (not light and K_OBJ and model.object_precision() == 'bf16' and ops.overlap_mode(B * NS) != '0' and not profile_ops):
         keep_mode, ops._MODE = ops._MODE, '0'
         ops.TIMERS = {}
         st_ss, rng_ss = state, rng
-        for i in range(min(20, args.steps)):
-            st_ss, _, rng_ss, _ = step(st_ss, rng_ss, args.steps + 1 + i)
+        for i in range(min(20, steps)):
+            st_ss, _, rng_ss, _ = step(st_ss, rng_ss, steps + 1 + i)
         sync()
         totals_ss = ops.timer_totals()
         ops.TIMERS = None
         ops._MODE = keep_mode
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        rows = B * NS
-        hit = float(batch_np['hit_fraction'])
-        enc_bytes = 52 + 4 * (NS + 1) + 2 * 60 * NS          # ray in, t_vals out, bf16 features out
-        fused_bytes = (16 * NS + 4 * (NS + 1) + 12) + (4 * NS + 20) + 4 * (NS + 1)    # composite + the next level's t_vals
-        # Roofline.  MLP kernels: MFMA-bound by definition -- algorithmic FLOPs per launch
-        # = 2 * 591 872 MAC * samples (one level; the dW launch covers both levels) / live HIP-event time /
-        # 2.5 PFLOP/s.  Encode / composite: HBM-bound -- algorithmic bytes per ray-level / time / 8 TB/s.
-        # (the fp32 weight-gradient launch is per level, the bf16 one covers both levels)
-        mfma = {k_fwd: 2.0 * MAC_BKGD * rows, k_bwd: 2.0 * MAC_BKGD * rows,
-                k_dw: (1 if f32 else N_LEVELS) * 2.0 * MAC_BKGD * rows}
-        # (the fused per-ray launch is latency-bound at 4096 rays, DESIGN.md 4: reported, not a tuning target)
-        hbm = {'encode_bkgd': float(enc_bytes) * B, 'composite_resample': float(fused_bytes) * B}
-        info = {}
-        for k, (n, s) in totals.items():
-            t = s / n
-            if k in mfma:
-                info[k] = dict(us=t * 1e6, bound='mfma', achieved=mfma[k] / t / 1e12, unit='TFLOP/s',
-                               frac=mfma[k] / t / peak)
-            elif k in hbm:
-                info[k] = dict(us=t * 1e6, bound='hbm', achieved=hbm[k] / t / 1e9, unit='GB/s',
-                               frac=hbm[k] / t / PEAK_HBM)
-        mlp = [k for k in info if k in mfma]
-        roof = None
-        if mlp:
-            dom = max(mlp, key=lambda k: info[k]['us'])      # the dominant kernel: longest launch
-            d = info[dom]
-            tr, src = pmc_traffic(int(_lib.lib().durf_version()), args.config, B, dom)
-            roof = dict(bound='mfma', kernel=dom, achieved=d['achieved'], peak=peak / 1e12, unit='TFLOP/s',
-                        frac=d['frac'], traffic=tr, traffic_source=src, launch_us=d['us'], all=info)
-            if not f32 and 'encode_bkgd' not in info and ops.FUSED_ENCODE:
-                # the background encode is no launch of its own any more: the forward computes its tiles' features itself
-                roof['encode_bkgd'] = 'fused into %s (durf_mlp_fwd_enc)' % k_fwd
-            if tr:      # what the counter bytes say about the launch: its HBM rate as a fraction of the 8 TB/s peak
-                roof['traffic_frac_of_hbm_peak'] = tr / (d['us'] * 1e-6) / PEAK_HBM
-            # end-to-end MFMA rate of the whole step (fwd + bwd-data + dW = 3 x fwd FLOPs, both levels, incl.
-            # the object MLPs on the measured fraction of hit rays) and the time outside the three MLP kernels
-            step_s = dt / args.steps
-            fl = 3 * N_LEVELS * 2.0 * (MAC_BKGD + hit * MAC_OBJ) * rows
-            roof['step_mlp_tflops'] = fl / step_s / 1e12
-            roof['step_mlp_frac'] = fl / step_s / peak
-            per_step = {k: totals[k][1] / sampled for k in mlp}
-            roof['timed_steps'] = '%d of %d (every %d)' % (sampled, args.steps, every)
-            roof['non_mlp_ms_per_step'] = (step_s - sum(per_step.values())) * 1e3
-            if totals_ss:
-                roof['single_stream'] = {k: dict(us=sv / nv * 1e6, frac=mfma[k] / (sv / nv) / peak)
-                                         for k, (nv, sv) in totals_ss.items() if k in mfma}
-            if not args.no_calibration and not f32:
-                roof['board'] = board_calibration(dev, d['achieved'])
-        if args.profile_ops:
-            for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
-                print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / sampled),
-                      file=sys.stderr)
-        cb = None if (args.no_cpu_baseline or world > 1) else cpu_baseline(batch_np, K_OBJ, NS, config)   # rank 0, N = 1 only
-        out = dict(metric='train_rays_per_sec', value=B * world * args.steps / dt, unit='rays/s',
-                   n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3,
-                   higher_is_better=True, scaling='weak', vs_baseline=None, dtype=args.precision, data='synthetic',
-                   config=dict(workload=label + ', %d samples/ray x 2 levels, 8x256 bkgd MLP + %d 8x128 object MLPs, '
-                                                'full train step%s' % (NS, K_OBJ, ' in exact fp32 (every Dense on fp32 MFMA)' if f32 else ''),
-                               name=args.config, rays_per_gpu=B, global_batch=B * world, num_samples=NS,
-                               num_levels=N_LEVELS, objects=K_OBJ, far=far, hit_fraction=hit, randomized=True,
-                               pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world,
-                               object_precision=model.object_precision() if K_OBJ else None,
-                               # object MLP launches on a side HIP stream (ops.py DURF_OVERLAP_OBJECTS): with '2' the timed
-                               # background kernels' durations include what runs beside them
-                               object_streams=(ops.overlap_mode(B * NS) if K_OBJ and model.object_precision() == 'bf16' else None),
-                               collective=('%s all-reduce, world size %d%s' % ('gloo' if shared_gpu else 'rccl', world,
-                                                                               ' (forced)' if args.force_dist else ''))
-                               if (world > 1 or args.force_dist) else None),
-                   loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,
-                   # distribution of the individual steps' GPU time: ms_per_step is the mean over the timed region and
-                   # includes any stall (a step far above the median is the host or the runtime, not the kernels)
-                   step_ms=dict(p50=step_times[len(step_times) // 2], p90=step_times[(9 * len(step_times)) // 10],
-                                max=step_times[-1],
-                                steps_per_sample=group,
-                                slow_steps=[i * group for i, t in enumerate(step_raw) if t > 1.5 * step_times[len(step_times) // 2]]))
-    else:
-        out = None
+    rows = B * NS
+    hit = float(batch_np['hit_fraction'])
+    # rows the background kernels actually run: a ray that hits exactly one box is evaluated ONCE instead of at its NS samples
+    #  whenever the objects are on -- (1 - hit) B NS + hit B rows (multi-hit rays are re-drawn in this batch)
+    dedup = bool(K_OBJ) and ops.DEDUP_HIT_RAYS and not f32
+    rows_run = ((1.0 - hit) * B * NS + hit * B) if dedup else float(rows)
+    enc_bytes = 52 + 4 * (NS + 1) + 2 * 60 * NS          # ray in, t_vals out, bf16 features out
+    fused_bytes = (16 * NS + 4 * (NS + 1) + 12) + (4 * NS + 20) + 4 * (NS + 1)    # composite + the next level's t_vals
+    # Roofline.  `frac` of an MLP kernel = ALGORITHMIC FLOPs per launch -- 2 * 591 872 MAC * B * NS samples of a
+    # level (the bf16 dW launch covers both levels) -- / live HIP-event time / the dense MFMA peak.  Next to it, per kernel:
+    #   mfma_launched_frac  the same with the rows and layers the launch really runs (de-duplicated rows; the dW launch
+    #                       without Dense_9 / the bottleneck rows of Dense_10, which k_bottleneck_grads computes)
+    #   mfma_executed_frac  SQ_VALU_MFMA_BUSY_CYCLES of the committed PMC pass of this library version (incl. tile padding)
+    #   hbm_*               algorithmic bytes of the launch and the PMC bytes, as rates against 8 TB/s and
+    #                       against the 6.29 TB/s a copy achieves
+    #   bound               the roof the launch is nearer to
+    lv = 1 if f32 else N_LEVELS
+    mfma = {k_fwd: 2.0 * MAC_BKGD * rows, k_bwd: 2.0 * MAC_BKGD * rows, k_dw: lv * 2.0 * MAC_BKGD * rows}
+    launched = {k_fwd: 2.0 * MAC_BKGD * rows_run, k_bwd: 2.0 * MAC_BKGD * rows_run,
+                k_dw: lv * 2.0 * (MAC_BKGD if f32 else MAC_DW_LAUNCH) * rows_run}
+    alg_bytes = {} if f32 else {k_fwd: BYTES_FWD * rows_run, k_bwd: BYTES_BWD * rows_run, k_dw: lv * BYTES_DW * rows_run}
+    # (the fused per-ray launch is latency-bound at 4096 rays, DESIGN.md 4: reported, not a tuning target)
+    hbm = {'encode_bkgd': float(enc_bytes) * B, 'composite_resample': float(fused_bytes) * B}
+    ver = int(_lib.lib().durf_version())
+    info = {}
+    for k, (n, s) in totals.items():
+        t = s / n
+        if k in mfma:
+            e = dict(us=t * 1e6, achieved=mfma[k] / t / 1e12, unit='TFLOP/s', frac=mfma[k] / t / peak,
+                     mfma_launched_frac=launched[k] / t / peak)
+            hbm_frac = None
+            if k in alg_bytes:
+                e['hbm_algorithmic_gbs'] = alg_bytes[k] / t / 1e9
+                hbm_frac = e['hbm_frac_of_peak'] = alg_bytes[k] / t / PEAK_HBM
+                e['hbm_frac_of_achievable'] = alg_bytes[k] / t / HBM_ACHIEVABLE
+            pm = None if light else pmc_entry(ver, cfg_name, B, k)
+            if pm:
+                e['traffic'] = pm['total_bytes']
+                e['traffic_tbs'] = pm['total_bytes'] / t / 1e12
+                e['hbm_frac_of_achievable'] = pm['total_bytes'] / t / HBM_ACHIEVABLE      # (the counter bytes, when there are any)
+                if pm.get('mfma_busy_cycles'):
+                    e['mfma_executed_frac'] = pm['mfma_busy_cycles'] / 32.0 * 32768.0 / t / peak
+            e['bound'] = 'hbm' if (hbm_frac is not None and hbm_frac > e['frac']) else 'mfma'
+            info[k] = e
+        elif k in hbm:
+            info[k] = dict(us=t * 1e6, bound='hbm', achieved=hbm[k] / t / 1e9, unit='GB/s', frac=hbm[k] / t / PEAK_HBM)
+    mlp = [k for k in info if k in mfma]
+    roof = None
+    if mlp:
+        dom = max(mlp, key=lambda k: info[k]['us'])      # the dominant kernel: longest launch
+        d = info[dom]
+        pm = None if light else pmc_entry(ver, cfg_name, B, dom)
+        if d['bound'] == 'hbm':        # priced against the roof it is nearer to: algorithmic bytes / time / 8 TB/s
+            roof = dict(bound='hbm', kernel=dom, achieved=d['hbm_algorithmic_gbs'], peak=PEAK_HBM / 1e9, unit='GB/s',
+                        frac=d['hbm_frac_of_peak'], mfma_frac=d['frac'])
+        else:
+            roof = dict(bound='mfma', kernel=dom, achieved=d['achieved'], peak=peak / 1e12, unit='TFLOP/s', frac=d['frac'])
+        roof.update(mfma_launched_frac=d['mfma_launched_frac'], mfma_executed_frac=d.get('mfma_executed_frac'),
+                    hbm_frac_of_achievable=d.get('hbm_frac_of_achievable'),
+                    traffic=pm['total_bytes'] if pm else None, traffic_source=pm['source'] if pm else None,
+                    launch_us=d['us'], rows_launched_over_rows=rows_run / rows, all=info)
+        # What actually caps the fused kernels on this board is neither roof: they run at the socket's power limit, and the
+        # shader clock follows what the launch's HBM traffic leaves of it (profiles/r05_store_overlap.txt)
+        roof['note'] = ('power-capped board: the same instruction streams run 1.6 GHz with their stash stores and 1.9-2.4 GHz '
+                        'without (profiles/r05_store_overlap.txt); fractions are against the nominal 2.5 PFLOP/s / 8 TB/s')
+        if not f32 and 'encode_bkgd' not in info and ops.FUSED_ENCODE:
+            # the background encode is no launch of its own any more: the forward computes its tiles' features itself
+            roof['encode_bkgd'] = 'fused into %s (durf_mlp_fwd_enc)' % k_fwd
+        if pm:      # what the counter bytes say about the launch: its HBM rate as a fraction of the 8 TB/s peak
+            roof['traffic_frac_of_hbm_peak'] = pm['total_bytes'] / (d['us'] * 1e-6) / PEAK_HBM
+        # end-to-end MFMA rate of the whole step (fwd + bwd-data + dW = 3 x fwd FLOPs, both levels, incl.
+        # the object MLPs on the measured fraction of hit rays) and the time outside the three MLP kernels
+        step_s = dt / steps
+        fl = 3 * N_LEVELS * 2.0 * (MAC_BKGD + hit * MAC_OBJ) * rows
+        roof['step_mlp_tflops'] = fl / step_s / 1e12
+        roof['step_mlp_frac'] = fl / step_s / peak
+        per_step = {k: totals[k][1] / sampled for k in mlp}
+        roof['timed_steps'] = '%d of %d (every %d)' % (sampled, steps, every)
+        roof['non_mlp_ms_per_step'] = (step_s - sum(per_step.values())) * 1e3
+        if totals_ss:
+            roof['single_stream'] = {k: dict(us=sv / nv * 1e6, frac=mfma[k] / (sv / nv) / peak)
+                                     for k, (nv, sv) in totals_ss.items() if k in mfma}
+        if not light and not args.no_calibration and not f32:
+            roof['board'] = board_calibration(dev, info[max(mlp, key=lambda k: info[k]['achieved'])]['achieved'])
+    if profile_ops:
+        for k, (n, s) in sorted(totals.items(), key=lambda kv: -kv[1][1]):
+            print('%-22s calls %4d  total %8.2f ms  per step %7.3f ms' % (k, n, s * 1e3, s * 1e3 / sampled),
+                  file=sys.stderr)
+    cb = None if (light or args.no_cpu_baseline or world > 1) else cpu_baseline(batch_np, K_OBJ, NS, config)   # rank 0, N = 1 only
+    out = dict(metric='train_rays_per_sec', value=B * world * steps / dt, unit='rays/s',
+               n_gpus=world, steps=steps, warmup=warmup, ms_per_step=dt / steps * 1e3,
+               higher_is_better=True, scaling='weak', vs_baseline=None, dtype=precision, data='synthetic',
+               config=dict(workload=label + ', %d samples/ray x 2 levels, 8x256 bkgd MLP + %d 8x128 object MLPs, '
+                                            'full train step%s' % (NS, K_OBJ, ' in exact fp32 (every Dense on fp32 MFMA)' if f32 else ''),
+                           name=cfg_name, rays_per_gpu=B, global_batch=B * world, num_samples=NS,
+                           num_levels=N_LEVELS, objects=K_OBJ, far=far, hit_fraction=hit, randomized=True,
+                           pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world,
+                           object_precision=model.object_precision() if K_OBJ else None,
+                           # object MLP launches on a side HIP stream (ops.py DURF_OVERLAP_OBJECTS): with '2' the timed
+                           # background kernels' durations include what runs beside them
+                           object_streams=(ops.overlap_mode(B * NS) if K_OBJ and model.object_precision() == 'bf16' else None),
+                           collective=('%s all-reduce, world size %d%s' % ('gloo' if shared_gpu else 'rccl', world,
+                                                                           ' (forced)' if args.force_dist else ''))
+                           if (world > 1 or args.force_dist) else None),
+               loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,
+               # distribution of the individual steps' GPU time: ms_per_step is the mean over the timed region and
+               # includes any stall (a step far above the median is the host or the runtime, not the kernels)
+               step_ms=dict(p50=step_times[len(step_times) // 2], p90=step_times[(9 * len(step_times)) // 10],
+                            max=step_times[-1],
+                            steps_per_sample=group,
+                            slow_steps=[i * group for i, t in enumerate(step_raw) if t > 1.5 * step_times[len(step_times) // 2]]))
+    return out
+
+
+# The other BASELINE.json configurations, the reference's own batch size and its own arithmetic: short passes behind the
+# headline's timed region, summarised under `workloads` in the same JSON line (N = 1, default headline only; --no-workloads
+# skips them).  name -> (config, rays per GPU (0 = the config's), precision, steps, warm-up)
+EXTRA_WORKLOADS = [
+    ('cfg1', 'cfg1', 0, 'bf16', 40, 10),
+    ('cfg2', 'cfg2', 0, 'bf16', 20, 5),
+    ('cfg3_512rays', 'cfg3', 512, 'bf16', 40, 10),
+    ('cfg4', 'cfg4', 0, 'bf16', 40, 10),
+    ('cfg5', 'cfg5', 0, 'bf16', 40, 10),
+    ('cfg3_f32', 'cfg3', 0, 'f32', 5, 2),
+]
+
+
+def summarize_workload(o):
+    r = o['roofline'] or {}
+    return dict(rays_per_s=o['value'], ms_per_step=o['ms_per_step'], steps=o['steps'], rays_per_gpu=o['config']['rays_per_gpu'],
+                num_samples=o['config']['num_samples'], objects=o['config']['objects'], dtype=o['dtype'],
+                pose_opt=o['config']['pose_opt'], dominant=r.get('kernel'), bound=r.get('bound'), frac=r.get('frac'),
+                mfma_frac=r.get('mfma_frac', r.get('frac') if r.get('bound') == 'mfma' else None),
+                dominant_us=r.get('launch_us'), step_mlp_frac=r.get('step_mlp_frac'),
+                non_mlp_ms_per_step=r.get('non_mlp_ms_per_step'), loss=o['loss'])
+
+
+def main():
+    args = parse_args()
+    if args.mode == 'eval':
+        raise SystemExit(eval_main(args))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))        # parent: spawns and waits; no GPU call in this process
+    if args.selftest_launch:
+        raise SystemExit(selftest_launch(args))
+
+    if args.force_dist:
+        os.environ['DURF_FORCE_DIST'] = '1'
+    import torch
+    import torch.distributed as dist
+    from durf_amd import train_boxpose
+
+    rank, world, local = train_boxpose.init_distributed()
+    flush_c_stdio()       # RCCL's version banner (every rank, C stdio, otherwise flushed at exit -- after rank 0's JSON line)
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    shared_gpu = os.environ.get('DURF_DIST_BACKEND') == 'gloo'      # tests: several gloo ranks on one device
+    if world > torch.cuda.device_count() and not shared_gpu:
+        raise SystemExit('--gpus %d but only %d visible' % (world, torch.cuda.device_count()))
+    dev = torch.device('cuda', local)
+    torch.cuda.set_device(dev)
+    if args.main_priority != 0:
+        main_stream = torch.cuda.Stream(device=dev, priority=args.main_priority)
+        main_stream.wait_stream(torch.cuda.current_stream())
+        torch.cuda.set_stream(main_stream)
+    prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]    # kept alive to the end (run_train)
+    for e in prewarm:
+        e.record()
+
+    out = run_train(args, args.config, dev, rank, world, args.steps, args.warmup, rays=args.rays, objects=args.objects,
+                    precision=args.precision)
+    default_headline = (args.config == 'cfg3' and args.rays == 0 and args.objects < 0 and args.precision == 'bf16' and
+                        not args.force_dist and not args.profile_ops)
+    if world == 1 and default_headline and not args.no_workloads:
+        extra = {}
+        for name, cfg, rays, prec, steps, warm in EXTRA_WORKLOADS:
+            try:
+                extra[name] = summarize_workload(run_train(args, cfg, dev, rank, world, steps, warm, rays=rays, precision=prec,
+                                                           light=True))
+            except Exception as e:                       # the headline stands whatever happens to a side pass
+                extra[name] = dict(error='%s: %s' % (type(e).__name__, e))
+        out['workloads'] = extra
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -17,15 +17,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DURF_WAVE 64
 
 void durf_set_error(const char* fmt, ...);
-
-namespace durf {
-// A/B switch of the 128-sample (4-wave) blocks the fused forward / backward use for launches that would leave half the
-// chip idle (mlp_fwd.hip launch_mlp_fwd): DURF_HALF_BLOCKS=0 keeps 256-sample blocks everywhere.  Read once.
-inline bool half_blocks_enabled() {
-    static const bool on = [] { const char* e = getenv("DURF_HALF_BLOCKS"); return !(e && e[0] == '0'); }();
-    return on;
-}
-}  // namespace durf
+namespace durf { void note_dispatch(unsigned bits); }      // durf_dispatch_seen() (include/durf_hip.h, csrc/api.hip)
 
 #define DURF_CHECK_LAUNCH(name)                                              \
     do {                                                                     \

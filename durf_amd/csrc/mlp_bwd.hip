@@ -1085,7 +1085,7 @@ k_bottleneck_grads(FinArgs A) {
 struct DwPlan {
     int nko[12], nki[12], MO[12], NI[12], nsplit[12];
     size_t part_off[12], bpart_off[12], part_total, bpart_total;
-    int max_split;
+    int max_split, total_wgs;
 };
 // total_rows: the sample rows (all levels) the launch is sized for -- a host-side number both the launch and its finalize
 // know; 0 = the largest plan (buffer sizes)
@@ -1115,9 +1115,12 @@ static DwPlan dw_plan(int width, size_t total_rows = 0) {
     // (268 -> 134 MB).  W = 128 (objects; the grid is total_wgs x K and a sparsely hit object leaves most of its
     // workgroups without tiles -- an early-exit workgroup still costs its dispatch): 256 per object (1024 -> 256: the
     // launch takes 137 -> 127 us at cfg3, K = 3, and 139 -> 73 us at cfg5, K = 8; rocprofv3).
-    static const int env_wgs = getenv("DURF_DW_WGS") ? atoi(getenv("DURF_DW_WGS")) : 0;
-    static const int env_wgs_obj = getenv("DURF_DW_WGS_OBJ") ? atoi(getenv("DURF_DW_WGS_OBJ")) : 0;
-    const int env_w = width == 256 ? env_wgs : env_wgs_obj;
+    // DURF_DW_WGS / DURF_DW_WGS_OBJ force a plan whatever the size (read per call: the parity suite runs the small oracle
+    // cases under the large batches' plan, tests/test_gpu_dispatch_matrix.py; a multiple of 128 up to the
+    // largest plan, which is what durf_dw_part_floats sizes the partial buffers for)
+    const char* env_s = getenv(width == 256 ? "DURF_DW_WGS" : "DURF_DW_WGS_OBJ");
+    int env_w = env_s ? atoi(env_s) : 0;
+    if (env_w % 128 != 0 || env_w < 128 || env_w > (width == 256 ? 512 : 256)) env_w = 0;
     // Round 4, small batches: every workgroup writes its fp32 partial tile whatever its share of the samples -- 134 MB per
     // launch with 512 workgroups, written here and read again by k_dw_finalize: ~50 us per step that do not shrink with
     // the batch.  ONE round of 256 workgroups halves that; the longer k loop per workgroup costs less than it saves below
@@ -1152,6 +1155,7 @@ static DwPlan dw_plan(int width, size_t total_rows = 0) {
         bo += (size_t)ns * P.MO[j] * 32;
     }
     P.part_total = po; P.bpart_total = bo;
+    P.total_wgs = total_wgs;
     return P;
 }
 
@@ -1264,11 +1268,12 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
             hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, s, rows, N, draw, ray_idx,
                                count, (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out, st, K);
             DURF_CHECK_LAUNCH("durf_mlp_bwd (M-split)");
+            note_dispatch(DURF_DISPATCH_BWD128_MSPLIT);
             return 0;
         }
     }
     // (as launch_mlp_fwd: 128-sample blocks of 4 waves when 256-sample blocks would leave half the chip idle)
-    const bool half = width == 256 && K == 1 && !d_enc && durf_cdiv(rows, 256) <= 128 && durf::half_blocks_enabled();
+    const bool half = width == 256 && K == 1 && !d_enc && durf_cdiv(rows, 256) <= 128;
     const unsigned nblk = durf_cdiv(rows, half ? 128u : 256u);
     dim3 grid(nblk < 256u ? nblk : 256u, K), block(half ? 256 : 512);     // persistent: at most one workgroup per CU and object
 #define LAUNCH_B(WW, PP, NWV)                                                                              \
@@ -1284,6 +1289,8 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
     else { if (d_enc) LAUNCH_B(128, true, 8) else LAUNCH_B(128, false, 8) }
 #undef LAUNCH_B
     DURF_CHECK_LAUNCH("durf_mlp_bwd");
+    note_dispatch((width == 128 ? DURF_DISPATCH_BWD128_SAMPLE : (half ? DURF_DISPATCH_BWD256_4W : DURF_DISPATCH_BWD256_8W)) |
+                  (d_enc ? DURF_DISPATCH_BWD_POSE : 0u));
     return 0;
 }
 
@@ -1382,6 +1389,8 @@ int launch_mlp_dw(void* stream, int width, const DwLevels& lv,
         hipLaunchKernelGGL(k_dw_all<128>, grid, block, lds, s, lv, a);
     }
     DURF_CHECK_LAUNCH("durf_mlp_dw");
+    note_dispatch(width == 256 ? (P.total_wgs <= 256 ? DURF_DISPATCH_DW256_256WG : DURF_DISPATCH_DW256_512WG)
+                               : (P.total_wgs <= 128 ? DURF_DISPATCH_DW128_128WG : DURF_DISPATCH_DW128_256WG));
     return 0;
 }
 

@@ -1099,18 +1099,17 @@ F32BlockTab block_table(const F32Spec& S) {
 // per launch at 4096 rays).  On the K object MLPs of a pose-optimisation step (cfg4: ~5 tiles per wave, 42 blocks x 8 splits
 // x K workgroups at occupancy 2 instead of 172 x 8 x K at 4) they LOSE: 87 -> 101-103 us (tools/time_objf32.py), cfg4
 // 636 -> 629 k rays/s -- the sixth layout of that launch measured slower than one tile per workgroup (review item 6).
-// DURF_F32_DW_B2 = 0 / 1 forces one or the other (A/B switch; bit-identical partials).
-bool dw_b2_enabled(bool wide) {
-    const char* e = getenv("DURF_F32_DW_B2");
-    return e ? e[0] != '0' : wide;
-}
+// (Bit-identical partials either way.)
+bool dw_b2_enabled(bool wide) { return wide; }
 void launch_dw_f32(hipStream_t s, const F32Spec& S, const F32DwArgs& a, int nsplit, int K, size_t params, float* scratch) {
     if (dw_b2_enabled(S.W == 256)) {
         const F32BlockTab T = block_table(S);
         hipLaunchKernelGGL(k_mlp_dw_f32_b2, dim3(T.base[12], nsplit, K), dim3(256), 0, s, S, T, a, nsplit, params, scratch);
+        durf::note_dispatch(DURF_DISPATCH_F32_DW_B2);
     } else {
         const F32TileTab T = tile_table(S);
         hipLaunchKernelGGL(k_mlp_dw_f32, dim3(T.base[12], nsplit, K), dim3(256), 0, s, S, T, a, nsplit, params, scratch);
+        durf::note_dispatch(DURF_DISPATCH_F32_DW_TILE);
     }
 }
 

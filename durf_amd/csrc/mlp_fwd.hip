@@ -920,14 +920,11 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
     hipStream_t s = (hipStream_t)stream;
     // A launch that fills at most half the chip with 256-sample blocks (8 waves) runs as 128-sample blocks (4 waves): twice the
     // workgroups, each with half the dependent work, one per CU as before (cfg1: 128 -> 256 workgroups).
-    const bool half = width == 256 && K == 1 && durf_cdiv(rows, 256) <= 128 && durf::half_blocks_enabled();
+    const bool half = width == 256 && K == 1 && durf_cdiv(rows, 256) <= 128;
     const unsigned per = half ? 128u : 256u;
     const unsigned nblk = durf_cdiv(rows, per);
-    // persistent: at most one workgroup per CU and object -- less DURF_FWD_RESERVE_CUS(n) CUs the caller wants left to a
-    // launch on another stream (a persistent grid on every CU starves it until its own tail)
-    unsigned wgs = 256u;
-    if (enc_in && K == 1) { const unsigned r = ((unsigned)enc_in->flags >> 8) & 0x7fu; wgs -= r; }
-    dim3 grid(nblk < wgs ? nblk : wgs, K), block(half ? 256 : 512);
+    // persistent: at most one workgroup per CU and object
+    dim3 grid(nblk < 256u ? nblk : 256u, K), block(half ? 256 : 512);
     const EncIn ei = enc_in ? *enc_in : EncIn{};
     // The object MLPs (W = 128 on compacted ray lists): the M-split kernel -- 4 waves x 64 samples, one output tile per wave --
     // whose launch is a few microseconds of latency instead of one 11-stage round of 256-sample blocks.  DURF_OBJ_MSPLIT=0
@@ -946,6 +943,7 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
             hipLaunchKernelGGL((k_mlp_fwd_ms<false>), g, b, ms::LDS_BYTES, s, rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16,
                                ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei, K);
         DURF_CHECK_LAUNCH("durf_mlp_fwd (M-split)");
+        note_dispatch(DURF_DISPATCH_FWD128_MSPLIT | (ei.obj ? DURF_DISPATCH_FWD_ENC : 0u));
         return 0;
     }
 #define LAUNCH_F(WW, TR, NWV, EN)                                                                 \
@@ -970,6 +968,9 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
     else { if (stash) LAUNCH_F(128, true, 8, false) else LAUNCH_F(128, false, 8, false) }
 #undef LAUNCH_F
     DURF_CHECK_LAUNCH("durf_mlp_fwd");
+    note_dispatch((width == 128 ? DURF_DISPATCH_FWD128_SAMPLE : (half ? DURF_DISPATCH_FWD256_4W : DURF_DISPATCH_FWD256_8W)) |
+                  (enc_in ? DURF_DISPATCH_FWD_ENC : 0u) | (tail_idx ? DURF_DISPATCH_FWD_TAIL : 0u) |
+                  ((enc_in && (enc_in->flags & DURF_FWD_RAW_FULL) && ray_idx) ? DURF_DISPATCH_FWD_RAW_FULL : 0u));
     return 0;
 }
 

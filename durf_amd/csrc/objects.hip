@@ -32,18 +32,8 @@ int durf_obj_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, co
     st.raw = rows * 4 * sizeof(float); st.stash = durf_mlp_stash_bytes(DURF_W_OBJ, rows); st.mask = durf_mlp_mask_bytes(rows);
     // ONE launch: the forward encodes its own tiles (enc_lane.h: k_encode_lane<true>'s body, bit-identical) and, in
     // training, writes the view-direction tile from the fragment it holds for the view layer (durf_expand_view's output).
-    // DURF_OBJ_SEPARATE_ENCODE=1 keeps the three launches (A/B switch; same results).
-    static const bool separate = [] { const char* e = getenv("DURF_OBJ_SEPARATE_ENCODE"); return e && e[0] != '0'; }();
+    // (The three separate launches -- durf_encode_obj, durf_mlp_fwd, durf_expand_view -- remain as entry points of their own.)
     int rc;
-    if (separate) {
-        rc = durf::launch_encode_obj(stream, K, B, N, idx, count, t_vals, origins_s, dirs_s, radii, barf_w, flags, enc, st.enc, nullptr);
-        if (rc) return rc;
-        rc = durf::launch_mlp_fwd(stream, DURF_W_OBJ, rows, N, enc, view_bf16, idx, count, wpack_fwd, raw, stash, relu_mask, K, st);
-        if (rc) return rc;
-        if (view_tile)
-            rc = durf::launch_expand_view(stream, rows, N, view_bf16, idx, count, view_tile, K, (size_t)B, durf_obj_view_stride(B, N));
-        return rc;
-    }
     EncIn ei{};
     ei.t_vals = t_vals; ei.origins_s = origins_s; ei.dirs_s = dirs_s; ei.radii = radii;
     ei.flags = flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER); ei.obj = 1;

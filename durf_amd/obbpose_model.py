@@ -292,14 +292,6 @@ class MipNerfModel:
         if cls is not None:
             dd = dict(idx=cls[0], count=cls[1], slot=cls[2], nrows=cls[1][2:3], multi_hit=cls[1][3])
             ctx['dedup'] = dd
-        hit_rays_late = obj_f32 and ops.HIT_RAYS_AFTER_FORWARD
-        if obj_f32 and not hit_rays_late:
-            # ... and the view layer + rgb head per box-hit ray on top of it (same input at both levels: once per step)
-            tail_side.wait_stream(torch.cuda.current_stream())           # ray classes, view27
-            with torch.cuda.stream(tail_side):
-                raw_tail = ops.bkgd_hit_rays_f32(B, view27, variables.mlp_flat('MLP_0'), dd['idx'][1], dd['count'][1:2],
-                                                 trunk=trunk)
-            raw_tail.record_stream(torch.cuda.current_stream())
         t_next = None
         for lvl in range(self.num_levels):
             last = lvl == self.num_levels - 1
@@ -323,7 +315,9 @@ class MipNerfModel:
                 side = ops.on_side(dev, bool(Kb) and ops.overlap_forward(rows))          # the object MLPs run in the shadow of the background MLP
                 enc_kw = dict(contraction=self.contraction, disable_integration=self.disable_integration, cylinder=cyl)
                 slabs = None
-                obj_first = bool(Kb) and side.enabled and ops.OBJECTS_FIRST
+                # side-stream forward: the object launches are issued BEFORE the persistent background forward, which takes
+                # every CU: they then run at its start instead of in its tail (round 4: 956-958 -> 961-963 k rays/s at cfg3)
+                obj_first = bool(Kb) and side.enabled
 
                 def launch_objects():                    # all K object MLPs of this level: one call (csrc/objects.hip)
                     with side:
@@ -347,8 +341,7 @@ class MipNerfModel:
                     raw_c, enc_b = ops.mlp_fwd_enc(rows, N, t_vals, o_s, d_s, radii, hit, view, packs['MLP_0'][0],
                                                    ray_idx=dd['idx'][0], count=dd['count'][0:1], stash=stash_b,
                                                    relu_mask=mask_b, tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
-                                                   view_tile=vt, raw_full=scatter,
-                                                   reserve_cus=ops.FWD_RESERVE_CUS if tail_side is not None else 0, **enc_kw)
+                                                   view_tile=vt, raw_full=scatter, **enc_kw)
                 elif dd is not None:
                     scatter = False
                     enc_b, _ = ops.encode_bkgd(t_vals, o_s, d_s, radii, hit, self.contraction,
@@ -362,7 +355,7 @@ class MipNerfModel:
                     if tail_side is not None:                # the fp32 hit-ray evaluation (side stream) must have landed
                         torch.cuda.current_stream().wait_stream(tail_side)
                         tail_side = None
-                    if hit_rays_late and lvl == 0:
+                    if obj_f32 and lvl == 0:
                         # the view layer + rgb head per box-hit ray (same input at both levels: once per step), HERE, on
                         # the main stream behind the level-0 forward: beside that persistent launch it found no CU until its
                         # tail and the main stream waited for it (160-180 us instead of 40; ~10 us now that it has the chip)

@@ -158,6 +158,23 @@ def tile_rows(rows):
     return (rows + 31) // 32 * 32
 
 
+# include/durf_hip.h DURF_DISPATCH_*: the kernel variants the launchers choose by size (tests/test_gpu_dispatch_matrix.py)
+DISPATCH = dict(FWD256_8W=0x1, FWD256_4W=0x2, FWD128_SAMPLE=0x4, FWD128_MSPLIT=0x8, BWD256_8W=0x10, BWD256_4W=0x20,
+                BWD128_SAMPLE=0x40, BWD128_MSPLIT=0x80, DW256_256WG=0x100, DW256_512WG=0x200, DW128_128WG=0x400,
+                DW128_256WG=0x800, FWD_ENC=0x1000, FWD_RAW_FULL=0x2000, FWD_TAIL=0x4000, F32_DW_TILE=0x8000,
+                F32_DW_B2=0x10000, BWD_POSE=0x20000)
+
+
+def dispatch_reset():
+    _lib.lib().durf_dispatch_reset()
+
+
+def dispatch_seen():
+    """names of the size-selected kernel variants launched since dispatch_reset() (durf_dispatch_seen)"""
+    m = int(_lib.lib().durf_dispatch_seen())
+    return {k for k, b in DISPATCH.items() if m & b}
+
+
 ENC_CONTRACT, ENC_NO_INTEGRATION, ENC_CYLINDER = 1, 2, 4
 FWD_RAW_FULL = 8          # mlp_fwd_enc only (include/durf_hip.h DURF_FWD_RAW_FULL)
 
@@ -267,32 +284,25 @@ def mlp_fwd(width, rows, N, enc_tile, view_bf16, wpack_fwd, ray_idx=None, count=
 
 # DURF_FUSED_ENCODE=0: the background encoding as its own launch in front of the forward (A/B switch; same results).
 FUSED_ENCODE = os.environ.get('DURF_FUSED_ENCODE', '1') != '0'
-# DURF_FWD_SCATTER_RAW=0: a de-duplicated forward writes compacted raw rows and expand_raw makes the full layout (A/B switch)
-FWD_SCATTER_RAW = os.environ.get('DURF_FWD_SCATTER_RAW', '1') != '0'
-# CUs the level-0 background forward of a pose-optimisation step leaves to the fp32 evaluation of the box-hit rays queued on
-# the side stream (k_bkgd_hit_rays: beside a persistent grid on all 256 CUs it runs 160-180 us instead of 40 and the main
-# stream waits for it).  Measured at cfg4 with 16: 636 -> 625 k rays/s (and 629 -> 623 with the 2 x 2 fp32 weight-gradient
-# kernel): the forward loses more than the join gains -- off by default, the knob stays for other shapes.
-FWD_RESERVE_CUS = int(os.environ.get('DURF_FWD_RESERVE_CUS', '0'))
-# DURF_HIT_RAYS_AFTER_FORWARD=0: that launch on the side stream beside the level-0 forward, as up to round 3 (A/B switch)
-HIT_RAYS_AFTER_FORWARD = os.environ.get('DURF_HIT_RAYS_AFTER_FORWARD', '1') != '0'
+# False: a de-duplicated forward writes compacted raw rows and expand_raw makes the full layout (the parity test of the
+# scattered store toggles it: tests/test_gpu_fused_encode.py; not an environment switch any more)
+FWD_SCATTER_RAW = True
 
 
 def mlp_fwd_enc(rows, N, t_vals, origins_s, dirs_s, radii, hit, view_bf16, wpack_fwd, contraction=True,
                 disable_integration=False, cylinder=False, ray_idx=None, count=None, stash=None, raw=None, relu_mask=None,
-                tail_idx=None, tail_count=None, view_tile=None, raw_full=False, reserve_cus=0):
+                tail_idx=None, tail_count=None, view_tile=None, raw_full=False):
     """durf_mlp_fwd_enc: the background forward that encodes its own tiles (encode_bkgd + mlp_fwd(256) as one launch)
     -> (raw, enc_tile); enc_tile is what encode_bkgd would have returned (the weight-gradient GEMMs read it).
     view_tile (training): a [tile_rows, 32] bf16 buffer the launch fills with expand_view's output; raw_full (with
-    ray_idx / tail_idx): raw comes back in the full [B*N,4] layout -- expand_raw's output, without that launch;
-    reserve_cus: the persistent grid leaves that many CUs to a launch queued on another stream"""
+    ray_idx / tail_idx): raw comes back in the full [B*N,4] layout -- expand_raw's output, without that launch"""
     dev = t_vals.device
     K = 0 if hit is None else hit.shape[1]
     if raw is None:
         raw = torch.empty(rows, 4, device=dev)
     enc_tile = torch.empty(tile_rows(rows), ENC_DIM, dtype=torch.bfloat16, device=dev)
     flags = ((ENC_CONTRACT if contraction else 0) | (ENC_NO_INTEGRATION if disable_integration else 0) |
-             (ENC_CYLINDER if cylinder else 0) | (FWD_RAW_FULL if raw_full else 0) | ((int(reserve_cus) & 0x7f) << 8))
+             (ENC_CYLINDER if cylinder else 0) | (FWD_RAW_FULL if raw_full else 0))
     with _Timed('mlp_fwd_256%s' % ('_train' if stash is not None else '')):
         _lib.check(_lib.lib().durf_mlp_fwd_enc(_stream(), rows, N, _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
                                                _p(_f32(radii)), _p(hit), K, flags, _p(enc_tile), _p(view_bf16),
@@ -339,11 +349,6 @@ def overlap_dw(rows):
     return overlap_mode(rows) == '2'
 
 
-MERGE_FINALIZE = os.environ.get('DURF_MERGE_FINALIZE', '1') != '0'    # A/B switch: one finalize launch pair for all MLPs
-# side-stream forward: issue the object launches BEFORE the persistent background forward, which takes every CU: they then
-# run at its start instead of in its tail (round 4, three interleaved runs on one box at cfg3: 956.2-958.0 -> 961.2-962.9 k
-# rays/s; DURF_OBJECTS_FIRST=0 is the A/B switch)
-OBJECTS_FIRST = os.environ.get('DURF_OBJECTS_FIRST', '1') != '0'
 _SIDE = {}
 
 

@@ -245,7 +245,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         else:
             geo = ([rows] * L, [N] * L, [None] * L)
         o0, sz = (lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]) if Kb else (0, 0)
-        merged = Kb and not ops.overlap_dw(rows) and ops.MERGE_FINALIZE and objects_ready is None
+        merged = Kb and not ops.overlap_dw(rows) and objects_ready is None
         if Kb and objects_ready is not None:           # bucketed all-reduce: the objects' gradients first, finalized on their own
             obj_side.join()                            # (the object backward may still be writing dz on the side stream)
             ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],

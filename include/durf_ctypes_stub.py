@@ -13,6 +13,10 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_last_error.argtypes = []
     L.durf_version.restype = i32
     L.durf_version.argtypes = []
+    L.durf_dispatch_seen.restype = i32
+    L.durf_dispatch_seen.argtypes = []
+    L.durf_dispatch_reset.restype = i32
+    L.durf_dispatch_reset.argtypes = []
     L.durf_mlp_param_count.restype = u64
     L.durf_mlp_param_count.argtypes = [i32, i32]
     #   (width, in_dim)

@@ -38,12 +38,34 @@ extern "C" {
 #define DURF_ENC_NO_INTEGRATION 2  /* MipNerfModel.disable_integration: PE instead of IPE (covariances zeroed) */
 #define DURF_ENC_CYLINDER 4        /* MipNerfModel.ray_shape == 'cylinder' (mip.cylinder_to_gaussian) */
 #define DURF_FWD_RAW_FULL 8        /* durf_mlp_fwd_enc only (not an encoder flag): see there */
-#define DURF_FWD_RESERVE_CUS(n) (((n) & 0x7f) << 8)   /* durf_mlp_fwd_enc only: launch on 256 - n CUs (n <= 127), see there */
 #define DURF_ENC_DIM 64      /* 60 (bkgd IPE) / 63 (object IPE) features padded to 64 */
 #define DURF_VIEW_DIM 32     /* 27 view-direction features padded to 32 */
 
 const char* durf_last_error(void);
 int durf_version(void);
+/* Which of the size- or switch-selected kernel variants have been launched by this process since durf_dispatch_reset():
+ * a bit mask of DURF_DISPATCH_*.  Test instrumentation of the launchers (one relaxed atomic OR per launch): the parity
+ * suite asserts that every variant below ran inside an oracle-compared test (tests/test_gpu_dispatch_matrix.py). */
+#define DURF_DISPATCH_FWD256_8W 0x1        /* k_mlp_fwd<256>: 256-sample blocks of 8 waves */
+#define DURF_DISPATCH_FWD256_4W 0x2        /* k_mlp_fwd<256>: 128-sample blocks of 4 waves (launches of <= 128 blocks) */
+#define DURF_DISPATCH_FWD128_SAMPLE 0x4    /* k_mlp_fwd<128>: the object MLPs, one wave per 32 samples */
+#define DURF_DISPATCH_FWD128_MSPLIT 0x8    /* k_mlp_fwd_ms: the object MLPs, one wave per output tile (< 2048 x 128 rows) */
+#define DURF_DISPATCH_BWD256_8W 0x10
+#define DURF_DISPATCH_BWD256_4W 0x20
+#define DURF_DISPATCH_BWD128_SAMPLE 0x40
+#define DURF_DISPATCH_BWD128_MSPLIT 0x80
+#define DURF_DISPATCH_DW256_256WG 0x100    /* k_dw_all<256>: one round of 256 workgroups (< 3072 x 256 rows over all levels) */
+#define DURF_DISPATCH_DW256_512WG 0x200    /* k_dw_all<256>: two rounds */
+#define DURF_DISPATCH_DW128_128WG 0x400    /* k_dw_all<128> per object */
+#define DURF_DISPATCH_DW128_256WG 0x800
+#define DURF_DISPATCH_FWD_ENC 0x1000       /* the forward encodes its own tiles (durf_mlp_fwd_enc / durf_obj_fwd_batch) */
+#define DURF_DISPATCH_FWD_RAW_FULL 0x2000  /* ... and writes raw in the full [B*N,4] layout (DURF_FWD_RAW_FULL) */
+#define DURF_DISPATCH_FWD_TAIL 0x4000      /* tail rows: the de-duplicated background evaluation */
+#define DURF_DISPATCH_F32_DW_TILE 0x8000   /* k_mlp_dw_f32: one output tile per workgroup (the fp32 object branch) */
+#define DURF_DISPATCH_F32_DW_B2 0x10000    /* k_mlp_dw_f32_b2: 2 x 2 blocks (W = 256) */
+#define DURF_DISPATCH_BWD_POSE 0x20000     /* k_mlp_bwd<.., POSE>: d(enc) for the box-pose gradient */
+int durf_dispatch_seen(void);
+int durf_dispatch_reset(void);
 
 /* ---- parameter layout -------------------------------------------------------
  * One contiguous fp32 buffer (so the data-parallel gradient exchange is a single
@@ -158,9 +180,7 @@ int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_ti
  * layout) -- one launch less per step.  enc_flags | DURF_FWD_RAW_FULL with a compacted list + tail (a de-duplicated batch,
  * N % 32 == 0): raw is written in the FULL [B*N,4] layout -- row ray_idx[j]*N + n for the compacted rows, and the one
  * evaluation of tail ray tail_idx[i] at all N samples of that ray -- i.e. exactly what durf_expand_raw makes of the compacted
- * raw (bit-identical), which then is not called: one launch less per level.  enc_flags | DURF_FWD_RESERVE_CUS(n): the
- * persistent grid takes 256 - n workgroups, leaving n CUs to a small launch the caller has queued on another stream (the fp32
- * evaluation of the box-hit rays of a pose-optimisation step), which otherwise waits for the tail of this one. */
+ * raw (bit-identical), which then is not called: one launch less per level. */
 int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
                      const float* radii, const int32_t* hit /* nullable */, int K, int enc_flags, void* enc_tile,
                      const void* view_bf16, const int32_t* ray_idx /* nullable */, const int32_t* count /* nullable */,

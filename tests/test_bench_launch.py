@@ -55,10 +55,30 @@ def test_pmc_traffic_is_version_gated(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     os.makedirs(tmp_path / 'profiles')
-    json.dump(dict(lib_version=7, workload='cfg3', rays_per_gpu=4096, source='x', mlp_dw_256=dict(total_bytes=5.0)),
+    json.dump(dict(lib_version=7, workload='cfg3', rays_per_gpu=4096, source='x',
+                   mlp_dw_256=dict(total_bytes=5.0, mfma_busy_cycles=64.0)),
               open(tmp_path / 'profiles' / 'r09_pmc_traffic.json', 'w'))
     monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
-    assert bench.pmc_traffic(7, 'cfg3', 4096, 'mlp_dw_256')[0] == 5.0
-    assert bench.pmc_traffic(8, 'cfg3', 4096, 'mlp_dw_256')[0] is None      # other build: stale numbers are not quoted
-    assert bench.pmc_traffic(7, 'cfg2', 4096, 'mlp_dw_256')[0] is None
-    assert bench.pmc_traffic(7, 'cfg3', 1024, 'mlp_dw_256')[0] is None
+    e = bench.pmc_entry(7, 'cfg3', 4096, 'mlp_dw_256')
+    assert e['total_bytes'] == 5.0 and e['mfma_busy_cycles'] == 64.0 and e['source'].startswith('r09_pmc_traffic.json')
+    assert bench.pmc_entry(8, 'cfg3', 4096, 'mlp_dw_256') is None      # other build: stale numbers are not quoted
+    assert bench.pmc_entry(7, 'cfg2', 4096, 'mlp_dw_256') is None
+    assert bench.pmc_entry(7, 'cfg3', 1024, 'mlp_dw_256') is None
+
+
+def test_extra_workloads_cover_every_baseline_config():
+    """the short passes behind the headline (`workloads` in the JSON line): every BASELINE.json configuration, the
+    reference's own 512-ray batch (configs/waymo.gin:17) and its own arithmetic (internal/math.py:22-24)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    names = [w[0] for w in bench.EXTRA_WORKLOADS]
+    assert names == ['cfg1', 'cfg2', 'cfg3_512rays', 'cfg4', 'cfg5', 'cfg3_f32']
+    for name, cfg, rays, prec, steps, warm in bench.EXTRA_WORKLOADS:
+        assert cfg in bench.WORKLOADS and prec in ('bf16', 'f32') and steps >= 5 and warm >= 2
+    o = dict(value=1.0, ms_per_step=2.0, steps=3, dtype='bf16', loss=0.5,
+             config=dict(rays_per_gpu=512, num_samples=64, objects=0, pose_opt=False),
+             roofline=dict(kernel='mlp_dw_256', bound='hbm', frac=0.7, mfma_frac=0.3, launch_us=9.0, step_mlp_frac=0.2,
+                           non_mlp_ms_per_step=0.1))
+    s = bench.summarize_workload(o)
+    assert s['dominant'] == 'mlp_dw_256' and s['bound'] == 'hbm' and s['frac'] == 0.7 and s['mfma_frac'] == 0.3
+    assert s['rays_per_s'] == 1.0 and s['ms_per_step'] == 2.0

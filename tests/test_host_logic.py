@@ -99,6 +99,18 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert L.durf_mlp_layer_offset(256, 60, layer, 1) - L.durf_mlp_layer_offset(256, 60, layer, 0) == fi * fo
 
 
+def test_dispatch_log_constants_match_the_header_and_the_log_works_without_a_gpu():
+    """ops.DISPATCH mirrors include/durf_hip.h's DURF_DISPATCH_* (the launchers' variant log the GPU suite's dispatch
+    matrix reads); the log itself is host state: readable and resettable with no device"""
+    from durf_amd import ops
+    hdr = open(os.path.join(ROOT, 'include', 'durf_hip.h')).read()
+    declared = {m.group(1): int(m.group(2), 16) for m in re.finditer(r'#define DURF_DISPATCH_(\w+) (0x[0-9a-fA-F]+)', hdr)}
+    assert declared == ops.DISPATCH
+    assert len(set(declared.values())) == len(declared) and all(v & (v - 1) == 0 for v in declared.values())
+    ops.dispatch_reset()
+    assert ops.dispatch_seen() == set()
+
+
 def test_integration_stub_is_generated_from_the_header():
     """INTEGRATION.md's ctypes stub and include/durf_ctypes_stub.py are generated from include/durf_hip.h, and the
     product's own binding table (durf_amd/_lib.py) declares the same argument types for every symbol."""
