@@ -21,7 +21,7 @@ struct Carver {                      // 256-byte aligned sub-buffers of the work
 };
 
 struct FwdWs {
-    float *o_s, *d_s, *raw_b, *obj_raw, *t_scratch;
+    float *o_s, *d_s, *raw_b, *obj_raw, *t_scratch, *u_rand;
     int32_t *hit, *idx_obj, *count_obj, *slot_obj, *idx_cls, *count_cls, *slot_cls;
     void *view, *wf_bkgd, *wf_obj, *enc, *obj_enc;
     size_t total;
@@ -47,6 +47,7 @@ FwdWs carve(void* workspace, int B, int N, int K) {
     w.raw_b = (float*)c.take(rows * 4 * 4);
     w.obj_enc = c.take(K > 0 ? (size_t)K * durf_obj_enc_stride(B, N) : 0);
     w.obj_raw = (float*)c.take(K > 0 ? (size_t)K * rows * 4 * 4 : 0);
+    w.u_rand = (float*)c.take((size_t)B * (N + 1) * 4);              // draw_noise: the resampling draws of the prologue
     w.total = (c.off + 255) & ~(size_t)255;
     return w;
 }
@@ -64,13 +65,15 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
     DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
     DURF_REQUIRE(L >= 1 && L <= DURF_FORWARD_MAX_LEVELS, "1 <= num_levels <= DURF_FORWARD_MAX_LEVELS");
     DURF_REQUIRE(((size_t)workspace & 255) == 0, "workspace aligned to 256 bytes");
+    DURF_REQUIRE(!a->draw_noise || (a->t_rand == nullptr && a->u_rand == nullptr), "draw_noise: the library makes the draws");
     const FwdWs w = carve(workspace, B, N, K);
     const size_t rows = (size_t)B * N;
     int rc;
 #define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)
     // ray setup + view encoding + level-0 sample positions (obbpose_model.py:99-131, mip.py:330-370): one launch
     STEP(durf_ray_prologue(stream, B, K, N, a->origins, a->directions, a->pose, a->ext, w.o_s, w.d_s, w.hit, a->zo, a->viewdirs,
-                           w.view, a->near, a->far, a->t_rand, a->lindisp, a->t_vals[0], nullptr, nullptr, 0));
+                           w.view, a->near, a->far, a->t_rand, a->lindisp, a->t_vals[0], nullptr, nullptr, 0, a->seed_lo, a->seed_hi,
+                           a->draw_noise ? w.u_rand : nullptr));
     if (K > 0)      // per-object hit lists + the ray classes of the de-duplicated background evaluation: one launch
         STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
                               a->dyn_mask));
@@ -95,7 +98,7 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
         STEP(durf_composite_fwd(stream, B, N, K, w.raw_b, raw_obj, w.slot_obj, t_vals, w.d_s, a->density_bias, a->bkgd_mode,
                                 a->rgb[lvl], a->depth[lvl], a->acc[lvl], a->weights[lvl], a->t_mids[lvl], a->t_dists[lvl]));
         if (lvl + 1 < L)
-            STEP(durf_resample(stream, B, N, t_vals, a->weights[lvl], a->resample_padding, a->u_rand, a->t_vals[lvl + 1]));
+            STEP(durf_resample(stream, B, N, t_vals, a->weights[lvl], a->resample_padding, a->draw_noise ? w.u_rand : a->u_rand, a->t_vals[lvl + 1]));
     }
 #undef STEP
     return 0;

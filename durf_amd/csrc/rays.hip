@@ -186,12 +186,40 @@ k_compact_all(int B, int K, int N, const int32_t* __restrict__ hit, int32_t* __r
 // ---------------------------------------------------------------------------
 // K2: level-0 t_vals (mip.py:353-368).  linspace(0,1,N+1)[i] == i/N in fp32.
 // ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11: "Parallel random numbers: as easy as 1, 2, 3"), counter (c0, 0, 0, 0), key (k0, k1):
+// the stratified-sampling draws of a step made INSIDE its first launch, as the reference makes them inside its program
+// (mip.py:364, math.py:257-260: jax.random.uniform on a key) instead of by a generator kernel in front of it.  Word 0 of
+// block i jitters level-0 sample position i, word 1 is the resampling draw i of the following levels.  Restated on the
+// CPU (with the generator's known-answer vectors) in oracle/philox_ref.py; tests/test_gpu_sampling_noise.py.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned k0, unsigned k1, unsigned& x0, unsigned& x1) {
+    unsigned c1 = 0u, c2 = 0u, c3 = 0u;
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        const unsigned lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
+        const unsigned lo1 = 0xCD9E8D57u * c2, hi1 = __umulhi(0xCD9E8D57u, c2);
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    x0 = c0; x1 = c1;
+}
+// 24 random bits -> [0, 1) (what jax.random.uniform's fp32 draw resolves, 2^-24 apart here)
+__device__ __forceinline__ float u01_24(unsigned x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
+
 __device__ __forceinline__ void sample_t_block(size_t blk, int B, int N, const float* __restrict__ near,
                                                const float* __restrict__ far, const float* __restrict__ t_rand,
-                                               int lindisp, float* __restrict__ t_vals) {
+                                               int lindisp, float* __restrict__ t_vals, bool draw = false, unsigned seed_lo = 0u,
+                                               unsigned seed_hi = 0u, float* __restrict__ u_rand_out = nullptr) {
     const size_t i = blk * blockDim.x + threadIdx.x;
     const size_t tot = (size_t)B * (N + 1);
     if (i >= tot) return;
+    float jitter = 0.0f;
+    if (draw) {
+        unsigned x0, x1;
+        philox4x32_10((unsigned)i, seed_lo, seed_hi, x0, x1);
+        jitter = u01_24(x0);
+        u_rand_out[i] = u01_24(x1);
+    }
     const int b = (int)(i / (N + 1)), n = (int)(i % (N + 1));
     const float nr = near[b], fr = far[b];
     auto tv = [&](int m) {
@@ -200,10 +228,10 @@ __device__ __forceinline__ void sample_t_block(size_t blk, int B, int N, const f
         return lindisp ? 1.0f / t : t;                                  // mip.py:354-356
     };
     float t = tv(n);
-    if (t_rand) {                                                       // :360-365
+    if (t_rand || draw) {                                               // :360-365
         const float lower = (n == 0) ? t : 0.5f * (t + tv(n - 1));
         const float upper = (n == N) ? t : 0.5f * (tv(n + 1) + t);
-        t = lower + (upper - lower) * t_rand[i];
+        t = lower + (upper - lower) * (draw ? jitter : t_rand[i]);
     }
     t_vals[i] = t;
 }
@@ -251,7 +279,7 @@ k_ray_prologue(int B, int K, int N, const float* __restrict__ origins, const flo
                const float* __restrict__ viewdirs, __bf16* __restrict__ view_bf16,
                const float* __restrict__ near, const float* __restrict__ far, const float* __restrict__ t_rand,
                int lindisp, float* __restrict__ t_vals, float* __restrict__ pose_copy, float* __restrict__ zero_buf,
-               size_t zero_count) {
+               size_t zero_count, unsigned seed_lo, unsigned seed_hi, float* __restrict__ u_rand_out) {
     // two chores of a training step that cost a launch of their own otherwise (ray-independent; done first so that the
     // stores are in flight under the ray setup): a snapshot of this timestep's poses (the step returns the poses it
     // rendered with, train_boxpose.py:315, and the optimizer updates them in place) and the zero fill of the gradient
@@ -265,7 +293,7 @@ k_ray_prologue(int B, int K, int N, const float* __restrict__ origins, const flo
     if ((int)blockIdx.x < (B + 255) / 256)                            // block-uniform: ray_setup_block has a barrier
         ray_setup_block(blockIdx.x, B, K, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo);
     if ((int)blockIdx.x < (B * DURF_VIEW_DIM + 255) / 256) view_enc_block(blockIdx.x, B, viewdirs, view_bf16, nullptr);
-    sample_t_block(blockIdx.x, B, N, near, far, t_rand, lindisp, t_vals);
+    sample_t_block(blockIdx.x, B, N, near, far, t_rand, lindisp, t_vals, u_rand_out != nullptr, seed_lo, seed_hi, u_rand_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -413,8 +441,11 @@ int durf_ray_setup(void* stream, int B, int K, const float* origins, const float
 int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
                       const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
                       const float* viewdirs, void* view_bf16, const float* near, const float* far, const float* t_rand,
-                      int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count) {
+                      int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count,
+                      uint32_t seed_lo, uint32_t seed_hi, float* u_rand_out) {
     DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
+    DURF_REQUIRE(u_rand_out == nullptr || t_rand == nullptr, "the draws come from t_rand OR from the launch's own generator");
+    DURF_REQUIRE(u_rand_out == nullptr || (size_t)B * (N + 1) < ((size_t)1 << 32), "in-kernel draws: 32-bit sample counter");
     DURF_REQUIRE(zero_buf == nullptr || ((size_t)zero_buf & 15) == 0, "zero_buf aligned to 16 bytes");
     if (B <= 0) {       // an empty shard still owes its caller the zero-filled gradient (it is all-reduced and fed to clip + Adam)
         if (zero_buf && zero_count) {
@@ -427,7 +458,8 @@ int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, c
     const size_t items = std::max((size_t)B * (N + 1), (size_t)B * DURF_VIEW_DIM);
     hipLaunchKernelGGL(k_ray_prologue, dim3(durf_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, B,
                        K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, (__bf16*)view_bf16, near,
-                       far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_buf ? zero_count : (size_t)0);
+                       far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_buf ? zero_count : (size_t)0, seed_lo, seed_hi,
+                       u_rand_out);
     DURF_CHECK_LAUNCH("durf_ray_prologue");
     return 0;
 }

@@ -36,7 +36,7 @@ __global__ void k_tv_rows(int K, const float* __restrict__ pose, const float* __
 }
 
 struct TrainWs {
-    float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *draw, *part, *bpart, *opart, *obpart, *scratch;
+    float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *draw, *part, *bpart, *opart, *obpart, *scratch, *u_rand;
     float *raw_c[ML], *raw_b[ML], *obj_raw[ML], *terms[ML];
     int32_t *hit, *idx_obj, *count_obj, *slot_obj, *idx_cls, *count_cls, *slot_cls;
     void *view, *wf_bkgd, *wb_bkgd, *wf_obj, *wb_obj, *view_tile, *obj_view_tile;
@@ -80,6 +80,7 @@ TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params, int 
     w.opart = (float*)c.take(K > 0 ? (size_t)K * durf_dw_part_floats(128) * 4 : 0);
     w.obpart = (float*)c.take(K > 0 ? (size_t)K * durf_dw_bpart_floats(128) * 4 : 0);
     w.scratch = (float*)c.take(durf_optim_scratch_floats(n_params) * 4);
+    w.u_rand = (float*)c.take((size_t)B * (N + 1) * 4);              // f.draw_noise: the resampling draws of the prologue
     for (int l = 0; l < L; l++) {
         w.terms[l] = (float*)c.take((size_t)7 * B * 4);
         w.enc[l] = c.take(trows * 64 * 2);
@@ -129,6 +130,7 @@ int check_args(const durf_train_args* a, void* workspace) {
                  (f.K == 0 || (f.obj_params == a->params + a->box_floats + a->mlp0_floats && f.obj_param_stride == a->obj_floats)),
                  "f.bkgd_params / f.obj_params point into params");
     DURF_REQUIRE(f.bkgd_mode == 0 || f.bkgd_mode == 1, "fixed background colour (grey or white)");
+    DURF_REQUIRE(!f.draw_noise || (f.t_rand == nullptr && f.u_rand == nullptr), "draw_noise: the library makes the draws");
     DURF_REQUIRE((a->flags & ~(DURF_TRAIN_OBJ_FP32 | DURF_TRAIN_POSE_OPT)) == 0, "unknown flags");
     if (a->flags & DURF_TRAIN_POSE_OPT) {
         DURF_REQUIRE(f.K > 0 && (a->flags & DURF_TRAIN_OBJ_FP32), "box-pose optimisation runs behind the fp32 object branch");
@@ -155,7 +157,8 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
     int rc;
     // ---- forward (obbpose_model.py:68-261), activations stashed ----
     STEP(durf_ray_prologue(stream, B, K, N, f.origins, f.directions, f.pose, f.ext, w.o_s, w.d_s, w.hit, f.zo, f.viewdirs, w.view,
-                           f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0], nullptr, a->grad, a->n_params));
+                           f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0], nullptr, a->grad, a->n_params, f.seed_lo, f.seed_hi,
+                           f.draw_noise ? w.u_rand : nullptr));
     if (K > 0)
         STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
                               f.dyn_mask));
@@ -203,7 +206,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
         if (lvl + 1 < L)        // composite + resample + the loss normalisers of this (level 0 only) and the next level: one launch
             STEP(durf_composite_resample(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, t_vals, w.d_s, f.density_bias,
                                          f.bkgd_mode, f.rgb[lvl], f.depth[lvl], f.acc[lvl], f.weights[lvl], f.t_mids[lvl],
-                                         f.t_dists[lvl], f.resample_padding, f.u_rand, f.t_vals[lvl + 1], a->lossmult, a->gt_depth,
+                                         f.t_dists[lvl], f.resample_padding, f.draw_noise ? w.u_rand : f.u_rand, f.t_vals[lvl + 1], a->lossmult, a->gt_depth,
                                          a->sky, f.dyn_mask, f.zo, a->eps, a->box_loss_mult, lvl, a->disable_multiscale,
                                          lvl == 0 ? w.prep : nullptr, lvl == 0 ? w.norms : nullptr, w.prep + (size_t)5 * B,
                                          w.norms + (size_t)(lvl + 1) * 5));

@@ -206,10 +206,17 @@ class MipNerfModel:
         f32 = self.mlp_precision == 'f32'
         obj_f32 = bool(Kd) and not f32 and self.object_precision() == 'f32'     # mixed: bf16 background, fp32 objects
         Kb = 0 if obj_f32 else Kd                                                # objects on the bf16 kernels
+        # randomized without injected draws: the step's first launch draws them itself (durf_ray_prologue's Philox stream keyed
+        # by the host's PRNG key `rng`; mip.py:364, math.py:257-260 draw inside the program too) -- no generator launch.  A
+        # torch.Generator as `rng` keeps the torch.rand path (its state cannot key a counter-based stream).
         g = _make_generator(rng, dev) if randomized else None
+        seed = None
         if randomized and noise is None:
-            u = torch.rand(2, B, N + 1, device=dev, generator=g)          # one launch for both levels' noise
-            noise = dict(t_rand=u[0], u_rand=u[1])
+            if isinstance(rng, torch.Generator):
+                u = torch.rand(2, B, N + 1, device=dev, generator=g)      # one launch for both levels' noise
+                noise = dict(t_rand=u[0], u_rand=u[1])
+            else:
+                seed = int(rng) if rng is not None else 0
         # (the fp32 object branch needs the box-hit rays' background evaluation as its own rows: always de-duplicated)
         use_dd = bool(Kd) and not f32 and (ops.DEDUP_HIT_RAYS or obj_f32)
         tail_side = trunk = None
@@ -233,9 +240,12 @@ class MipNerfModel:
         # ray setup + view encoding + level-0 sample positions: one launch; both compactions: one launch
         # (the launch also snapshots the poses: the outputs must not alias the parameters the optimizer updates in place)
         pose_used = torch.empty_like(pose)
-        o_s, d_s, hit, zo, view, t_vals0 = ops.ray_prologue(rays.origins, rays.directions, pose, ext, rays.viewdirs, near,
-                                                            far, N, noise['t_rand'] if randomized else None, self.lindisp,
-                                                            pose_copy=pose_used, zero=zero_fill)
+        pro = ops.ray_prologue(rays.origins, rays.directions, pose, ext, rays.viewdirs, near, far, N,
+                               noise['t_rand'] if (randomized and seed is None) else None, self.lindisp,
+                               pose_copy=pose_used, zero=zero_fill, seed=seed)
+        o_s, d_s, hit, zo, view, t_vals0 = pro[:6]
+        if seed is not None:
+            noise = dict(t_rand=None, u_rand=pro[6])
         if use_dd:
             (idx, count, slot), cls = ops.compact_all(hit, N)     # cls also counts the boxes each ray hits
         else:
@@ -466,9 +476,14 @@ class MipNerfModel:
                                       'density noise)')
         B, N = rays.origins.shape[0], self.num_samples
         dev = rays.origins.device
+        seed = None
         if randomized and noise is None:
-            u = torch.rand(2, B, N + 1, device=dev, generator=_make_generator(rng, dev))
-            noise = dict(t_rand=u[0], u_rand=u[1])
+            if isinstance(rng, torch.Generator):
+                u = torch.rand(2, B, N + 1, device=dev, generator=rng)
+                noise = dict(t_rand=u[0], u_rand=u[1])
+            else:                                   # the library draws (durf_forward_args.draw_noise), as in apply()
+                seed = int(rng) if rng is not None else 0
+                noise = dict(t_rand=None, u_rand=None)
         pose = variables['params']['box_centers'][int(ts)].contiguous()
         flags = ((ops.ENC_CONTRACT if self.contraction else 0) | (ops.ENC_NO_INTEGRATION if self.disable_integration else 0) |
                  (ops.ENC_CYLINDER if self.ray_shape == 'cylinder' else 0))
@@ -478,7 +493,7 @@ class MipNerfModel:
             rays, pose, ext.reshape(-1, 3).contiguous() if K else None, variables.mlp_flat('MLP_0'),
             variables.flat[o0:o0 + K * lay.mlp_size[W_OBJ]] if K else None, lay.mlp_size[W_OBJ], N, self.num_levels, alpha, flags,
             lindisp=self.lindisp, bkgd_mode=bk, density_bias=self.density_bias, resample_padding=self.resample_padding,
-            t_rand=noise['t_rand'] if randomized else None, u_rand=noise['u_rand'] if randomized else None)
+            t_rand=noise['t_rand'] if randomized else None, u_rand=noise['u_rand'] if randomized else None, seed=seed)
         box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
         return [tuple(o) + ([pose[:, :3], box_rot0], dyn, zo) for o in outs]
 

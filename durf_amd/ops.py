@@ -71,10 +71,13 @@ def ray_setup(origins, dirs, pose, ext):
     return o_s, d_s, hit, zo
 
 
-def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, lindisp=False, pose_copy=None, zero=None):
+def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, lindisp=False, pose_copy=None, zero=None,
+                 seed=None):
     """ray_setup + view_enc (bf16) + sample_t as ONE launch (durf_ray_prologue)
     -> origins_s[B,3], dirs_s[B,3], hit[B,K] int32, zo[B], view[B,32] bf16, t_vals[B,N+1]
-    pose_copy [K,6]: receives a snapshot of `pose`; zero: a contiguous fp32 tensor the launch zero fills (the gradient)"""
+    pose_copy [K,6]: receives a snapshot of `pose`; zero: a contiguous fp32 tensor the launch zero fills (the gradient)
+    seed (int, instead of t_rand): the launch draws the step's stratified-sampling noise itself (Philox under this key) and
+    also returns u_rand[B,N+1], the resampling draws of the following levels -> (..., t_vals, u_rand)"""
     B, K = origins.shape[0], pose.shape[0]
     dev = origins.device
     if zero is not None:
@@ -85,12 +88,23 @@ def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, 
     zo = torch.empty(B, device=dev)
     view = torch.empty(B, VIEW_DIM, dtype=torch.bfloat16, device=dev)
     t = torch.empty(B, N + 1, device=dev)
+    u_out = None
+    if seed is not None:
+        assert t_rand is None
+        u_out = torch.empty(B, N + 1, device=dev)
+    lo, hi = (0, 0) if seed is None else split_seed(seed)
     _lib.check(_lib.lib().durf_ray_prologue(_stream(), B, K, N, _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
                                             _p(_f32(ext)), _p(o_s), _p(d_s), _p(hit), _p(zo), _p(_f32(viewdirs)), _p(view),
                                             _p(_f32(near)), _p(_f32(far)), _p(None if t_rand is None else _f32(t_rand)),
                                             int(lindisp), _p(t), _p(pose_copy if K else None), _p(zero),
-                                            0 if zero is None else zero.numel()), 'durf_ray_prologue')
-    return o_s, d_s, hit, zo, view, t
+                                            0 if zero is None else zero.numel(), lo, hi, _p(u_out)), 'durf_ray_prologue')
+    return (o_s, d_s, hit, zo, view, t) if seed is None else (o_s, d_s, hit, zo, view, t, u_out)
+
+
+def split_seed(seed):
+    """host PRNG key (any Python int) -> the two 32-bit key words of the in-kernel Philox stream"""
+    s = int(seed) & 0xFFFFFFFFFFFFFFFF
+    return s & 0xFFFFFFFF, s >> 32
 
 
 def compact_all(hit, N):
@@ -974,7 +988,8 @@ class ForwardArgs(C.Structure):
                                            'bkgd_params', 'obj_params')] +
                 [('obj_param_stride', C.c_size_t), ('t_rand', C.c_void_p), ('u_rand', C.c_void_p)] +
                 [(n, _vp4) for n in ('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')] +
-                [('dyn_mask', C.c_void_p), ('zo', C.c_void_p)])
+                [('dyn_mask', C.c_void_p), ('zo', C.c_void_p), ('draw_noise', C.c_int), ('seed_lo', C.c_uint32),
+                 ('seed_hi', C.c_uint32)])
 
 
 class TrainArgs(C.Structure):
@@ -993,7 +1008,7 @@ TRAIN_OBJ_FP32, TRAIN_POSE_OPT = 1, 2          # durf_train_args.flags
 
 
 def _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
-                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep):
+                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=None):
     B, K = rays.origins.shape[0], pose.shape[0]
     a.B, a.N, a.K, a.num_levels, a.enc_flags, a.lindisp, a.bkgd_mode = B, N, K, num_levels, enc_flags, int(lindisp), bkgd_mode
     a.density_bias, a.resample_padding = density_bias, resample_padding
@@ -1006,13 +1021,15 @@ def _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_st
     a.bkgd_params = _p(_f32(bkgd_params))
     a.obj_params, a.obj_param_stride = (_p(_f32(obj_params)) if K else None), int(obj_param_stride)
     a.t_rand, a.u_rand = _p(t_rand), _p(u_rand)
+    a.draw_noise = int(seed is not None)
+    a.seed_lo, a.seed_hi = (0, 0) if seed is None else split_seed(seed)
     for i, name in enumerate(('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')):
         setattr(a, name, _vp4(*([o[i].data_ptr() for o in outs] + [None] * (FORWARD_MAX_LEVELS - num_levels))))
     a.dyn_mask, a.zo = _p(dyn), _p(zo)
 
 
 def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp=False,
-                 bkgd_mode=BKGD_GREY, density_bias=-1.0, resample_padding=0.01, t_rand=None, u_rand=None):
+                 bkgd_mode=BKGD_GREY, density_bias=-1.0, resample_padding=0.01, t_rand=None, u_rand=None, seed=None):
     """MipNerfModel.__call__ in inference as ONE library call (durf_forward): -> list[num_levels] of
     (rgb, depth, acc, weights, t_vals, t_mids, t_dists), dyn_mask [B,1] int32, zo [B]"""
     B, K = rays.origins.shape[0], pose.shape[0]
@@ -1024,7 +1041,7 @@ def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, 
     a = ForwardArgs()
     keep = []
     _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
-                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep)
+                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=seed)
     ws = torch.empty(int(L.durf_forward_workspace_bytes(B, N, K)), dtype=torch.uint8, device=dev)
     assert ws.data_ptr() % 256 == 0
     with _Timed('forward_call'):
@@ -1036,7 +1053,7 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
                lossmult, pixels, gt_depth, sky, target6, prev6, eps, box_loss_mult, bg, disable_multiscale, level_mults,
                stat_mults, lr, max_val, max_norm, step, lindisp=False, bkgd_mode=BKGD_GREY, density_bias=-1.0,
                resample_padding=0.01, t_rand=None, u_rand=None, update=True, obj_fp32=False, want_pos=False, want_rot=False,
-               tv_loss_mult=0.0):
+               tv_loss_mult=0.0, seed=None):
     """One shard's training step as ONE library call (durf_train_step; update=False: durf_loss_backward, parameters
     untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None).
     obj_fp32: the object branch on the exact-fp32 kernels; want_pos / want_rot: box-pose optimisation behind it (`pose` must
@@ -1054,7 +1071,7 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
     keep = []
     o0 = box_floats + mlp0_floats
     _fill_forward_args(a.f, rays, pose, ext, params_flat[box_floats:o0], params_flat[o0:] if K else None, obj_floats, N, num_levels,
-                       alpha, enc_flags, lindisp, bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep)
+                       alpha, enc_flags, lindisp, bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=seed)
     hold = [t.reshape(-1).contiguous() for t in (lossmult, gt_depth, sky)] + [pixels.contiguous()]
     a.lossmult, a.gt_depth, a.sky, a.pixels = (_p(_f32(t)) for t in hold)
     hold += [target6.contiguous(), prev6.contiguous()] if K else []

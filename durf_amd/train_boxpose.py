@@ -395,9 +395,14 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
     rays = batch['rays']
     B = rays.origins.shape[0]
     dev = variables.flat.device
+    seed = None
     if config.randomized and noise is None:
-        u = torch.rand(2, B, N + 1, device=dev, generator=om._make_generator(rng, dev))
-        noise = dict(t_rand=u[0], u_rand=u[1])
+        if isinstance(rng, torch.Generator):
+            u = torch.rand(2, B, N + 1, device=dev, generator=rng)
+            noise = dict(t_rand=u[0], u_rand=u[1])
+        else:                                       # the library draws (durf_forward_args.draw_noise), as train_step does
+            seed = int(rng) if rng is not None else 0
+            noise = dict(t_rand=None, u_rand=None)
     ts = int(batch['ts'])
     pose = variables['params']['box_centers'][ts]          # a view of the parameters: the pose gradient goes to the same rows
     assert pose.is_contiguous()
@@ -414,7 +419,7 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         density_bias=model.density_bias, resample_padding=model.resample_padding,
         t_rand=noise['t_rand'] if config.randomized else None, u_rand=noise['u_rand'] if config.randomized else None,
         update=update, obj_fp32=obj_fp32, want_pos=pose_opt and not model.no_pose_opt, want_rot=pose_opt and not model.no_yaw_opt,
-        tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0)
+        tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0, seed=seed)
     box_rot0 = pose_used[0, 3:] if K > 0 else torch.zeros(3, device=dev)
     ret = [tuple(o) + ([pose_used[:, :3], box_rot0], dyn, zo) for o in outs]
     st = ops.stats_views(out, L)

@@ -48,8 +48,8 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_compact_all.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, B, K, N, hit, idx_obj, count_obj, slot_obj, idx_cls, count_cls, slot_cls, dyn)
     L.durf_ray_prologue.restype = i32
-    L.durf_ray_prologue.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64]
-    #   (stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count)
+    L.durf_ray_prologue.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64, C.c_uint32, C.c_uint32, vp]
+    #   (stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count, seed_lo, seed_hi, u_rand_out)
     L.durf_sample_t.restype = i32
     L.durf_sample_t.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
     #   (stream, B, N, near, far, t_rand, lindisp, t_vals)

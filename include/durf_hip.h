@@ -115,12 +115,18 @@ int durf_compact_all(void* stream, int B, int K, int N, const int32_t* hit, int3
  * output) and durf_sample_t -- same kernels' code, same results.  Two chores of a training step ride along (each a launch of
  * its own otherwise): pose_copy [K,6] receives a snapshot of `pose` (train_step returns the poses it rendered with,
  * train_boxpose.py:315, while the optimizer updates the parameters in place), and zero_buf[0..zero_count) -- the flat
- * gradient buffer, 16-byte aligned -- is zero filled. */
+ * gradient buffer, 16-byte aligned -- is zero filled.
+ * u_rand_out (nullable [B,N+1]; t_rand must then be NULL): the launch DRAWS the step's stratified-sampling noise itself, as
+ * the reference draws inside its program (mip.py:364, math.py:257-260): Philox4x32-10 with counter (i, 0, 0, 0) and key
+ * (seed_lo, seed_hi) for i in [0, B (N+1)); its output word 0, as (x >> 8) 2^-24 in [0, 1), jitters level-0 sample
+ * position i exactly as t_rand[i] would, word 1 is written to u_rand_out[i] -- the u_rand of durf_composite_resample /
+ * durf_resample for the following levels.  No generator launch in front of the step; oracle/philox_ref.py restates it. */
 int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
                       const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
                       const float* viewdirs, void* view_bf16, const float* near, const float* far,
                       const float* t_rand /* nullable */, int lindisp, float* t_vals, float* pose_copy /* nullable */,
-                      float* zero_buf /* nullable */, size_t zero_count);
+                      float* zero_buf /* nullable */, size_t zero_count, uint32_t seed_lo, uint32_t seed_hi,
+                      float* u_rand_out /* nullable */);
 
 /* mip.sample_along_rays t_vals (mip.py:353-368). t_rand nullable (randomized=False). */
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
@@ -349,13 +355,15 @@ typedef struct durf_forward_args {
     const float *bkgd_params;           /* MLP_0: Dense_0..11 (kernel[in,out], bias) flat */
     const float *obj_params;            /* BoxMLP_0 .. BoxMLP_{K-1}, obj_param_stride floats apart */
     size_t obj_param_stride;
-    const float *t_rand, *u_rand;       /* nullable [B,N+1] each: randomized=False */
+    const float *t_rand, *u_rand;       /* nullable [B,N+1] each: randomized=False (or draw_noise) */
     /* outputs, per level: rgb [B,3], depth / acc [B], weights / t_mids / t_dists [B,N], t_vals [B,N+1] */
     float *rgb[DURF_FORWARD_MAX_LEVELS], *depth[DURF_FORWARD_MAX_LEVELS], *acc[DURF_FORWARD_MAX_LEVELS];
     float *weights[DURF_FORWARD_MAX_LEVELS], *t_vals[DURF_FORWARD_MAX_LEVELS], *t_mids[DURF_FORWARD_MAX_LEVELS];
     float *t_dists[DURF_FORWARD_MAX_LEVELS];
     int32_t* dyn_mask;                  /* [B] boxes hit per ray (the 10-tuple's dyn_mask) */
     float* zo;                          /* [B] */
+    int draw_noise;                     /* != 0 (t_rand = u_rand = NULL): randomized=True with the draws made by the library */
+    uint32_t seed_lo, seed_hi;          /*   -- durf_ray_prologue's Philox stream under this key (the host's PRNG key) */
 } durf_forward_args;
 size_t durf_forward_workspace_bytes(int B, int N, int K);
 int durf_forward(void* stream, const durf_forward_args* args, void* workspace);

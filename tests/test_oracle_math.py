@@ -160,3 +160,21 @@ def test_piecewise_constant_pdf_single_bin():
             s = R.sorted_piecewise_constant_pdf(torch.rand(1, 625, generator=g), bins[None], w[None], 625,
                                                 randomized)[0]
             assert (s >= bins[i]).all() and (s <= bins[i + 1]).all()
+
+
+def test_philox_restatement_reproduces_the_generators_known_answer_vectors():
+    """oracle/philox_ref.py (the checker of the in-kernel sampling draws, tests/test_gpu_sampling_noise.py) against the
+    published Random123 vectors for philox4x32 with 10 rounds, and the shape / range of the draws it derives from them"""
+    import numpy as np
+    from oracle import philox_ref as P
+    for ctr, key, want in P.KAT:
+        got = P.philox4x32_10(np.array([ctr], dtype=np.uint32), np.array([key], dtype=np.uint32))[0]
+        assert [int(x) for x in got] == list(want)
+    t, u = P.step_draws((7 << 32) | 9, 33, 64)
+    assert t.shape == u.shape == (33, 65) and t.dtype == np.float32
+    assert 0.0 <= t.min() and t.max() < 1.0 and 0.0 <= u.min() and u.max() < 1.0
+    t2, _ = P.step_draws((7 << 32) | 10, 33, 64)
+    assert not np.array_equal(t, t2)
+    # counter i is the flat sample position: a larger batch extends the stream, it does not reshuffle it
+    tb, ub = P.step_draws((7 << 32) | 9, 66, 64)
+    assert np.array_equal(tb.reshape(-1)[:t.size], t.reshape(-1)) and np.array_equal(ub.reshape(-1)[:u.size], u.reshape(-1))
