@@ -10,6 +10,7 @@
 // Flow per level:  durf_loss_prep  -> per-ray {m, dm, sm, min dist^2, dyn}  -> durf_reduce_rows
 //                  -> norm[] (device)  -> durf_loss_bwd -> d(raw) [B*N,4] + per-ray loss terms
 #include "loss_common.h"
+#include "optim_scrub.h"
 
 struct ObjPtrsL { const float* p[DURF_MAX_OBJ]; };
 
@@ -271,11 +272,11 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
 struct TvalPtrs { const float* p[DURF_MAX_LEVELS]; };
 struct StatMults { float coarse, sky, depth, near, empty, tv; };
 
-__global__ void __launch_bounds__(1024)
-k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __restrict__ sums,
-              const float* __restrict__ weight_l2, const float* __restrict__ pose6,
-              const float* __restrict__ prev6, const float* __restrict__ target6, TvalPtrs tv, TvalPtrs terms, int B,
-              StatMults m, int mode, float* __restrict__ out) {
+__device__ __forceinline__ void
+train_stats_body(int L, int K, int N, const float* __restrict__ norms, float* __restrict__ sums,
+                 const float* __restrict__ weight_l2, const float* __restrict__ pose6,
+                 const float* __restrict__ prev6, const float* __restrict__ target6, const TvalPtrs& tv, const TvalPtrs& terms, int B,
+                 const StatMults& m, int mode, float* __restrict__ out) {
     // terms given: the per-ray loss terms [LT_ROWS, B] of every level are reduced HERE (the order of k_reduce_rows, so
     // the sums are the ones durf_loss_bwd's own reduction launch would have produced) and left in sums [L, LT_ROWS]
     // (all rows at once: the 1024 threads form the same strided partial sums, xor-shuffle trees and in-order sum of the 16
@@ -386,6 +387,35 @@ k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __res
     }
 }
 
+__global__ void __launch_bounds__(1024)
+k_train_stats(int L, int K, int N, const float* __restrict__ norms, float* __restrict__ sums,
+              const float* __restrict__ weight_l2, const float* __restrict__ pose6,
+              const float* __restrict__ prev6, const float* __restrict__ target6, TvalPtrs tv, TvalPtrs terms, int B,
+              StatMults m, int mode, float* __restrict__ out) {
+    train_stats_body(L, K, N, norms, sums, weight_l2, pose6, prev6, target6, tv, terms, B, m, mode, out);
+}
+
+// The tail of a training step as ONE launch instead of three: workgroup 0 assembles the logged scalars (k_train_stats'
+// body), the others run the optimizer's scrub pass over the flat gradient, four 256-thread virtual blocks each
+// (optim_scrub.h: k_grad_scrub's body, same partials), with the multi-hit outcome (k_poison_multi_hit) folded in.  The
+// two halves share nothing; as launches of their own they were 4.7 + 10 + 6 us of a 0.45-0.7 ms step.
+__global__ void __launch_bounds__(1024)
+k_stats_scrub(int L, int K, int N, const float* __restrict__ norms, float* __restrict__ sums,
+              const float* __restrict__ weight_l2, const float* __restrict__ pose6,
+              const float* __restrict__ prev6, const float* __restrict__ target6, TvalPtrs tv, TvalPtrs terms, int B,
+              StatMults m, int mode, float* __restrict__ out, size_t n, float* __restrict__ g, float inv_world, float max_val,
+              float* __restrict__ part, PoisonArgs pa) {
+    if (blockIdx.x == 0) {
+        train_stats_body(L, K, N, norms, sums, weight_l2, pose6, prev6, target6, tv, terms, B, m, mode, out);
+        return;
+    }
+    __shared__ float s_sq[16], s_mx[16];
+    const int sub = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const size_t vb = (size_t)(blockIdx.x - 1) * 4 + sub;
+    const size_t nvb = (n + OPT_BLOCK * OPT_PER_THREAD - 1) / (OPT_BLOCK * OPT_PER_THREAD);
+    scrub_vblock(n, g, inv_world, max_val, part, vb, tid, s_sq + 4 * sub, s_mx + 4 * sub, pa, vb < nvb);
+}
+
 namespace durf {
 void launch_reduce_rows(hipStream_t s, int rows, int n, int min_row, const float* in, float* out) {
     hipLaunchKernelGGL(k_reduce_rows, dim3(rows), dim3(1024), 0, s, n, min_row, in, out);
@@ -451,6 +481,31 @@ int durf_train_stats(void* stream, int L, int K, int N, const float* norms, floa
     hipLaunchKernelGGL(k_train_stats, dim3(1), dim3(1024), 0, (hipStream_t)stream, L, K, N, norms, sums, weight_l2,
                        pose6, prev6, target6, tv, tm, B, m, mode, out);
     DURF_CHECK_LAUNCH("durf_train_stats");
+    return 0;
+}
+
+int durf_stats_scrub(void* stream, int L, int K, int N, const float* norms, float* sums, const float* weight_l2,
+                     const float* pose6, const float* prev6, const float* target6, const float* const* t_vals,
+                     const float* mults, int mode, float* out, const float* const* terms, int B, size_t n, float* grad,
+                     float inv_world, float max_val, float* scratch, const int32_t* cls_count, size_t box_floats, int K_boxes,
+                     size_t mlp0_floats, size_t obj_floats) {
+    DURF_REQUIRE(L >= 1 && L <= DURF_MAX_LEVELS, "1 <= num_levels <= DURF_MAX_LEVELS");
+    DURF_REQUIRE(n > 0 && grad != nullptr && scratch != nullptr, "the flat gradient and the scrub partials");
+    DURF_REQUIRE(cls_count == nullptr || (K_boxes >= 1 && K_boxes <= DURF_MAX_OBJ && obj_floats > 0 &&
+                                          n == box_floats + mlp0_floats + (size_t)K_boxes * obj_floats),
+                 "multi-hit outcome: flat layout box_centers | MLP_0 | K object MLPs, the WHOLE buffer");
+    TvalPtrs tv, tm;
+    for (int l = 0; l < DURF_MAX_LEVELS; l++) {
+        tv.p[l] = l < L ? t_vals[l] : nullptr;
+        tm.p[l] = (terms && l < L) ? terms[l] : nullptr;
+    }
+    const StatMults m = {mults[0], mults[1], mults[2], mults[3], mults[4], mults[5]};
+    PoisonArgs pa{};
+    pa.cls_count = cls_count; pa.box_floats = box_floats; pa.mlp0_floats = mlp0_floats; pa.obj_floats = obj_floats; pa.K = K_boxes;
+    const size_t nvb = durf_cdiv(n, OPT_BLOCK * OPT_PER_THREAD);
+    hipLaunchKernelGGL(k_stats_scrub, dim3(1 + durf_cdiv(nvb, 4)), dim3(1024), 0, (hipStream_t)stream, L, K, N, norms, sums,
+                       weight_l2, pose6, prev6, target6, tv, tm, B, m, mode, out, n, grad, inv_world, max_val, scratch, pa);
+    DURF_CHECK_LAUNCH("durf_stats_scrub");
     return 0;
 }
 

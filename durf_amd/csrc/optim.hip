@@ -4,39 +4,12 @@
 //   1. scrub (nan/+inf -> 0, -inf -> -FLT_MAX), value clip, per-block sum of squares / abs max
 //   2. Adam update with the scaled gradient; every workgroup first derives the global norm, abs max and clip multiplier
 //      from the per-block partials (a separate single-workgroup launch in round 1)
-#include "durf_common.h"
-
-#define OPT_BLOCK 256
-#define OPT_PER_THREAD 8
+#include "optim_scrub.h"
 
 __global__ void __launch_bounds__(OPT_BLOCK)
 k_grad_scrub(size_t n, float* __restrict__ g, float inv_world, float max_val, float* __restrict__ part) {
     __shared__ float s_sq[OPT_BLOCK / 64], s_mx[OPT_BLOCK / 64];
-    const size_t base = (size_t)blockIdx.x * OPT_BLOCK * OPT_PER_THREAD;
-    float sq = 0.0f, mx = 0.0f;
-#pragma unroll
-    for (int i = 0; i < OPT_PER_THREAD; i++) {
-        const size_t idx = base + (size_t)i * OPT_BLOCK + threadIdx.x;
-        if (idx < n) {
-            float v = g[idx] * inv_world;                       // pmean over devices (:253)
-            if (v != v || v == __builtin_inff()) v = 0.0f;      // nan_to_num(g, posinf=0.0) (:263)
-            else if (v == -__builtin_inff()) v = -3.4028234663852886e+38f;
-            if (max_val > 0.0f) v = fminf(fmaxf(v, -max_val), max_val);   // :275-277
-            g[idx] = v;
-            sq += v * v;
-            mx = fmaxf(mx, fabsf(v));
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { sq += __shfl_xor(sq, o, 64); mx = fmaxf(mx, __shfl_xor(mx, o, 64)); }
-    if ((threadIdx.x & 63) == 0) { s_sq[threadIdx.x >> 6] = sq; s_mx[threadIdx.x >> 6] = mx; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = 0.0f, m = 0.0f;
-        for (int w = 0; w < OPT_BLOCK / 64; w++) { a += s_sq[w]; m = fmaxf(m, s_mx[w]); }
-        part[2 * blockIdx.x] = a;
-        part[2 * blockIdx.x + 1] = m;
-    }
+    scrub_vblock(n, g, inv_world, max_val, part, blockIdx.x, threadIdx.x, s_sq, s_mx, PoisonArgs{}, true);
 }
 
 // The global norm / clip multiplier from the per-block partials.  Every workgroup of the Adam launch recomputes it (537
@@ -117,6 +90,20 @@ int durf_poison_multi_hit(void* stream, size_t n, float* grad, const int32_t* cl
 
 size_t durf_optim_scratch_floats(size_t n) {
     return 2 * (size_t)durf_cdiv(n, OPT_BLOCK * OPT_PER_THREAD) + 4;
+}
+
+// The Adam half of durf_clip_adam alone, behind a scrub that ran elsewhere (durf_stats_scrub): `scratch` holds that pass's
+// partials of the same n.
+int durf_adam_apply(void* stream, size_t n, float* params, float* m, float* v, const float* grad, float max_norm, float lr,
+                    int step, const float* scratch, float* stats) {
+    if (n == 0) return 0;
+    const int nb = (int)durf_cdiv(n, OPT_BLOCK * OPT_PER_THREAD);
+    const double b1 = 0.9, b2 = 0.999;
+    const double t = (double)step + 1.0;
+    hipLaunchKernelGGL(k_adam, dim3(durf_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, n, params, m, v, grad, nb, scratch,
+                       max_norm, stats, lr, (float)b1, (float)b2, 1e-8f, (float)(1.0 - pow(b1, t)), (float)(1.0 - pow(b2, t)));
+    DURF_CHECK_LAUNCH("durf_adam_apply");
+    return 0;
 }
 
 // grad is modified in place (mean over world, scrub, value clip); stats[4] receives

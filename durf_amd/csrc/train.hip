@@ -149,7 +149,9 @@ int check_args(const durf_train_args* a, void* workspace) {
 
 #define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)
 
-int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
+// tail: the multi-hit outcome and the logged scalars as launches of their own (durf_loss_backward: the caller gets the
+// un-post-processed gradient); durf_train_step folds both into the optimizer's first launch (durf_stats_scrub)
+int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool tail = true) {
     const durf_forward_args& f = a->f;
     const int B = f.B, N = f.N, K = f.K, L = f.num_levels;
     const size_t rows = (size_t)B * N;
@@ -275,6 +277,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w) {
             hipLaunchKernelGGL(k_tv_rows, dim3(1), dim3(64), 0, hs, K, f.pose, a->prev6, c, g_rows);
         }
     }
+    if (!tail) return 0;
     if (K > 1)                  // rays that hit two boxes: the reference's NaN -> zero update (durf_poison_multi_hit)
         STEP(durf_poison_multi_hit(stream, a->n_params, a->grad, w.count_cls, a->box_floats, K, a->mlp0_floats, a->obj_floats));
     // ---- the logged scalars (utils.Stats), one launch ----
@@ -308,9 +311,20 @@ int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
     if (rc != 0) return rc;
     DURF_REQUIRE(a->adam_m && a->adam_v && a->grad_stats, "Adam moments and grad_stats");
     const TrainWs w = carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params, a->flags);
-    STEP(loss_backward(stream, a, w));
-    return durf_clip_adam(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, 1.0f, a->max_val, a->max_norm, a->lr, a->step,
-                          w.scratch, a->grad_stats);
+    STEP(loss_backward(stream, a, w, false));
+    // the step's tail in two launches (as durf_amd/train_boxpose.py issues it on one device): the logged scalars + the
+    // multi-hit outcome + the optimizer's scrub pass, then Adam
+    const durf_forward_args& f = a->f;
+    const int K = f.K, L = f.num_levels;
+    const float* tv[ML];
+    const float* terms[ML];
+    for (int l = 0; l < L; l++) { tv[l] = f.t_vals[l]; terms[l] = w.terms[l]; }
+    STEP(durf_stats_scrub(stream, L, K, f.N, w.norms, w.sums, nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
+                          K ? a->target6 : nullptr, tv, a->stat_mults, 3 /* assemble | psnr */, a->stats, terms, f.B, a->n_params,
+                          a->grad, 1.0f, a->max_val, w.scratch, K > 1 ? w.count_cls : nullptr, a->box_floats, K > 1 ? K : 0,
+                          a->mlp0_floats, a->obj_floats));
+    return durf_adam_apply(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, a->max_norm, a->lr, a->step, w.scratch,
+                           a->grad_stats);
 }
 
 }  // extern "C"

@@ -277,13 +277,13 @@ class MipNerfModel:
         raw_tail = None
         ret = []
         t_vals = weights = None
-        box_rot0 = pose_used[0, 3:] if K > 0 else torch.zeros(3, device=dev)
+        box_rot0 = pose_used[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))
         if cls is not None:
             dyn_mask = cls[3].reshape(B, 1)
         elif K > 1:
             dyn_mask = hit.sum(dim=-1, keepdim=True, dtype=torch.int32)
         else:
-            dyn_mask = hit if K == 1 else torch.zeros(B, 1, dtype=torch.int32, device=dev)
+            dyn_mask = hit if K == 1 else ops.const_tensor(dev, (B, 1), torch.int32)
         if loss_prep is not None:
             if self.num_levels < 2:
                 loss_prep = None
@@ -494,7 +494,7 @@ class MipNerfModel:
             variables.flat[o0:o0 + K * lay.mlp_size[W_OBJ]] if K else None, lay.mlp_size[W_OBJ], N, self.num_levels, alpha, flags,
             lindisp=self.lindisp, bkgd_mode=bk, density_bias=self.density_bias, resample_padding=self.resample_padding,
             t_rand=noise['t_rand'] if randomized else None, u_rand=noise['u_rand'] if randomized else None, seed=seed)
-        box_rot0 = pose[0, 3:] if K > 0 else torch.zeros(3, device=dev)
+        box_rot0 = pose[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))
         return [tuple(o) + ([pose[:, :3], box_rot0], dyn, zo) for o in outs]
 
     def apply(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,

@@ -119,13 +119,26 @@ def compact_all(hit, N):
     return (idx, count, slot), (idx2, count4, slot2, dyn)
 
 
+_CONST = {}
+
+
+def const_tensor(device, shape, dtype=torch.float32, value=0):
+    """A cached, READ-ONLY constant tensor (the K = 0 model's empty hit lists, zero dyn_mask / box_rot / multi-hit count):
+    a torch.zeros / torch.full per step is a fill launch each -- five of them were 5 % of a cfg1 step."""
+    key = (str(device), tuple(shape), dtype, value)
+    t = _CONST.get(key)
+    if t is None:
+        t = _CONST[key] = torch.full(tuple(shape), value, dtype=dtype, device=device)
+    return t
+
+
 def compact_hits(hit):
     """-> idx[K,B] int32, count[K] int32, slot[B,K] int32"""
     B, K = hit.shape
     dev = hit.device
     if K == 0:
-        return (torch.zeros(1, B, dtype=torch.int32, device=dev), torch.zeros(1, dtype=torch.int32, device=dev),
-                torch.full((B, 1), -1, dtype=torch.int32, device=dev))
+        return (const_tensor(dev, (1, B), torch.int32), const_tensor(dev, (1,), torch.int32),
+                const_tensor(dev, (B, 1), torch.int32, -1))
     # the kernel writes every slot and count entry, and idx[k, :count[k]] is all anyone reads
     idx = torch.empty(K, B, dtype=torch.int32, device=dev)
     count = torch.empty(K, dtype=torch.int32, device=dev)
@@ -562,6 +575,41 @@ def train_stats(norms, sums, weight_l2, pose6, prev6, target6, t_vals_levels, mu
                                            (C.c_void_p * L)(*[t.data_ptr() for t in terms]) if terms is not None else None,
                                            int(terms[0].shape[1]) if terms is not None else 0), 'durf_train_stats')
     return out
+
+
+def stats_scrub(norms, sums, weight_l2, pose6, prev6, target6, t_vals_levels, mults, mode, terms, grad, inv_world, max_val,
+                poison=None):
+    """train_stats + the scrub pass of clip_adam (+ the multi-hit outcome: poison = (cls_count, box_floats, K, mlp0_floats,
+    obj_floats) of poison_multi_hit, single device only) as ONE launch (durf_stats_scrub) -> (out [2 + 17 L], scratch);
+    adam_apply(.., scratch) finishes the update"""
+    L = norms.shape[0]
+    K = 0 if pose6 is None else pose6.shape[0]
+    N = t_vals_levels[0].shape[1] - 1
+    dev = norms.device
+    out = torch.empty(2 + 17 * L, device=dev)
+    n = grad.numel()
+    scratch = torch.empty(int(_lib.lib().durf_optim_scratch_floats(n)), device=dev)
+    ptrs = (C.c_void_p * L)(*[t.data_ptr() for t in t_vals_levels])
+    m = (C.c_float * 6)(*[float(x) for x in mults])
+    cls, bf, Kb, m0, of = poison if poison is not None else (None, 0, 0, 0, 0)
+    _lib.check(_lib.lib().durf_stats_scrub(_stream(), L, K, N, _p(norms), _p(sums), _p(weight_l2),
+                                           _p(pose6) if K else None, _p(prev6) if K else None, _p(target6) if K else None,
+                                           ptrs, m, mode, _p(out),
+                                           (C.c_void_p * L)(*[t.data_ptr() for t in terms]) if terms is not None else None,
+                                           int(terms[0].shape[1]) if terms is not None else 0, n, _p(_f32(grad)),
+                                           float(inv_world), float(max_val), _p(scratch), _p(cls), int(bf), int(Kb), int(m0),
+                                           int(of)), 'durf_stats_scrub')
+    return out, scratch
+
+
+def adam_apply(params, m, v, grad, max_norm, lr, step, scratch):
+    """the Adam pass of clip_adam behind stats_scrub's scrub pass -> stats[4] as clip_adam"""
+    _bump_generation(params)
+    stats = torch.empty(4, device=params.device)
+    _lib.check(_lib.lib().durf_adam_apply(_stream(), params.numel(), _p(_f32(params)), _p(_f32(m)), _p(_f32(v)),
+                                          _p(_f32(grad)), float(max_norm), float(lr), int(step), _p(scratch), _p(stats)),
+               'durf_adam_apply')
+    return stats
 
 
 def stats_views(out, L):

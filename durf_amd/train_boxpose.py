@@ -71,11 +71,13 @@ def level_multipliers(config, level, num_levels):
             0.000001]
 
 
-def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=None, objects_ready=None):
+def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=None, objects_ready=None, defer_poison=False):
     """value_and_grad(loss_fn) (train_boxpose.py:67-252) for this rank's shard.
     Returns (grad_flat, raw stats dict of device tensors, pose).
     objects_ready(grad_slice): called as soon as the K object MLPs' gradients are final (before the background MLP's
-    weight-gradient launch is issued) -- the hook of the bucketed all-reduce; forces the objects' own finalize launch."""
+    weight-gradient launch is issued) -- the hook of the bucketed all-reduce; forces the objects' own finalize launch.
+    defer_poison: the multi-hit outcome (ops.poison_multi_hit) is NOT applied here; raw['poison'] carries its arguments for
+    the optimizer's first launch (ops.stats_scrub; single device only -- an all-reduce has to see the NaNs)."""
     pose_opt = not (model.no_pose_opt and model.no_yaw_opt)
     rays = batch['rays']
     L = model.num_levels
@@ -209,10 +211,14 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     cls_count = dd['count'] if dd is not None else (
         ops.compact_classes(ctx['hit'], N)[1] if (lay.K > 1 and K > 0 and not f32) else None)
 
+    poison_args = None
+    if cls_count is not None and lay.K > 1:
+        poison_args = (cls_count, lay.box[1] - lay.box[0], lay.K, lay.mlp_size[om.W_BKGD], lay.mlp_size[om.W_OBJ])
+
     def poison(upto=None):
         # rays that hit two boxes: the reference's gradient is NaN -> 0 for everything they touch (ops.poison_multi_hit);
         # on the local gradient, before whoever all-reduces it
-        if cls_count is not None and lay.K > 1:
+        if poison_args is not None and not defer_poison:
             ops.poison_multi_hit(grad, cls_count, lay.box[1] - lay.box[0], lay.K, lay.mlp_size[om.W_BKGD],
                                  lay.mlp_size[om.W_OBJ], upto=upto)
 
@@ -295,9 +301,9 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     if dd is not None:
         multi = dd['multi_hit']
     else:
-        multi = (dyn > 1).sum() if lay.K > 1 else torch.zeros((), dtype=torch.int64, device=dev)
+        multi = (dyn > 1).sum() if lay.K > 1 else ops.const_tensor(dev, (), torch.int64)
     raw = dict(norms=norms, sums=sums, terms=terms, weight_l2=weight_l2, ret=ret, ctx=ctx, pose6=pose_ts if lay.K > 0 else None,
-               multi_hit=multi)
+               multi_hit=multi, poison=poison_args if defer_poison else None)
     return grad, raw, pose
 
 
@@ -333,15 +339,19 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     lay = variables.layout
     bucket = dist is not None and _bucketed() and lay.K > 0
     ready = (lambda g_obj: pending.append(dist.all_reduce(g_obj, async_op=True))) if bucket else None
-    grad, raw, pose = loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=noise, objects_ready=ready)
+    # the step's tail as two launches -- {logged scalars + multi-hit outcome + scrub} and Adam -- whenever the scalars are
+    # not all-reduced in between; with a process group the multi-hit NaNs have to exist before the all-reduce (own launch)
+    merged_tail = dist is None or not reduce_stats
+    grad, raw, pose = loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=noise, objects_ready=ready,
+                                    defer_poison=dist is None)
     world = 1
     if dist is not None:                                    # lax.pmean(grad) (:253)
         world = dist.get_world_size()
         rest = grad[:lay.mlp_off['BoxMLP_0']] if bucket else grad        # [box_centers | MLP_0] when the objects went ahead
         pending.append(dist.all_reduce(rest, async_op=True))
     L = model.num_levels
-    if dist is None or not reduce_stats:
-        out = _assemble_stats(config, batch, raw, prev, ops.STATS_ASSEMBLE | ops.STATS_PSNR)
+    if merged_tail:
+        out = None
     else:                                                   # lax.pmean(stats) (:255), then the PSNRs (:291-292)
         out = _assemble_stats(config, batch, raw, prev, ops.STATS_ASSEMBLE)
         dist.all_reduce(out)
@@ -350,9 +360,18 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
                         _stat_mults(config), ops.STATS_PSNR, out=out)
     for work in pending:
         work.wait()                                         # orders the current stream behind the collective(s)
+    if merged_tail:
+        pose6 = raw['pose6']
+        Kp = 0 if pose6 is None else pose6.shape[0]
+        out, scratch = ops.stats_scrub(raw['norms'], raw['sums'], raw['weight_l2'], pose6,
+                                       prev[0].contiguous() if Kp else None, batch['target'].contiguous() if Kp else None,
+                                       [r[4] for r in raw['ret']], _stat_mults(config), ops.STATS_ASSEMBLE | ops.STATS_PSNR,
+                                       raw['terms'], grad, 1.0 / world, float(config.grad_max_val), poison=raw['poison'])
+        gs = ops.adam_apply(variables.flat, state.m, state.v, grad, float(config.grad_max_norm), float(lr), state.step, scratch)
+    else:
+        gs = ops.clip_adam(variables.flat, state.m, state.v, grad, 1.0 / world, float(config.grad_max_val),
+                           float(config.grad_max_norm), float(lr), state.step)
     st = ops.stats_views(out, L)
-    gs = ops.clip_adam(variables.flat, state.m, state.v, grad, 1.0 / world, float(config.grad_max_val),
-                       float(config.grad_max_norm), float(lr), state.step)
     model.prefetch_const_trunk(variables)                   # (fp32 hit-ray path only) the next step's parameter-only work
     new_state = TrainState(variables, state.m, state.v, state.step + 1)
     ret = raw['ret']
@@ -420,7 +439,7 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         t_rand=noise['t_rand'] if config.randomized else None, u_rand=noise['u_rand'] if config.randomized else None,
         update=update, obj_fp32=obj_fp32, want_pos=pose_opt and not model.no_pose_opt, want_rot=pose_opt and not model.no_yaw_opt,
         tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0, seed=seed)
-    box_rot0 = pose_used[0, 3:] if K > 0 else torch.zeros(3, device=dev)
+    box_rot0 = pose_used[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))
     ret = [tuple(o) + ([pose_used[:, :3], box_rot0], dyn, zo) for o in outs]
     st = ops.stats_views(out, L)
     if not update:
@@ -434,7 +453,7 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         offset_yaw=st['offset_yaw'], pose=pose_out, weights=[r[3] for r in ret], samples=[r[4] for r in ret],
         weight_l2=st['weight_l2'], psnr=st['psnrs'][-1], psnrs=st['psnrs'], obj_psnr=st['obj_psnrs'][-1],
         grad_norm=gs[0], grad_abs_max=gs[1], grad_norm_clipped=gs[3],
-        multi_hit_rays=(dyn > 1).sum() if K > 1 else torch.zeros((), dtype=torch.int64, device=dev))
+        multi_hit_rays=(dyn > 1).sum() if K > 1 else ops.const_tensor(dev, (), torch.int64))
     new_rng = (int(rng) + 1) if isinstance(rng, int) else rng
     return TrainState(variables, state.m, state.v, state.step + 1), stats, new_rng, pose_out
 

@@ -227,6 +227,12 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_optim_scratch_floats.restype = u64
     L.durf_optim_scratch_floats.argtypes = [u64]
     #   (n)
+    L.durf_stats_scrub.restype = i32
+    L.durf_stats_scrub.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(f32), i32, vp, C.POINTER(vp), i32, u64, vp, f32, f32, vp, vp, u64, i32, u64, u64]
+    #   (stream, L, K, N, norms, sums, weight_l2, pose6, prev6, target6, t_vals, mults, mode, out, terms, B, n, grad, inv_world, max_val, scratch, cls_count, box_floats, K_boxes, mlp0_floats, obj_floats)
+    L.durf_adam_apply.restype = i32
+    L.durf_adam_apply.argtypes = [vp, u64, vp, vp, vp, vp, f32, f32, i32, vp, vp]
+    #   (stream, n, params, m, v, grad, max_norm, lr, step, scratch, stats)
     L.durf_poison_multi_hit.restype = i32
     L.durf_poison_multi_hit.argtypes = [vp, u64, vp, vp, u64, i32, u64, u64]
     #   (stream, n, grad, cls_count, box_floats, K, mlp0_floats, obj_floats)

@@ -538,6 +538,19 @@ int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, 
  * flax.optim.Adam).  grad is scaled by inv_world (pmean), scrubbed and clipped in place;
  * stats[4] = {grad_norm, grad_abs_max, clip multiplier, grad_norm_clipped}. */
 size_t durf_optim_scratch_floats(size_t n);
+/* The tail of a training step in TWO launches instead of four: durf_stats_scrub = durf_train_stats (same arguments, same
+ * scalars in `out`) + the first pass of durf_clip_adam over grad[0..n) (pmean scale inv_world, nan_to_num, value clip, the
+ * partials of the global norm in `scratch`, durf_optim_scratch_floats(n) floats) as ONE launch, with the multi-hit outcome
+ * of durf_poison_multi_hit folded into that pass when cls_count is given (single device: with a data-parallel all-reduce
+ * the NaNs have to exist BEFORE it, i.e. durf_poison_multi_hit stays a call of its own there); durf_adam_apply = the Adam
+ * pass of durf_clip_adam behind it.  Parameters, moments, gradient, scalars: bit-identical to the four separate calls. */
+int durf_stats_scrub(void* stream, int L, int K, int N, const float* norms, float* sums, const float* weight_l2 /* nullable */,
+                     const float* pose6, const float* prev6, const float* target6, const float* const* t_vals,
+                     const float* mults, int mode, float* out, const float* const* terms /* nullable */, int B, size_t n,
+                     float* grad, float inv_world, float max_val, float* scratch, const int32_t* cls_count /* nullable */,
+                     size_t box_floats, int K_boxes, size_t mlp0_floats, size_t obj_floats);
+int durf_adam_apply(void* stream, size_t n, float* params, float* m, float* v, const float* grad, float max_norm, float lr,
+                    int step, const float* scratch, float* stats);
 /* Reference semantics of rays that hit two boxes (obbpose_model.py:120-122: NaN colours -> NaN loss -> NaN gradient of
  * everything their path touches -> nan_to_num -> 0, train_boxpose.py:263): when cls_count[3] (durf_compact_classes) is
  * non-zero, the gradient segments of MLP_0 and of the boxes in cls_count[4] (their BoxMLP and their box_centers columns)

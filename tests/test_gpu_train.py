@@ -651,3 +651,47 @@ def test_the_prefetched_trunk_is_dropped_when_the_parameters_change_behind_torch
     want = run()
     for lvl in range(2):
         assert torch.equal(torch.nan_to_num(got[lvl][0]), torch.nan_to_num(want[lvl][0]))
+
+
+@pytest.mark.parametrize('multi_hit', [False, True])
+def test_the_two_launch_tail_equals_the_four_separate_launches(cuda, multi_hit):
+    """train_step's tail on one device is {logged scalars + multi-hit outcome + the optimizer's scrub pass} as ONE launch
+    (durf_stats_scrub) and Adam (durf_adam_apply) -- round 5's launch diet.  Against durf_poison_multi_hit +
+    durf_train_stats + durf_clip_adam (train_boxpose.py:257-289) on the same gradient: parameters, both moments, every logged
+    scalar and the gradient statistics are the same bits, with and without rays that hit two boxes."""
+    B, K, N = 256, 3, 32
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n'
+                    'Config.randomized = False\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
+                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = 0.0\n' % N)
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(B, K, seed=405, allow_multi_hit=multi_hit, **(dict(hit_range=(0.2, 0.4)) if multi_hit else {}))
+    db = H.device_batch(b, cuda)
+    prev = db['init'][0:1]
+    results = []
+    for merged in (False, True):
+        model, variables = obbpose_model.construct_mipnerf(7, db, device=cuda)
+        state = train_boxpose.create_train_state(variables)
+        state.m.normal_(generator=torch.Generator(device=cuda).manual_seed(1)).mul_(1e-3)
+        state.v.uniform_(generator=torch.Generator(device=cuda).manual_seed(2)).mul_(1e-6)
+        grad, raw, _ = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, 10.0, prev, defer_poison=merged)
+        if multi_hit:
+            assert int(raw['multi_hit']) > 0
+            assert (raw['poison'] is not None) == merged        # (NaNs of those rays reach MLP_0's gradient either way)
+        tvs = [r[4] for r in raw['ret']]
+        stat_args = (raw['norms'], raw['sums'], raw['weight_l2'], raw['pose6'], prev[0].contiguous(), db['target'].contiguous(),
+                     tvs, train_boxpose._stat_mults(config), ops.STATS_ASSEMBLE | ops.STATS_PSNR)
+        if merged:
+            out, scratch = ops.stats_scrub(*stat_args, raw['terms'], grad, 1.0, 0.1, poison=raw['poison'])
+            gs = ops.adam_apply(variables.flat, state.m, state.v, grad, 1.0, 5e-4, 3, scratch)
+        else:
+            out = ops.train_stats(*stat_args, terms=raw['terms'])
+            gs = ops.clip_adam(variables.flat, state.m, state.v, grad, 1.0, 0.1, 1.0, 5e-4, 3)
+        torch.cuda.synchronize()
+        results.append([variables.flat.clone(), state.m.clone(), state.v.clone(), grad.clone(), out.clone(), gs.clone(),
+                        raw['sums'].clone()])
+    for name, a, c in zip(('params', 'm', 'v', 'scrubbed gradient', 'logged scalars', 'gradient statistics', 'term sums'),
+                          results[0], results[1]):
+        assert torch.equal(a.view(torch.int32), c.view(torch.int32)), name      # (bitwise: the multi-hit loss is NaN, as the reference's)
+    assert multi_hit or float(results[0][5][0]) > 0          # (this multi-hit batch touches every box: an all-zero update)
