@@ -576,8 +576,10 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
                            # object MLP launches on a side HIP stream (ops.py DURF_OVERLAP_OBJECTS): with '2' the timed
                            # background kernels' durations include what runs beside them
                            object_streams=(ops.overlap_mode(B * NS) if K_OBJ and model.object_precision() == 'bf16' else None),
-                           collective=('%s all-reduce, world size %d%s' % ('gloo' if shared_gpu else 'rccl', world,
-                                                                           ' (forced)' if args.force_dist else ''))
+                           collective=('%s all-reduce, world size %d%s%s' % (
+                               'gloo' if shared_gpu else 'rccl', world, ' (forced)' if args.force_dist else '',
+                               ', issued in the compute stream by the library (DURF_INSTREAM_ALLREDUCE)'
+                               if train_boxpose._INSTREAM.get('comm') is not None else ''))
                            if (world > 1 or args.force_dist) else None),
                loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,
                # distribution of the individual steps' GPU time: ms_per_step is the mean over the timed region and
@@ -659,6 +661,7 @@ def main():
         out['workloads'] = extra
     if dist.is_initialized():
         dist.barrier()
+        train_boxpose.shutdown_instream()
         dist.destroy_process_group()
     if out is not None:
         # the ONE JSON line goes out last, after the process group is gone: RCCL prints a version banner to stdout when it

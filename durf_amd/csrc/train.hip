@@ -149,6 +149,11 @@ int check_args(const durf_train_args* a, void* workspace) {
 
 #define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)
 
+__global__ void k_scale(int n, float* __restrict__ x, float c) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] *= c;
+}
+
 // tail: the multi-hit outcome and the logged scalars as launches of their own (durf_loss_backward: the caller gets the
 // un-post-processed gradient); durf_train_step folds both into the optimizer's first launch (durf_stats_scrub)
 int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool tail = true) {
@@ -312,6 +317,38 @@ int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
     DURF_REQUIRE(a->adam_m && a->adam_v && a->grad_stats, "Adam moments and grad_stats");
     const TrainWs w = carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params, a->flags);
     STEP(loss_backward(stream, a, w, false));
+    if (a->comm != nullptr) {
+        // One rank's share of a data-parallel step (train_boxpose.py:253-255; durf_amd/train_boxpose.py train_step): the
+        // multi-hit NaNs have to exist BEFORE the exchange (the reference's pmean sees them), then ONE all-reduce of the flat
+        // gradient in this stream, and the optimizer on the mean.
+        DURF_REQUIRE(a->world >= 1, "world: the ranks of comm");
+        const durf_forward_args& f = a->f;
+        const int K = f.K, L = f.num_levels;
+        const float inv_world = 1.0f / (float)a->world;
+        const float* tv[ML];
+        const float* terms[ML];
+        for (int l = 0; l < L; l++) { tv[l] = f.t_vals[l]; terms[l] = w.terms[l]; }
+        if (K > 1)
+            STEP(durf_poison_multi_hit(stream, a->n_params, a->grad, w.count_cls, a->box_floats, K, a->mlp0_floats, a->obj_floats));
+        STEP(durf_allreduce_sum(stream, a->comm, a->grad, a->n_params));
+        if (!a->reduce_stats) {          // shard-local scalars (the reference reads them every print_every steps only)
+            STEP(durf_stats_scrub(stream, L, K, f.N, w.norms, w.sums, nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
+                                  K ? a->target6 : nullptr, tv, a->stat_mults, 3, a->stats, terms, f.B, a->n_params, a->grad,
+                                  inv_world, a->max_val, w.scratch, nullptr, 0, 0, 0, 0));
+            return durf_adam_apply(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, a->max_norm, a->lr, a->step,
+                                   w.scratch, a->grad_stats);
+        }
+        // lax.pmean(stats) (:255), then the PSNRs from the averaged losses (:291-292)
+        const int ns = 2 + 17 * L;
+        STEP(durf_train_stats(stream, L, K, f.N, w.norms, w.sums, nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
+                              K ? a->target6 : nullptr, tv, a->stat_mults, 1, a->stats, terms, f.B));
+        STEP(durf_allreduce_sum(stream, a->comm, a->stats, (size_t)ns));
+        hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, (hipStream_t)stream, ns, a->stats, inv_world);
+        STEP(durf_train_stats(stream, L, K, f.N, w.norms, w.sums, nullptr, nullptr, nullptr, nullptr, tv, a->stat_mults, 2, a->stats,
+                              nullptr, 0));
+        return durf_clip_adam(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, inv_world, a->max_val, a->max_norm,
+                              a->lr, a->step, w.scratch, a->grad_stats);
+    }
     // the step's tail in two launches (as durf_amd/train_boxpose.py issues it on one device): the logged scalars + the
     // multi-hit outcome + the optimizer's scrub pass, then Adam
     const durf_forward_args& f = a->f;

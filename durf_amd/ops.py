@@ -612,6 +612,39 @@ def adam_apply(params, m, v, grad, max_norm, lr, step, scratch):
     return stats
 
 
+class Comm:
+    """A communicator of the library's own in-stream all-reduce (csrc/comm.hip: RCCL resolved at run time)"""
+
+    def __init__(self, world, rank, uid):
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(uid), COMM_ID_BYTES)
+        _lib.check(_lib.lib().durf_comm_init(int(world), int(rank), C.cast(buf, C.c_void_p), C.byref(h)), 'durf_comm_init')
+        self.handle, self.world, self.rank = h, int(world), int(rank)
+
+    def all_reduce_sum(self, t):
+        """in place, on the current stream (fp32, contiguous)"""
+        assert t.dtype == torch.float32 and t.is_contiguous()
+        _lib.check(_lib.lib().durf_allreduce_sum(_stream(), self.handle, _p(t), t.numel()), 'durf_allreduce_sum')
+
+    def destroy(self):
+        if self.handle:
+            _lib.check(_lib.lib().durf_comm_destroy(self.handle), 'durf_comm_destroy')
+            self.handle = None
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_available():
+    return bool(_lib.lib().durf_comm_available())
+
+
+def comm_unique_id():
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    _lib.check(_lib.lib().durf_comm_unique_id(C.cast(buf, C.c_void_p)), 'durf_comm_unique_id')
+    return buf.raw
+
+
 def stats_views(out, L):
     """dict of named views into the durf_train_stats buffer"""
     d = {'loss': out[0], 'sampling_stats': out[1 + 15 * L:1 + 17 * L], 'weight_l2': out[1 + 17 * L]}
@@ -1049,7 +1082,8 @@ class TrainArgs(C.Structure):
                 [(n, C.c_size_t) for n in ('n_params', 'box_floats', 'mlp0_floats', 'obj_floats')] +
                 [(n, C.c_void_p) for n in ('grad', 'stats', 'adam_m', 'adam_v')] +
                 [('lr', C.c_float), ('max_val', C.c_float), ('max_norm', C.c_float), ('step', C.c_int), ('grad_stats', C.c_void_p),
-                 ('flags', C.c_int), ('want_pos', C.c_int), ('want_rot', C.c_int), ('tv_loss_mult', C.c_float)])
+                 ('flags', C.c_int), ('want_pos', C.c_int), ('want_rot', C.c_int), ('tv_loss_mult', C.c_float),
+                 ('comm', C.c_void_p), ('world', C.c_int), ('reduce_stats', C.c_int)])
 
 
 TRAIN_OBJ_FP32, TRAIN_POSE_OPT = 1, 2          # durf_train_args.flags
@@ -1101,7 +1135,7 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
                lossmult, pixels, gt_depth, sky, target6, prev6, eps, box_loss_mult, bg, disable_multiscale, level_mults,
                stat_mults, lr, max_val, max_norm, step, lindisp=False, bkgd_mode=BKGD_GREY, density_bias=-1.0,
                resample_padding=0.01, t_rand=None, u_rand=None, update=True, obj_fp32=False, want_pos=False, want_rot=False,
-               tv_loss_mult=0.0, seed=None):
+               tv_loss_mult=0.0, seed=None, comm=None, world=1, reduce_stats=False):
     """One shard's training step as ONE library call (durf_train_step; update=False: durf_loss_backward, parameters
     untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None).
     obj_fp32: the object branch on the exact-fp32 kernels; want_pos / want_rot: box-pose optimisation behind it (`pose` must
@@ -1139,6 +1173,7 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
         raise NotImplementedError('durf_train_step: DURF_TRAIN_POSE_OPT needs DURF_TRAIN_OBJ_FP32 (csrc/train.hip)')
     a.flags = (TRAIN_OBJ_FP32 if (K and obj_fp32) else 0) | (TRAIN_POSE_OPT if pose_opt else 0)
     a.want_pos, a.want_rot, a.tv_loss_mult = int(bool(want_pos)), int(bool(want_rot)), float(tv_loss_mult)
+    a.comm, a.world, a.reduce_stats = (comm.handle if comm is not None else None), int(world), int(bool(reduce_stats))
     ws = torch.empty(int(L.durf_train_workspace_bytes_flags(B, N, K, num_levels, params_flat.numel(), a.flags)), dtype=torch.uint8,
                      device=dev)
     assert ws.data_ptr() % 256 == 0

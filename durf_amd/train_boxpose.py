@@ -59,6 +59,35 @@ def _bucketed():
     return os.environ.get('DURF_BUCKET_ALLREDUCE', '0') != '0'
 
 
+# DURF_INSTREAM_ALLREDUCE=1 (nccl backend): the gradient all-reduce is issued by the library itself IN the compute stream
+# (csrc/comm.hip: its own RCCL communicator, the unique id handed round through torch.distributed's store) instead of by
+# torch.distributed on its communication stream -- no event hop there and back (~22 us of idle GPU per step measured on a
+# world-size-1 group, profiles/r05_rccl_instream.txt), and the same call sequence a host that is not Python gets from
+# durf_train_step(args.comm).  Off by default: torch.distributed's path is the one the multi-GPU tests have exercised.
+_INSTREAM = {}
+
+
+def _instream_comm(dist):
+    import os
+    if os.environ.get('DURF_INSTREAM_ALLREDUCE', '0') == '0' or dist.get_backend() != 'nccl' or not ops.comm_available():
+        return None
+    if 'comm' not in _INSTREAM:
+        store = dist.distributed_c10d._get_default_store()
+        rank, world = dist.get_rank(), dist.get_world_size()
+        if rank == 0:
+            store.set('durf_rccl_unique_id', ops.comm_unique_id())
+        _INSTREAM['comm'] = ops.Comm(world, rank, store.get('durf_rccl_unique_id'))
+    return _INSTREAM['comm']
+
+
+def shutdown_instream():
+    """destroy the in-stream communicator (before torch.distributed's process group goes)"""
+    c = _INSTREAM.pop('comm', None)
+    if c is not None:
+        torch.cuda.synchronize()
+        c.destroy()
+
+
 def level_multipliers(config, level, num_levels):
     """Multipliers of one level's terms in the total loss (train_boxpose.py:211-220), in the
     order durf_loss_bwd expects: rgb, sky, depth, near, empty, distortion."""
@@ -337,7 +366,8 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     dist = _dist()
     pending = []
     lay = variables.layout
-    bucket = dist is not None and _bucketed() and lay.K > 0
+    comm = _instream_comm(dist) if dist is not None else None
+    bucket = dist is not None and comm is None and _bucketed() and lay.K > 0
     ready = (lambda g_obj: pending.append(dist.all_reduce(g_obj, async_op=True))) if bucket else None
     # the step's tail as two launches -- {logged scalars + multi-hit outcome + scrub} and Adam -- whenever the scalars are
     # not all-reduced in between; with a process group the multi-hit NaNs have to exist before the all-reduce (own launch)
@@ -347,14 +377,20 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     world = 1
     if dist is not None:                                    # lax.pmean(grad) (:253)
         world = dist.get_world_size()
-        rest = grad[:lay.mlp_off['BoxMLP_0']] if bucket else grad        # [box_centers | MLP_0] when the objects went ahead
-        pending.append(dist.all_reduce(rest, async_op=True))
+        if comm is not None:
+            comm.all_reduce_sum(grad)                       # in the compute stream: what follows is ordered behind it
+        else:
+            rest = grad[:lay.mlp_off['BoxMLP_0']] if bucket else grad    # [box_centers | MLP_0] when the objects went ahead
+            pending.append(dist.all_reduce(rest, async_op=True))
     L = model.num_levels
     if merged_tail:
         out = None
     else:                                                   # lax.pmean(stats) (:255), then the PSNRs (:291-292)
         out = _assemble_stats(config, batch, raw, prev, ops.STATS_ASSEMBLE)
-        dist.all_reduce(out)
+        if comm is not None:
+            comm.all_reduce_sum(out)
+        else:
+            dist.all_reduce(out)
         out /= world
         ops.train_stats(raw['norms'], raw['sums'], None, None, None, None, [r[4] for r in raw['ret']],
                         _stat_mults(config), ops.STATS_PSNR, out=out)
@@ -399,11 +435,14 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
     variables = state.variables
     lay = variables.layout
     K, L, N = lay.K, model.num_levels, model.num_samples
+    dist = _dist()
+    comm = _instream_comm(dist) if dist is not None else None
     if (model.mlp_precision != 'bf16' or (K and not model.dynamics) or L < 2 or
             config.weight_decay_mult != 0 or config.rand_bkgd or (config.randomized and model.density_noise > 0) or
-            _dist() is not None):
-        raise NotImplementedError('durf_train_step covers the single-device step with a bf16 background MLP, >= 2 levels, no '
-                                  'density noise / weight decay / random background (see csrc/train.hip)')
+            (dist is not None and (comm is None or not update))):
+        raise NotImplementedError('durf_train_step covers the step with a bf16 background MLP, >= 2 levels, no density noise / '
+                                  'weight decay / random background; data-parallel only through the library\'s own in-stream '
+                                  'all-reduce (DURF_INSTREAM_ALLREDUCE=1; see csrc/train.hip, csrc/comm.hip)')
     pose_opt = bool(K) and not (model.no_pose_opt and model.no_yaw_opt)
     obj_fp32 = bool(K) and model.object_precision() == 'f32'
     if pose_opt and not obj_fp32:
@@ -438,7 +477,8 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         density_bias=model.density_bias, resample_padding=model.resample_padding,
         t_rand=noise['t_rand'] if config.randomized else None, u_rand=noise['u_rand'] if config.randomized else None,
         update=update, obj_fp32=obj_fp32, want_pos=pose_opt and not model.no_pose_opt, want_rot=pose_opt and not model.no_yaw_opt,
-        tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0, seed=seed)
+        tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0, seed=seed, comm=comm,
+        world=dist.get_world_size() if dist is not None else 1, reduce_stats=dist is not None and reduce_stats)
     box_rot0 = pose_used[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))
     ret = [tuple(o) + ([pose_used[:, :3], box_rot0], dyn, zo) for o in outs]
     st = ops.stats_views(out, L)

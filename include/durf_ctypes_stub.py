@@ -140,6 +140,20 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_train_step.restype = i32
     L.durf_train_step.argtypes = [vp, vp, vp]
     #   (stream, args, workspace)
+    L.durf_comm_available.restype = i32
+    L.durf_comm_available.argtypes = []
+    L.durf_comm_unique_id.restype = i32
+    L.durf_comm_unique_id.argtypes = [vp]
+    #   (id_out)
+    L.durf_comm_init.restype = i32
+    L.durf_comm_init.argtypes = [i32, i32, vp, C.POINTER(vp)]
+    #   (world, rank, id, comm_out)
+    L.durf_comm_destroy.restype = i32
+    L.durf_comm_destroy.argtypes = [vp]
+    #   (comm)
+    L.durf_allreduce_sum.restype = i32
+    L.durf_allreduce_sum.argtypes = [vp, vp, vp, u64]
+    #   (stream, comm, buf, n)
     L.durf_mlp_f32_act_floats.restype = u64
     L.durf_mlp_f32_act_floats.argtypes = [i32, i32]
     #   (width, in_dim)

@@ -406,11 +406,31 @@ typedef struct durf_train_args {
     int flags;                                            /* DURF_TRAIN_OBJ_FP32 | DURF_TRAIN_POSE_OPT (0: the bf16 object branch, frozen poses) */
     int want_pos, want_rot;                               /* DURF_TRAIN_POSE_OPT: !no_pose_opt, !no_yaw_opt (obbpose_model.py:100-104) */
     float tv_loss_mult;                                   /*   Config.tv_loss_mult (position prior against prev6) */
+    void* comm;                                           /* durf_train_step only, nullable: a durf_comm_init communicator -- the step then is
+                                                             one rank's share of a data-parallel step: the multi-hit outcome, ONE in-stream
+                                                             all-reduce of grad (durf_allreduce_sum), clip + Adam on the mean (1 / world) */
+    int world;                                            /*   ranks of comm (1 / world scales the summed gradient; lax.pmean) */
+    int reduce_stats;                                     /*   != 0: the logged scalars are averaged over the ranks too (lax.pmean(stats), :255) */
 } durf_train_args;
 size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params);
 size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, size_t n_params, int flags);
 int durf_loss_backward(void* stream, const durf_train_args* args, void* workspace);
 int durf_train_step(void* stream, const durf_train_args* args, void* workspace);
+
+/* ---- the data-parallel exchange on the caller's stream (csrc/comm.hip) -------------------------------------
+ * jax.lax.pmean(grad, 'batch') (train_boxpose.py:253) as ONE in-place RCCL all-reduce (sum; durf_clip_adam / durf_stats_scrub
+ * fold the 1 / world into their scrub pass) of the flat fp32 gradient, issued by this library IN `stream` -- for hosts that
+ * are not Python (durf_train_args.comm: the whole data-parallel step is then one C call per rank) and for hosts that do
+ * not want the hop to a communication stream and back.  One process per GPU: rank 0 calls durf_comm_unique_id and hands the
+ * DURF_COMM_ID_BYTES bytes to every rank by its own means (file, socket, its launcher's store); every rank then calls
+ * durf_comm_init (collective: ncclCommInitRank) with its device current.  RCCL is resolved at run time, from the copy the
+ * process has loaded already if there is one (durf_comm_available() == 0: none found). */
+#define DURF_COMM_ID_BYTES 128
+int durf_comm_available(void);
+int durf_comm_unique_id(void* id_out /* HOST, DURF_COMM_ID_BYTES bytes */);
+int durf_comm_init(int world, int rank, const void* id /* HOST */, void** comm_out /* HOST: receives the communicator */);
+int durf_comm_destroy(void* comm);
+int durf_allreduce_sum(void* stream, void* comm, float* buf /* device, in place */, size_t n);
 
 /* ---- exact-fp32 MLP (csrc/mlp_f32.hip) -----------------------------------------------------------
  * The reference's Dense layers are fp32 (obbpose_model.py:326-327; HIGHEST-precision matmul, internal/math.py:22-24).

@@ -115,12 +115,14 @@ def test_two_ranks_through_bench_workload_with_distinct_shards(cuda, tmp_path):
     assert a['losses'][2] == b['losses'][2]                                            # all-reduced when logged
 
 
-def _rccl_worker(_i, out_dir, force, bucket, pose_opt):
-    """one process; force: through a world-size-1 `nccl` (= RCCL) group, else the plain single-GPU path"""
+def _rccl_worker(_i, out_dir, force, bucket, pose_opt, instream=0, one_call=False):
+    """one process; force: through a world-size-1 `nccl` (= RCCL) group, else the plain single-GPU path; instream: the
+    all-reduce issued by the library in the compute stream (csrc/comm.hip); one_call: the step as durf_train_step"""
     for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'DURF_DIST_BACKEND', 'DURF_RDZV_FILE'):
         os.environ.pop(k, None)
     os.environ['DURF_FORCE_DIST'] = '1' if force else '0'
     os.environ['DURF_BUCKET_ALLREDUCE'] = '1' if bucket else '0'
+    os.environ['DURF_INSTREAM_ALLREDUCE'] = '1' if instream else '0'
     sys.path.insert(0, ROOT)
     import bench
     from durf_amd import train_boxpose
@@ -133,15 +135,19 @@ def _rccl_worker(_i, out_dir, force, bucket, pose_opt):
     wl = bench.setup_workload('cfg4' if pose_opt else 'cfg3', dev, 0, 1, rays=256)
     state, losses = wl['state'], []
     rng = 0
+    step = train_boxpose.train_step_one_call if one_call else train_boxpose.train_step
     for i in range(3):
-        state, stats, rng, _ = train_boxpose.train_step(wl['model'], wl['config'], rng, state, wl['batch'], 5e-4, 3.0,
-                                                        wl['alpha'], wl['prev'], reduce_stats=(i == 2))
+        state, stats, rng, _ = step(wl['model'], wl['config'], rng, state, wl['batch'], 5e-4, 3.0,
+                                    wl['alpha'], wl['prev'], reduce_stats=(i == 2))
         losses.append(float(stats.loss))
     torch.cuda.synchronize()
+    if instream:
+        assert train_boxpose._INSTREAM.get('comm') is not None, 'the in-stream communicator was not created'
     torch.save(dict(flat=state.variables.flat.cpu(), m=state.m.cpu(), losses=losses),
-               os.path.join(out_dir, 'rccl_%d_%d.pt' % (force, bucket)))
+               os.path.join(out_dir, 'rccl_%d_%d_%d_%d.pt' % (force, bucket, instream, one_call)))
     if force:
         dist.barrier()
+        train_boxpose.shutdown_instream()
         dist.destroy_process_group()
 
 
@@ -151,11 +157,15 @@ def test_train_step_through_rccl_world_size_one(cuda, tmp_path, pose_opt):
     (RCCL: the one-GPU box cannot host more ranks), so train_step issues the asynchronous gradient all-reduce, waits
     for it on the compute stream, folds 1 / world into clip + Adam and all-reduces the logged scalars on the logging
     step.  Three steps must leave parameters, Adam moments and losses BIT-identical to the plain path -- also with
-    the objects' gradients all-reduced ahead of the background MLP's (DURF_BUCKET_ALLREDUCE=1: two collectives)."""
-    for force, bucket in ((0, 0), (1, 0), (1, 1)):
-        mp.spawn(_rccl_worker, args=(str(tmp_path), force, bucket, pose_opt), nprocs=1, join=True)
-    base = torch.load(os.path.join(str(tmp_path), 'rccl_0_0.pt'))
-    for tag in ('rccl_1_0.pt', 'rccl_1_1.pt'):
+    the objects' gradients all-reduced ahead of the background MLP's (DURF_BUCKET_ALLREDUCE=1: two collectives), with the
+    all-reduce issued by the library itself in the compute stream (DURF_INSTREAM_ALLREDUCE=1: csrc/comm.hip, its own RCCL
+    communicator from a unique id passed through the store), and with the whole step as ONE C call on that communicator
+    (durf_train_step with args.comm: what a host that is not Python would run per rank)."""
+    for force, bucket, instream, one_call in ((0, 0, 0, False), (1, 0, 0, False), (1, 1, 0, False), (1, 0, 1, False),
+                                              (1, 0, 1, True)):
+        mp.spawn(_rccl_worker, args=(str(tmp_path), force, bucket, pose_opt, instream, one_call), nprocs=1, join=True)
+    base = torch.load(os.path.join(str(tmp_path), 'rccl_0_0_0_0.pt'))
+    for tag in ('rccl_1_0_0_0.pt', 'rccl_1_1_0_0.pt', 'rccl_1_0_1_0.pt', 'rccl_1_0_1_1.pt'):
         got = torch.load(os.path.join(str(tmp_path), tag))
         assert torch.equal(got['flat'], base['flat']) and torch.equal(got['m'], base['m']), tag
         assert got['losses'] == base['losses'], tag
