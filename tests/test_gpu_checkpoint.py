@@ -18,7 +18,18 @@ def test_save_restore_resumes_bit_identically(cuda, tmp_path, name):
     state, rng = w['state'], 0
     for i in range(3):
         state, stats, rng, _ = train_boxpose.train_step(model, config, rng, state, batch, 5e-4, 3.0, alpha, prev)
-    checkpoints.save_checkpoint(str(tmp_path), state, state.step, keep=1)
+    path = checkpoints.save_checkpoint(str(tmp_path), state, state.step, keep=1)
+    # the FILE the trained device state produced, byte for byte against the independent encoder (oracle/flax_msgpack_ref.py:
+    # written from the msgpack and flax-serialization specifications, no `msgpack` package), and read back by it
+    from oracle import flax_msgpack_ref as F
+    from tests import helpers
+    sv, as_oracle = state.variables, helpers.oracle_params_from_variables
+    want = F.serialize(F.state_dict(as_oracle(sv), as_oracle(sv.like(state.m)), as_oracle(sv.like(state.v)), state.step))
+    with open(path, 'rb') as f:
+        written = f.read()
+    assert written == want, 'checkpoint bytes differ from the independent encoder'
+    tree = F.restore(written)
+    assert int(tree['optimizer']['state']['step']) == 3
     # the uninterrupted run: step 4 and a test render
     H, W = 16, 24
     tb = synthetic.device_batch(synthetic.make_batch(H * W, w['K'], seed=5, far=w['far'], allow_multi_hit=True), cuda)

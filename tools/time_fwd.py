@@ -5,12 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from durf_amd import ops
 dev = torch.device('cuda:0')
-rows, N, W, IN = 4096 * 128, 128, 256, 60
+rows, N, W, IN = int(os.environ.get('ROWS', 4096 * 128)), 128, 256, 60
 torch.manual_seed(0)
 flat = (torch.rand(ops.mlp_param_count(W, IN), device=dev) - 0.5) * 0.2
 wf, wb = ops.pack_weights(W, IN, flat, want_bwd=True)
 enc = (torch.randn(rows * 64, device=dev) * 0.5).to(torch.bfloat16)
-view = (torch.randn(4096 * 32, device=dev) * 0.5).to(torch.bfloat16)
+view = (torch.randn(rows // N * 32, device=dev) * 0.5).to(torch.bfloat16)
 raw = torch.empty(rows, 4, device=dev)
 stash = torch.empty(ops.mlp_stash_bytes(W, rows), dtype=torch.uint8, device=dev)
 mask = torch.empty(ops.mlp_mask_bytes(rows), dtype=torch.uint8, device=dev)
