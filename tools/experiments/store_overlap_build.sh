@@ -17,8 +17,10 @@ build() {
   done
   wait
   objs=""
-  for f in api rays render mlp_f32 loss optim pose objects data forward train; do objs="$objs $root/durf_amd/csrc/build/$f.o"; done
-  hipcc --offload-arch=gfx950 -shared -fPIC $out/mlp_fwd.o $out/mlp_bwd.o $objs -o $root/durf_amd/variants/libdurf_$name.so
+  for f in $(sed -n "s/^SRCS = //p" $root/durf_amd/csrc/Makefile | sed "s/\.hip//g"); do
+    case $f in mlp_fwd|mlp_bwd) ;; *) objs="$objs $root/durf_amd/csrc/build/$f.o";; esac
+  done
+  hipcc --offload-arch=gfx950 -shared -fPIC $out/mlp_fwd.o $out/mlp_bwd.o $objs -ldl -o $root/durf_amd/variants/libdurf_$name.so
   echo built $name
 }
 build xbase
