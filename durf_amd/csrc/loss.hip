@@ -57,20 +57,18 @@ k_reduce_rows(int n, int min_row, const float* __restrict__ in, float* __restric
     }
 }
 
+// one ray (one wave) of one level: the body of k_loss_bwd and of k_loss_bwd_levels
 template <int P>
-__global__ void __launch_bounds__(256)
-k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw_obj,
-           const int32_t* __restrict__ slot, const float* __restrict__ t_vals,
-           const float* __restrict__ dirs_s, const float* __restrict__ pixels,
-           const float* __restrict__ lossmult, const float* __restrict__ gt_depth,
-           const float* __restrict__ sky, const int32_t* __restrict__ dyn,
-           const float* __restrict__ zo, const float* __restrict__ norm, LossCfg c,
-           float* __restrict__ draw, float* __restrict__ terms, float* __restrict__ rgb_out,
-           float* __restrict__ depth_out, float* __restrict__ acc_out, float* __restrict__ weights_out,
-           float* __restrict__ t_mids_out, float* __restrict__ t_dists_out, float* __restrict__ draw_ray_sum) {
-    const int lane = threadIdx.x & 63;
-    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (b >= B) return;
+__device__ __forceinline__ void
+loss_bwd_ray(int b, int lane, int B, int N, int K, const float* __restrict__ raw_bkgd, const ObjPtrsL& raw_obj,
+             const int32_t* __restrict__ slot, const float* __restrict__ t_vals,
+             const float* __restrict__ dirs_s, const float* __restrict__ pixels,
+             const float* __restrict__ lossmult, const float* __restrict__ gt_depth,
+             const float* __restrict__ sky, const int32_t* __restrict__ dyn,
+             const float* __restrict__ zo, const float* __restrict__ norm, const LossCfg& c,
+             float* __restrict__ draw, float* __restrict__ terms, float* __restrict__ rgb_out,
+             float* __restrict__ depth_out, float* __restrict__ acc_out, float* __restrict__ weights_out,
+             float* __restrict__ t_mids_out, float* __restrict__ t_dists_out, float* __restrict__ draw_ray_sum) {
     const float dx = dirs_s[b * 3], dy = dirs_s[b * 3 + 1], dz = dirs_s[b * 3 + 2];
     const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
     const float* tv = t_vals + (size_t)b * (N + 1);
@@ -259,6 +257,47 @@ k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw
         terms[(size_t)LT_SKY * B + b] = rm.sm * es * es;
         terms[(size_t)LT_DIST * B + b] = t_dist;
     }
+}
+
+template <int P>
+__global__ void __launch_bounds__(256)
+k_loss_bwd(int B, int N, int K, const float* __restrict__ raw_bkgd, ObjPtrsL raw_obj,
+           const int32_t* __restrict__ slot, const float* __restrict__ t_vals,
+           const float* __restrict__ dirs_s, const float* __restrict__ pixels,
+           const float* __restrict__ lossmult, const float* __restrict__ gt_depth,
+           const float* __restrict__ sky, const int32_t* __restrict__ dyn,
+           const float* __restrict__ zo, const float* __restrict__ norm, LossCfg c,
+           float* __restrict__ draw, float* __restrict__ terms, float* __restrict__ rgb_out,
+           float* __restrict__ depth_out, float* __restrict__ acc_out, float* __restrict__ weights_out,
+           float* __restrict__ t_mids_out, float* __restrict__ t_dists_out, float* __restrict__ draw_ray_sum) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    loss_bwd_ray<P>(b, lane, B, N, K, raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, c,
+                    draw, terms, rgb_out, depth_out, acc_out, weights_out, t_mids_out, t_dists_out, draw_ray_sum);
+}
+
+// Every level's loss + composite backward as ONE launch (blockIdx.y = level): stop_level_grad makes each level's loss
+// gradient a function of the forward alone, so on one stream the launches of the levels below the last only sat between
+// two backward kernels (a 512-ray step: two launches of ~8 us).  Same body per (level, ray): bit-identical outputs.
+struct LossLevelK {
+    const float* raw_bkgd; ObjPtrsL raw_obj; const float* t_vals; const float* norm; LossCfg c;
+    float *draw, *terms, *rgb_out, *depth_out, *acc_out, *weights_out, *t_mids_out, *t_dists_out, *draw_ray_sum;
+};
+struct LossLevelsK { LossLevelK l[DURF_MAX_LEVELS]; };
+
+template <int P>
+__global__ void __launch_bounds__(256)
+k_loss_bwd_levels(int B, int N, int K, const int32_t* __restrict__ slot, const float* __restrict__ dirs_s,
+                  const float* __restrict__ pixels, const float* __restrict__ lossmult, const float* __restrict__ gt_depth,
+                  const float* __restrict__ sky, const int32_t* __restrict__ dyn, const float* __restrict__ zo, LossLevelsK A) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const LossLevelK& a = A.l[blockIdx.y];
+    loss_bwd_ray<P>(b, lane, B, N, K, a.raw_bkgd, a.raw_obj, slot, a.t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo,
+                    a.norm, a.c, a.draw, a.terms, a.rgb_out, a.depth_out, a.acc_out, a.weights_out, a.t_mids_out, a.t_dists_out,
+                    a.draw_ray_sum);
 }
 
 
@@ -464,6 +503,35 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
 #undef LAUNCH_L
     if (term_sums) hipLaunchKernelGGL(k_reduce_rows, dim3(LT_ROWS), dim3(1024), 0, s, B, -1, terms, term_sums);
     DURF_CHECK_LAUNCH("durf_loss_bwd");
+    return 0;
+}
+
+int durf_loss_bwd_levels(void* stream, int B, int N, int K, int L, const durf_loss_level* levels, const int32_t* slot,
+                         const float* dirs_s, const float* pixels, const float* lossmult, const float* gt_depth,
+                         const float* sky, const int32_t* dyn, const float* zo, float eps, float box_loss_mult,
+                         int disable_multiscale, float bg, float density_bias) {
+    DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
+    DURF_REQUIRE(L >= 1 && L <= DURF_MAX_LEVELS && levels != nullptr, "1 <= L <= DURF_MAX_LEVELS level descriptions");
+    if (B <= 0) return 0;
+    LossLevelsK A{};
+    for (int l = 0; l < L; l++) {
+        const durf_loss_level& h = levels[l];
+        LossLevelK& a = A.l[l];
+        a.raw_bkgd = h.raw_bkgd; a.t_vals = h.t_vals; a.norm = h.norm;
+        for (int k = 0; k < DURF_MAX_OBJ; k++) a.raw_obj.p[k] = (k < K) ? h.raw_obj[k] : nullptr;
+        a.c.eps = eps; a.c.c_rgb = h.mults[0]; a.c.c_sky = h.mults[1]; a.c.c_depth = h.mults[2]; a.c.c_near = h.mults[3];
+        a.c.c_empty = h.mults[4]; a.c.c_dist = h.mults[5]; a.c.box_loss_mult = box_loss_mult; a.c.level = h.level;
+        a.c.bg = bg; a.c.density_bias = density_bias; a.c.disable_multiscale = disable_multiscale;
+        a.draw = h.draw; a.terms = h.terms; a.rgb_out = h.rgb_out; a.depth_out = h.depth_out; a.acc_out = h.acc_out;
+        a.weights_out = h.weights_out; a.t_mids_out = h.t_mids_out; a.t_dists_out = h.t_dists_out; a.draw_ray_sum = h.draw_ray_sum;
+        DURF_REQUIRE(a.raw_bkgd && a.t_vals && a.norm && a.draw && a.terms, "raw, t_vals, norm, draw and terms of every level");
+    }
+    dim3 grid(durf_cdiv(B, 4), L), block(256);
+#define LAUNCH_LL(P) hipLaunchKernelGGL(k_loss_bwd_levels<P>, grid, block, 0, (hipStream_t)stream, B, N, K, slot, dirs_s, pixels, \
+                                        lossmult, gt_depth, sky, dyn, zo, A)
+    if (N <= 64) LAUNCH_LL(1); else if (N <= 128) LAUNCH_LL(2); else LAUNCH_LL(4);
+#undef LAUNCH_LL
+    DURF_CHECK_LAUNCH("durf_loss_bwd_levels");
     return 0;
 }
 

@@ -36,7 +36,8 @@ __global__ void k_tv_rows(int K, const float* __restrict__ pose, const float* __
 }
 
 struct TrainWs {
-    float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *draw, *part, *bpart, *opart, *obpart, *scratch, *u_rand;
+    float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *part, *bpart, *opart, *obpart, *scratch, *u_rand;
+    float* draw[ML];      // d(loss)/d(raw) of every level (ONE loss launch fills them all: durf_loss_bwd_levels)
     float *raw_c[ML], *raw_b[ML], *obj_raw[ML], *terms[ML];
     int32_t *hit, *idx_obj, *count_obj, *slot_obj, *idx_cls, *count_cls, *slot_cls;
     void *view, *wf_bkgd, *wb_bkgd, *wf_obj, *wb_obj, *view_tile, *obj_view_tile;
@@ -74,7 +75,7 @@ TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params, int 
     w.prep = (float*)c.take((size_t)2 * 5 * B * 4);
     w.ray_sums = (float*)c.take((size_t)L * B * 4 * 4);
     w.sums = (float*)c.take((size_t)L * 7 * 4);
-    w.draw = (float*)c.take(rows * 4 * 4);
+    for (int l = 0; l < L; l++) w.draw[l] = (float*)c.take(rows * 4 * 4);
     w.part = (float*)c.take(durf_dw_part_floats(256) * 4);
     w.bpart = (float*)c.take(durf_dw_bpart_floats(256) * 4);
     w.opart = (float*)c.take(K > 0 ? (size_t)K * durf_dw_part_floats(128) * 4 : 0);
@@ -221,29 +222,39 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     }
     // ---- losses + backward (train_boxpose.py:67-252), last level first ----
     // (the view-direction tile of the weight-gradient launch was written by the level-0 forward)
+    {   // every level's loss + composite backward: ONE launch (stop_level_grad: functions of the forward alone)
+        durf_loss_level ll[ML] = {};
+        for (int lvl = 0; lvl < L; lvl++) {
+            const bool last = lvl == L - 1;
+            durf_loss_level& h = ll[lvl];
+            h.raw_bkgd = w.raw_b[lvl]; h.t_vals = f.t_vals[lvl]; h.norm = w.norms + (size_t)lvl * 5; h.level = lvl;
+            for (int k = 0; k < K; k++) h.raw_obj[k] = raw_obj[lvl][k];
+            for (int i = 0; i < 6; i++) h.mults[i] = a->level_mults[lvl][i];
+            h.draw = w.draw[lvl]; h.terms = w.terms[lvl];
+            if (last) { h.rgb_out = f.rgb[lvl]; h.depth_out = f.depth[lvl]; h.acc_out = f.acc[lvl]; h.weights_out = f.weights[lvl];
+                        h.t_mids_out = f.t_mids[lvl]; h.t_dists_out = f.t_dists[lvl]; }
+            h.draw_ray_sum = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;
+        }
+        STEP(durf_loss_bwd_levels(stream, B, N, K, L, ll, w.slot_obj, w.d_s, a->pixels, a->lossmult, a->gt_depth, a->sky, f.dyn_mask,
+                                  f.zo, a->eps, a->box_loss_mult, a->disable_multiscale, a->bg, f.density_bias));
+    }
     for (int lvl = L - 1; lvl >= 0; lvl--) {
-        const bool last = lvl == L - 1;
         float* rs = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;
-        STEP(durf_loss_bwd(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, f.t_vals[lvl], w.d_s, a->pixels, a->lossmult,
-                           a->gt_depth, a->sky, f.dyn_mask, f.zo, w.norms + (size_t)lvl * 5, a->eps, a->level_mults[lvl],
-                           a->box_loss_mult, lvl, a->disable_multiscale, a->bg, f.density_bias, w.draw, w.terms[lvl], nullptr,
-                           last ? f.rgb[lvl] : nullptr, last ? f.depth[lvl] : nullptr, last ? f.acc[lvl] : nullptr,
-                           last ? f.weights[lvl] : nullptr, last ? f.t_mids[lvl] : nullptr, last ? f.t_dists[lvl] : nullptr, rs));
         if (f32o) {       // the object branch in fp32: backward (+ d(enc) -> the 21 pose sums per object), all K at once
-            STEP(durf_objf32_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw, f.obj_params, f.obj_param_stride, w.obj_ws,
+            STEP(durf_objf32_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw[lvl], f.obj_params, f.obj_param_stride, w.obj_ws,
                                        w.act32[lvl], w.dz32[lvl], pose_opt ? w.d_enc32[lvl] : nullptr));
             if (pose_opt)
                 STEP(durf_encode_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.d_enc32[lvl], f.t_vals[lvl], w.o_s, w.d_s,
                                                f.radii, f.origins, f.directions, f.pose, f.barf_w, w.pose_scratch, w.pose_sums, 1));
         }
         if (K > 0) {
-            STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw, w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
+            STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
                               nullptr, w.idx_cls + B, w.count_cls + 1, rs));
             if (!f32o)
-                STEP(durf_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw, w.wb_obj, w.obj_mask[lvl], w.obj_dz[lvl],
+                STEP(durf_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw[lvl], w.wb_obj, w.obj_mask[lvl], w.obj_dz[lvl],
                                         w.obj_dz_out[lvl], nullptr));
         } else {
-            STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw, nullptr, nullptr, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl], nullptr,
+            STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], nullptr, nullptr, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl], nullptr,
                               nullptr, nullptr, nullptr));
         }
     }

@@ -554,6 +554,47 @@ def loss_bwd(raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth
     return draw, (terms if defer_sums else sums)
 
 
+class LossLevel(C.Structure):
+    """durf_loss_level (include/durf_hip.h), field for field"""
+    _fields_ = ([('raw_bkgd', C.c_void_p), ('raw_obj', C.c_void_p * 16), ('t_vals', C.c_void_p), ('norm', C.c_void_p),
+                 ('mults', C.c_float * 6), ('level', C.c_int)] +
+                [(n, C.c_void_p) for n in ('draw', 'terms', 'rgb_out', 'depth_out', 'acc_out', 'weights_out', 't_mids_out',
+                                           't_dists_out', 'draw_ray_sum')])
+
+
+def loss_bwd_levels(levels, slot, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, bg, density_bias=-1.0,
+                    disable_multiscale=False):
+    """loss_bwd(defer_sums=True) of EVERY level as one launch (durf_loss_bwd_levels).  levels: one dict per level with
+    raw_bkgd, raw_obj (list), t_vals, norm, mults, level[, render_out (6 tensors)][, draw_ray_sum]
+    -> [(draw [B*N,4], terms [7,B])] per level"""
+    L = len(levels)
+    B, N = levels[0]['t_vals'].shape[0], levels[0]['t_vals'].shape[1] - 1
+    K = len(levels[0]['raw_obj'])
+    dev = levels[0]['t_vals'].device
+    arr = (LossLevel * L)()
+    out, keep = [], []
+    for i, lv in enumerate(levels):
+        a = arr[i]
+        draw = torch.empty(B * N, 4, device=dev)
+        terms = torch.empty(TERM_ROWS, B, device=dev)
+        a.raw_bkgd, a.t_vals, a.norm = _p(_f32(lv['raw_bkgd'])), _p(_f32(lv['t_vals'])), _p(lv['norm'])
+        for k, r in enumerate(lv['raw_obj']):
+            a.raw_obj[k] = r.data_ptr()
+        a.mults = (C.c_float * 6)(*[float(x) for x in lv['mults']])
+        a.level = int(lv['level'])
+        a.draw, a.terms = _p(draw), _p(terms)
+        ro = lv.get('render_out') or (None,) * 6
+        a.rgb_out, a.depth_out, a.acc_out, a.weights_out, a.t_mids_out, a.t_dists_out = (_p(t) for t in ro)
+        a.draw_ray_sum = _p(lv.get('draw_ray_sum'))
+        keep.append(lv)
+        out.append((draw, terms))
+    _lib.check(_lib.lib().durf_loss_bwd_levels(_stream(), B, N, K, L, C.cast(arr, C.c_void_p), _p(slot), _p(_f32(dirs_s)),
+                                               _p(_f32(pixels)), _p(_f32(lossmult)), _p(_f32(gt_depth)), _p(_f32(sky)), _p(dyn),
+                                               _p(_f32(zo)), float(eps), float(box_loss_mult), int(disable_multiscale),
+                                               float(bg), float(density_bias)), 'durf_loss_bwd_levels')
+    return out
+
+
 STAT_ROWS = ('losses', 'obj_losses', 'd_losses', 'n_losses', 'e_losses', 's_losses', 'distr_losses', 'tv_losses',
              'offsets', 'offset_x', 'offset_y', 'offset_z', 'offset_yaw', 'psnrs', 'obj_psnrs')
 STATS_ASSEMBLE, STATS_PSNR = 1, 2

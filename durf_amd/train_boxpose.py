@@ -189,6 +189,21 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                     ready[lvl].record(side.side)
     elif not f32 and view_tile is None:
         view_tile = make_view_tile()
+    if not side.enabled and prep is not None and L >= 2:
+        # one stream: every level's loss + composite backward as ONE launch in front of the backward kernels (stop_level_grad:
+        # each is a function of the forward alone) instead of one launch per level between them
+        lvs = []
+        for lvl in range(L):
+            lv = ctx['levels'][lvl]
+            lvs.append(dict(raw_bkgd=lv['raw_b'], raw_obj=lv['raws'], t_vals=lv['t_vals'], norm=norms[lvl],
+                            mults=level_multipliers(config, lvl, L), level=lvl,
+                            render_out=(lv['rgb'], lv['depth'], lv['acc'], lv['weights'], lv['t_mids'], lv['t_dists'])
+                            if lv['deferred'] else None,
+                            draw_ray_sum=None if dd is None else ray_sums[lvl]))
+        res = ops.loss_bwd_levels(lvs, ctx['slot'], ctx['d_s'], pixels, lossmult, gt_depth, sky, dyn, ctx['zo'], float(eps),
+                                  float(config.box_loss_mult), bg, model.density_bias, config.disable_multiscale_loss)
+        for lvl in range(L):
+            draws[lvl], terms[lvl] = res[lvl]
     # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
     for lvl in reversed(range(L)):
         lv = ctx['levels'][lvl]
@@ -199,7 +214,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             draw, terms[lvl] = level_loss(lvl)
         else:
             draw = draws[lvl]
-            main.wait_event(ready[lvl])
+            if ready[lvl] is not None:
+                main.wait_event(ready[lvl])
         if obj_side.enabled:
             draw.record_stream(obj_side.side)     # (read by the object backward on the side stream)
         if f32:                               # exact-fp32 parity instrument: per-MLP fp32 backward + weight gradients

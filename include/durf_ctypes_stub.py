@@ -92,6 +92,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_loss_bwd.restype = i32
     L.durf_loss_bwd.argtypes = [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, C.POINTER(f32), f32, i32, i32, f32, f32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, B, N, K, raw_bkgd, raw_obj, slot, t_vals, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, norm, eps, mults, box_loss_mult, level, disable_multiscale, bg, density_bias, draw, terms, term_sums, rgb_out, depth_out, acc_out, weights_out, t_mids_out, t_dists_out, draw_ray_sum)
+    L.durf_loss_bwd_levels.restype = i32
+    L.durf_loss_bwd_levels.argtypes = [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, f32, f32, i32, f32, f32]
+    #   (stream, B, N, K, L, levels, slot, dirs_s, pixels, lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, disable_multiscale, bg, density_bias)
     L.durf_train_stats.restype = i32
     L.durf_train_stats.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(vp), C.POINTER(f32), i32, vp, C.POINTER(vp), i32]
     #   (stream, L, K, N, norms, sums, weight_l2, pose6, prev6, target6, t_vals, mults, mode, out, terms, B)

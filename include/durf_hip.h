@@ -258,6 +258,26 @@ int durf_loss_bwd(void* stream, int B, int N, int K, const float* raw_bkgd, cons
                   float* draw_ray_sum /* nullable [B,4]: sum over each ray's samples of draw (the head gradient of the
                   ONE background sample a box-hit ray is evaluated with, see durf_expand_raw) */);
 
+/* durf_loss_bwd for EVERY level in one launch (stop_level_grad: each level's loss gradient depends on the forward only;
+ * on one stream the levels below the last otherwise sit between two backward kernels as launches of their own).
+ * levels: HOST array of L descriptions -- the per-level arguments of durf_loss_bwd (no term_sums: durf_train_stats reduces
+ * the terms); everything else is shared.  Outputs bit-identical to L calls of durf_loss_bwd. */
+typedef struct durf_loss_level {
+    const float* raw_bkgd;                 /* [B*N,4] */
+    const float* raw_obj[DURF_MAX_OBJ];    /* device pointers, the first K used */
+    const float* t_vals;                   /* [B,N+1] */
+    const float* norm;                     /* [5] this level's normalisers (durf_loss_prep / durf_composite_resample) */
+    float mults[6];                        /* rgb, sky, depth, near, empty, distortion multipliers of this level */
+    int level;
+    float *draw, *terms;                   /* out: [B*N,4], [7,B] */
+    float *rgb_out, *depth_out, *acc_out, *weights_out, *t_mids_out, *t_dists_out;   /* nullable: the level's rendered outputs */
+    float* draw_ray_sum;                   /* nullable [B,4] */
+} durf_loss_level;
+int durf_loss_bwd_levels(void* stream, int B, int N, int K, int L, const durf_loss_level* levels /* HOST */,
+                         const int32_t* slot, const float* dirs_s, const float* pixels, const float* lossmult,
+                         const float* gt_depth, const float* sky, const int32_t* dyn, const float* zo, float eps,
+                         float box_loss_mult, int disable_multiscale, float bg, float density_bias);
+
 /* Scalars of utils.Stats from the per-level sums (train_boxpose.py:123-249,291-292) in one launch.
  * norms [L,5] (durf_loss_prep), sums [L,7] (durf_loss_bwd), weight_l2 nullable device scalar,
  * pose6/prev6/target6 [K,6] (box_centers[ts], prev[0], batch target), t_vals: L host-side device

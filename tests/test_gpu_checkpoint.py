@@ -29,7 +29,7 @@ def test_save_restore_resumes_bit_identically(cuda, tmp_path, name):
         written = f.read()
     assert written == want, 'checkpoint bytes differ from the independent encoder'
     tree = F.restore(written)
-    assert int(tree['optimizer']['state']['step']) == 3
+    assert tree['optimizer']['state']['step'].item() == 3
     # the uninterrupted run: step 4 and a test render
     H, W = 16, 24
     tb = synthetic.device_batch(synthetic.make_batch(H * W, w['K'], seed=5, far=w['far'], allow_multi_hit=True), cuda)

@@ -225,7 +225,8 @@ def test_argument_structs_match_the_header(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include <stdint.h>', '#include "%s/include/durf_hip.h"' % root,
              'int main(void) {']
-    for cname, cls in (('durf_forward_args', ops.ForwardArgs), ('durf_train_args', ops.TrainArgs)):
+    for cname, cls in (('durf_forward_args', ops.ForwardArgs), ('durf_train_args', ops.TrainArgs),
+                       ('durf_loss_level', ops.LossLevel)):
         lines.append('  printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
         for name, _ in cls._fields_:
             lines.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, name, cname, name))
@@ -235,7 +236,8 @@ def test_argument_structs_match_the_header(tmp_path):
     exe = tmp_path / 'layout'
     subprocess.run(['gcc', str(src), '-o', str(exe)], check=True)
     got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
-    for cname, cls in (('durf_forward_args', ops.ForwardArgs), ('durf_train_args', ops.TrainArgs)):
+    for cname, cls in (('durf_forward_args', ops.ForwardArgs), ('durf_train_args', ops.TrainArgs),
+                       ('durf_loss_level', ops.LossLevel)):
         assert int(got[cname]) == ctypes.sizeof(cls), cname
         for name, _ in cls._fields_:
             assert int(got['%s.%s' % (cname, name)]) == getattr(cls, name).offset, (cname, name)
