@@ -10,7 +10,7 @@ run() {   # label, bench args...
   echo "=== $label: python3 bench.py $*" >> $out
   python3 /root/repo/bench.py "$@" 2>/dev/null | tail -1 >> $out
   rm -rf /tmp/p_ow
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ow -- python3 /root/repo/bench.py "$@" --steps 10 --warmup 12 --no-cpu-baseline --no-calibration > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_ow -- python3 /root/repo/bench.py "$@" --steps 10 --warmup 12 --no-cpu-baseline --no-calibration --no-workloads > /dev/null 2>&1
   echo "--- rocprofv3 --kernel-trace --stats, 22 steps (eval: 12 images)" >> $out
   python3 /root/repo/tools/summarize_rocprof.py /tmp/p_ow | head -${ROWS:-18} >> $out
 }
