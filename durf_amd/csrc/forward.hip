@@ -70,17 +70,17 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
     const size_t rows = (size_t)B * N;
     int rc;
 #define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)
-    // ray setup + view encoding + level-0 sample positions (obbpose_model.py:99-131, mip.py:330-370): one launch
-    STEP(durf_ray_prologue(stream, B, K, N, a->origins, a->directions, a->pose, a->ext, w.o_s, w.d_s, w.hit, a->zo, a->viewdirs,
-                           w.view, a->near, a->far, a->t_rand, a->lindisp, a->t_vals[0], nullptr, nullptr, 0, a->seed_lo, a->seed_hi,
-                           a->draw_noise ? w.u_rand : nullptr));
+    // ray setup + view encoding + level-0 sample positions (obbpose_model.py:99-131, mip.py:330-370) + the bf16 weight
+    // streams of every MLP: one launch
+    STEP(durf_ray_prologue_pack(stream, B, K, N, a->origins, a->directions, a->pose, a->ext, w.o_s, w.d_s, w.hit, a->zo, a->viewdirs,
+                                w.view, a->near, a->far, a->t_rand, a->lindisp, a->t_vals[0], nullptr, nullptr, 0, a->seed_lo, a->seed_hi,
+                                a->draw_noise ? w.u_rand : nullptr, a->bkgd_params, 60, w.wf_bkgd, nullptr, K, a->obj_params,
+                                a->obj_param_stride, 63, w.wf_obj, nullptr));
     if (K > 0)      // per-object hit lists + the ray classes of the de-duplicated background evaluation: one launch
         STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
                               a->dyn_mask));
     else
         STEP((int)hipMemsetAsync(a->dyn_mask, 0, (size_t)B * 4, (hipStream_t)stream));
-    STEP(durf_pack_weights_all(stream, a->bkgd_params, 60, w.wf_bkgd, nullptr, K, a->obj_params, a->obj_param_stride, 63,
-                               w.wf_obj, nullptr));
     const float* raw_obj[DURF_MAX_OBJ > 0 ? DURF_MAX_OBJ : 1];
     for (int k = 0; k < K; k++) raw_obj[k] = w.obj_raw + (size_t)k * rows * 4;
     for (int lvl = 0; lvl < L; lvl++) {

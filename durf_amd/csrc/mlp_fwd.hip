@@ -27,28 +27,10 @@ k_pack_fwd(int in_dim, const float* __restrict__ P, bf16x8* __restrict__ out, si
     pack_fwd_vec<W>(in_dim, P, out, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
-// Every weight stream of the model in one launch: blockIdx.y = 0 the background MLP (W = 256), 1..K the object MLPs
-// (W = 128); blockIdx.x runs over the forward vectors, then the backward ones (bwd streams nullable: inference).
-struct PackAll {
-    const float* p_bkgd; bf16x8* f_bkgd; bf16x8* b_bkgd; int in_bkgd;
-    const float* p_obj; bf16x8* f_obj; bf16x8* b_obj; int in_obj;
-    size_t p_stride, f_stride, b_stride;
-};
+// Every weight stream of the model in one launch (PackAll / pack_all_vec: mlp_pack.h): blockIdx.y = MLP
 __global__ void __launch_bounds__(256)
 k_pack_all(PackAll a) {
-    const int vec = blockIdx.x * blockDim.x + threadIdx.x;
-    if (blockIdx.y == 0) {
-        constexpr int NF = MlpSpec<256>::TOTAL_CHUNKS * 64;
-        if (a.p_bkgd == nullptr) return;
-        if (vec < NF) pack_fwd_vec<256>(a.in_bkgd, a.p_bkgd, a.f_bkgd, vec);
-        else if (a.b_bkgd) pack_bwd_vec<256>(a.in_bkgd, a.p_bkgd, a.b_bkgd, vec - NF);
-    } else {
-        constexpr int NF = MlpSpec<128>::TOTAL_CHUNKS * 64;
-        const size_t k = blockIdx.y - 1;
-        const float* P = a.p_obj + k * a.p_stride;
-        if (vec < NF) pack_fwd_vec<128>(a.in_obj, P, (bf16x8*)((char*)a.f_obj + k * a.f_stride), vec);
-        else if (a.b_obj) pack_bwd_vec<128>(a.in_obj, P, (bf16x8*)((char*)a.b_obj + k * a.b_stride), vec - NF);
-    }
+    pack_all_vec(a, (int)blockIdx.y, (int)(blockIdx.x * blockDim.x + threadIdx.x));
 }
 
 // ---------------------------------------------------------------------------

@@ -122,3 +122,26 @@ __device__ __forceinline__ void pack_bwd_vec(int in_dim, const float* __restrict
     }
     out[vec] = v;
 }
+
+// Every weight stream of the model as ONE index space: MLP 0 = the background MLP (W = 256), 1..K the object MLPs (W = 128);
+// `vec` runs over an MLP's forward vectors, then its backward ones (bwd streams nullable: inference).  Shared by k_pack_all
+// (mlp_fwd.hip: its own launch) and by the step prologue (rays.hip: the packing rides in the ray-setup launch).
+struct PackAll {
+    const float* p_bkgd; bf16x8* f_bkgd; bf16x8* b_bkgd; int in_bkgd;
+    const float* p_obj; bf16x8* f_obj; bf16x8* b_obj; int in_obj;
+    size_t p_stride, f_stride, b_stride;
+};
+__device__ __forceinline__ void pack_all_vec(const PackAll& a, int mlp, int vec) {
+    if (mlp == 0) {
+        constexpr int NF = MlpSpec<256>::TOTAL_CHUNKS * 64, NB = BwdSpec<256>::TOTAL_CHUNKS * 64;
+        if (a.p_bkgd == nullptr) return;
+        if (vec < NF) pack_fwd_vec<256>(a.in_bkgd, a.p_bkgd, a.f_bkgd, vec);
+        else if (a.b_bkgd && vec < NF + NB) pack_bwd_vec<256>(a.in_bkgd, a.p_bkgd, a.b_bkgd, vec - NF);
+    } else {
+        constexpr int NF = MlpSpec<128>::TOTAL_CHUNKS * 64, NB = BwdSpec<128>::TOTAL_CHUNKS * 64;
+        const size_t k = mlp - 1;
+        const float* P = a.p_obj + k * a.p_stride;
+        if (vec < NF) pack_fwd_vec<128>(a.in_obj, P, (bf16x8*)((char*)a.f_obj + k * a.f_stride), vec);
+        else if (a.b_obj && vec < NF + NB) pack_bwd_vec<128>(a.in_obj, P, (bf16x8*)((char*)a.b_obj + k * a.b_stride), vec - NF);
+    }
+}

@@ -5,6 +5,7 @@
 // rounding.  These kernels are HBM-write-bound (31 KB written per ray-level for the
 // background encoding); lanes are arranged so every store instruction writes full lines.
 #include "durf_common.h"
+#include "mlp_pack.h"          // PackAll / pack_all_vec: the weight packing can ride in the step prologue
 
 // ---------------------------------------------------------------------------
 // K1: ray_setup.  One thread per ray, K-loop; rotation matrices built once per block.
@@ -279,13 +280,26 @@ k_ray_prologue(int B, int K, int N, const float* __restrict__ origins, const flo
                const float* __restrict__ viewdirs, __bf16* __restrict__ view_bf16,
                const float* __restrict__ near, const float* __restrict__ far, const float* __restrict__ t_rand,
                int lindisp, float* __restrict__ t_vals, float* __restrict__ pose_copy, float* __restrict__ zero_buf,
-               size_t zero_count, unsigned seed_lo, unsigned seed_hi, float* __restrict__ u_rand_out) {
+               size_t zero_count, unsigned seed_lo, unsigned seed_hi, float* __restrict__ u_rand_out, PackAll pk, int nb_pro,
+               int pack_blocks_bkgd, int pack_blocks_obj) {
+    // Workgroups behind the nb_pro of the prologue proper pack the step's bf16 weight streams (durf_ray_prologue_pack): the
+    // packing depends on the parameters only, so it shares this launch instead of being the next one (12 us of a 0.4-0.7 ms
+    // small-batch step).  MLP-major: the background MLP's vectors, then each object's.
+    if ((int)blockIdx.x >= nb_pro) {
+        const int pb = (int)blockIdx.x - nb_pro;
+        if (pb < pack_blocks_bkgd) pack_all_vec(pk, 0, pb * 256 + (int)threadIdx.x);
+        else {
+            const int rel = pb - pack_blocks_bkgd;
+            pack_all_vec(pk, 1 + rel / pack_blocks_obj, (rel % pack_blocks_obj) * 256 + (int)threadIdx.x);
+        }
+        return;
+    }
     // two chores of a training step that cost a launch of their own otherwise (ray-independent; done first so that the
     // stores are in flight under the ray setup): a snapshot of this timestep's poses (the step returns the poses it
     // rendered with, train_boxpose.py:315, and the optimizer updates them in place) and the zero fill of the gradient
     if (pose_copy && blockIdx.x == 0 && (int)threadIdx.x < K * 6) pose_copy[threadIdx.x] = pose[threadIdx.x];
     if (zero_buf) {
-        const size_t nthr = (size_t)gridDim.x * blockDim.x, gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const size_t nthr = (size_t)nb_pro * blockDim.x, gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
         const size_t n4 = zero_count >> 2;                                   // (16-byte aligned buffer: the wrapper checks)
         for (size_t i = gid; i < n4; i += nthr) ((float4*)zero_buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gid < (zero_count & 3)) zero_buf[n4 * 4 + gid] = 0.0f;
@@ -438,30 +452,67 @@ int durf_ray_setup(void* stream, int B, int K, const float* origins, const float
     return 0;
 }
 
-int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
-                      const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
-                      const float* viewdirs, void* view_bf16, const float* near, const float* far, const float* t_rand,
-                      int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count,
-                      uint32_t seed_lo, uint32_t seed_hi, float* u_rand_out) {
+static int launch_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
+                           const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
+                           const float* viewdirs, void* view_bf16, const float* near, const float* far, const float* t_rand,
+                           int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count,
+                           uint32_t seed_lo, uint32_t seed_hi, float* u_rand_out, const PackAll* pack, int K_pack) {
     DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
+    DURF_REQUIRE(zero_buf == nullptr || ((size_t)zero_buf & 15) == 0, "zero_buf aligned to 16 bytes");
     DURF_REQUIRE(u_rand_out == nullptr || t_rand == nullptr, "the draws come from t_rand OR from the launch's own generator");
     DURF_REQUIRE(u_rand_out == nullptr || (size_t)B * (N + 1) < ((size_t)1 << 32), "in-kernel draws: 32-bit sample counter");
-    DURF_REQUIRE(zero_buf == nullptr || ((size_t)zero_buf & 15) == 0, "zero_buf aligned to 16 bytes");
+    PackAll pk{};
+    int pb_bkgd = 0, pb_obj = 0;
+    if (pack) {
+        pk = *pack;
+        if (pk.p_bkgd) pb_bkgd = (int)durf_cdiv((size_t)(MlpSpec<256>::TOTAL_CHUNKS + (pk.b_bkgd ? BwdSpec<256>::TOTAL_CHUNKS : 0)) * 64, 256);
+        if (K_pack > 0) pb_obj = (int)durf_cdiv((size_t)(MlpSpec<128>::TOTAL_CHUNKS + (pk.b_obj ? BwdSpec<128>::TOTAL_CHUNKS : 0)) * 64, 256);
+    }
+    const int pack_blocks = pb_bkgd + (K_pack > 0 ? K_pack * pb_obj : 0);
     if (B <= 0) {       // an empty shard still owes its caller the zero-filled gradient (it is all-reduced and fed to clip + Adam)
         if (zero_buf && zero_count) {
             DURF_REQUIRE(hipMemsetAsync(zero_buf, 0, zero_count * sizeof(float), (hipStream_t)stream) == hipSuccess,
                          "zero fill of an empty shard's gradient");
         }
-        return 0;
+        if (pack_blocks == 0) return 0;
     }
     // the grid covers the largest of the three index spaces (rays, view-encoding features, sample positions)
-    const size_t items = std::max((size_t)B * (N + 1), (size_t)B * DURF_VIEW_DIM);
-    hipLaunchKernelGGL(k_ray_prologue, dim3(durf_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, B,
+    const size_t items = B > 0 ? std::max((size_t)B * (N + 1), (size_t)B * DURF_VIEW_DIM) : 0;
+    const int nb_pro = (int)durf_cdiv(items, 256);
+    hipLaunchKernelGGL(k_ray_prologue, dim3(nb_pro + pack_blocks), dim3(256), 0, (hipStream_t)stream, B,
                        K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, (__bf16*)view_bf16, near,
                        far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_buf ? zero_count : (size_t)0, seed_lo, seed_hi,
-                       u_rand_out);
+                       u_rand_out, pk, nb_pro, pb_bkgd, pb_obj > 0 ? pb_obj : 1);
     DURF_CHECK_LAUNCH("durf_ray_prologue");
     return 0;
+}
+
+int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
+                      const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
+                      const float* viewdirs, void* view_bf16, const float* near, const float* far, const float* t_rand,
+                      int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count,
+                      uint32_t seed_lo, uint32_t seed_hi, float* u_rand_out) {
+    return launch_prologue(stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far,
+                           t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count, seed_lo, seed_hi, u_rand_out, nullptr, 0);
+}
+
+int durf_ray_prologue_pack(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
+                           const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
+                           const float* viewdirs, void* view_bf16, const float* near, const float* far, const float* t_rand,
+                           int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count,
+                           uint32_t seed_lo, uint32_t seed_hi, float* u_rand_out,
+                           const float* bkgd_params, int in_bkgd, void* bkgd_fwd, void* bkgd_bwd, int K_pack,
+                           const float* obj_params, size_t obj_param_stride, int in_obj, void* obj_fwd, void* obj_bwd) {
+    DURF_REQUIRE(bkgd_params == nullptr || (bkgd_fwd != nullptr && in_bkgd > 0 && in_bkgd <= DURF_ENC_DIM),
+                 "background MLP: forward stream and 1 <= in_dim <= 64");
+    DURF_REQUIRE(K_pack >= 0 && (K_pack == 0 || (obj_params != nullptr && obj_fwd != nullptr && in_obj > 0 && in_obj <= DURF_ENC_DIM)),
+                 "object MLPs: parameters, forward streams and 1 <= in_dim <= 64");
+    PackAll a{};
+    a.p_bkgd = bkgd_params; a.f_bkgd = (bf16x8*)bkgd_fwd; a.b_bkgd = (bf16x8*)bkgd_bwd; a.in_bkgd = in_bkgd;
+    a.p_obj = obj_params; a.f_obj = (bf16x8*)obj_fwd; a.b_obj = (bf16x8*)obj_bwd; a.in_obj = in_obj;
+    a.p_stride = obj_param_stride; a.f_stride = durf_wpack_fwd_bytes(128); a.b_stride = durf_wpack_bwd_bytes(128);
+    return launch_prologue(stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far,
+                           t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count, seed_lo, seed_hi, u_rand_out, &a, K_pack);
 }
 
 int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* idx,

@@ -164,18 +164,18 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     hipStream_t hs = (hipStream_t)stream;
     int rc;
     // ---- forward (obbpose_model.py:68-261), activations stashed ----
-    STEP(durf_ray_prologue(stream, B, K, N, f.origins, f.directions, f.pose, f.ext, w.o_s, w.d_s, w.hit, f.zo, f.viewdirs, w.view,
-                           f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0], nullptr, a->grad, a->n_params, f.seed_lo, f.seed_hi,
-                           f.draw_noise ? w.u_rand : nullptr));
+    const bool f32o = K > 0 && (a->flags & DURF_TRAIN_OBJ_FP32), pose_opt = f32o && (a->flags & DURF_TRAIN_POSE_OPT);
+    const int Kb = f32o ? 0 : K;                          // objects on the bf16 kernels
+    // (ray setup, view encoding, level-0 samples, the step's draws, the gradient's zero fill AND every bf16 weight stream: one launch)
+    STEP(durf_ray_prologue_pack(stream, B, K, N, f.origins, f.directions, f.pose, f.ext, w.o_s, w.d_s, w.hit, f.zo, f.viewdirs, w.view,
+                                f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0], nullptr, a->grad, a->n_params, f.seed_lo, f.seed_hi,
+                                f.draw_noise ? w.u_rand : nullptr, f.bkgd_params, 60, w.wf_bkgd, w.wb_bkgd, Kb, f.obj_params,
+                                f.obj_param_stride, 63, w.wf_obj, w.wb_obj));
     if (K > 0)
         STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
                               f.dyn_mask));
     else
         STEP((int)hipMemsetAsync(f.dyn_mask, 0, (size_t)B * 4, hs));
-    const bool f32o = K > 0 && (a->flags & DURF_TRAIN_OBJ_FP32), pose_opt = f32o && (a->flags & DURF_TRAIN_POSE_OPT);
-    const int Kb = f32o ? 0 : K;                          // objects on the bf16 kernels
-    STEP(durf_pack_weights_all(stream, f.bkgd_params, 60, w.wf_bkgd, w.wb_bkgd, Kb, f.obj_params, f.obj_param_stride, 63, w.wf_obj,
-                               w.wb_obj));
     if (f32o) {
         // the object branch in exact fp32 (MipNerfModel.object_precision, obbpose_model._forward): fp32 view features and
         // weight streams, and the background MLP's ONE evaluation of every box-hit ray redone in fp32 -- the constant

@@ -240,9 +240,15 @@ class MipNerfModel:
         # ray setup + view encoding + level-0 sample positions: one launch; both compactions: one launch
         # (the launch also snapshots the poses: the outputs must not alias the parameters the optimizer updates in place)
         pose_used = torch.empty_like(pose)
+        # (the launch also packs every bf16 weight stream of the step: the K object MLPs sit back to back in the flat buffer)
+        pack_arg = None
+        if not f32:
+            o0 = lay.mlp_off['BoxMLP_0'] if Kb else 0
+            pack_arg = (variables.mlp_flat('MLP_0'), Kb, variables.flat[o0:o0 + Kb * lay.mlp_size[W_OBJ]] if Kb else None,
+                        lay.mlp_size[W_OBJ], train)
         pro = ops.ray_prologue(rays.origins, rays.directions, pose, ext, rays.viewdirs, near, far, N,
                                noise['t_rand'] if (randomized and seed is None) else None, self.lindisp,
-                               pose_copy=pose_used, zero=zero_fill, seed=seed)
+                               pose_copy=pose_used, zero=zero_fill, seed=seed, pack=pack_arg)
         o_s, d_s, hit, zo, view, t_vals0 = pro[:6]
         if seed is not None:
             noise = dict(t_rand=None, u_rand=pro[6])
@@ -252,11 +258,8 @@ class MipNerfModel:
             (idx, count, slot), cls = ops.compact_hits(hit), None
         view27 = ops.view_enc(rays.viewdirs, want_f32=True)[1] if (f32 or obj_f32) else None
         packs = {}
-        if not f32:                                  # every weight stream in one launch; the K object MLPs sit back
-            o0 = lay.mlp_off['BoxMLP_0'] if Kb else 0    # to back in the flat buffer
-            pk_b, pk_o = ops.pack_weights_all(variables.mlp_flat('MLP_0'), Kb,
-                                              variables.flat[o0:o0 + Kb * lay.mlp_size[W_OBJ]] if Kb else None,
-                                              lay.mlp_size[W_OBJ], want_bwd=train)
+        if not f32:
+            pk_b, pk_o = pro[-1]
             packs = {'MLP_0': pk_b}
             if Kb:
                 packs['obj'] = pk_o

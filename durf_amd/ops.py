@@ -72,12 +72,14 @@ def ray_setup(origins, dirs, pose, ext):
 
 
 def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, lindisp=False, pose_copy=None, zero=None,
-                 seed=None):
+                 seed=None, pack=None):
     """ray_setup + view_enc (bf16) + sample_t as ONE launch (durf_ray_prologue)
     -> origins_s[B,3], dirs_s[B,3], hit[B,K] int32, zo[B], view[B,32] bf16, t_vals[B,N+1]
     pose_copy [K,6]: receives a snapshot of `pose`; zero: a contiguous fp32 tensor the launch zero fills (the gradient)
     seed (int, instead of t_rand): the launch draws the step's stratified-sampling noise itself (Philox under this key) and
-    also returns u_rand[B,N+1], the resampling draws of the following levels -> (..., t_vals, u_rand)"""
+    also returns u_rand[B,N+1], the resampling draws of the following levels -> (..., t_vals, u_rand)
+    pack = (bkgd_params, K, obj_params, obj_param_stride, want_bwd): pack_weights_all's work rides in the same launch
+    (durf_ray_prologue_pack); its result ((bkgd_fwd, bkgd_bwd), (obj_fwd, obj_bwd) or None) is appended to the tuple"""
     B, K = origins.shape[0], pose.shape[0]
     dev = origins.device
     if zero is not None:
@@ -93,12 +95,28 @@ def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, 
         assert t_rand is None
         u_out = torch.empty(B, N + 1, device=dev)
     lo, hi = (0, 0) if seed is None else split_seed(seed)
-    _lib.check(_lib.lib().durf_ray_prologue(_stream(), B, K, N, _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
-                                            _p(_f32(ext)), _p(o_s), _p(d_s), _p(hit), _p(zo), _p(_f32(viewdirs)), _p(view),
-                                            _p(_f32(near)), _p(_f32(far)), _p(None if t_rand is None else _f32(t_rand)),
-                                            int(lindisp), _p(t), _p(pose_copy if K else None), _p(zero),
-                                            0 if zero is None else zero.numel(), lo, hi, _p(u_out)), 'durf_ray_prologue')
-    return (o_s, d_s, hit, zo, view, t) if seed is None else (o_s, d_s, hit, zo, view, t, u_out)
+    common = (_stream(), B, K, N, _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
+              _p(_f32(ext)), _p(o_s), _p(d_s), _p(hit), _p(zo), _p(_f32(viewdirs)), _p(view),
+              _p(_f32(near)), _p(_f32(far)), _p(None if t_rand is None else _f32(t_rand)),
+              int(lindisp), _p(t), _p(pose_copy if K else None), _p(zero),
+              0 if zero is None else zero.numel(), lo, hi, _p(u_out))
+    out = (o_s, d_s, hit, zo, view, t) if seed is None else (o_s, d_s, hit, zo, view, t, u_out)
+    if pack is None:
+        _lib.check(_lib.lib().durf_ray_prologue(*common), 'durf_ray_prologue')
+        return out
+    bkgd_params, Kp, obj_params, obj_param_stride, want_bwd = pack
+    L = _lib.lib()
+    u8 = lambda n: torch.empty(int(n), dtype=torch.uint8, device=dev)
+    bf = u8(L.durf_wpack_fwd_bytes(W_BKGD_))
+    bb = u8(L.durf_wpack_bwd_bytes(W_BKGD_)) if want_bwd else None
+    of = ob = None
+    if Kp:
+        of = u8(Kp * int(L.durf_wpack_fwd_bytes(W_OBJ_)))
+        ob = u8(Kp * int(L.durf_wpack_bwd_bytes(W_OBJ_))) if want_bwd else None
+    _lib.check(L.durf_ray_prologue_pack(*common, _p(_f32(bkgd_params)), IN_BKGD, _p(bf), _p(bb), int(Kp),
+                                        _p(obj_params) if Kp else None, int(obj_param_stride), IN_OBJ_, _p(of), _p(ob)),
+               'durf_ray_prologue_pack')
+    return out + (((bf, bb), ((of, ob) if Kp else None)),)
 
 
 def split_seed(seed):

@@ -127,6 +127,17 @@ int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, c
                       const float* t_rand /* nullable */, int lindisp, float* t_vals, float* pose_copy /* nullable */,
                       float* zero_buf /* nullable */, size_t zero_count, uint32_t seed_lo, uint32_t seed_hi,
                       float* u_rand_out /* nullable */);
+/* durf_ray_prologue + durf_pack_weights_all as ONE launch (same results of both): the step's bf16 weight streams depend on
+ * the parameters only, so their packing rides in workgroups behind the prologue's own.  Arguments: durf_ray_prologue's, then
+ * durf_pack_weights_all's (K_pack = object MLPs to pack: 0 when the object branch runs on the fp32 kernels). */
+int durf_ray_prologue_pack(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
+                           const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
+                           const float* viewdirs, void* view_bf16, const float* near, const float* far,
+                           const float* t_rand /* nullable */, int lindisp, float* t_vals, float* pose_copy /* nullable */,
+                           float* zero_buf /* nullable */, size_t zero_count, uint32_t seed_lo, uint32_t seed_hi,
+                           float* u_rand_out /* nullable */, const float* bkgd_params, int in_bkgd, void* bkgd_fwd,
+                           void* bkgd_bwd /* nullable */, int K_pack, const float* obj_params, size_t obj_param_stride,
+                           int in_obj, void* obj_fwd, void* obj_bwd /* nullable */);
 
 /* mip.sample_along_rays t_vals (mip.py:353-368). t_rand nullable (randomized=False). */
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
