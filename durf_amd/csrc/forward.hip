@@ -66,6 +66,8 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
     DURF_REQUIRE(L >= 1 && L <= DURF_FORWARD_MAX_LEVELS, "1 <= num_levels <= DURF_FORWARD_MAX_LEVELS");
     DURF_REQUIRE(((size_t)workspace & 255) == 0, "workspace aligned to 256 bytes");
     DURF_REQUIRE(!a->draw_noise || (a->t_rand == nullptr && a->u_rand == nullptr), "draw_noise: the library makes the draws");
+    for (int l = 0; l < L && a->density_noise != 0.0f; l++)
+        DURF_REQUIRE(a->density_rand[l] != nullptr || a->draw_noise, "density_noise: density_rand[level] or draw_noise");
     const FwdWs w = carve(workspace, B, N, K);
     const size_t rows = (size_t)B * N;
     int rc;
@@ -95,6 +97,8 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, nullptr, 0, a->enc_flags, w.enc, w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b, nullptr, nullptr, nullptr,
                               nullptr, nullptr));
         }
+        if (a->density_noise != 0.0f)      // obbpose_model.py:236-240
+            STEP(durf_density_noise(stream, rows, w.raw_b, a->density_noise, a->density_rand[lvl], a->seed_lo, a->seed_hi, lvl));
         STEP(durf_composite_fwd(stream, B, N, K, w.raw_b, raw_obj, w.slot_obj, t_vals, w.d_s, a->density_bias, a->bkgd_mode,
                                 a->rgb[lvl], a->depth[lvl], a->acc[lvl], a->weights[lvl], a->t_mids[lvl], a->t_dists[lvl]));
         if (lvl + 1 < L)

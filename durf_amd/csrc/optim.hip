@@ -76,6 +76,49 @@ k_poison_multi_hit(size_t n, float* __restrict__ g, const int32_t* __restrict__ 
     }
 }
 
+// Config.weight_decay_mult (train_boxpose.py:73-75): loss += mult * mean(theta^2) over EVERY parameter, so
+// d(loss)/d(theta) += (2 mult / n) theta.  One pass: the gradient term on [lo, hi) (a bucketed exchange hands the object
+// MLPs' slice over before the rest exists) and, when asked for, per-block sums of squares over all n; a single-workgroup
+// launch adds those in index order (deterministic) into the scalar durf_train_stats logs and adds to the loss.
+__global__ void __launch_bounds__(OPT_BLOCK)
+k_weight_decay(size_t n, const float* __restrict__ p, float* __restrict__ g, size_t lo, size_t hi, float c,
+               float* __restrict__ part) {
+    __shared__ float s_sq[OPT_BLOCK / 64];
+    const size_t base = (size_t)blockIdx.x * (OPT_BLOCK * OPT_PER_THREAD);
+    float sq = 0.0f;
+#pragma unroll
+    for (int j = 0; j < OPT_PER_THREAD; j++) {
+        const size_t i = base + (size_t)j * OPT_BLOCK + threadIdx.x;
+        if (i < n) {
+            const float t = p[i];
+            sq = __fadd_rn(sq, __fmul_rn(t, t));
+            if (i >= lo && i < hi) g[i] = __fadd_rn(g[i], __fmul_rn(c, t));
+        }
+    }
+    if (part == nullptr) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float a = 0.0f;
+        for (int w = 0; w < OPT_BLOCK / 64; w++) a += s_sq[w];
+        part[blockIdx.x] = a;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+k_weight_l2(int nblocks, const float* __restrict__ part, float mult, float inv_n, float* __restrict__ out) {
+    __shared__ float s_sq[4];
+    float sq = 0.0f;
+    for (int i = threadIdx.x; i < nblocks; i += 256) sq += part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+    if ((threadIdx.x & 63) == 0) s_sq[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = mult * (((s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3])) * inv_n);
+}
+
 extern "C" {
 
 int durf_poison_multi_hit(void* stream, size_t n, float* grad, const int32_t* cls_count, size_t box_floats, int K,
@@ -85,6 +128,24 @@ int durf_poison_multi_hit(void* stream, size_t n, float* grad, const int32_t* cl
     hipLaunchKernelGGL(k_poison_multi_hit, dim3(32), dim3(256), 0, (hipStream_t)stream, n, grad, cls_count, box_floats, K,
                        mlp0_floats, obj_floats);
     DURF_CHECK_LAUNCH("durf_poison_multi_hit");
+    return 0;
+}
+
+// Config.weight_decay_mult: grad[lo:hi) += (2 mult / n) params[lo:hi); weight_l2 (nullable) <- mult * mean(params^2) over
+// all n.  scratch: durf_optim_scratch_floats(n) floats (only read between this call's two launches).
+int durf_weight_decay(void* stream, size_t n, const float* params, float* grad, size_t lo, size_t hi, float mult,
+                      float* scratch, float* weight_l2) {
+    if (n == 0) return 0;
+    DURF_REQUIRE(params != nullptr && grad != nullptr && lo <= hi && hi <= n, "params, grad, 0 <= lo <= hi <= n");
+    DURF_REQUIRE(weight_l2 == nullptr || scratch != nullptr, "weight_l2 needs the scratch of durf_optim_scratch_floats(n)");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)durf_cdiv(n, OPT_BLOCK * OPT_PER_THREAD);
+    const float c = (float)(2.0 * (double)mult / (double)n);
+    hipLaunchKernelGGL(k_weight_decay, dim3(nb), dim3(OPT_BLOCK), 0, s, n, params, grad, lo, hi, c,
+                       weight_l2 != nullptr ? scratch : nullptr);
+    if (weight_l2 != nullptr)
+        hipLaunchKernelGGL(k_weight_l2, dim3(1), dim3(256), 0, s, nb, scratch, mult, (float)(1.0 / (double)n), weight_l2);
+    DURF_CHECK_LAUNCH("durf_weight_decay");
     return 0;
 }
 

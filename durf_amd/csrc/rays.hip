@@ -192,8 +192,8 @@ k_compact_all(int B, int K, int N, const int32_t* __restrict__ hit, int32_t* __r
 // (mip.py:364, math.py:257-260: jax.random.uniform on a key) instead of by a generator kernel in front of it.  Word 0 of
 // block i jitters level-0 sample position i, word 1 is the resampling draw i of the following levels.  Restated on the
 // CPU (with the generator's known-answer vectors) in oracle/philox_ref.py; tests/test_gpu_sampling_noise.py.
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned k0, unsigned k1, unsigned& x0, unsigned& x1) {
-    unsigned c1 = 0u, c2 = 0u, c3 = 0u;
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned k0, unsigned k1, unsigned& x0, unsigned& x1, unsigned c1 = 0u) {
+    unsigned c2 = 0u, c3 = 0u;
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         const unsigned lo0 = 0xD2511F53u * c0, hi0 = __umulhi(0xD2511F53u, c0);
@@ -439,6 +439,28 @@ k_encode_lane(int rays, int N, const int32_t* __restrict__ idx, const int32_t* _
 }
 
 // ---------------------------------------------------------------------------
+// MipNerfModel.density_noise (obbpose_model.py:236-240): raw_density += density_noise * random.normal(key, shape) on the
+// randomized path.  The standard-normal draws are the caller's (`normal` [rows]) or made here: Philox block (row, 1 + level,
+// 0, 0) under the step's key -- word 1 of the counter keeps it clear of the sampling draws above, which use (i, 0, 0, 0) --
+// through Box-Muller, z = sqrt(-2 ln u1) cos(2 pi u2) with u1 in (0, 1], u2 in [0, 1) from 24 bits each
+// (oracle/philox_ref.py: density_draws).  The product and the sum are rounded separately, as the tensor expression is.
+__global__ void __launch_bounds__(256)
+k_density_noise(size_t rows, float* __restrict__ raw, float scale, const float* __restrict__ normal, unsigned seed_lo,
+                unsigned seed_hi, unsigned level) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    float z;
+    if (normal != nullptr) {
+        z = normal[i];
+    } else {
+        unsigned x0, x1;
+        philox4x32_10((unsigned)i, seed_lo, seed_hi, x0, x1, 1u + level);
+        const float u1 = (float)((x0 >> 8) + 1u) * 5.9604644775390625e-08f, u2 = u01_24(x1);
+        z = sqrtf(-2.0f * logf(u1)) * cospif(2.0f * u2);
+    }
+    raw[i * 4 + 3] = __fadd_rn(raw[i * 4 + 3], __fmul_rn(scale, z));
+}
+
 extern "C" {
 
 int durf_ray_setup(void* stream, int B, int K, const float* origins, const float* dirs,
@@ -541,6 +563,16 @@ int durf_compact_all(void* stream, int B, int K, int N, const int32_t* hit, int3
     hipLaunchKernelGGL(k_compact_all, dim3(K + 2), dim3(1024), 0, (hipStream_t)stream, B, K, N, hit, idx_obj, count_obj,
                        slot_obj, idx_cls, count_cls, slot_cls, dyn);
     DURF_CHECK_LAUNCH("durf_compact_all");
+    return 0;
+}
+
+int durf_density_noise(void* stream, size_t rows, float* raw, float scale, const float* normal, uint32_t seed_lo,
+                       uint32_t seed_hi, int level) {
+    if (rows == 0 || scale == 0.0f) return 0;
+    DURF_REQUIRE(raw != nullptr && level >= 0 && rows <= 0xffffffffull, "raw [rows,4], level >= 0");
+    hipLaunchKernelGGL(k_density_noise, dim3(durf_cdiv(rows, 256)), dim3(256), 0, (hipStream_t)stream, rows, raw, scale, normal,
+                       seed_lo, seed_hi, (unsigned)level);
+    DURF_CHECK_LAUNCH("durf_density_noise");
     return 0;
 }
 

@@ -4,8 +4,9 @@
 // of its own: the stage entry points of this library in the order the Python path issues them on ONE stream, every
 // intermediate carved out of a caller-owned workspace.  Scope: every BASELINE.json training configuration -- bf16 background
 // MLP; object MLPs on the bf16 kernels (frozen poses: cfg2 / cfg3 / cfg5) or, with obj_fp32, on the exact-fp32 kernels with
-// the box-pose gradient behind them (cfg4: want_pos / want_rot, the TV prior); >= 2 levels, no density noise, no weight
-// decay, fixed background colour.  Results are bit-identical to train_boxpose.train_step (tests/test_gpu_train_call.py).
+// the box-pose gradient behind them (cfg4: want_pos / want_rot, the TV prior); >= 2 levels; density noise (f.density_noise),
+// weight decay (weight_decay_mult) and every background mode included.  Results are bit-identical to
+// train_boxpose.train_step (tests/test_gpu_train_call.py).
 #include "durf_common.h"
 #include "../../include/durf_hip.h"
 
@@ -36,7 +37,7 @@ __global__ void k_tv_rows(int K, const float* __restrict__ pose, const float* __
 }
 
 struct TrainWs {
-    float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *part, *bpart, *opart, *obpart, *scratch, *u_rand;
+    float *o_s, *d_s, *norms, *prep, *ray_sums, *sums, *part, *bpart, *opart, *obpart, *scratch, *u_rand, *weight_l2;
     float* draw[ML];      // d(loss)/d(raw) of every level (ONE loss launch fills them all: durf_loss_bwd_levels)
     float *raw_c[ML], *raw_b[ML], *obj_raw[ML], *terms[ML];
     int32_t *hit, *idx_obj, *count_obj, *slot_obj, *idx_cls, *count_cls, *slot_cls;
@@ -82,6 +83,7 @@ TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params, int 
     w.obpart = (float*)c.take(K > 0 ? (size_t)K * durf_dw_bpart_floats(128) * 4 : 0);
     w.scratch = (float*)c.take(durf_optim_scratch_floats(n_params) * 4);
     w.u_rand = (float*)c.take((size_t)B * (N + 1) * 4);              // f.draw_noise: the resampling draws of the prologue
+    w.weight_l2 = (float*)c.take(4);                                 // weight_decay_mult * mean(theta^2) (durf_weight_decay)
     for (int l = 0; l < L; l++) {
         w.terms[l] = (float*)c.take((size_t)7 * B * 4);
         w.enc[l] = c.take(trows * 64 * 2);
@@ -130,7 +132,9 @@ int check_args(const durf_train_args* a, void* workspace) {
     DURF_REQUIRE(f.bkgd_params == a->params + a->box_floats &&
                  (f.K == 0 || (f.obj_params == a->params + a->box_floats + a->mlp0_floats && f.obj_param_stride == a->obj_floats)),
                  "f.bkgd_params / f.obj_params point into params");
-    DURF_REQUIRE(f.bkgd_mode == 0 || f.bkgd_mode == 1, "fixed background colour (grey or white)");
+    DURF_REQUIRE(f.bkgd_mode >= 0 && f.bkgd_mode <= 2, "bkgd_mode: 0 grey / 1 white / 2 none (rand_bkgd: bg = 0)");
+    for (int l = 0; l < f.num_levels && f.density_noise != 0.0f; l++)
+        DURF_REQUIRE(f.density_rand[l] != nullptr || f.draw_noise, "density_noise: density_rand[level] or draw_noise");
     DURF_REQUIRE(!f.draw_noise || (f.t_rand == nullptr && f.u_rand == nullptr), "draw_noise: the library makes the draws");
     DURF_REQUIRE((a->flags & ~(DURF_TRAIN_OBJ_FP32 | DURF_TRAIN_POSE_OPT)) == 0, "unknown flags");
     if (a->flags & DURF_TRAIN_POSE_OPT) {
@@ -211,6 +215,8 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, nullptr, 0, f.enc_flags, w.enc[lvl], w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl],
                               w.mask[lvl], nullptr, nullptr, lvl == 0 ? w.view_tile : nullptr));
         }
+        if (f.density_noise != 0.0f)       // obbpose_model.py:236-240, on the background's raw density as the Python path adds it
+            STEP(durf_density_noise(stream, rows, w.raw_b[lvl], f.density_noise, f.density_rand[lvl], f.seed_lo, f.seed_hi, lvl));
         if (lvl + 1 < L)        // composite + resample + the loss normalisers of this (level 0 only) and the next level: one launch
             STEP(durf_composite_resample(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, t_vals, w.d_s, f.density_bias,
                                          f.bkgd_mode, f.rgb[lvl], f.depth[lvl], f.acc[lvl], f.weights[lvl], f.t_mids[lvl],
@@ -285,6 +291,11 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     STEP(durf_dw_finalize_all(stream, 60, L, seg_rows, per_ray, seg_count, w.part, w.bpart, g_bkgd, f.bkgd_params, Kb, Kb ? B : 0,
                               Kb ? N : 0, Kb ? w.count_obj : nullptr, Kb ? L : 1, 63, Kb ? w.opart : nullptr, Kb ? w.obpart : nullptr,
                               Kb ? g_obj : nullptr, Kb ? a->obj_floats : 0, Kb ? f.obj_params : nullptr));
+    const float* wl2 = nullptr;
+    if (a->weight_decay_mult != 0.0f) {       // train_boxpose.py:73-75 (in front of the pose rows' additions, as the Python path orders it)
+        STEP(durf_weight_decay(stream, a->n_params, a->params, a->grad, 0, a->n_params, a->weight_decay_mult, w.scratch, w.weight_l2));
+        wl2 = w.weight_l2;
+    }
     if (pose_opt) {             // d(loss)/d(box_centers[ts]) (obbpose_model.py:99-131) + the TV prior, into this timestep's rows
         float* g_rows = a->grad + (f.pose - a->params);
         STEP(durf_pose_finish(stream, K, f.pose, w.pose_sums, a->want_pos, a->want_rot, g_rows));
@@ -300,7 +311,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     const float* tv[ML];
     const float* terms[ML];
     for (int l = 0; l < L; l++) { tv[l] = f.t_vals[l]; terms[l] = w.terms[l]; }
-    STEP(durf_train_stats(stream, L, K, N, w.norms, w.sums, nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
+    STEP(durf_train_stats(stream, L, K, N, w.norms, w.sums, wl2, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
                           K ? a->target6 : nullptr, tv, a->stat_mults, 3 /* assemble | psnr */, a->stats, terms, B));
     return 0;
 }
@@ -339,11 +350,12 @@ int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
         const float* tv[ML];
         const float* terms[ML];
         for (int l = 0; l < L; l++) { tv[l] = f.t_vals[l]; terms[l] = w.terms[l]; }
+        const float* wl2 = a->weight_decay_mult != 0.0f ? w.weight_l2 : nullptr;
         if (K > 1)
             STEP(durf_poison_multi_hit(stream, a->n_params, a->grad, w.count_cls, a->box_floats, K, a->mlp0_floats, a->obj_floats));
         STEP(durf_allreduce_sum(stream, a->comm, a->grad, a->n_params));
         if (!a->reduce_stats) {          // shard-local scalars (the reference reads them every print_every steps only)
-            STEP(durf_stats_scrub(stream, L, K, f.N, w.norms, w.sums, nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
+            STEP(durf_stats_scrub(stream, L, K, f.N, w.norms, w.sums, wl2, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
                                   K ? a->target6 : nullptr, tv, a->stat_mults, 3, a->stats, terms, f.B, a->n_params, a->grad,
                                   inv_world, a->max_val, w.scratch, nullptr, 0, 0, 0, 0));
             return durf_adam_apply(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, a->max_norm, a->lr, a->step,
@@ -351,7 +363,7 @@ int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
         }
         // lax.pmean(stats) (:255), then the PSNRs from the averaged losses (:291-292)
         const int ns = 2 + 17 * L;
-        STEP(durf_train_stats(stream, L, K, f.N, w.norms, w.sums, nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
+        STEP(durf_train_stats(stream, L, K, f.N, w.norms, w.sums, wl2, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
                               K ? a->target6 : nullptr, tv, a->stat_mults, 1, a->stats, terms, f.B));
         STEP(durf_allreduce_sum(stream, a->comm, a->stats, (size_t)ns));
         hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, (hipStream_t)stream, ns, a->stats, inv_world);
@@ -367,7 +379,7 @@ int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
     const float* tv[ML];
     const float* terms[ML];
     for (int l = 0; l < L; l++) { tv[l] = f.t_vals[l]; terms[l] = w.terms[l]; }
-    STEP(durf_stats_scrub(stream, L, K, f.N, w.norms, w.sums, nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
+    STEP(durf_stats_scrub(stream, L, K, f.N, w.norms, w.sums, a->weight_decay_mult != 0.0f ? w.weight_l2 : nullptr, K ? f.pose : nullptr, K ? a->prev6 : nullptr,
                           K ? a->target6 : nullptr, tv, a->stat_mults, 3 /* assemble | psnr */, a->stats, terms, f.B, a->n_params,
                           a->grad, 1.0f, a->max_val, w.scratch, K > 1 ? w.count_cls : nullptr, a->box_floats, K > 1 ? K : 0,
                           a->mlp0_floats, a->obj_floats));

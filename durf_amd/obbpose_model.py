@@ -394,9 +394,14 @@ class MipNerfModel:
                         launch_objects()
                     side.join()
                 raws = slabs.raws() if Kb else (lvd['raws'] if obj_f32 else [])
-            if randomized and self.density_noise > 0:    # :236-240 (added once to the merged raw density)
-                dn = noise['density'][lvl] if 'density' in noise else torch.randn(B, N, device=dev, generator=g)
-                raw_b[:, 3] += self.density_noise * dn.reshape(-1)
+            if randomized and self.density_noise > 0:    # :236-240: one launch (the draws: injected, the library's own
+                # under the host's key, or a torch.Generator's)
+                if 'density' in noise:
+                    ops.density_noise(raw_b, self.density_noise, normal=noise['density'][lvl])
+                elif seed is not None:
+                    ops.density_noise(raw_b, self.density_noise, seed=seed, level=lvl)
+                else:
+                    ops.density_noise(raw_b, self.density_noise, normal=torch.randn(B, N, device=dev, generator=g))
             deferred = False
             if fused and not last:
                 rgb, depth, acc, weights, t_mids, t_dists, t_next = ops.composite_resample(
@@ -465,18 +470,19 @@ class MipNerfModel:
         """whether durf_forward (apply_one_call) covers this model's inference path"""
         K = variables.layout.K
         return (self.mlp_precision == 'bf16' and not (K and (not self.dynamics or self.object_precision() != 'bf16')) and
-                not (randomized and self.density_noise > 0) and variables.flat.device.type == 'cuda')
+                variables.flat.device.type == 'cuda')
 
     def apply_one_call(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha, noise=None):
         """`apply` through ONE library call (durf_forward, csrc/forward.hip): the orchestration of `_forward(train=False)`
         done in C for hosts that are not Python; same arguments, same list of 10-tuples, bit-identical results
-        (tests/test_gpu_forward_call.py).  bf16 MLPs, objects on the bf16 kernels, no density noise."""
+        (tests/test_gpu_forward_call.py).  bf16 MLPs, objects on the bf16 kernels.  noise: dict(t_rand, u_rand[, density:
+        the standard-normal draws [B,N] per level]) injected draws; otherwise `rng` keys the library's own (an int) or is the
+        torch.Generator they come from."""
         self._check()
         lay = variables.layout
         K = lay.K
         if not self.supports_one_call(variables, randomized):
-            raise NotImplementedError('durf_forward covers the bf16 inference path (dynamics=True, bf16 object MLPs, no '
-                                      'density noise)')
+            raise NotImplementedError('durf_forward covers the bf16 inference path (dynamics=True, bf16 object MLPs)')
         B, N = rays.origins.shape[0], self.num_samples
         dev = rays.origins.device
         seed = None
@@ -484,9 +490,15 @@ class MipNerfModel:
             if isinstance(rng, torch.Generator):
                 u = torch.rand(2, B, N + 1, device=dev, generator=rng)
                 noise = dict(t_rand=u[0], u_rand=u[1])
+                if self.density_noise > 0:          # (level by level, as apply() draws them)
+                    noise['density'] = [torch.randn(B, N, device=dev, generator=rng) for _ in range(self.num_levels)]
             else:                                   # the library draws (durf_forward_args.draw_noise), as in apply()
                 seed = int(rng) if rng is not None else 0
                 noise = dict(t_rand=None, u_rand=None)
+        dn = self.density_noise if (randomized and self.density_noise > 0) else 0.0
+        if dn and seed is None and 'density' not in noise:      # injected sampling draws only: the generator apply() falls back to
+            gd = _make_generator(rng, dev)
+            noise = dict(noise, density=[torch.randn(B, N, device=dev, generator=gd) for _ in range(self.num_levels)])
         pose = variables['params']['box_centers'][int(ts)].contiguous()
         flags = ((ops.ENC_CONTRACT if self.contraction else 0) | (ops.ENC_NO_INTEGRATION if self.disable_integration else 0) |
                  (ops.ENC_CYLINDER if self.ray_shape == 'cylinder' else 0))
@@ -496,7 +508,8 @@ class MipNerfModel:
             rays, pose, ext.reshape(-1, 3).contiguous() if K else None, variables.mlp_flat('MLP_0'),
             variables.flat[o0:o0 + K * lay.mlp_size[W_OBJ]] if K else None, lay.mlp_size[W_OBJ], N, self.num_levels, alpha, flags,
             lindisp=self.lindisp, bkgd_mode=bk, density_bias=self.density_bias, resample_padding=self.resample_padding,
-            t_rand=noise['t_rand'] if randomized else None, u_rand=noise['u_rand'] if randomized else None, seed=seed)
+            t_rand=noise['t_rand'] if randomized else None, u_rand=noise['u_rand'] if randomized else None, seed=seed,
+            density_noise=dn, density_rand=noise.get('density') if dn else None)
         box_rot0 = pose[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))
         return [tuple(o) + ([pose[:, :3], box_rot0], dyn, zo) for o in outs]
 

@@ -671,6 +671,33 @@ def adam_apply(params, m, v, grad, max_norm, lr, step, scratch):
     return stats
 
 
+def weight_decay(params, grad, mult, lo=0, hi=None, want_l2=True):
+    """Config.weight_decay_mult (train_boxpose.py:73-75): grad[lo:hi) += (2 mult / n) params[lo:hi); -> weight_l2 [1] =
+    mult * mean(params^2) over the whole buffer (None unless want_l2)"""
+    n = params.numel()
+    hi = n if hi is None else hi
+    L = _lib.lib()
+    out = torch.empty(1, device=params.device) if want_l2 else None
+    scratch = torch.empty(int(L.durf_optim_scratch_floats(n)), device=params.device) if want_l2 else None
+    _lib.check(L.durf_weight_decay(_stream(), n, _p(_f32(params)), _p(_f32(grad)), int(lo), int(hi), float(mult), _p(scratch),
+                                   _p(out)), 'durf_weight_decay')
+    return out
+
+
+def density_noise(raw, scale, normal=None, seed=None, level=0):
+    """MipNerfModel.density_noise (obbpose_model.py:236-240): raw[:, 3] += scale * z in place; z = `normal` [rows] or the
+    library's own draws under `seed` (Philox block (row, 1 + level, 0, 0) through Box-Muller; oracle/philox_ref.py)"""
+    assert raw.dim() == 2 and raw.shape[1] == 4 and raw.is_contiguous()
+    assert (normal is None) != (seed is None), 'either the draws or the key they are made under'
+    if normal is not None:
+        normal = _f32(normal.reshape(-1).contiguous())
+        assert normal.numel() == raw.shape[0]
+    lo, hi = (0, 0) if seed is None else split_seed(seed)
+    _lib.check(_lib.lib().durf_density_noise(_stream(), raw.shape[0], _p(_f32(raw)), float(scale), _p(normal), lo, hi, int(level)),
+               'durf_density_noise')
+    return raw
+
+
 class Comm:
     """A communicator of the library's own in-stream all-reduce (csrc/comm.hip: RCCL resolved at run time)"""
 
@@ -1129,7 +1156,7 @@ class ForwardArgs(C.Structure):
                 [('obj_param_stride', C.c_size_t), ('t_rand', C.c_void_p), ('u_rand', C.c_void_p)] +
                 [(n, _vp4) for n in ('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')] +
                 [('dyn_mask', C.c_void_p), ('zo', C.c_void_p), ('draw_noise', C.c_int), ('seed_lo', C.c_uint32),
-                 ('seed_hi', C.c_uint32)])
+                 ('seed_hi', C.c_uint32), ('density_noise', C.c_float), ('density_rand', _vp4)])
 
 
 class TrainArgs(C.Structure):
@@ -1142,14 +1169,15 @@ class TrainArgs(C.Structure):
                 [(n, C.c_void_p) for n in ('grad', 'stats', 'adam_m', 'adam_v')] +
                 [('lr', C.c_float), ('max_val', C.c_float), ('max_norm', C.c_float), ('step', C.c_int), ('grad_stats', C.c_void_p),
                  ('flags', C.c_int), ('want_pos', C.c_int), ('want_rot', C.c_int), ('tv_loss_mult', C.c_float),
-                 ('comm', C.c_void_p), ('world', C.c_int), ('reduce_stats', C.c_int)])
+                 ('comm', C.c_void_p), ('world', C.c_int), ('reduce_stats', C.c_int), ('weight_decay_mult', C.c_float)])
 
 
 TRAIN_OBJ_FP32, TRAIN_POSE_OPT = 1, 2          # durf_train_args.flags
 
 
 def _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
-                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=None):
+                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=None,
+                       density_noise=0.0, density_rand=None):
     B, K = rays.origins.shape[0], pose.shape[0]
     a.B, a.N, a.K, a.num_levels, a.enc_flags, a.lindisp, a.bkgd_mode = B, N, K, num_levels, enc_flags, int(lindisp), bkgd_mode
     a.density_bias, a.resample_padding = density_bias, resample_padding
@@ -1164,13 +1192,20 @@ def _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_st
     a.t_rand, a.u_rand = _p(t_rand), _p(u_rand)
     a.draw_noise = int(seed is not None)
     a.seed_lo, a.seed_hi = (0, 0) if seed is None else split_seed(seed)
+    a.density_noise = float(density_noise)
+    if density_noise and density_rand is not None:          # the caller's standard-normal draws, [B,N] per level
+        dr = [_f32(t.reshape(-1).contiguous()) for t in density_rand]
+        assert len(dr) == num_levels and all(t.numel() == B * N for t in dr)
+        keep.extend(dr)
+        a.density_rand = _vp4(*([t.data_ptr() for t in dr] + [None] * (FORWARD_MAX_LEVELS - num_levels)))
     for i, name in enumerate(('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')):
         setattr(a, name, _vp4(*([o[i].data_ptr() for o in outs] + [None] * (FORWARD_MAX_LEVELS - num_levels))))
     a.dyn_mask, a.zo = _p(dyn), _p(zo)
 
 
 def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp=False,
-                 bkgd_mode=BKGD_GREY, density_bias=-1.0, resample_padding=0.01, t_rand=None, u_rand=None, seed=None):
+                 bkgd_mode=BKGD_GREY, density_bias=-1.0, resample_padding=0.01, t_rand=None, u_rand=None, seed=None,
+                 density_noise=0.0, density_rand=None):
     """MipNerfModel.__call__ in inference as ONE library call (durf_forward): -> list[num_levels] of
     (rgb, depth, acc, weights, t_vals, t_mids, t_dists), dyn_mask [B,1] int32, zo [B]"""
     B, K = rays.origins.shape[0], pose.shape[0]
@@ -1182,7 +1217,8 @@ def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, 
     a = ForwardArgs()
     keep = []
     _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
-                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=seed)
+                       bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=seed,
+                       density_noise=density_noise, density_rand=density_rand)
     ws = torch.empty(int(L.durf_forward_workspace_bytes(B, N, K)), dtype=torch.uint8, device=dev)
     assert ws.data_ptr() % 256 == 0
     with _Timed('forward_call'):
@@ -1194,7 +1230,8 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
                lossmult, pixels, gt_depth, sky, target6, prev6, eps, box_loss_mult, bg, disable_multiscale, level_mults,
                stat_mults, lr, max_val, max_norm, step, lindisp=False, bkgd_mode=BKGD_GREY, density_bias=-1.0,
                resample_padding=0.01, t_rand=None, u_rand=None, update=True, obj_fp32=False, want_pos=False, want_rot=False,
-               tv_loss_mult=0.0, seed=None, comm=None, world=1, reduce_stats=False):
+               tv_loss_mult=0.0, seed=None, comm=None, world=1, reduce_stats=False, density_noise=0.0, density_rand=None,
+               weight_decay_mult=0.0):
     """One shard's training step as ONE library call (durf_train_step; update=False: durf_loss_backward, parameters
     untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None).
     obj_fp32: the object branch on the exact-fp32 kernels; want_pos / want_rot: box-pose optimisation behind it (`pose` must
@@ -1212,7 +1249,9 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
     keep = []
     o0 = box_floats + mlp0_floats
     _fill_forward_args(a.f, rays, pose, ext, params_flat[box_floats:o0], params_flat[o0:] if K else None, obj_floats, N, num_levels,
-                       alpha, enc_flags, lindisp, bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=seed)
+                       alpha, enc_flags, lindisp, bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=seed,
+                       density_noise=density_noise, density_rand=density_rand)
+    a.weight_decay_mult = float(weight_decay_mult)
     hold = [t.reshape(-1).contiguous() for t in (lossmult, gt_depth, sky)] + [pixels.contiguous()]
     a.lossmult, a.gt_depth, a.sky, a.pixels = (_p(_f32(t)) for t in hold)
     hold += [target6.contiguous(), prev6.contiguous()] if K else []

@@ -268,7 +268,6 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                  lay.mlp_size[om.W_OBJ], upto=upto)
 
     flat = variables.flat
-    wd_c = 2.0 * config.weight_decay_mult / flat.numel()          # d/d theta of weight_decay_mult * mean(theta^2) (:73-75)
     first_only = None                   # bucketed exchange: the objects' slice is FINAL (and in flight) once handed over
 
     def hand_over_objects(o0, n):
@@ -277,7 +276,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
         # after this line may write it (the collective reduces it in place)
         nonlocal first_only
         if config.weight_decay_mult != 0:
-            grad[o0:o0 + n] += wd_c * flat[o0:o0 + n]
+            ops.weight_decay(flat, grad, config.weight_decay_mult, o0, o0 + n, want_l2=False)
         poison()
         first_only = o0
         objects_ready(grad[o0:o0 + n])
@@ -323,11 +322,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     side.join()
     weight_l2 = None
     if config.weight_decay_mult != 0:                                          # :73-75
-        weight_l2 = config.weight_decay_mult * (flat * flat).sum() / flat.numel()
-        if first_only is None:
-            grad += wd_c * flat
-        else:
-            grad[:first_only] += wd_c * flat[:first_only]
+        # (one launch pair, durf_weight_decay: the gradient term on whatever has not left for its all-reduce yet + the scalar)
+        weight_l2 = ops.weight_decay(flat, grad, config.weight_decay_mult, 0, flat.numel() if first_only is None else first_only)
     if K > 0 and pose_opt:                      # no_pose_opt and no_yaw_opt: box_centers get no gradient (:100-104)
         # (k_pose_finish ADDS: straight into this timestep's rows of the zero-filled gradient when they are a view)
         g_ts = grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6)
@@ -444,7 +440,7 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
     train_step done in C for hosts that are not Python; same arguments, same (new_state, stats, rng, pose), bit-identical
     results (tests/test_gpu_train_call.py).  Scope of the C entry point: every BASELINE.json training configuration on one
     device -- bf16 background MLP, the object branch in bf16 (frozen poses) or in fp32 with box-pose optimisation behind it
-    (cfg4), >= 2 levels, no density noise, no weight decay, fixed background colour.  update=False: gradient and scalars
+    (cfg4), >= 2 levels; weight decay, density noise and `rand_bkgd` included.  update=False: gradient and scalars
     only (durf_loss_backward) -> (grad, stats buffer views, per-level outputs).  reduce_stats is accepted (and has nothing
     to do on one device) so that this function can be handed to train_loop as its step_fn."""
     model._check()
@@ -454,11 +450,10 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
     dist = _dist()
     comm = _instream_comm(dist) if dist is not None else None
     if (model.mlp_precision != 'bf16' or (K and not model.dynamics) or L < 2 or
-            config.weight_decay_mult != 0 or config.rand_bkgd or (config.randomized and model.density_noise > 0) or
             (dist is not None and (comm is None or not update))):
-        raise NotImplementedError('durf_train_step covers the step with a bf16 background MLP, >= 2 levels, no density noise / '
-                                  'weight decay / random background; data-parallel only through the library\'s own in-stream '
-                                  'all-reduce (DURF_INSTREAM_ALLREDUCE=1; see csrc/train.hip, csrc/comm.hip)')
+        raise NotImplementedError('durf_train_step covers the step with a bf16 background MLP and >= 2 levels; data-parallel only '
+                                  'through the library\'s own in-stream all-reduce (DURF_INSTREAM_ALLREDUCE=1; see csrc/train.hip, '
+                                  'csrc/comm.hip)')
     pose_opt = bool(K) and not (model.no_pose_opt and model.no_yaw_opt)
     obj_fp32 = bool(K) and model.object_precision() == 'f32'
     if pose_opt and not obj_fp32:
@@ -474,9 +469,15 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         if isinstance(rng, torch.Generator):
             u = torch.rand(2, B, N + 1, device=dev, generator=rng)
             noise = dict(t_rand=u[0], u_rand=u[1])
+            if model.density_noise > 0:             # (level by level, as the model draws them)
+                noise['density'] = [torch.randn(B, N, device=dev, generator=rng) for _ in range(L)]
         else:                                       # the library draws (durf_forward_args.draw_noise), as train_step does
             seed = int(rng) if rng is not None else 0
             noise = dict(t_rand=None, u_rand=None)
+    dn = model.density_noise if (config.randomized and model.density_noise > 0) else 0.0
+    if dn and seed is None and 'density' not in noise:      # injected sampling draws only: the generator the model falls back to
+        gd = om._make_generator(rng, dev)
+        noise = dict(noise, density=[torch.randn(B, N, device=dev, generator=gd) for _ in range(L)])
     ts = int(batch['ts'])
     pose = variables['params']['box_centers'][ts]          # a view of the parameters: the pose gradient goes to the same rows
     assert pose.is_contiguous()
@@ -487,14 +488,17 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         rays, pose, batch['ext'].reshape(-1, 3).contiguous() if K else None, variables.flat, state.m, state.v,
         lay.box[1] - lay.box[0], lay.mlp_size[om.W_BKGD], lay.mlp_size[om.W_OBJ], N, L, alpha, flags,
         rays.lossmult, batch['pixels'][..., :3], batch['depth'], batch['sky'], batch['target'] if K else None,
-        prev[0] if K else None, eps, config.box_loss_mult, 1.0 if config.white_bkgd else 0.5, config.disable_multiscale_loss,
+        prev[0] if K else None, eps, config.box_loss_mult, 0.0 if config.rand_bkgd else (1.0 if config.white_bkgd else 0.5),
+        config.disable_multiscale_loss,
         [level_multipliers(config, lvl, L) for lvl in range(L)], _stat_mults(config), lr, config.grad_max_val,
-        config.grad_max_norm, state.step, lindisp=model.lindisp, bkgd_mode=ops.BKGD_WHITE if config.white_bkgd else ops.BKGD_GREY,
+        config.grad_max_norm, state.step, lindisp=model.lindisp,
+        bkgd_mode=ops.BKGD_RAND if config.rand_bkgd else (ops.BKGD_WHITE if config.white_bkgd else ops.BKGD_GREY),
         density_bias=model.density_bias, resample_padding=model.resample_padding,
         t_rand=noise['t_rand'] if config.randomized else None, u_rand=noise['u_rand'] if config.randomized else None,
         update=update, obj_fp32=obj_fp32, want_pos=pose_opt and not model.no_pose_opt, want_rot=pose_opt and not model.no_yaw_opt,
         tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0, seed=seed, comm=comm,
-        world=dist.get_world_size() if dist is not None else 1, reduce_stats=dist is not None and reduce_stats)
+        world=dist.get_world_size() if dist is not None else 1, reduce_stats=dist is not None and reduce_stats,
+        density_noise=dn, density_rand=noise.get('density') if dn else None, weight_decay_mult=config.weight_decay_mult)
     box_rot0 = pose_used[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))
     ret = [tuple(o) + ([pose_used[:, :3], box_rot0], dyn, zo) for o in outs]
     st = ops.stats_views(out, L)

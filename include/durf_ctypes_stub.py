@@ -56,6 +56,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_sample_t.restype = i32
     L.durf_sample_t.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
     #   (stream, B, N, near, far, t_rand, lindisp, t_vals)
+    L.durf_density_noise.restype = i32
+    L.durf_density_noise.argtypes = [vp, u64, vp, f32, vp, C.c_uint32, C.c_uint32, i32]
+    #   (stream, rows, raw, scale, normal, seed_lo, seed_hi, level)
     L.durf_view_enc.restype = i32
     L.durf_view_enc.argtypes = [vp, i32, vp, vp, vp]
     #   (stream, B, viewdirs, out_bf16, out_f32)
@@ -259,6 +262,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_clip_adam.restype = i32
     L.durf_clip_adam.argtypes = [vp, u64, vp, vp, vp, vp, f32, f32, f32, f32, i32, vp, vp]
     #   (stream, n, params, m, v, grad, inv_world, max_val, max_norm, lr, step, scratch, stats)
+    L.durf_weight_decay.restype = i32
+    L.durf_weight_decay.argtypes = [vp, u64, vp, vp, u64, u64, f32, vp, vp]
+    #   (stream, n, params, grad, lo, hi, mult, scratch, weight_l2)
     L.durf_gen_batch.restype = i32
     L.durf_gen_batch.argtypes = [vp, i32, i32, C.POINTER(f32), vp, f32, f32, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, B, n_cams, cams_host, ray_idx, near, far, images, depth, sky, img_channels, origins, directions, viewdirs, radii, lossmult, near_out, far_out, pixels, depth_out, sky_out)

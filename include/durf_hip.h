@@ -143,6 +143,12 @@ int durf_ray_prologue_pack(void* stream, int B, int K, int N, const float* origi
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
                   const float* t_rand, int lindisp /* MipNerfModel.lindisp, mip.py:354-356 */, float* t_vals);
 
+/* MipNerfModel.density_noise on the randomized path (obbpose_model.py:236-240): raw[:, 3] += scale * z over the [rows, 4] raw
+ * outputs of one level, z ~ N(0, 1) the caller's (`normal` [rows]) or, when NULL, drawn here: Philox4x32-10 block
+ * (row, 1 + level, 0, 0) under (seed_lo, seed_hi) through Box-Muller (restated in oracle/philox_ref.py). */
+int durf_density_noise(void* stream, size_t rows, float* raw, float scale, const float* normal /* nullable */,
+                       uint32_t seed_lo, uint32_t seed_hi, int level);
+
 /* view-direction encoding mip.pos_enc(viewdirs,0,4,True) (mip.py:36-45) -> [B,32]
  * bf16 (27 features, zero padded) and/or fp32 [B,27]. */
 int durf_view_enc(void* stream, int B, const float* viewdirs, void* out_bf16, float* out_f32);
@@ -378,7 +384,7 @@ int durf_expand_raw(void* stream, int B, int N, const float* raw_c /* compacted 
 typedef struct durf_forward_args {
     int B, N, K, num_levels;            /* rays, MipNerfModel.num_samples, boxes (0: static model), num_levels */
     int enc_flags;                      /* DURF_ENC_CONTRACT | DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER */
-    int lindisp, bkgd_mode;             /* MipNerfModel.lindisp; 0 grey 0.5 / 1 white / 2 none (rand_bkgd handled by the caller) */
+    int lindisp, bkgd_mode;             /* MipNerfModel.lindisp; 0 grey 0.5 / 1 white / 2 none (rand_bkgd: mip.py:324 draws the colour 0) */
     float density_bias, resample_padding;
     float barf_w[10];                   /* weighted_ipe's per-degree weights for this step's alpha (mip.py:217-218) */
     const float *origins, *directions, *viewdirs, *radii, *near, *far;     /* Rays fields, [B,3] x3, [B] x3 */
@@ -395,6 +401,10 @@ typedef struct durf_forward_args {
     float* zo;                          /* [B] */
     int draw_noise;                     /* != 0 (t_rand = u_rand = NULL): randomized=True with the draws made by the library */
     uint32_t seed_lo, seed_hi;          /*   -- durf_ray_prologue's Philox stream under this key (the host's PRNG key) */
+    float density_noise;                /* randomized: MipNerfModel.density_noise, the std of the normal noise on the background's raw
+                                           density (obbpose_model.py:236-240; durf_density_noise); 0: none */
+    const float* density_rand[DURF_FORWARD_MAX_LEVELS];   /*   its standard-normal draws, [B,N] per level; NULL: the library's own,
+                                                               under (seed_lo, seed_hi) */
 } durf_forward_args;
 size_t durf_forward_workspace_bytes(int B, int N, int K);
 int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
@@ -411,8 +421,9 @@ int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
  * object MLPs, their encodings and the background MLP's one evaluation of those rays in fp32) with, under
  * DURF_TRAIN_POSE_OPT, the box-pose gradient behind them (cfg4: obbpose_model.py:99-131; want_pos = !no_pose_opt,
  * want_rot = !no_yaw_opt, the TV prior tv_loss_mult of train_boxpose.py:136,219 on the positions; f.pose must then be this
- * timestep's rows of box_centers INSIDE params: their gradient lands in the same rows of grad); >= 2 levels, no density
- * noise, no weight decay, fixed background colour (f.bkgd_mode 0 / 1, bg = 0.5 / 1.0).  `f` carries the rays, boxes,
+ * timestep's rows of box_centers INSIDE params: their gradient lands in the same rows of grad); >= 2 levels.  The knobs
+ * off the shipped configs ride along: f.density_noise (obbpose_model.py:236-240), weight_decay_mult (train_boxpose.py:73-75),
+ * f.bkgd_mode 0 / 1 / 2 with bg = 0.5 / 1.0 / 0 (2: Config.rand_bkgd, no background colour).  `f` carries the rays, boxes,
  * draws and -- as outputs -- each level's rendered values; f.bkgd_params / f.obj_params must point into `params`.
  * workspace: durf_train_workspace_bytes_flags(B, N, K, num_levels, n_params, flags) bytes, 256-byte aligned
  * (durf_train_workspace_bytes = flags 0). */
@@ -442,6 +453,7 @@ typedef struct durf_train_args {
                                                              all-reduce of grad (durf_allreduce_sum), clip + Adam on the mean (1 / world) */
     int world;                                            /*   ranks of comm (1 / world scales the summed gradient; lax.pmean) */
     int reduce_stats;                                     /*   != 0: the logged scalars are averaged over the ranks too (lax.pmean(stats), :255) */
+    float weight_decay_mult;                              /* Config.weight_decay_mult (train_boxpose.py:73-75; durf_weight_decay); 0: none */
 } durf_train_args;
 size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params);
 size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, size_t n_params, int flags);
@@ -613,6 +625,12 @@ int durf_poison_multi_hit(void* stream, size_t n, float* grad, const int32_t* cl
                           size_t mlp0_floats, size_t obj_floats);
 int durf_clip_adam(void* stream, size_t n, float* params, float* m, float* v, float* grad, float inv_world,
                    float max_val, float max_norm, float lr, int step, float* scratch, float* stats);
+/* Config.weight_decay_mult (train_boxpose.py:73-75: loss += mult * mean(theta^2) over every parameter): grad[lo:hi) +=
+ * (2 mult / n) params[lo:hi) -- a range, because a bucketed exchange hands the object MLPs' slice over before the rest of the
+ * gradient exists -- and, when weight_l2 != NULL, weight_l2[0] = mult * mean(params^2) over all n (summed in a fixed order;
+ * durf_train_stats adds it to the loss).  scratch: durf_optim_scratch_floats(n) floats. */
+int durf_weight_decay(void* stream, size_t n, const float* params, float* grad, size_t lo, size_t hi, float mult,
+                      float* scratch /* nullable with weight_l2 */, float* weight_l2 /* nullable */);
 
 /* ---- callers / data either side of the hot path ---------------------------------
  * Rays of a 'timestep' batch generated on the device (obbpose_dataset.py:1868-1916 pinhole rays with

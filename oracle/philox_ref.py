@@ -52,3 +52,21 @@ def step_draws(seed, B, N):
     x = philox4x32_10(ctr, key)
     u = lambda w: ((w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(B, N + 1)
     return u(x[:, 0]), u(x[:, 1])
+
+
+def density_draws(seed, rows, level):
+    """Standard-normal draws [rows] float32 as durf_density_noise(normal = NULL) makes them (MipNerfModel.density_noise,
+    /root/reference/internal/obbpose_model.py:236-240 draws them with jax.random.normal on the step's key): Philox block
+    (row, 1 + level, 0, 0) under the step's key -- word 1 of the counter keeps them clear of step_draws' (i, 0, 0, 0) --
+    through Box-Muller: u1 = ((x0 >> 8) + 1) 2^-24 in (0, 1], u2 = (x1 >> 8) 2^-24 in [0, 1), z = sqrt(-2 ln u1) cos(2 pi u2).
+    Evaluated in float64 here and rounded once: the device's fp32 logf / cospif / sqrtf agree to a few ulp (the tolerance the
+    test states)."""
+    ctr = np.zeros((rows, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(rows, dtype=np.uint32)
+    ctr[:, 1] = np.uint32(1 + level)
+    s = int(seed) & 0xFFFFFFFFFFFFFFFF
+    key = np.tile(np.array([s & 0xFFFFFFFF, s >> 32], dtype=np.uint32), (rows, 1))
+    x = philox4x32_10(ctr, key)
+    u1 = ((x[:, 0] >> np.uint32(8)).astype(np.float64) + 1.0) * 2.0 ** -24
+    u2 = (x[:, 1] >> np.uint32(8)).astype(np.float64) * 2.0 ** -24
+    return (np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)).astype(np.float32)

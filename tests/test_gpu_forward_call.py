@@ -53,6 +53,39 @@ def test_one_call_forward_is_bit_identical_to_apply(cuda, B, K, N, randomized, k
         _same(got, want, 'B=%d K=%d N=%d' % (B, K, N))
 
 
+@pytest.mark.parametrize('K,mode', [(2, 'injected'), (0, 'key'), (3, 'generator'), (1, 'sampling draws only')])
+def test_one_call_forward_with_density_noise_and_no_background_colour(cuda, K, mode):
+    """MipNerfModel.density_noise > 0 (obbpose_model.py:236-240; the class default, both shipped gin files set 0) and
+    rand_bkgd (mip.py:324: no background colour at all) through durf_forward: the normal draws injected, made by the library
+    under the host's key, or taken from a torch.Generator -- each bit-identical to apply() given the same source."""
+    B, N = 384, 32
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.1\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\n' % N)
+    b = synthetic.make_batch(B, K, seed=931 + K, allow_multi_hit=K > 1)
+    db = H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+    g = torch.Generator(device='cpu').manual_seed(4)
+    noise = dict(t_rand=torch.rand(B, N + 1, generator=g).to(cuda), u_rand=torch.rand(B, N + 1, generator=g).to(cuda))
+    if mode == 'injected':
+        noise['density'] = [torch.randn(B, N, 1, generator=g).to(cuda) for _ in range(2)]
+    kw = dict(randomized=True, rand_bkgd=True, white_bkgd=False, alpha=6.5)
+    if mode in ('injected', 'sampling draws only'):
+        want = model.apply(variables, 5, db['rays'], db['init'], db['ext'], b['ts'], noise=noise, **kw)
+        got = model.apply_one_call(variables, 5, db['rays'], db['init'], db['ext'], b['ts'], noise=noise, **kw)
+    elif mode == 'key':
+        want = model.apply(variables, 77, db['rays'], db['init'], db['ext'], b['ts'], **kw)
+        got = model.apply_one_call(variables, 77, db['rays'], db['init'], db['ext'], b['ts'], **kw)
+    else:
+        gens = [torch.Generator(device=cuda).manual_seed(9) for _ in range(2)]
+        want = model.apply(variables, gens[0], db['rays'], db['init'], db['ext'], b['ts'], **kw)
+        got = model.apply_one_call(variables, gens[1], db['rays'], db['init'], db['ext'], b['ts'], **kw)
+    _same(got, want, 'density noise, %s' % mode)
+    model.density_noise = 0.0
+    quiet = model.apply(variables, 77, db['rays'], db['init'], db['ext'], b['ts'], noise=noise, **kw)
+    assert not torch.equal(quiet[1][3], want[1][3]), 'the noise must matter in this test'
+
+
 def test_one_call_forward_reproduces_the_reference_model_outputs(cuda):
     """... and directly: the fixture made by the reference's own MipNerfModel.__call__ (tests/golden/ref_model_*.npz)"""
     case = 'ref_model_waymo_K3_N128'

@@ -58,3 +58,51 @@ def test_a_step_that_draws_for_itself_equals_the_step_that_is_handed_the_draws(c
         assert new_rng == rng + 1
         out.append((state.variables.flat.clone(), state.m.clone(), float(stats.loss)))
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+
+
+@pytest.mark.parametrize('rows,seed,level', [(77 * 32, 0, 0), (512 * 128, 20200823, 1), (100001, (1 << 40) + 12345, 3)])
+def test_density_noise_draws_are_the_oracles_normal_stream(cuda, rows, seed, level):
+    """durf_density_noise (MipNerfModel.density_noise, obbpose_model.py:236-240): the library's own standard-normal draws
+    against oracle/philox_ref.density_draws -- the Philox words bit for bit underneath, Box-Muller in fp32 here and in float64
+    there, hence the tolerance: 4 ulp of the largest |z| a 24-bit u1 can give (5.77) -- and injected draws exactly."""
+    base = torch.randn(rows, 4, device=cuda)
+    got = ops.density_noise(base.clone(), 1.0, seed=seed, level=level)
+    z_ref = torch.from_numpy(philox_ref.density_draws(seed, rows, level))
+    assert torch.equal(got[:, :3], base[:, :3]), 'the colour channels are not touched'
+    z = (got[:, 3].double() - base[:, 3].double()).cpu()
+    # (the sum base + z is rounded once in fp32: |base| < 6, |z| < 6 -> half an ulp of 16 on top of the draw's own error)
+    torch.testing.assert_close(z, z_ref.double(), rtol=0, atol=4 * 2.0 ** -21 + 2.0 ** -20)
+    zero = ops.density_noise(torch.zeros(rows, 4, device=cuda), 1.0, seed=seed, level=level)[:, 3].cpu()
+    torch.testing.assert_close(zero, z_ref, rtol=0, atol=4 * 2.0 ** -21)
+    assert abs(float(zero.mean())) < 4.0 / rows ** 0.5 and abs(float(zero.std()) - 1.0) < 0.02
+    other = ops.density_noise(torch.zeros(rows, 4, device=cuda), 1.0, seed=seed, level=level + 1)[:, 3].cpu()
+    assert abs(float(np.corrcoef(zero.numpy(), other.numpy())[0, 1])) < 4.0 / rows ** 0.5, 'levels draw independently'
+    # injected draws: scale * z and the sum rounded separately, as the tensor expression raw[:, 3] += scale * z is
+    nz = torch.randn(rows, device=cuda)
+    fed = ops.density_noise(base.clone(), 0.1, normal=nz)
+    assert torch.equal(fed[:, 3], base[:, 3] + 0.1 * nz) and torch.equal(fed[:, :3], base[:, :3])
+
+
+def test_a_model_that_draws_its_density_noise_equals_the_model_handed_the_oracles_draws(cuda):
+    B, K, N, rng = 256, 2, 32, 99
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.1\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\n' % N)
+    b = synthetic.make_batch(B, K, seed=11)
+    db = H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
+    t_ref, u_ref = philox_ref.step_draws(rng, B, N)
+    noise = dict(t_rand=torch.from_numpy(t_ref).to(cuda), u_rand=torch.from_numpy(u_ref).to(cuda),
+                 density=[torch.from_numpy(philox_ref.density_draws(rng, B * N, lvl)).to(cuda) for lvl in range(2)])
+    kw = dict(randomized=True, rand_bkgd=False, white_bkgd=False, alpha=10.0)
+    own = model.apply(variables, rng, db['rays'], db['init'], db['ext'], b['ts'], **kw)
+    fed = model.apply(variables, rng, db['rays'], db['init'], db['ext'], b['ts'], noise=noise, **kw)
+    single = own[0][8].reshape(-1) <= 1          # (a ray that hits two boxes renders NaN on both sides)
+    for lvl in range(2):
+        for i in (0, 1, 2, 3, 4):
+            # (draws a few ulp apart x 0.1 on the raw density; the second level's sample positions amplify that through
+            # the inverse of the first level's weight histogram -- still 50 x below what the noise itself does, next line)
+            torch.testing.assert_close(own[lvl][i][single], fed[lvl][i][single], rtol=1e-3, atol=2e-4)
+    model.density_noise = 0.0
+    quiet = model.apply(variables, rng, db['rays'], db['init'], db['ext'], b['ts'], **kw)
+    assert (quiet[1][3][single] - own[1][3][single]).abs().max() > 1e-2, 'the noise must matter in this test'

@@ -31,6 +31,12 @@ POSE = 'MipNerfModel.no_pose_opt = False\nMipNerfModel.no_yaw_opt = False\n'
     (600, 2, 32, True, 'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = False\n'),     # yaw only: no TV term
     (512, 1, 32, False, POSE + 'Config.tv_loss_mult = 0.0\nConfig.white_bkgd = True\n'),
     (512, 3, 32, True, 'MipNerfModel.obj_precision = "f32"\n'),          # fp32 object branch, frozen poses
+    # the class defaults no shipped gin file keeps (utils.py:142-144, obbpose_model.py:57): density noise drawn by the library
+    # under the step's key, weight decay, no background colour
+    (700, 2, 32, True, 'MipNerfModel.density_noise = 0.1\nConfig.weight_decay_mult = 1e-4\nConfig.rand_bkgd = True\n'),
+    (512, 0, 64, True, 'MipNerfModel.density_noise = 0.05\nConfig.weight_decay_mult = 1e-2\n'),
+    (512, 0, 32, False, 'MipNerfModel.density_noise = 0.1\nConfig.rand_bkgd = True\n'),      # not randomized: no noise either
+    (512, 2, 32, True, POSE + 'Config.weight_decay_mult = 1e-2\nMipNerfModel.density_noise = 0.1\n'),   # decay under the pose rows' gradient
 ])
 def test_one_call_train_step_is_bit_identical_to_train_step(cuda, B, K, N, randomized, extra):
     utils.clear_gin()
@@ -68,18 +74,45 @@ def test_one_call_train_step_is_bit_identical_to_train_step(cuda, B, K, N, rando
             _eq(wa, wc, 'step %d: logged weights / samples' % step)
 
 
+@pytest.mark.parametrize('K', [0, 2])
+def test_one_call_train_step_takes_its_draws_from_a_generator_as_train_step_does(cuda, K):
+    """`rng` a torch.Generator: sampling draws and density noise come from it, in the same order on both paths"""
+    B, N = 512, 32
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.1\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\nConfig.randomized = True\nConfig.rand_bkgd = True\n'
+                    'Config.weight_decay_mult = 1e-3\n' % N)
+    config = utils.configured(utils.Config)
+    db = H.device_batch(synthetic.make_batch(B, K, seed=977), cuda)
+    out = []
+    for fn in (train_boxpose.train_step, train_boxpose.train_step_one_call):
+        model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+        state = train_boxpose.create_train_state(variables)
+        rng = torch.Generator(device=cuda).manual_seed(31)
+        for _ in range(2):
+            state, stats, rng, _ = fn(model, config, rng, state, db, 5e-4, 0.7, 6.5, db['init'][0:1])
+        torch.cuda.synchronize()
+        out.append((state.variables.flat.clone(), stats))
+    _eq(out[0][0], out[1][0], 'parameters after 2 steps')
+    _eq(out[0][1].loss, out[1][1].loss, 'loss')
+    _eq(out[0][1].weight_l2, out[1][1].weight_l2, 'weight_l2')
+    assert float(out[0][1].weight_l2) > 0
+
+
 def test_loss_backward_gives_the_gradient_of_loss_and_grad(cuda):
     B, K, N = 2048, 3, 64
     utils.clear_gin()
-    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
-                    'MipNerfModel.no_yaw_opt = True\nConfig.randomized = True\nConfig.rand_bkgd = False\n' % N)
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.1\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\nConfig.randomized = True\nConfig.rand_bkgd = False\n'
+                    'Config.weight_decay_mult = 1e-4\n' % N)
     config = utils.configured(utils.Config)
     b = synthetic.make_batch(B, K, seed=961)
     db = H.device_batch(b, cuda)
     model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
     state = train_boxpose.create_train_state(variables)
     g = torch.Generator().manual_seed(2)
-    noise = dict(t_rand=torch.rand(B, N + 1, generator=g).to(cuda), u_rand=torch.rand(B, N + 1, generator=g).to(cuda))
+    noise = dict(t_rand=torch.rand(B, N + 1, generator=g).to(cuda), u_rand=torch.rand(B, N + 1, generator=g).to(cuda),
+                 density=[torch.randn(B, N, generator=g).to(cuda) for _ in range(2)])
     flat0 = variables.flat.clone()
     want, raw, _ = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, 10.0, db['init'][0:1], noise=noise)
     got, st, ret = train_boxpose.train_step_one_call(model, config, 0, state, db, 5e-4, 3.0, 10.0, db['init'][0:1], noise=noise,
@@ -93,10 +126,13 @@ def test_loss_backward_gives_the_gradient_of_loss_and_grad(cuda):
 
 def test_unsupported_configurations_are_refused(cuda):
     utils.clear_gin()
-    utils.parse_gin('MipNerfModel.num_samples = 32\nMipNerfModel.no_pose_opt = False\nMipNerfModel.no_yaw_opt = False\n')
-    config = utils.configured(utils.Config)
     db = H.device_batch(synthetic.make_batch(256, 1, seed=5), cuda)
-    model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
-    with pytest.raises(NotImplementedError):
-        train_boxpose.train_step_one_call(model, config, 0, train_boxpose.create_train_state(variables), db, 5e-4, 3.0, 10.0,
-                                          db['init'][0:1])
+    for gin in ('MipNerfModel.no_pose_opt = False\nMipNerfModel.obj_precision = "bf16"\n',     # pose gradient behind bf16 objects
+                'MipNerfModel.num_levels = 1\n', 'MipNerfModel.mlp_precision = "f32"\n'):
+        utils.clear_gin()
+        utils.parse_gin('MipNerfModel.num_samples = 32\n' + gin)
+        config = utils.configured(utils.Config)
+        model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+        with pytest.raises(NotImplementedError):
+            train_boxpose.train_step_one_call(model, config, 0, train_boxpose.create_train_state(variables), db, 5e-4, 3.0, 10.0,
+                                              db['init'][0:1])

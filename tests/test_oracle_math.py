@@ -178,3 +178,21 @@ def test_philox_restatement_reproduces_the_generators_known_answer_vectors():
     # counter i is the flat sample position: a larger batch extends the stream, it does not reshuffle it
     tb, ub = P.step_draws((7 << 32) | 9, 66, 64)
     assert np.array_equal(tb.reshape(-1)[:t.size], t.reshape(-1)) and np.array_equal(ub.reshape(-1)[:u.size], u.reshape(-1))
+
+
+def test_density_noise_draws_of_the_philox_restatement_are_standard_normal():
+    """oracle/philox_ref.density_draws (the checker of durf_density_noise): moments of N(0, 1), independent across levels and
+    of the sampling draws made under the same key (their counters differ in word 1)"""
+    import numpy as np
+    from oracle import philox_ref as P
+    n = 1 << 18
+    z0, z1 = P.density_draws(20200823, n, 0).astype(np.float64), P.density_draws(20200823, n, 1).astype(np.float64)
+    for z in (z0, z1):
+        assert abs(z.mean()) < 4 / n ** 0.5 and abs(z.std() - 1) < 0.01
+        assert abs((z ** 3).mean()) < 0.05 and abs((z ** 4).mean() - 3) < 0.1
+        assert np.isfinite(z).all() and np.abs(z).max() < 5.78          # sqrt(-2 ln 2^-24) = 5.768
+    t, u = P.step_draws(20200823, 1 << 10, 255)
+    lim = 4 / n ** 0.5
+    assert abs(np.corrcoef(z0, z1)[0, 1]) < lim and abs(np.corrcoef(z0, t.ravel())[0, 1]) < lim
+    assert abs(np.corrcoef(z0, u.ravel())[0, 1]) < lim
+    assert np.array_equal(P.density_draws(20200823, 1000, 1), P.density_draws(20200823, n, 1)[:1000].astype(np.float32))
