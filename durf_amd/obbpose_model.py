@@ -23,19 +23,22 @@ IN_BKGD, IN_OBJ, W_BKGD, W_OBJ = 60, 63, 256, 128
 # ----------------------------------------------------------------------------
 # parameters
 # ----------------------------------------------------------------------------
-def _layer_shapes(width, in_dim):
-    return [(in_dim, width)] + [(width, width)] * 4 + [(width + in_dim, width)] + [(width, width)] * 2 + \
-           [(width, 1), (width, width), (width + 27, 128), (128, 3)]
+def _layer_shapes(width, in_dim, use_viewdirs=True):
+    trunk = [(in_dim, width)] + [(width, width)] * 4 + [(width + in_dim, width)] + [(width, width)] * 2
+    if not use_viewdirs:        # obbpose_model.py:336-352 without a condition: density head, then the rgb head straight off the trunk
+        return trunk + [(width, 1), (width, 3)]
+    return trunk + [(width, 1), (width, width), (width + 27, 128), (128, 3)]
 
 
 class ParamLayout:
     """Offsets of every leaf in the flat fp32 parameter buffer (include/durf_hip.h)."""
 
-    def __init__(self, T, K):
-        self.T, self.K = T, K
+    def __init__(self, T, K, use_viewdirs=True):
+        # use_viewdirs=False: the 10-Dense tree of MipNerfModel.use_viewdirs = False (static model only: durf_amd/noview.py)
+        self.T, self.K, self.use_viewdirs = T, K, bool(use_viewdirs)
         self.box = (0, T * K * 6)
         off = T * K * 6
-        self.mlp_size = {W_BKGD: sum(a * b + b for a, b in _layer_shapes(W_BKGD, IN_BKGD)),
+        self.mlp_size = {W_BKGD: sum(a * b + b for a, b in _layer_shapes(W_BKGD, IN_BKGD, use_viewdirs)),
                          W_OBJ: sum(a * b + b for a, b in _layer_shapes(W_OBJ, IN_OBJ))}
         self.mlp_off = {'MLP_0': off}
         off += self.mlp_size[W_BKGD]
@@ -51,6 +54,11 @@ class ParamLayout:
     def mlp_dims(name):
         return (W_BKGD, IN_BKGD) if name == 'MLP_0' else (W_OBJ, IN_OBJ)
 
+    def layer_shapes(self, name):
+        """(fan_in, fan_out) of Dense_0.. of MLP `name`, in parameter order"""
+        width, in_dim = self.mlp_dims(name)
+        return _layer_shapes(width, in_dim, self.use_viewdirs or name != 'MLP_0')
+
 
 class Variables(dict):
     """flax-style {'params': {...}} tree whose leaves are views of `flat`."""
@@ -63,7 +71,7 @@ class Variables(dict):
             width, in_dim = layout.mlp_dims(name)
             off = layout.mlp_off[name]
             d = {}
-            for i, (fi, fo) in enumerate(_layer_shapes(width, in_dim)):
+            for i, (fi, fo) in enumerate(layout.layer_shapes(name)):
                 d['Dense_%d' % i] = {'kernel': flat[off:off + fi * fo].view(fi, fo),
                                      'bias': flat[off + fi * fo:off + fi * fo + fo]}
                 off += fi * fo + fo
@@ -173,7 +181,6 @@ class MipNerfModel:
         if self.mlp_precision not in ('bf16', 'f32'): bad.append('mlp_precision')
         if self.obj_precision not in ('auto', 'bf16', 'f32'): bad.append('obj_precision')
         if self.ray_shape not in ('cone', 'cylinder'): bad.append('ray_shape')
-        if not self.use_viewdirs: bad.append('use_viewdirs=False')
         if (self.min_deg_point, self.max_deg_point, self.deg_view) != (0, 10, 4): bad.append('degrees')
         if ((self.disable_integration or not self.dynamics or self.ray_shape != 'cone') and
                 not (self.no_pose_opt and self.no_yaw_opt)):
@@ -185,6 +192,20 @@ class MipNerfModel:
         _check_mlp(utils.configured(MLP), W_BKGD)
         _check_mlp(utils.configured(BoxMLP), W_OBJ)
 
+    def _kernel_variables(self, variables):
+        """the 12-Dense parameter tree the kernels evaluate: `variables` itself, or -- use_viewdirs=False, whose tree has no
+        bottleneck and no view layer -- its embedding (durf_amd/noview.py)"""
+        if variables.layout.use_viewdirs != bool(self.use_viewdirs) and not hasattr(variables, '_noview_of'):
+            raise ValueError('MipNerfModel.use_viewdirs = %r but the parameter tree was built for %r'
+                             % (self.use_viewdirs, variables.layout.use_viewdirs))
+        if variables.layout.use_viewdirs:
+            return variables
+        if variables.layout.K and self.dynamics:
+            raise NotImplementedError('use_viewdirs=False is the static model\'s knob (no boxes, or dynamics=False): with dynamic '
+                                      'boxes the reference itself fails on it (obbpose_model.py:192-199: viewdirs_enc is undefined)')
+        from . import noview
+        return noview.embed(variables)
+
     # -- forward -------------------------------------------------------------
     def _forward(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
                  train=False, noise=None, loss_prep=None, zero_fill=None):
@@ -192,6 +213,7 @@ class MipNerfModel:
         norms [L,5]) -- the inputs of durf_loss_prep; the fused per-ray launches then fill `norms` for every level.
         zero_fill: a flat fp32 tensor (the step's gradient buffer) the prologue launch zero fills on its way."""
         self._check()
+        variables = self._kernel_variables(variables)
         lay = variables.layout
         K, N = lay.K, self.num_samples
         Kd = K if self.dynamics else 0         # dynamics=False: boxes only select rays (obbpose_model.py:167,232,257-260)
@@ -479,6 +501,7 @@ class MipNerfModel:
         the standard-normal draws [B,N] per level]) injected draws; otherwise `rng` keys the library's own (an int) or is the
         torch.Generator they come from."""
         self._check()
+        variables = self._kernel_variables(variables)
         lay = variables.layout
         K = lay.K
         if not self.supports_one_call(variables, randomized):
@@ -541,13 +564,13 @@ def construct_mipnerf(rng, example_batch, device='cuda'):
     if init.dim() == 1:    # K == 0
         init = init.reshape(init.shape[0] if init.numel() else model.timesteps, 0, 6)
     T, K = init.shape[0], init.shape[1]
-    layout = ParamLayout(T, K)
+    layout = ParamLayout(T, K, model.use_viewdirs)
     gen = rng if isinstance(rng, torch.Generator) else torch.Generator().manual_seed(int(rng))
     flat = torch.zeros(layout.total, dtype=torch.float32)
     v = Variables(flat, layout)
     v['params']['box_centers'].copy_(init_boxes(None, init.float().cpu()))
     for name in layout.mlp_names():
-        for i in range(12):
+        for i in range(len(layout.layer_shapes(name))):
             k = v['params'][name]['Dense_%d' % i]['kernel']
             glorot_uniform_(k, k.shape[0], k.shape[1], gen)
     return model, Variables(flat.to(device), layout)

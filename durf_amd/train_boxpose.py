@@ -108,6 +108,10 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     defer_poison: the multi-hit outcome (ops.poison_multi_hit) is NOT applied here; raw['poison'] carries its arguments for
     the optimizer's first launch (ops.stats_scrub; single device only -- an all-reduce has to see the NaNs)."""
     pose_opt = not (model.no_pose_opt and model.no_yaw_opt)
+    # use_viewdirs=False: the step runs on the 12-Dense embedding of the 10-Dense tree (durf_amd/noview.py); the gradient of
+    # the real parameters is read back from it below, before anything that works on the real buffer (weight decay)
+    real = variables
+    variables = model._kernel_variables(variables)
     rays = batch['rays']
     L = model.num_levels
     dev = variables.flat.device
@@ -320,6 +324,9 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                     ops.obj_dw_batch([lv['slabs'] for lv in levels], ctx['view_tiles_obj'], ctx['count'],
                                      grad[o0:o0 + K * sz], sz, variables.flat[o0:o0 + K * sz])
     side.join()
+    if real is not variables:
+        from . import noview
+        grad, flat = noview.gather_grad(grad, real), real.flat
     weight_l2 = None
     if config.weight_decay_mult != 0:                                          # :73-75
         # (one launch pair, durf_weight_decay: the gradient term on whatever has not left for its all-reduce yet + the scalar)
@@ -449,9 +456,9 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
     K, L, N = lay.K, model.num_levels, model.num_samples
     dist = _dist()
     comm = _instream_comm(dist) if dist is not None else None
-    if (model.mlp_precision != 'bf16' or (K and not model.dynamics) or L < 2 or
+    if (model.mlp_precision != 'bf16' or (K and not model.dynamics) or L < 2 or not lay.use_viewdirs or
             (dist is not None and (comm is None or not update))):
-        raise NotImplementedError('durf_train_step covers the step with a bf16 background MLP and >= 2 levels; data-parallel only '
+        raise NotImplementedError('durf_train_step covers the step with a bf16 background MLP (12-Dense tree) and >= 2 levels; data-parallel only '
                                   'through the library\'s own in-stream all-reduce (DURF_INSTREAM_ALLREDUCE=1; see csrc/train.hip, '
                                   'csrc/comm.hip)')
     pose_opt = bool(K) and not (model.no_pose_opt and model.no_yaw_opt)

@@ -431,6 +431,9 @@ def mlp_layer_shapes(in_dim, view_dim, cfg):
         if i % cfg['skip_layer'] == 0 and i > 0:
             d = W + in_dim
     shapes.append((d, cfg['num_density_channels']))
+    if view_dim is None:                                                  # no condition: Dense_9 is the rgb head
+        shapes.append((d, cfg['num_rgb_channels']))
+        return shapes
     shapes.append((d, W))
     dv = W + view_dim
     for _ in range(cfg['net_depth_condition']):
@@ -455,13 +458,14 @@ def mlp_apply(params, x, condition, cfg):
             x = torch.cat([x, inputs], dim=-1)
     k, b = params[li]; li += 1
     raw_density = (x @ k + b).reshape(-1, num_samples, cfg['num_density_channels'])
-    k, b = params[li]; li += 1
-    bottleneck = x @ k + b
-    cond = condition[:, None, :].expand(-1, num_samples, -1).reshape(-1, condition.shape[-1])
-    x = torch.cat([bottleneck, cond], dim=-1)
-    for _ in range(cfg['net_depth_condition']):
+    if condition is not None:                                             # :336-350 (None: the rgb head reads the trunk)
         k, b = params[li]; li += 1
-        x = torch.relu(x @ k + b)
+        bottleneck = x @ k + b
+        cond = condition[:, None, :].expand(-1, num_samples, -1).reshape(-1, condition.shape[-1])
+        x = torch.cat([bottleneck, cond], dim=-1)
+        for _ in range(cfg['net_depth_condition']):
+            k, b = params[li]; li += 1
+            x = torch.relu(x @ k + b)
     k, b = params[li]; li += 1
     raw_rgb = (x @ k + b).reshape(-1, num_samples, cfg['num_rgb_channels'])
     return raw_rgb, raw_density
@@ -541,7 +545,11 @@ def model_apply(params, rays, ts, ext, randomized, rand_bkgd, white_bkgd, alpha,
         origins_s, dirs_s = origins, dirs
         zo_ret = torch.zeros(B, dtype=dt)
 
-    viewdirs_enc = pos_enc(rays.viewdirs, 0, c['deg_view'], True)         # :193,:222
+    # :193,:222 (use_viewdirs=False: the background MLP gets no condition, :230-231; the object loop of the reference reads
+    # `viewdirs_enc` regardless, :199 -- undefined then, so the knob only exists for a model without boxes / dynamics)
+    viewdirs_enc = pos_enc(rays.viewdirs, 0, c['deg_view'], True) if c['use_viewdirs'] else None
+    if viewdirs_enc is None and c['dynamics'] and K > 0:
+        raise NameError("name 'viewdirs_enc' is not defined")             # what the reference does at :199
 
     ret = []
     t_vals = weights = None
@@ -850,13 +858,14 @@ def mlp_apply_bf16(params, x, condition, cfg):
             x = torch.cat([x, inputs], dim=-1)
     k, b = params[li]; li += 1
     raw_density = (x @ _bf(k) + b).reshape(-1, num_samples, cfg['num_density_channels'])
-    k, b = params[li]; li += 1
-    bottleneck = _bf(x @ _bf(k) + b)
-    cond = _bf(condition)[:, None, :].expand(-1, num_samples, -1).reshape(-1, condition.shape[-1])
-    x = torch.cat([bottleneck, cond], dim=-1)
-    for _ in range(cfg['net_depth_condition']):
+    if condition is not None:
         k, b = params[li]; li += 1
-        x = _bf(torch.relu(x @ _bf(k) + b))
+        bottleneck = _bf(x @ _bf(k) + b)
+        cond = _bf(condition)[:, None, :].expand(-1, num_samples, -1).reshape(-1, condition.shape[-1])
+        x = torch.cat([bottleneck, cond], dim=-1)
+        for _ in range(cfg['net_depth_condition']):
+            k, b = params[li]; li += 1
+            x = _bf(torch.relu(x @ _bf(k) + b))
     k, b = params[li]; li += 1
     raw_rgb = (x @ _bf(k) + b).reshape(-1, num_samples, cfg['num_rgb_channels'])
     return raw_rgb, raw_density

@@ -34,6 +34,11 @@ CASES = {
     'ref_model_K2_N32_static_flat': dict(B=48, K=2, seed=205, randomized=False, white_bkgd=False, alpha=10.0,
                                          model=dict(num_samples=32, density_noise=0.0, dynamics=False, contraction=False)),
     # the shape the metric is quoted on: Waymo knobs, K = 3, 128 samples/ray x 2 levels, stratified sampling
+    # use_viewdirs = False: the MLP without a condition -- 10 Dense layers, the rgb head straight off the trunk
+    # (obbpose_model.py:221-232,336-352); a model with dynamics = False, the only kind the reference can run with the knob off
+    # (K = 2 with dynamics = False: the reference indexes box_centers[0] even for a static scene, so it cannot run K = 0)
+    'ref_model_K2_N32_static_noview': dict(B=64, K=2, seed=207, randomized=True, white_bkgd=False, alpha=10.0,
+                                           model=dict(num_samples=32, density_noise=0.0, use_viewdirs=False, dynamics=False)),
     'ref_model_waymo_K3_N128': dict(B=128, K=3, seed=206, randomized=True, white_bkgd=False, alpha=10.0,
                                     model=dict(num_samples=128, density_noise=0.0)),
 }
@@ -47,10 +52,13 @@ def build(case):
     b = synthetic.make_batch(B, K, seed=seed)
     cb = {k: (torch.tensor(v) if isinstance(v, np.ndarray) else v) for k, v in b.items() if k != 'rays'}
     utils.clear_gin()
+    if not c['model'].get('use_viewdirs', True):
+        utils.parse_gin('MipNerfModel.use_viewdirs = False\n')
     model, variables = obbpose_model.construct_mipnerf(seed, cb, device='cpu')
+    utils.clear_gin()
     g = torch.Generator().manual_seed(seed)
     for nm in variables.layout.mlp_names():
-        for i in range(12):
+        for i in range(len(variables.layout.layer_shapes(nm))):
             bias = variables['params'][nm]['Dense_%d' % i]['bias']
             bias.copy_((torch.rand(bias.shape, generator=g) - 0.5) * 0.1)
     noise = dict(t_rand=torch.rand(B, N + 1, generator=g, dtype=torch.float64),

@@ -18,7 +18,7 @@ def oracle_params_from_variables(variables, dt=torch.float32):
     out = {'box_centers': p['box_centers'].detach().cpu().to(dt).clone()}
     for name in variables.layout.mlp_names():
         out[name] = [[p[name]['Dense_%d' % i]['kernel'].detach().cpu().to(dt).clone(),
-                      p[name]['Dense_%d' % i]['bias'].detach().cpu().to(dt).clone()] for i in range(12)]
+                      p[name]['Dense_%d' % i]['bias'].detach().cpu().to(dt).clone()] for i in range(len(p[name]))]
     return out
 
 

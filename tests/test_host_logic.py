@@ -55,9 +55,10 @@ def test_gin_reader_errors_and_syntax():
 
 def test_unsupported_knobs_fail_loudly():
     utils.clear_gin()
-    m = obbpose_model.MipNerfModel(use_viewdirs=False, density_noise=0.0)
+    m = obbpose_model.MipNerfModel(stop_level_grad=False, density_noise=0.0)
     with pytest.raises(NotImplementedError):
         m._check()
+    obbpose_model.MipNerfModel(use_viewdirs=False)._check()        # (the static model's knob: durf_amd/noview.py, tests/test_noview.py)
     m = obbpose_model.MipNerfModel(num_samples=100)
     with pytest.raises(NotImplementedError):
         m._check()
