@@ -27,7 +27,10 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
                  const float* __restrict__ radii, const float* __restrict__ origins,
                  const float* __restrict__ dirs, const float* __restrict__ pose, BarfW bw,
                  float* __restrict__ rows_out /* [21][B] per object, column j = compact ray index */,
-                 size_t idx_stride, size_t denc_stride, size_t rows_stride) {
+                 size_t idx_stride, size_t denc_stride, size_t rows_stride, int enc_flags) {
+    // MipNerfModel.ray_shape = 'cylinder' (mip.cylinder_to_gaussian, mip.py:133-152) and disable_integration
+    // (obbpose_model.py:163-164: the variances are zeroed, so only the means carry a gradient)
+    const bool cyl = (enc_flags & DURF_ENC_CYLINDER) != 0, noint = (enc_flags & DURF_ENC_NO_INTEGRATION) != 0;
     __shared__ float part[4][6];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int kb = blockIdx.y;                      // object within this call
@@ -51,14 +54,15 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
         // forward quantities (same formulas as frustum_gaussian)
         const float mu = (t0 + t1) / 2.0f, hw = (t1 - t0) / 2.0f;
         const float mu2 = mu * mu, hw2 = hw * hw, den = 3.0f * mu2 + hw2, hw4 = hw2 * hw2;
-        const float t_mean = mu + (2.0f * mu * hw2) / den;
-        const float t_var = hw2 / 3.0f - (4.0f / 15.0f) * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
-        const float r_var = (radius * radius) * (mu2 / 4.0f + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / den);
+        float t_mean = mu + (2.0f * mu * hw2) / den;
+        float t_var = hw2 / 3.0f - (4.0f / 15.0f) * ((hw4 * (12.0f * mu2 - hw2)) / (den * den));
+        float r_var = (radius * radius) * (mu2 / 4.0f + (5.0f / 12.0f) * hw2 - (4.0f / 15.0f) * hw4 / den);
+        if (cyl) { t_mean = mu; r_var = (radius * radius) / 4.0f; t_var = ((t1 - t0) * (t1 - t0)) / 12.0f; }
         float x[3], var[3];
 #pragma unroll
         for (int i = 0; i < 3; i++) {
             x[i] = d[i] * t_mean + o[i];
-            var[i] = t_var * (d[i] * d[i]) + r_var * (1.0f - d[i] * (d[i] / m));
+            var[i] = noint ? 0.0f : t_var * (d[i] * d[i]) + r_var * (1.0f - d[i] * (d[i] / m));
         }
         const float* ge = d_enc + ((size_t)j * N + n) * DURF_ENC_DIM;
         float gx[3] = {0.f, 0.f, 0.f}, gv[3] = {0.f, 0.f, 0.f};
@@ -73,7 +77,7 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
             const float e = PRECISE ? expf(-0.5f * (var[i] * sc * sc)) : __expf(-0.5f * (var[i] * sc * sc));
             const float cz = PRECISE ? cosf(z) : __cosf(z), sz = PRECISE ? sinf(z) : __sinf(z);
             const float g = ge[3 + f] * bw.w[f / 6];
-            const float gxf = g * e * sc * cz, gvf = g * (-0.5f * sc * sc) * e * sz;
+            const float gxf = g * e * sc * cz, gvf = noint ? 0.0f : g * (-0.5f * sc * sc) * e * sz;
             if (i == 0) { gx[0] += gxf; gv[0] += gvf; }
             else if (i == 1) { gx[1] += gxf; gv[1] += gvf; }
             else { gx[2] += gxf; gv[2] += gvf; }
@@ -221,8 +225,9 @@ extern "C" {
 static int encode_obj_bwd_launch(void* stream, int K, int B, int N, int k0, const int32_t* idx, const int32_t* count,
                                  const float* d_enc, size_t denc_stride, const float* t_vals, const float* origins_s,
                                  const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                                 const float* pose, const float* barf_w, float* scratch, float* sums, int precise) {
+                                 const float* pose, const float* barf_w, float* scratch, float* sums, int precise, int enc_flags) {
     DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
+    DURF_REQUIRE((enc_flags & ~(DURF_ENC_CYLINDER | DURF_ENC_NO_INTEGRATION)) == 0, "enc_flags: DURF_ENC_CYLINDER | DURF_ENC_NO_INTEGRATION");
     if (B <= 0 || K <= 0) return 0;
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
@@ -231,7 +236,7 @@ static int encode_obj_bwd_launch(void* stream, int K, int B, int N, int k0, cons
 #define LAUNCH_E2(P, PR)                                                                                  \
     hipLaunchKernelGGL((k_encode_obj_bwd<P, PR>), grid, block, 0, s, B, N, k0, idx, count, d_enc, t_vals, \
                        origins_s, dirs_s, radii, origins, dirs, pose, bw, scratch, (size_t)B, denc_stride, \
-                       (size_t)POSE_ROWS * B)
+                       (size_t)POSE_ROWS * B, enc_flags)
 #define LAUNCH_E(P) { if (precise) LAUNCH_E2(P, true); else LAUNCH_E2(P, false); }
     if (N <= 64) LAUNCH_E(1) else if (N <= 128) LAUNCH_E(2) else LAUNCH_E(4)
 #undef LAUNCH_E2
@@ -244,17 +249,17 @@ static int encode_obj_bwd_launch(void* stream, int K, int B, int N, int k0, cons
 int durf_encode_obj_bwd(void* stream, int B, int N, int k_obj, const int32_t* idx, const int32_t* count,
                         const float* d_enc, const float* t_vals, const float* origins_s,
                         const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                        const float* pose, const float* barf_w, float* scratch, float* sums, int precise) {
+                        const float* pose, const float* barf_w, float* scratch, float* sums, int precise, int enc_flags) {
     return encode_obj_bwd_launch(stream, 1, B, N, k_obj, idx, count, d_enc, 0, t_vals, origins_s, dirs_s, radii, origins,
-                                 dirs, pose, barf_w, scratch, sums, precise);
+                                 dirs, pose, barf_w, scratch, sums, precise, enc_flags);
 }
 
 int durf_encode_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
                               const float* d_enc, const float* t_vals, const float* origins_s,
                               const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                              const float* pose, const float* barf_w, float* scratch, float* sums, int precise) {
+                              const float* pose, const float* barf_w, float* scratch, float* sums, int precise, int enc_flags) {
     return encode_obj_bwd_launch(stream, K, B, N, 0, idx, count, d_enc, (size_t)B * N * DURF_ENC_DIM, t_vals, origins_s,
-                                 dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise);
+                                 dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise, enc_flags);
 }
 
 // sums [K,21] (all levels accumulated) -> adds d(loss)/d(box_centers[ts]) into grad6 [K,6]

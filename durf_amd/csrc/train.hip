@@ -251,7 +251,8 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
                                        w.act32[lvl], w.dz32[lvl], pose_opt ? w.d_enc32[lvl] : nullptr));
             if (pose_opt)
                 STEP(durf_encode_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.d_enc32[lvl], f.t_vals[lvl], w.o_s, w.d_s,
-                                               f.radii, f.origins, f.directions, f.pose, f.barf_w, w.pose_scratch, w.pose_sums, 1));
+                                               f.radii, f.origins, f.directions, f.pose, f.barf_w, w.pose_scratch, w.pose_sums, 1,
+                                               obj_flags));
         }
         if (K > 0) {
             STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],

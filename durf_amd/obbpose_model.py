@@ -182,9 +182,10 @@ class MipNerfModel:
         if self.obj_precision not in ('auto', 'bf16', 'f32'): bad.append('obj_precision')
         if self.ray_shape not in ('cone', 'cylinder'): bad.append('ray_shape')
         if (self.min_deg_point, self.max_deg_point, self.deg_view) != (0, 10, 4): bad.append('degrees')
-        if ((self.disable_integration or not self.dynamics or self.ray_shape != 'cone') and
-                not (self.no_pose_opt and self.no_yaw_opt)):
-            bad.append('disable_integration / dynamics=False / cylinder rays with box-pose optimisation')
+        if not self.dynamics and not (self.no_pose_opt and self.no_yaw_opt):
+            # (the reference's pose gradient then runs through the BACKGROUND encoding of the box-hit rays, whose origins are
+            # in box coordinates, obbpose_model.py:121-122: a backward through contraction + IPE that is not built)
+            bad.append('dynamics=False with box-pose optimisation')
         if not self.stop_level_grad: bad.append('stop_level_grad=False')
         if self.num_samples % 32 or not (32 <= self.num_samples <= 256): bad.append('num_samples')
         if bad:

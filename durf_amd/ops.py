@@ -966,7 +966,7 @@ def clip_adam(params, m, v, grad, inv_world, max_val, max_norm, lr, step):
 
 
 def encode_obj_bwd(k_obj, idx_k, count_k, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, alpha,
-                   sums, scratch=None, precise=False):
+                   sums, scratch=None, precise=False, enc_flags=0):
     """accumulates the 21 pose sums of object k (one level) into sums[k] (sums: [K,21], caller-zeroed)"""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     if scratch is None:
@@ -976,11 +976,11 @@ def encode_obj_bwd(k_obj, idx_k, count_k, d_enc, t_vals, origins_s, dirs_s, radi
     _lib.check(_lib.lib().durf_encode_obj_bwd(_stream(), B, N, k_obj, _p(idx_k), _p(count_k), _p(_f32(d_enc)),
                                               _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
                                               _p(_f32(radii)), _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
-                                              wa, _p(scratch), _p(_f32(sums)), int(precise)), 'durf_encode_obj_bwd')
+                                              wa, _p(scratch), _p(_f32(sums)), int(precise), int(enc_flags)), 'durf_encode_obj_bwd')
 
 
 def encode_obj_bwd_batch(K, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, alpha, sums,
-                         precise=False):
+                         precise=False, enc_flags=0):
     """all K objects of one level in one launch pair: idx [K,B], count [K], d_enc [K, B*N, 64] (obj_bwd_batch's slab)"""
     B, N = t_vals.shape[0], t_vals.shape[1] - 1
     scratch = torch.empty(K * 21 * B, device=t_vals.device)
@@ -989,7 +989,7 @@ def encode_obj_bwd_batch(K, idx, count, d_enc, t_vals, origins_s, dirs_s, radii,
     _lib.check(_lib.lib().durf_encode_obj_bwd_batch(_stream(), int(K), B, N, _p(idx), _p(count), _p(_f32(d_enc)),
                                                     _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)),
                                                     _p(_f32(radii)), _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
-                                                    wa, _p(scratch), _p(_f32(sums)), int(precise)),
+                                                    wa, _p(scratch), _p(_f32(sums)), int(precise), int(enc_flags)),
                'durf_encode_obj_bwd_batch')
 
 

@@ -162,6 +162,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     sums = torch.empty(L, ops.TERM_ROWS, device=dev)      # filled by the stats launch from the per-ray terms (ops.train_stats)
     terms = [None] * L
     radii = rays.radii.reshape(-1).contiguous()
+    obj_enc_flags = ((ops.ENC_NO_INTEGRATION if model.disable_integration else 0) |          # the pose gradient's way back
+                     (ops.ENC_CYLINDER if model.ray_shape == 'cylinder' else 0))              # through the object encoding
     pose_ts = variables['params']['box_centers'][ctx['ts']].contiguous()
     pose_sums = zbuf[n_par:].view(-1, 21) if n_sums else (torch.zeros(max(K, 1), 21, device=dev) if pose_opt else None)
 
@@ -235,7 +237,8 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                  want_d_enc=pose_opt)
             if pose_opt:
                 ops.encode_obj_bwd_batch(K, ctx['idx'], ctx['count'], sl.d_enc, lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
-                                         rays.origins, rays.directions, pose_ts, alpha, pose_sums, precise=True)
+                                         rays.origins, rays.directions, pose_ts, alpha, pose_sums, precise=True,
+                                         enc_flags=obj_enc_flags)
         if f32:
             continue
         obj_side.fork()                      # the object backward runs in the shadow of the background backward
@@ -251,7 +254,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                 if pose_opt:                            # d(loss)/d(box pose) through the object encoding, all K at once
                     ops.encode_obj_bwd_batch(K, ctx['idx'], ctx['count'], lv['slabs'].d_enc, lv['t_vals'],
                                              ctx['o_s'], ctx['d_s'], radii, rays.origins, rays.directions, pose_ts, alpha,
-                                             pose_sums)
+                                             pose_sums, enc_flags=obj_enc_flags)
     levels = ctx['levels']
 
     # the ray classes' counts (multi-hit rays, the boxes they hit): from the de-duplicated forward, or -- with the A/B

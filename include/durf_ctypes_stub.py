@@ -239,11 +239,11 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_dw_finalize_all.argtypes = [vp, i32, i32, C.POINTER(u64), C.POINTER(i32), C.POINTER(vp), vp, vp, vp, vp, i32, i32, i32, vp, i32, i32, vp, vp, vp, u64, vp]
     #   (stream, in_bkgd, nseg, rows, rows_per_ray, seg_count, part_bkgd, bpart_bkgd, grad_bkgd, bkgd_params, K, B, N, obj_count, nlevels, in_obj, part_obj, bpart_obj, grad_obj, obj_grad_stride, obj_params)
     L.durf_encode_obj_bwd.restype = i32
-    L.durf_encode_obj_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp, i32]
-    #   (stream, B, N, k_obj, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise)
+    L.durf_encode_obj_bwd.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp, i32, i32]
+    #   (stream, B, N, k_obj, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise, enc_flags)
     L.durf_encode_obj_bwd_batch.restype = i32
-    L.durf_encode_obj_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp, i32]
-    #   (stream, K, B, N, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise)
+    L.durf_encode_obj_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp, i32, i32]
+    #   (stream, K, B, N, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise, enc_flags)
     L.durf_pose_finish.restype = i32
     L.durf_pose_finish.argtypes = [vp, i32, vp, vp, i32, i32, vp]
     #   (stream, K, pose, sums, want_pos, want_rot, grad6)

@@ -582,18 +582,19 @@ int durf_dw_finalize_all(void* stream, int in_bkgd, int nseg, const size_t* rows
  * (scratch: 21*B floats; sums [K,21], zeroed by the caller once per step); durf_pose_finish
  * turns them into d(loss)/d(box_centers[ts]) added to grad6 [K,6]
  * (want_pos = !no_pose_opt, want_rot = !no_yaw_opt, obbpose_model.py:100-104).  precise != 0: libm exp / sin / cos
- * (behind the fp32 object branch); 0: the hardware transcendentals (behind the bf16 object MLPs). */
+ * (behind the fp32 object branch); 0: the hardware transcendentals (behind the bf16 object MLPs).  enc_flags: the
+ * forward's DURF_ENC_CYLINDER (mip.py:133-152) | DURF_ENC_NO_INTEGRATION (obbpose_model.py:163-164: means only). */
 int durf_encode_obj_bwd(void* stream, int B, int N, int k_obj, const int32_t* idx, const int32_t* count,
                         const float* d_enc, const float* t_vals, const float* origins_s,
                         const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                        const float* pose, const float* barf_w, float* scratch, float* sums, int precise);
+                        const float* pose, const float* barf_w, float* scratch, float* sums, int precise, int enc_flags);
 /* The same for all K objects of a level in one launch pair (blockIdx.y = object): idx [K,B], count [K], d_enc [K, B*N, 64]
  * (the slab durf_obj_bwd_batch fills), pose [K,6], scratch K*21*B floats, sums [K,21] accumulated over levels. */
 int durf_encode_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
                               const float* d_enc, const float* t_vals, const float* origins_s,
                               const float* dirs_s, const float* radii, const float* origins, const float* dirs,
                               const float* pose, const float* barf_w /* host float[10] */, float* scratch, float* sums,
-                              int precise);
+                              int precise, int enc_flags);
 int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, int want_pos, int want_rot,
                      float* grad6);
 

@@ -201,8 +201,18 @@ def test_train_step(cuda, K, N, B):
     assert new_state.step == 1
 
 
-@pytest.mark.parametrize('K,alpha,tv', [(2, 4.5, 0.0), (1, 10.0, 0.01)])
-def test_box_pose_gradients(cuda, K, alpha, tv):
+@pytest.mark.parametrize('K,alpha,tv,knobs', [
+    (2, 4.5, 0.0, {}), (1, 10.0, 0.01, {}),
+    # knobs off the shipped configs under pose optimisation: cylinder rays (mip.py:133-152: other Gaussians along the ray) and
+    # un-integrated encodings (obbpose_model.py:163-164: the variances are zeroed, the gradient runs through the means alone)
+    (2, 6.5, 0.0, dict(ray_shape='cylinder')), (2, 5.5, 0.01, dict(disable_integration=True)),
+    (1, 4.5, 0.0, dict(ray_shape='cylinder', disable_integration=True)),
+    # every frequency on and none damped (sin(2^9 x) at full weight): fp32 itself is the limit here -- the ORACLE in fp32 is
+    # 0.11 (rotation) / 0.06 (position) away from the oracle in float64 on this batch -- so this case is held to the float64
+    # oracle at 0.15 (measured 0.05)
+    (2, 10.0, 0.01, dict(disable_integration=True)),
+])
+def test_box_pose_gradients(cuda, K, alpha, tv, knobs):
     """cfg4: BARF pose optimisation on (no_pose_opt = no_yaw_opt = False) in the PRODUCTION precision (bf16 background
     MLP; the box-hit rays -- object MLPs and the background MLP's one evaluation per hit ray -- in fp32, which is what
     MipNerfModel.obj_precision = 'auto' selects when the pose is optimised).  d(loss)/d(box_centers[ts]) through
@@ -214,21 +224,24 @@ def test_box_pose_gradients(cuda, K, alpha, tv):
     utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n'
                     'MipNerfModel.no_pose_opt = False\nMipNerfModel.no_yaw_opt = False\n'
                     'Config.randomized = False\nConfig.rand_bkgd = False\nConfig.grad_max_norm = 1.0\n'
-                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = %g\n' % (N, tv))
+                    'Config.grad_max_val = 0.1\nConfig.tv_loss_mult = %g\n' % (N, tv) +
+                    ''.join('MipNerfModel.%s = %s\n' % (k, ('"%s"' % v) if isinstance(v, str) else v) for k, v in knobs.items()))
     config = utils.configured(utils.Config)
     b = synthetic.make_batch(B, K, seed=77 + K, noise_boxes=0.05)
-    ob, db = H.oracle_batch(b), H.device_batch(b, cuda)
+    undamped = bool(knobs.get('disable_integration')) and alpha >= 10.0
+    odt, tol = (torch.float64, 0.15) if undamped else (torch.float32, 5e-2)
+    ob, db = H.oracle_batch(b, odt), H.device_batch(b, cuda)
     model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
     assert model.mlp_precision == 'bf16' and model.object_precision() == 'f32'
-    params = H.oracle_params_from_variables(variables)
+    params = H.oracle_params_from_variables(variables, odt)
     prev_c, prev_d = ob['init'][0:1] + 0.01, db['init'][0:1] + 0.01
     grad, raw, pose = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, alpha, prev_d)
     torch.cuda.synchronize()
     ocfg = dict(R.CONFIG_DEFAULTS, randomized=False, tv_loss_mult=tv)
-    mcfg = dict(num_samples=N, no_pose_opt=False, no_yaw_opt=False)
+    mcfg = dict(num_samples=N, no_pose_opt=False, no_yaw_opt=False, **knobs)
     _, _, ostats, ograds = R.train_step(params, R.new_opt_state(params), ob, ocfg, mcfg, 5e-4, 3.0, alpha, prev_c)
     lay = variables.layout
-    got = grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6).cpu()
+    got = grad[lay.box[0]:lay.box[1]].view(lay.T, K, 6).cpu().to(odt)
     want = ograds[0]
     ts = b['ts']
     assert float(want[ts].abs().max()) > 0
@@ -236,15 +249,16 @@ def test_box_pose_gradients(cuda, K, alpha, tv):
     assert float(got[other].abs().max()) == 0.0 and float(want[other].abs().max()) == 0.0
     for k in range(K):
         rp, rr = _rel(got[ts, k, :3], want[ts, k, :3]), _rel(got[ts, k, 3:], want[ts, k, 3:])
-        assert rp < 5e-2 and rr < 5e-2, 'object %d: position rel err %g, rotation rel err %g\ngot %s\nwant %s' % (
+        assert rp < tol and rr < tol, 'object %d: position rel err %g, rotation rel err %g\ngot %s\nwant %s' % (
             k, rp, rr, got[ts, k], want[ts, k])
     # the object MLPs' own gradients come out of the fp32 kernels: fp32-class agreement
     for k in range(K):
         so = slice(lay.mlp_off['BoxMLP_%d' % k], lay.mlp_off['BoxMLP_%d' % k] + lay.mlp_size[128])
-        og_k = torch.cat([x.reshape(-1) for x in ograds])[so]
-        assert _rel(grad.cpu()[so], og_k) < 5e-3, 'BoxMLP_%d grad rel err %g' % (k, _rel(grad.cpu()[so], og_k))
+        og_k = torch.cat([x.reshape(-1) for x in ograds])[so].float()
+        # (undamped: the first layer's gradient sees the same fp32 noise of sin(2^9 x); measured 1e-2)
+        assert _rel(grad.cpu()[so], og_k) < (3e-2 if undamped else 5e-3), 'BoxMLP_%d grad rel err %g' % (k, _rel(grad.cpu()[so], og_k))
     # the MLP gradients are unaffected by switching pose optimisation on
-    og = torch.cat([x.reshape(-1) for x in ograds])
+    og = torch.cat([x.reshape(-1) for x in ograds]).float()
     sl = slice(lay.mlp_off['MLP_0'], lay.mlp_off['MLP_0'] + lay.mlp_size[256])
     assert _rel(grad.cpu()[sl], og[sl]) < 5e-2
 

@@ -31,6 +31,7 @@ POSE = 'MipNerfModel.no_pose_opt = False\nMipNerfModel.no_yaw_opt = False\n'
     (600, 2, 32, True, 'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = False\n'),     # yaw only: no TV term
     (512, 1, 32, False, POSE + 'Config.tv_loss_mult = 0.0\nConfig.white_bkgd = True\n'),
     (512, 3, 32, True, 'MipNerfModel.obj_precision = "f32"\n'),          # fp32 object branch, frozen poses
+    (512, 2, 32, True, POSE + 'MipNerfModel.ray_shape = "cylinder"\nMipNerfModel.disable_integration = True\n'),
     # the class defaults no shipped gin file keeps (utils.py:142-144, obbpose_model.py:57): density noise drawn by the library
     # under the step's key, weight decay, no background colour
     (700, 2, 32, True, 'MipNerfModel.density_noise = 0.1\nConfig.weight_decay_mult = 1e-4\nConfig.rand_bkgd = True\n'),
