@@ -207,9 +207,6 @@ def test_train_step(cuda, K, N, B):
     # un-integrated encodings (obbpose_model.py:163-164: the variances are zeroed, the gradient runs through the means alone)
     (2, 6.5, 0.0, dict(ray_shape='cylinder')), (2, 5.5, 0.01, dict(disable_integration=True)),
     (1, 4.5, 0.0, dict(ray_shape='cylinder', disable_integration=True)),
-    # every frequency on and none damped (sin(2^9 x) at full weight): fp32 itself is the limit here -- the ORACLE in fp32 is
-    # 0.11 (rotation) / 0.06 (position) away from the oracle in float64 on this batch -- so this case is held to the float64
-    # oracle at 0.15 (measured 0.05)
     (2, 10.0, 0.01, dict(disable_integration=True)),
 ])
 def test_box_pose_gradients(cuda, K, alpha, tv, knobs):
@@ -228,7 +225,11 @@ def test_box_pose_gradients(cuda, K, alpha, tv, knobs):
                     ''.join('MipNerfModel.%s = %s\n' % (k, ('"%s"' % v) if isinstance(v, str) else v) for k, v in knobs.items()))
     config = utils.configured(utils.Config)
     b = synthetic.make_batch(B, K, seed=77 + K, noise_boxes=0.05)
-    undamped = bool(knobs.get('disable_integration')) and alpha >= 10.0
+    # un-integrated encodings are undamped (sin(2^deg x) at full weight) and fp32 itself becomes the limit of this gradient:
+    # the ORACLE in fp32 is 2-11 % away from the oracle in float64 on these batches (profiles/r05_noint_pose_noise_floor.txt,
+    # tools/experiments/noint_pose_noise_floor.py), against 1e-6 with integration -- so those cases are held to the float64
+    # oracle at 0.15 (measured <= 0.05)
+    undamped = bool(knobs.get('disable_integration'))
     odt, tol = (torch.float64, 0.15) if undamped else (torch.float32, 5e-2)
     ob, db = H.oracle_batch(b, odt), H.device_batch(b, cuda)
     model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
