@@ -86,6 +86,9 @@ def parse_args():
     ap.add_argument('--chunk', type=int, default=8192, help='render_image chunk (eval mode)')
     ap.add_argument('--one-call', action='store_true',
                     help='eval mode: every chunk through the single C entry point durf_forward (no per-kernel timers)')
+    ap.add_argument('--python-step', action='store_true',
+                    help='train mode: every step through train_step\'s Python-issued launches instead of the single C entry '
+                         'point durf_train_step (bit-identical; the default takes the C call wherever it covers the workload)')
     ap.add_argument('--force-dist', action='store_true',
                     help='one rank, but through the data-parallel path: a world-size-1 RCCL group (DURF_FORCE_DIST=1), so the '
                          'gradient all-reduce + stream wait run and their per-step cost shows against a plain run')
@@ -405,8 +408,7 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
 
     def step(state, rng, i):
         # the logged scalars are all-reduced only every print_every steps
-        return train_boxpose.train_step(model, config, rng, state, batch, lr, eps, alpha, prev,
-                                        reduce_stats=(i % config.print_every == 0))
+        return step_fn(model, config, rng, state, batch, lr, eps, alpha, prev, reduce_stats=(i % config.print_every == 0))
 
     rng = 1000 * rank                                  # stratified-sampling noise differs per rank
     # The warm-up runs exactly what the timed region runs, the live HIP-event timers included, after --prewarm-events
@@ -415,6 +417,12 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     # timing events, none after this pre-warm even with --warmup 2).  `step_ms` in the JSON line (p50 / p90 / max /
     # slow_steps) shows any such outlier.
     profile_ops = args.profile_ops and not light
+    # The step runs through the ONE C call (durf_train_step: the drop-in boundary itself; bit-identical to the Python-issued
+    # launches of train_step and 1-3 % faster -- no interpreter between the launches) wherever that entry point covers the
+    # workload; its timing hooks (durf_train_args.timing) record the same HIP events around the same launches.  --python-step
+    # (and --profile-ops, which times every wrapped op) keeps the Python-issued launches.
+    step_fn = train_boxpose.train_step if (args.python_step or profile_ops) else train_boxpose.best_step_fn(model, state.variables)
+    host_path = 'durf_train_step (one C call)' if step_fn is train_boxpose.train_step_one_call else 'train_step (Python-issued launches)'
     ops.TIMED_NAMES = None if profile_ops else {k_fwd, k_bwd, k_dw, 'encode_bkgd', 'composite_resample'}
     ops.TIMERS = {}
     # Only every `every`-th step carries the event records (--time-every; default min(8, steps / 5)): a record makes the
@@ -463,7 +471,8 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     # part, the step holds the collective) gives the same kernels' undisturbed durations: `roofline.single_stream`.
     totals_ss = None
     if (not light and K_OBJ and model.object_precision() == 'bf16' and ops.overlap_mode(B * NS) != '0' and not profile_ops):
-        keep_mode, ops._MODE = ops._MODE, '0'
+        keep_mode = ops._MODE
+        ops.set_overlap_mode('0')
         ops.TIMERS = {}
         st_ss, rng_ss = state, rng
         for i in range(min(20, steps)):
@@ -471,7 +480,7 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
         sync()
         totals_ss = ops.timer_totals()
         ops.TIMERS = None
-        ops._MODE = keep_mode
+        ops.set_overlap_mode(keep_mode)
     if rank != 0:
         return None
 
@@ -572,7 +581,7 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
                            name=cfg_name, rays_per_gpu=B, global_batch=B * world, num_samples=NS,
                            num_levels=N_LEVELS, objects=K_OBJ, far=far, hit_fraction=hit, randomized=True,
                            pose_opt=not (model.no_pose_opt and model.no_yaw_opt), parallelism='dp%d' % world,
-                           object_precision=model.object_precision() if K_OBJ else None,
+                           object_precision=model.object_precision() if K_OBJ else None, host_path=host_path,
                            # object MLP launches on a side HIP stream (ops.py DURF_OVERLAP_OBJECTS): with '2' the timed
                            # background kernels' durations include what runs beside them
                            object_streams=(ops.overlap_mode(B * NS) if K_OBJ and model.object_precision() == 'bf16' else None),
@@ -608,7 +617,7 @@ def summarize_workload(o):
     r = o['roofline'] or {}
     return dict(rays_per_s=o['value'], ms_per_step=o['ms_per_step'], steps=o['steps'], rays_per_gpu=o['config']['rays_per_gpu'],
                 num_samples=o['config']['num_samples'], objects=o['config']['objects'], dtype=o['dtype'],
-                pose_opt=o['config']['pose_opt'], dominant=r.get('kernel'), bound=r.get('bound'), frac=r.get('frac'),
+                pose_opt=o['config']['pose_opt'], host_path=o['config'].get('host_path'), dominant=r.get('kernel'), bound=r.get('bound'), frac=r.get('frac'),
                 mfma_frac=r.get('mfma_frac', r.get('frac') if r.get('bound') == 'mfma' else None),
                 dominant_us=r.get('launch_us'), step_mlp_frac=r.get('step_mlp_frac'),
                 non_mlp_ms_per_step=r.get('non_mlp_ms_per_step'), loss=o['loss'])

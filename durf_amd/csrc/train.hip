@@ -9,6 +9,9 @@
 // train_boxpose.train_step (tests/test_gpu_train_call.py).
 #include "durf_common.h"
 #include "../../include/durf_hip.h"
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
 
 namespace {
 
@@ -22,6 +25,57 @@ struct Carver {
         return p;
     }
 };
+
+// The K object MLPs of a LARGE step run beside the background MLP's kernels on a second stream, as durf_amd/obbpose_model.py
+// and train_boxpose.py place them (ops.overlap_mode: from 2048 x 128 sample rows per level; below that every kernel is one
+// latency-bound round and a fork / join is one more dependency in the chain): the forward's object launches are issued
+// BEFORE the persistent background launch takes every CU, the object backward runs in its shadow, the objects' weight
+// gradients (their own split-K launch + finalize) beside the background's.  One side stream + two events per device,
+// created on first use; DURF_OVERLAP_OBJECTS=0 keeps everything on the caller's stream.  No result depends on it (no atomics).
+struct SideStream { hipStream_t s; hipEvent_t forked, joined; bool ok; };
+std::mutex g_side_mutex;
+
+SideStream* side_stream_of_device() {
+    static SideStream tab[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    SideStream& t = tab[dev];
+    if (!t.ok) {
+        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipEventCreateWithFlags(&t.forked, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&t.joined, hipEventDisableTiming) != hipSuccess) return nullptr;
+        t.ok = true;
+    }
+    return &t;
+}
+
+struct Overlap {
+    hipStream_t main;
+    SideStream* sd;                       // nullptr: one stream
+    void* obj() const { return sd ? (void*)sd->s : (void*)main; }
+    // fork: the side stream waits for everything issued so far on the caller's stream; join: the reverse
+    int fork() const {
+        if (!sd) return 0;
+        std::lock_guard<std::mutex> lock(g_side_mutex);          // (record + wait as a pair: the events are per device)
+        if (hipEventRecord(sd->forked, main) != hipSuccess || hipStreamWaitEvent(sd->s, sd->forked, 0) != hipSuccess) return 1;
+        return 0;
+    }
+    int join() const {
+        if (!sd) return 0;
+        std::lock_guard<std::mutex> lock(g_side_mutex);
+        if (hipEventRecord(sd->joined, sd->s) != hipSuccess || hipStreamWaitEvent(main, sd->joined, 0) != hipSuccess) return 1;
+        return 0;
+    }
+};
+
+Overlap overlap_for(void* stream, size_t rows, int Kb) {
+    Overlap o{(hipStream_t)stream, nullptr};
+    const char* e = getenv("DURF_OVERLAP_OBJECTS");
+    const bool want = (e == nullptr || !strcmp(e, "auto")) ? rows >= (size_t)2048 * 128 : strcmp(e, "0") != 0;
+    if (Kb > 0 && want) o.sd = side_stream_of_device();
+    return o;
+}
 
 constexpr int ML = DURF_FORWARD_MAX_LEVELS;
 constexpr int OBJ32_NSPLIT = 8;        // ops.objf32_dw_batch's default: same split-K partial order as the Python path
@@ -120,6 +174,13 @@ TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params, int 
     return w;
 }
 
+// the workspace of one call; the class counts live in the caller's buffer when it asked for them (durf_train_args.cls_count)
+TrainWs workspace_of(const durf_train_args* a, void* workspace) {
+    TrainWs w = carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params, a->flags);
+    if (a->cls_count != nullptr) w.count_cls = a->cls_count;
+    return w;
+}
+
 int check_args(const durf_train_args* a, void* workspace) {
     DURF_REQUIRE(a != nullptr && workspace != nullptr, "arguments and workspace");
     const durf_forward_args& f = a->f;
@@ -153,6 +214,12 @@ int check_args(const durf_train_args* a, void* workspace) {
 }
 
 #define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)
+// a launch bracketed by the caller's timing events (durf_train_args.timing), recorded on the stream it is issued to
+#define TIMED(id, call) do {                                                                       \
+        if (tm && tm->begin[id]) (void)hipEventRecord((hipEvent_t)tm->begin[id], hs);               \
+        STEP(call);                                                                                \
+        if (tm && tm->end[id]) (void)hipEventRecord((hipEvent_t)tm->end[id], hs);                   \
+    } while (0)
 
 __global__ void k_scale(int n, float* __restrict__ x, float c) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -166,13 +233,14 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     const int B = f.B, N = f.N, K = f.K, L = f.num_levels;
     const size_t rows = (size_t)B * N;
     hipStream_t hs = (hipStream_t)stream;
+    const durf_step_timing* tm = a->timing;
     int rc;
     // ---- forward (obbpose_model.py:68-261), activations stashed ----
     const bool f32o = K > 0 && (a->flags & DURF_TRAIN_OBJ_FP32), pose_opt = f32o && (a->flags & DURF_TRAIN_POSE_OPT);
     const int Kb = f32o ? 0 : K;                          // objects on the bf16 kernels
     // (ray setup, view encoding, level-0 samples, the step's draws, the gradient's zero fill AND every bf16 weight stream: one launch)
     STEP(durf_ray_prologue_pack(stream, B, K, N, f.origins, f.directions, f.pose, f.ext, w.o_s, w.d_s, w.hit, f.zo, f.viewdirs, w.view,
-                                f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0], nullptr, a->grad, a->n_params, f.seed_lo, f.seed_hi,
+                                f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0], K > 0 ? a->pose_used : nullptr, a->grad, a->n_params, f.seed_lo, f.seed_hi,
                                 f.draw_noise ? w.u_rand : nullptr, f.bkgd_params, 60, w.wf_bkgd, w.wb_bkgd, Kb, f.obj_params,
                                 f.obj_param_stride, 63, w.wf_obj, w.wb_obj));
     if (K > 0)
@@ -194,31 +262,43 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     for (int l = 0; l < L; l++)
         for (int k = 0; k < K; k++) raw_obj[l][k] = w.obj_raw[l] + (size_t)k * rows * 4;
     const int obj_flags = f.enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER);
+    const Overlap ov = overlap_for(stream, rows, Kb);
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = f.t_vals[lvl];
+        if (ov.sd) {              // bf16 objects of a large step: issued first, on the side stream (joined before the composite)
+            STEP(ov.fork());
+            STEP(durf_obj_fwd_batch(ov.obj(), K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, f.radii, f.barf_w, obj_flags,
+                                    w.view, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
+                                    lvl == 0 ? w.obj_view_tile : nullptr));
+        }
         if (K > 0) {
             // (bf16 objects: the forward writes raw in the full layout itself, DURF_FWD_RAW_FULL; fp32 objects: the box-hit
             // rays' rows come from k_bkgd_hit_rays' fp32 evaluation instead, through durf_expand_raw)
-            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags | (f32o ? 0 : DURF_FWD_RAW_FULL),
-                                  w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, f32o ? w.raw_c[lvl] : w.raw_b[lvl], w.stash[lvl],
-                                  w.mask[lvl], w.idx_cls + B, w.count_cls + 1, lvl == 0 ? w.view_tile : nullptr));
+            TIMED(DURF_TIMED_FWD + lvl,
+                  durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags | (f32o ? 0 : DURF_FWD_RAW_FULL),
+                                   w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, f32o ? w.raw_c[lvl] : w.raw_b[lvl], w.stash[lvl],
+                                   w.mask[lvl], w.idx_cls + B, w.count_cls + 1, lvl == 0 ? w.view_tile : nullptr));
             if (f32o) STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], w.raw_tail));
             if (f32o)
                 STEP(durf_objf32_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, nullptr, w.view27, f.obj_params,
                                            f.obj_param_stride, w.obj_ws, w.obj_raw[lvl], w.act32[lvl], t_vals, w.o_s, w.d_s,
                                            f.radii, f.barf_w, obj_flags));
-            else
+            else if (!ov.sd)
                 STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, f.radii, f.barf_w, obj_flags,
                                         w.view, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
                                         lvl == 0 ? w.obj_view_tile : nullptr));
+            STEP(ov.join());
         } else {
-            STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, nullptr, 0, f.enc_flags, w.enc[lvl], w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl],
-                              w.mask[lvl], nullptr, nullptr, lvl == 0 ? w.view_tile : nullptr));
+            TIMED(DURF_TIMED_FWD + lvl,
+                  durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, nullptr, 0, f.enc_flags, w.enc[lvl], w.view, nullptr,
+                                   nullptr, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl], w.mask[lvl], nullptr, nullptr,
+                                   lvl == 0 ? w.view_tile : nullptr));
         }
         if (f.density_noise != 0.0f)       // obbpose_model.py:236-240, on the background's raw density as the Python path adds it
             STEP(durf_density_noise(stream, rows, w.raw_b[lvl], f.density_noise, f.density_rand[lvl], f.seed_lo, f.seed_hi, lvl));
         if (lvl + 1 < L)        // composite + resample + the loss normalisers of this (level 0 only) and the next level: one launch
-            STEP(durf_composite_resample(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, t_vals, w.d_s, f.density_bias,
+            TIMED(DURF_TIMED_COMPOSITE + lvl,
+                 durf_composite_resample(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, t_vals, w.d_s, f.density_bias,
                                          f.bkgd_mode, f.rgb[lvl], f.depth[lvl], f.acc[lvl], f.weights[lvl], f.t_mids[lvl],
                                          f.t_dists[lvl], f.resample_padding, f.draw_noise ? w.u_rand : f.u_rand, f.t_vals[lvl + 1], a->lossmult, a->gt_depth,
                                          a->sky, f.dyn_mask, f.zo, a->eps, a->box_loss_mult, lvl, a->disable_multiscale,
@@ -255,14 +335,17 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
                                                obj_flags));
         }
         if (K > 0) {
-            STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
-                              nullptr, w.idx_cls + B, w.count_cls + 1, rs));
-            if (!f32o)
-                STEP(durf_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw[lvl], w.wb_obj, w.obj_mask[lvl], w.obj_dz[lvl],
+            STEP(ov.fork());      // (the object backward below reads d(raw) of this level: written by the loss launch on this stream)
+            TIMED(DURF_TIMED_BWD + lvl,
+                  durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
+                               nullptr, w.idx_cls + B, w.count_cls + 1, rs));
+            if (!f32o)            // (large step: in the shadow of the background backward just issued; the fork is in front of it)
+                STEP(durf_obj_bwd_batch(ov.obj(), K, B, N, w.idx_obj, w.count_obj, w.draw[lvl], w.wb_obj, w.obj_mask[lvl], w.obj_dz[lvl],
                                         w.obj_dz_out[lvl], nullptr));
         } else {
-            STEP(durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], nullptr, nullptr, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl], nullptr,
-                              nullptr, nullptr, nullptr));
+            TIMED(DURF_TIMED_BWD + lvl,
+                  durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], nullptr, nullptr, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl], nullptr,
+                               nullptr, nullptr, nullptr));
         }
     }
     // ---- weight gradients of every MLP over every level: the objects' split-K partials, the background's, one finalize ----
@@ -285,13 +368,20 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         STEP(durf_objf32_dw_batch(stream, K, B, N, w.count_obj, L, act, dz32, OBJ32_NSPLIT, w.dw32_scratch, g_obj, a->obj_floats));
     } else if (K > 0) {
         for (int l = 0; l < L; l++) { enc[l] = w.obj_enc[l]; stash[l] = w.obj_stash[l]; dz[l] = w.obj_dz[l]; dzo[l] = w.obj_dz_out[l]; }
-        STEP(durf_obj_dw_partials(stream, K, B, N, w.count_obj, L, enc, ovt, stash, dz, dzo, w.opart, w.obpart));
+        if (ov.sd)            // large step: split-K launch + finalize of their own, beside the background's (same sums: the finalize
+                              // launches add each MLP's partials in the same order whether they are merged or not)
+            STEP(durf_obj_dw_batch(ov.obj(), K, B, N, w.count_obj, L, enc, ovt, stash, dz, dzo, 63, w.opart, w.obpart, g_obj,
+                                   a->obj_floats, f.obj_params));
+        else
+            STEP(durf_obj_dw_partials(stream, K, B, N, w.count_obj, L, enc, ovt, stash, dz, dzo, w.opart, w.obpart));
     }
+    const int Km = ov.sd ? 0 : Kb;          // object MLPs finalized together with the background MLP
     for (int l = 0; l < L; l++) { enc[l] = w.enc[l]; stash[l] = w.stash[l]; dz[l] = w.dz[l]; dzo[l] = w.dz_out[l]; }
-    STEP(durf_mlp_dw_levels(stream, 256, L, seg_rows, per_ray, seg_count, enc, vt, stash, dz, dzo, w.part, w.bpart));
-    STEP(durf_dw_finalize_all(stream, 60, L, seg_rows, per_ray, seg_count, w.part, w.bpart, g_bkgd, f.bkgd_params, Kb, Kb ? B : 0,
-                              Kb ? N : 0, Kb ? w.count_obj : nullptr, Kb ? L : 1, 63, Kb ? w.opart : nullptr, Kb ? w.obpart : nullptr,
-                              Kb ? g_obj : nullptr, Kb ? a->obj_floats : 0, Kb ? f.obj_params : nullptr));
+    TIMED(DURF_TIMED_DW, durf_mlp_dw_levels(stream, 256, L, seg_rows, per_ray, seg_count, enc, vt, stash, dz, dzo, w.part, w.bpart));
+    STEP(durf_dw_finalize_all(stream, 60, L, seg_rows, per_ray, seg_count, w.part, w.bpart, g_bkgd, f.bkgd_params, Km, Km ? B : 0,
+                              Km ? N : 0, Km ? w.count_obj : nullptr, Km ? L : 1, 63, Km ? w.opart : nullptr, Km ? w.obpart : nullptr,
+                              Km ? g_obj : nullptr, Km ? a->obj_floats : 0, Km ? f.obj_params : nullptr));
+    STEP(ov.join());
     const float* wl2 = nullptr;
     if (a->weight_decay_mult != 0.0f) {       // train_boxpose.py:73-75 (in front of the pose rows' additions, as the Python path orders it)
         STEP(durf_weight_decay(stream, a->n_params, a->params, a->grad, 0, a->n_params, a->weight_decay_mult, w.scratch, w.weight_l2));
@@ -331,14 +421,14 @@ size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, siz
 int durf_loss_backward(void* stream, const durf_train_args* a, void* workspace) {
     int rc = check_args(a, workspace);
     if (rc != 0) return rc;
-    return loss_backward(stream, a, carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params, a->flags));
+    return loss_backward(stream, a, workspace_of(a, workspace));
 }
 
 int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
     int rc = check_args(a, workspace);
     if (rc != 0) return rc;
     DURF_REQUIRE(a->adam_m && a->adam_v && a->grad_stats, "Adam moments and grad_stats");
-    const TrainWs w = carve(workspace, a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params, a->flags);
+    const TrainWs w = workspace_of(a, workspace);
     STEP(loss_backward(stream, a, w, false));
     if (a->comm != nullptr) {
         // One rank's share of a data-parallel step (train_boxpose.py:253-255; durf_amd/train_boxpose.py train_step): the

@@ -375,6 +375,13 @@ _MODE = os.environ.get('DURF_OVERLAP_OBJECTS', 'auto')
 OVERLAP_MIN_ROWS = 2048 * 128
 
 
+def set_overlap_mode(mode):
+    """'auto' / '0' .. '3' for the Python-issued launches AND for the one-call C step (which reads DURF_OVERLAP_OBJECTS per call)"""
+    global _MODE
+    _MODE = mode
+    os.environ['DURF_OVERLAP_OBJECTS'] = mode
+
+
 def overlap_mode(rows):
     """'0' .. '3' for a step (or a render chunk) of `rows` sample rows per level"""
     if _MODE == 'auto':
@@ -1169,10 +1176,45 @@ class TrainArgs(C.Structure):
                 [(n, C.c_void_p) for n in ('grad', 'stats', 'adam_m', 'adam_v')] +
                 [('lr', C.c_float), ('max_val', C.c_float), ('max_norm', C.c_float), ('step', C.c_int), ('grad_stats', C.c_void_p),
                  ('flags', C.c_int), ('want_pos', C.c_int), ('want_rot', C.c_int), ('tv_loss_mult', C.c_float),
-                 ('comm', C.c_void_p), ('world', C.c_int), ('reduce_stats', C.c_int), ('weight_decay_mult', C.c_float)])
+                 ('comm', C.c_void_p), ('world', C.c_int), ('reduce_stats', C.c_int), ('weight_decay_mult', C.c_float),
+                 ('pose_used', C.c_void_p), ('cls_count', C.c_void_p), ('timing', C.c_void_p)])
 
 
 TRAIN_OBJ_FP32, TRAIN_POSE_OPT = 1, 2          # durf_train_args.flags
+TIMED_FWD, TIMED_BWD, TIMED_COMPOSITE, TIMED_DW, TIMED_STAGES = 0, 4, 8, 12, 13      # durf_step_timing slots
+
+
+class StepTiming(C.Structure):
+    """durf_step_timing (include/durf_hip.h)"""
+    _fields_ = [('begin', C.c_void_p * TIMED_STAGES), ('end', C.c_void_p * TIMED_STAGES)]
+
+
+def _step_timing(num_levels, keep):
+    """the live timers of a one-call step (bench.py's roofline): HIP events the C call records around the launches the
+    Python-issued path brackets with _Timed -- the same names in TIMERS.  None unless timers are armed for this step."""
+    if TIMERS is None or not TIMERS_ACTIVE:
+        return None
+    want = lambda name: TIMED_NAMES is None or name in TIMED_NAMES
+    slots = []
+    if want('mlp_fwd_256_train'):
+        slots += [('mlp_fwd_256_train', TIMED_FWD + l) for l in range(num_levels)]
+    if want('mlp_bwd_256'):
+        slots += [('mlp_bwd_256', TIMED_BWD + l) for l in range(num_levels)]
+    if want('composite_resample'):
+        slots += [('composite_resample', TIMED_COMPOSITE + l) for l in range(num_levels - 1)]
+    if want('mlp_dw_256'):
+        slots += [('mlp_dw_256', TIMED_DW)]
+    if not slots:
+        return None
+    tm = StepTiming()
+    for name, i in slots:
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        for e in pair:
+            e.record()                      # (torch creates the underlying event on its first record; the call re-records it)
+        tm.begin[i], tm.end[i] = pair[0].cuda_event, pair[1].cuda_event
+        TIMERS.setdefault(name, []).append(pair)
+    keep.append(tm)
+    return tm
 
 
 def _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
@@ -1233,7 +1275,8 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
                tv_loss_mult=0.0, seed=None, comm=None, world=1, reduce_stats=False, density_noise=0.0, density_rand=None,
                weight_decay_mult=0.0):
     """One shard's training step as ONE library call (durf_train_step; update=False: durf_loss_backward, parameters
-    untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None).
+    untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None, pose_used [K,6] or None -- the
+    poses the step rendered with -- and the class counts [8] int32 or None: [3] = rays that hit two boxes).
     obj_fp32: the object branch on the exact-fp32 kernels; want_pos / want_rot: box-pose optimisation behind it (`pose` must
     then be a view of this timestep's rows of box_centers inside params_flat)"""
     if update:
@@ -1272,10 +1315,15 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
     a.flags = (TRAIN_OBJ_FP32 if (K and obj_fp32) else 0) | (TRAIN_POSE_OPT if pose_opt else 0)
     a.want_pos, a.want_rot, a.tv_loss_mult = int(bool(want_pos)), int(bool(want_rot)), float(tv_loss_mult)
     a.comm, a.world, a.reduce_stats = (comm.handle if comm is not None else None), int(world), int(bool(reduce_stats))
+    pose_used = torch.empty_like(pose) if K else None
+    cls = torch.empty(8, dtype=torch.int32, device=dev) if K else None
+    a.pose_used, a.cls_count = _p(pose_used), _p(cls)
+    tm = _step_timing(num_levels, keep) if update else None
+    a.timing = C.cast(C.pointer(tm), C.c_void_p) if tm is not None else None
     ws = torch.empty(int(L.durf_train_workspace_bytes_flags(B, N, K, num_levels, params_flat.numel(), a.flags)), dtype=torch.uint8,
                      device=dev)
     assert ws.data_ptr() % 256 == 0
     with _Timed('train_call'):
         fn = L.durf_train_step if update else L.durf_loss_backward
         _lib.check(fn(_stream(), C.byref(a), _p(ws)), 'durf_train_step' if update else 'durf_loss_backward')
-    return outs, dyn, zo, grad, stats, (gstats if update else None)
+    return outs, dyn, zo, grad, stats, (gstats if update else None), pose_used, cls

@@ -186,7 +186,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                 view_tile.record_stream(main)
                 view_ready = torch.cuda.Event()
                 view_ready.record(side.side)
-            if prep is not None:                  # (the fused forward filled every level's normalisers already)
+            if prep is not None and L < 2:        # (the fused forward filled every level's normalisers already)
                 for lvl in range(L - 1):
                     draws[lvl], terms[lvl] = level_loss(lvl)
                     draws[lvl].record_stream(main)
@@ -195,9 +195,10 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                     ready[lvl].record(side.side)
     elif not f32 and view_tile is None:
         view_tile = make_view_tile()
-    if not side.enabled and prep is not None and L >= 2:
-        # one stream: every level's loss + composite backward as ONE launch in front of the backward kernels (stop_level_grad:
-        # each is a function of the forward alone) instead of one launch per level between them
+    if prep is not None and L >= 2:
+        # every level's loss + composite backward as ONE launch in front of the backward kernels (stop_level_grad: each is a
+        # function of the forward alone) instead of one launch per level between them -- on this stream at every batch size
+        # (round 5: the lower levels' launches on the side stream cost two more cross-stream hops than they hid)
         lvs = []
         for lvl in range(L):
             lv = ctx['levels'][lvl]
@@ -445,6 +446,30 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
     return new_state, stats, new_rng, pose              # (the prologue's snapshot: does not alias the updated parameters)
 
 
+def one_call_refusal(model, variables, update=True):
+    """why durf_train_step does not cover this step (None: it does) -- the conditions train_step_one_call raises on"""
+    lay = variables.layout
+    K, L = lay.K, model.num_levels
+    dist = _dist()
+    if model.mlp_precision != 'bf16' or (K and not model.dynamics) or L < 2 or not lay.use_viewdirs:
+        return 'durf_train_step covers the step with a bf16 background MLP (12-Dense tree), dynamic boxes and >= 2 levels'
+    if dist is not None and (_instream_comm(dist) is None or not update):
+        return ('durf_train_step is data-parallel only through the library\'s own in-stream all-reduce '
+                '(DURF_INSTREAM_ALLREDUCE=1; see csrc/train.hip, csrc/comm.hip)')
+    if bool(K) and not (model.no_pose_opt and model.no_yaw_opt) and model.object_precision() != 'f32':
+        # (train_step runs this combination -- obj_precision='bf16' forced under pose optimisation -- on the bf16 object
+        # kernels; the C entry point only has the fp32 hit-ray branch behind the pose gradient)
+        return "durf_train_step optimises box poses with the hit rays in fp32 only (MipNerfModel.obj_precision = 'auto' or 'f32')"
+    return None
+
+
+def best_step_fn(model, variables):
+    """the faster host path of a training step for this model: the one C call (durf_train_step -- bit-identical to train_step,
+    1-3 % faster at every measured shape: no interpreter between the launches, two cross-stream hops fewer) wherever it covers
+    the step, else train_step.  bench.py and train_loop use it; the parity tests name the path they mean."""
+    return train_step_one_call if one_call_refusal(model, variables) is None else train_step
+
+
 def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, update=True, reduce_stats=True):
     """`train_step` through ONE library call (durf_train_step, csrc/train.hip): the orchestration of loss_and_grad /
     train_step done in C for hosts that are not Python; same arguments, same (new_state, stats, rng, pose), bit-identical
@@ -459,18 +484,11 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
     K, L, N = lay.K, model.num_levels, model.num_samples
     dist = _dist()
     comm = _instream_comm(dist) if dist is not None else None
-    if (model.mlp_precision != 'bf16' or (K and not model.dynamics) or L < 2 or not lay.use_viewdirs or
-            (dist is not None and (comm is None or not update))):
-        raise NotImplementedError('durf_train_step covers the step with a bf16 background MLP (12-Dense tree) and >= 2 levels; data-parallel only '
-                                  'through the library\'s own in-stream all-reduce (DURF_INSTREAM_ALLREDUCE=1; see csrc/train.hip, '
-                                  'csrc/comm.hip)')
+    why = one_call_refusal(model, variables, update)
+    if why is not None:
+        raise NotImplementedError(why)
     pose_opt = bool(K) and not (model.no_pose_opt and model.no_yaw_opt)
     obj_fp32 = bool(K) and model.object_precision() == 'f32'
-    if pose_opt and not obj_fp32:
-        # (train_step runs this combination -- obj_precision='bf16' forced under pose optimisation -- on the bf16 object
-        # kernels; the C entry point only has the fp32 hit-ray branch behind the pose gradient)
-        raise NotImplementedError("durf_train_step optimises box poses with the hit rays in fp32 only "
-                                  "(MipNerfModel.obj_precision = 'auto' or 'f32')")
     rays = batch['rays']
     B = rays.origins.shape[0]
     dev = variables.flat.device
@@ -491,10 +509,11 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
     ts = int(batch['ts'])
     pose = variables['params']['box_centers'][ts]          # a view of the parameters: the pose gradient goes to the same rows
     assert pose.is_contiguous()
-    pose_used = pose.clone()                               # what the step renders with (the update below is in place)
     flags = ((ops.ENC_CONTRACT if model.contraction else 0) | (ops.ENC_NO_INTEGRATION if model.disable_integration else 0) |
              (ops.ENC_CYLINDER if model.ray_shape == 'cylinder' else 0))
-    outs, dyn, zo, grad, out, gs = ops.train_call(
+    # (pose_used: what the step renders with -- the update is in place; snapshot by the call's first launch, like cls, the
+    # ray classes' counts: no launch of their own)
+    outs, dyn, zo, grad, out, gs, pose_used, cls = ops.train_call(
         rays, pose, batch['ext'].reshape(-1, 3).contiguous() if K else None, variables.flat, state.m, state.v,
         lay.box[1] - lay.box[0], lay.mlp_size[om.W_BKGD], lay.mlp_size[om.W_OBJ], N, L, alpha, flags,
         rays.lossmult, batch['pixels'][..., :3], batch['depth'], batch['sky'], batch['target'] if K else None,
@@ -509,6 +528,8 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0, seed=seed, comm=comm,
         world=dist.get_world_size() if dist is not None else 1, reduce_stats=dist is not None and reduce_stats,
         density_noise=dn, density_rand=noise.get('density') if dn else None, weight_decay_mult=config.weight_decay_mult)
+    if pose_used is None:
+        pose_used = pose                                       # K = 0: [0, 6]
     box_rot0 = pose_used[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))
     ret = [tuple(o) + ([pose_used[:, :3], box_rot0], dyn, zo) for o in outs]
     st = ops.stats_views(out, L)
@@ -523,7 +544,7 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         offset_yaw=st['offset_yaw'], pose=pose_out, weights=[r[3] for r in ret], samples=[r[4] for r in ret],
         weight_l2=st['weight_l2'], psnr=st['psnrs'][-1], psnrs=st['psnrs'], obj_psnr=st['obj_psnrs'][-1],
         grad_norm=gs[0], grad_abs_max=gs[1], grad_norm_clipped=gs[3],
-        multi_hit_rays=(dyn > 1).sum() if K > 1 else ops.const_tensor(dev, (), torch.int64))
+        multi_hit_rays=cls[3] if K > 1 else ops.const_tensor(dev, (), torch.int64))
     new_rng = (int(rng) + 1) if isinstance(rng, int) else rng
     return TrainState(variables, state.m, state.v, state.step + 1), stats, new_rng, pose_out
 
@@ -631,7 +652,7 @@ def train_loop(model, config, state, dataset, test_dataset=None, train_dir=None,
     Returns (state, history) with history = list of (step, dict of logged scalars)."""
     import time
     from . import checkpoints
-    step_fn = step_fn or train_step
+    step_fn = step_fn or best_step_fn(model, state.variables)       # (the one C call wherever it covers the step)
     lr_fn, eps_fn, alpha_fn = make_schedules(config)
     if train_dir is not None:
         state = checkpoints.restore_checkpoint(train_dir, state)                         # :404

@@ -429,6 +429,16 @@ int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
  * (durf_train_workspace_bytes = flags 0). */
 #define DURF_TRAIN_OBJ_FP32 1
 #define DURF_TRAIN_POSE_OPT 2
+/* Live timing of the step's dominant launches for a roofline line (bench.py): hipEvent_t handles (created with timing
+ * enabled, any may be NULL) that the call records on `stream` right before / after the background MLP's forward and backward
+ * launch of level l (DURF_TIMED_FWD + l, DURF_TIMED_BWD + l), the fused per-ray launch behind level l's forward
+ * (DURF_TIMED_COMPOSITE + l) and the weight-gradient launch (DURF_TIMED_DW). */
+#define DURF_TIMED_FWD 0
+#define DURF_TIMED_BWD 4
+#define DURF_TIMED_COMPOSITE 8
+#define DURF_TIMED_DW 12
+#define DURF_TIMED_STAGES 13
+typedef struct durf_step_timing { void* begin[DURF_TIMED_STAGES]; void* end[DURF_TIMED_STAGES]; } durf_step_timing;
 typedef struct durf_train_args {
     durf_forward_args f;
     const float *lossmult, *pixels, *gt_depth, *sky;     /* Rays.lossmult [B], batch pixels [B,3], depth [B], sky [B] */
@@ -454,6 +464,11 @@ typedef struct durf_train_args {
     int world;                                            /*   ranks of comm (1 / world scales the summed gradient; lax.pmean) */
     int reduce_stats;                                     /*   != 0: the logged scalars are averaged over the ranks too (lax.pmean(stats), :255) */
     float weight_decay_mult;                              /* Config.weight_decay_mult (train_boxpose.py:73-75; durf_weight_decay); 0: none */
+    float* pose_used;                                     /* nullable out [K,6]: f.pose as the step rendered with it (snapshot taken by the first
+                                                             launch; durf_train_step updates box_centers in place under pose optimisation) */
+    int32_t* cls_count;                                   /* nullable out [8]: durf_compact_all's class counts, kept where the caller can read
+                                                             them ([3] = rays that hit two boxes, utils.Stats.multi_hit_rays) instead of in the workspace */
+    const durf_step_timing* timing;                       /* nullable: events to record around the dominant launches (above) */
 } durf_train_args;
 size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params);
 size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, size_t n_params, int flags);

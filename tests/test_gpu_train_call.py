@@ -137,3 +137,38 @@ def test_unsupported_configurations_are_refused(cuda):
         with pytest.raises(NotImplementedError):
             train_boxpose.train_step_one_call(model, config, 0, train_boxpose.create_train_state(variables), db, 5e-4, 3.0, 10.0,
                                               db['init'][0:1])
+
+
+def test_timing_hooks_of_the_one_call_step(cuda):
+    """durf_train_args.timing (bench.py's live roofline timers when the step runs through the C call): HIP events recorded
+    around the background MLP's forward / backward launch of every level, the fused per-ray launch and the weight-gradient
+    launch -- under the names the Python-issued path's timers use -- without changing a bit of the step"""
+    from durf_amd import ops
+    B, K, N = 1024, 2, 64
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\nConfig.randomized = True\nConfig.rand_bkgd = False\n' % N)
+    config = utils.configured(utils.Config)
+    db = H.device_batch(synthetic.make_batch(B, K, seed=981), cuda)
+    out = {}
+    for timed in (False, True):
+        model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+        state = train_boxpose.create_train_state(variables)
+        assert train_boxpose.best_step_fn(model, variables) is train_boxpose.train_step_one_call
+        ops.TIMERS, ops.TIMED_NAMES, ops.TIMERS_ACTIVE = ({} if timed else None), None, True
+        try:
+            for i in range(2):
+                state, stats, _, _ = train_boxpose.train_step_one_call(model, config, 5 + i, state, db, 5e-4, 3.0, 10.0, db['init'][0:1])
+            totals = ops.timer_totals() if timed else None
+        finally:
+            ops.TIMERS = None
+        out[timed] = (state.variables.flat.clone(), float(stats.loss), totals)
+    assert torch.equal(out[False][0], out[True][0]) and out[False][1] == out[True][1]
+    totals = out[True][2]
+    # 2 steps x 2 levels of forward / backward, 2 x 1 fused per-ray launch (the last level's composite is the loss launch's), 2 x 1 dW
+    assert {k: v[0] for k, v in totals.items()} == {'mlp_fwd_256_train': 4, 'mlp_bwd_256': 4, 'composite_resample': 2, 'mlp_dw_256': 2,
+                                                    'train_call': 2}         # (+ the wrapper's own bracket around the whole call)
+    assert totals['train_call'][1] > totals['mlp_dw_256'][1] + totals['mlp_fwd_256_train'][1] + totals['mlp_bwd_256'][1]
+    for name, (n, sec) in totals.items():
+        assert 2e-6 < sec / n < 5e-3, (name, sec / n)
+    assert totals['mlp_dw_256'][1] / 2 > totals['composite_resample'][1] / 2

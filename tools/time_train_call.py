@@ -15,7 +15,9 @@ utils.parse_gin('MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True
 config = utils.configured(utils.Config)
 b = synthetic.make_batch(B, K, seed=1, far=40.0)
 db = synthetic.device_batch(b, dev)
-for name, fn in (('train_step (Python-issued launches)', train_boxpose.train_step), ('durf_train_step (one C call)', train_boxpose.train_step_one_call)) * 2:
+MODES = (('train_step (Python-issued launches)', train_boxpose.train_step), ('durf_train_step (one C call)', train_boxpose.train_step_one_call))
+only = os.environ.get('ONLY')            # ONLY=python / ONLY=c: one path (for a kernel trace of it)
+for name, fn in ((MODES[0],) if only == 'python' else (MODES[1],) if only == 'c' else MODES * 2):
     model, variables = obbpose_model.construct_mipnerf(0, db, device=dev)
     state = train_boxpose.create_train_state(variables)
     rng = 0
