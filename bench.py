@@ -69,7 +69,7 @@ def parse_args():
     ap.add_argument('--time-every', type=int, default=0,
                     help='record the roofline HIP events on every n-th timed step only (0: min(8, steps / 5); 1: every step, '
                          'as up to round 3 -- each record costs the stream 3-6 us on either side of the launch it brackets)')
-    ap.add_argument('--prewarm-events', type=int, default=512,
+    ap.add_argument('--prewarm-events', type=int, default=768,
                     help='timing events recorded (and kept alive) before the warm-up: grows the HIP runtime\'s event pool there')
     ap.add_argument('--max-ahead', type=int, default=0, help='bound the number of steps the host may enqueue ahead of the GPU (0 = unbounded)')
     ap.add_argument('--no-calibration', action='store_true', help='skip the vendor-GEMM board calibration line')
@@ -304,6 +304,7 @@ def eval_main(args):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     totals = ops.timer_totals()
+    ops.recycle_timers()
     ops.TIMERS = None
     ops.TIMERS_ACTIVE = True
     NS = w['N']
@@ -437,7 +438,8 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     flush_c_stdio()       # (the communicator, and with it the banner, is created lazily by the first collective)
     # live HIP-event timers over the timed region (recorded on the launch stream): the kernels the roofline
     # reports, or every wrapped op with --profile-ops (every timed op costs two event records)
-    ops.TIMERS = {}                                    # drop the warm-up's records
+    ops.recycle_timers()                               # drop the warm-up's records (their events return to the pool)
+    ops.TIMERS = {}
     # GPU timestamps (diagnostic: `step_ms`) after every `group`-th step -- a record between two steps costs the stream
     # 5-11 us like any other (0.3 % of a 4096-ray step, 1.5 % of a 512-ray one), so the outlier check works on groups of steps
     group = 1 if (args.max_ahead > 0 or steps < 16) else 4
@@ -479,6 +481,7 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
             st_ss, _, rng_ss, _ = step(st_ss, rng_ss, steps + 1 + i)
         sync()
         totals_ss = ops.timer_totals()
+        ops.recycle_timers()
         ops.TIMERS = None
         ops.set_overlap_mode(keep_mode)
     if rank != 0:
@@ -654,6 +657,8 @@ def main():
     prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]    # kept alive to the end (run_train)
     for e in prewarm:
         e.record()
+    from durf_amd import ops as _ops
+    _ops.EVENT_POOL.extend(prewarm)          # ... and they are the timing events the one-call step is handed (ops._step_timing)
 
     out = run_train(args, args.config, dev, rank, world, args.steps, args.warmup, rays=args.rays, objects=args.objects,
                     precision=args.precision)

@@ -5,6 +5,7 @@
 // bf16 MLPs; rays that hit exactly one box take the de-duplicated background evaluation (durf_expand_raw); K = 0 is the
 // static model.  Results are bit-identical to MipNerfModel.apply (tests/test_gpu_forward_call.py).
 #include "durf_common.h"
+#include "side_stream.h"
 #include "../../include/durf_hip.h"
 
 namespace {
@@ -77,22 +78,29 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
     STEP(durf_ray_prologue_pack(stream, B, K, N, a->origins, a->directions, a->pose, a->ext, w.o_s, w.d_s, w.hit, a->zo, a->viewdirs,
                                 w.view, a->near, a->far, a->t_rand, a->lindisp, a->t_vals[0], nullptr, nullptr, 0, a->seed_lo, a->seed_hi,
                                 a->draw_noise ? w.u_rand : nullptr, a->bkgd_params, 60, w.wf_bkgd, nullptr, K, a->obj_params,
-                                a->obj_param_stride, 63, w.wf_obj, nullptr));
+                                a->obj_param_stride, 63, w.wf_obj, nullptr, K == 0 ? (float*)a->dyn_mask : nullptr, K == 0 ? (size_t)B : 0));
     if (K > 0)      // per-object hit lists + the ray classes of the de-duplicated background evaluation: one launch
         STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
                               a->dyn_mask));
-    else
-        STEP((int)hipMemsetAsync(a->dyn_mask, 0, (size_t)B * 4, (hipStream_t)stream));
     const float* raw_obj[DURF_MAX_OBJ > 0 ? DURF_MAX_OBJ : 1];
     for (int k = 0; k < K; k++) raw_obj[k] = w.obj_raw + (size_t)k * rows * 4;
+    // (a large chunk's object MLPs on the library's side stream, issued before the persistent background launch: side_stream.h)
+    const durf::Overlap ov = durf::overlap_for(stream, rows, K);
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = a->t_vals[lvl];
         if (K > 0) {
+            STEP(ov.fork());
+            if (ov.sd)
+                STEP(durf_obj_fwd_batch(ov.obj(), K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, a->radii, a->barf_w,
+                                        a->enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), w.view, w.wf_obj, w.obj_enc,
+                                        w.obj_raw, nullptr, nullptr, nullptr));
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, w.hit, K, a->enc_flags | DURF_FWD_RAW_FULL, w.enc, w.view, w.idx_cls, w.count_cls,
                                   w.wf_bkgd, w.raw_b, nullptr, nullptr, w.idx_cls + B, w.count_cls + 1, nullptr));
-            STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, a->radii, a->barf_w,
-                                    a->enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), w.view, w.wf_obj, w.obj_enc,
-                                    w.obj_raw, nullptr, nullptr, nullptr));
+            if (!ov.sd)
+                STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, a->radii, a->barf_w,
+                                        a->enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER), w.view, w.wf_obj, w.obj_enc,
+                                        w.obj_raw, nullptr, nullptr, nullptr));
+            STEP(ov.join());
         } else {
             STEP(durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, a->radii, nullptr, 0, a->enc_flags, w.enc, w.view, nullptr, nullptr, w.wf_bkgd, w.raw_b, nullptr, nullptr, nullptr,
                               nullptr, nullptr));

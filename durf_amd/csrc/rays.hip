@@ -281,7 +281,7 @@ k_ray_prologue(int B, int K, int N, const float* __restrict__ origins, const flo
                const float* __restrict__ near, const float* __restrict__ far, const float* __restrict__ t_rand,
                int lindisp, float* __restrict__ t_vals, float* __restrict__ pose_copy, float* __restrict__ zero_buf,
                size_t zero_count, unsigned seed_lo, unsigned seed_hi, float* __restrict__ u_rand_out, PackAll pk, int nb_pro,
-               int pack_blocks_bkgd, int pack_blocks_obj) {
+               int pack_blocks_bkgd, int pack_blocks_obj, float* __restrict__ zero_buf2, size_t zero_count2) {
     // Workgroups behind the nb_pro of the prologue proper pack the step's bf16 weight streams (durf_ray_prologue_pack): the
     // packing depends on the parameters only, so it shares this launch instead of being the next one (12 us of a 0.4-0.7 ms
     // small-batch step).  MLP-major: the background MLP's vectors, then each object's.
@@ -303,6 +303,10 @@ k_ray_prologue(int B, int K, int N, const float* __restrict__ origins, const flo
         const size_t n4 = zero_count >> 2;                                   // (16-byte aligned buffer: the wrapper checks)
         for (size_t i = gid; i < n4; i += nthr) ((float4*)zero_buf)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (gid < (zero_count & 3)) zero_buf[n4 * 4 + gid] = 0.0f;
+    }
+    if (zero_buf2) {          // a second, small region (the one-call step: dyn_mask of a model without boxes, or the pose sums)
+        const size_t nthr = (size_t)nb_pro * blockDim.x;
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_count2; i += nthr) zero_buf2[i] = 0.0f;
     }
     if ((int)blockIdx.x < (B + 255) / 256)                            // block-uniform: ray_setup_block has a barrier
         ray_setup_block(blockIdx.x, B, K, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo);
@@ -478,7 +482,8 @@ static int launch_prologue(void* stream, int B, int K, int N, const float* origi
                            const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
                            const float* viewdirs, void* view_bf16, const float* near, const float* far, const float* t_rand,
                            int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count,
-                           uint32_t seed_lo, uint32_t seed_hi, float* u_rand_out, const PackAll* pack, int K_pack) {
+                           uint32_t seed_lo, uint32_t seed_hi, float* u_rand_out, const PackAll* pack, int K_pack,
+                           float* zero_buf2 = nullptr, size_t zero_count2 = 0) {
     DURF_REQUIRE(K >= 0 && K <= DURF_MAX_OBJ, "0 <= K <= DURF_MAX_OBJ");
     DURF_REQUIRE(zero_buf == nullptr || ((size_t)zero_buf & 15) == 0, "zero_buf aligned to 16 bytes");
     DURF_REQUIRE(u_rand_out == nullptr || t_rand == nullptr, "the draws come from t_rand OR from the launch's own generator");
@@ -496,6 +501,8 @@ static int launch_prologue(void* stream, int B, int K, int N, const float* origi
             DURF_REQUIRE(hipMemsetAsync(zero_buf, 0, zero_count * sizeof(float), (hipStream_t)stream) == hipSuccess,
                          "zero fill of an empty shard's gradient");
         }
+        if (zero_buf2 && zero_count2)
+            DURF_REQUIRE(hipMemsetAsync(zero_buf2, 0, zero_count2 * sizeof(float), (hipStream_t)stream) == hipSuccess, "zero fill");
         if (pack_blocks == 0) return 0;
     }
     // the grid covers the largest of the three index spaces (rays, view-encoding features, sample positions)
@@ -504,7 +511,7 @@ static int launch_prologue(void* stream, int B, int K, int N, const float* origi
     hipLaunchKernelGGL(k_ray_prologue, dim3(nb_pro + pack_blocks), dim3(256), 0, (hipStream_t)stream, B,
                        K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, (__bf16*)view_bf16, near,
                        far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_buf ? zero_count : (size_t)0, seed_lo, seed_hi,
-                       u_rand_out, pk, nb_pro, pb_bkgd, pb_obj > 0 ? pb_obj : 1);
+                       u_rand_out, pk, nb_pro, pb_bkgd, pb_obj > 0 ? pb_obj : 1, zero_buf2, zero_buf2 ? zero_count2 : (size_t)0);
     DURF_CHECK_LAUNCH("durf_ray_prologue");
     return 0;
 }
@@ -524,7 +531,8 @@ int durf_ray_prologue_pack(void* stream, int B, int K, int N, const float* origi
                            int lindisp, float* t_vals, float* pose_copy, float* zero_buf, size_t zero_count,
                            uint32_t seed_lo, uint32_t seed_hi, float* u_rand_out,
                            const float* bkgd_params, int in_bkgd, void* bkgd_fwd, void* bkgd_bwd, int K_pack,
-                           const float* obj_params, size_t obj_param_stride, int in_obj, void* obj_fwd, void* obj_bwd) {
+                           const float* obj_params, size_t obj_param_stride, int in_obj, void* obj_fwd, void* obj_bwd,
+                           float* zero_buf2, size_t zero_count2) {
     DURF_REQUIRE(bkgd_params == nullptr || (bkgd_fwd != nullptr && in_bkgd > 0 && in_bkgd <= DURF_ENC_DIM),
                  "background MLP: forward stream and 1 <= in_dim <= 64");
     DURF_REQUIRE(K_pack >= 0 && (K_pack == 0 || (obj_params != nullptr && obj_fwd != nullptr && in_obj > 0 && in_obj <= DURF_ENC_DIM)),
@@ -534,7 +542,8 @@ int durf_ray_prologue_pack(void* stream, int B, int K, int N, const float* origi
     a.p_obj = obj_params; a.f_obj = (bf16x8*)obj_fwd; a.b_obj = (bf16x8*)obj_bwd; a.in_obj = in_obj;
     a.p_stride = obj_param_stride; a.f_stride = durf_wpack_fwd_bytes(128); a.b_stride = durf_wpack_bwd_bytes(128);
     return launch_prologue(stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far,
-                           t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count, seed_lo, seed_hi, u_rand_out, &a, K_pack);
+                           t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count, seed_lo, seed_hi, u_rand_out, &a, K_pack, zero_buf2,
+                           zero_count2);
 }
 
 int durf_compact_hits(void* stream, int B, int K, const int32_t* hit, int32_t* idx,

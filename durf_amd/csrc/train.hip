@@ -9,9 +9,7 @@
 // train_boxpose.train_step (tests/test_gpu_train_call.py).
 #include "durf_common.h"
 #include "../../include/durf_hip.h"
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
+#include "side_stream.h"
 
 namespace {
 
@@ -19,63 +17,15 @@ struct Carver {
     char* base;
     size_t off;
     void* take(size_t bytes) {
-        off = (off + 255) & ~(size_t)255;
+        // (large buffers start on 2 MB boundaries, as the host allocator's own blocks do: the forward ran 2-3 % slower on
+        // streams that started at arbitrary 256-byte offsets of one big block)
+        const size_t al = bytes >= ((size_t)1 << 20) ? ((size_t)2 << 20) : (size_t)256;
+        off = (off + al - 1) & ~(al - 1);
         void* p = base ? base + off : nullptr;
         off += bytes;
         return p;
     }
 };
-
-// The K object MLPs of a LARGE step run beside the background MLP's kernels on a second stream, as durf_amd/obbpose_model.py
-// and train_boxpose.py place them (ops.overlap_mode: from 2048 x 128 sample rows per level; below that every kernel is one
-// latency-bound round and a fork / join is one more dependency in the chain): the forward's object launches are issued
-// BEFORE the persistent background launch takes every CU, the object backward runs in its shadow, the objects' weight
-// gradients (their own split-K launch + finalize) beside the background's.  One side stream + two events per device,
-// created on first use; DURF_OVERLAP_OBJECTS=0 keeps everything on the caller's stream.  No result depends on it (no atomics).
-struct SideStream { hipStream_t s; hipEvent_t forked, joined; bool ok; };
-std::mutex g_side_mutex;
-
-SideStream* side_stream_of_device() {
-    static SideStream tab[64] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(g_side_mutex);
-    SideStream& t = tab[dev];
-    if (!t.ok) {
-        if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipEventCreateWithFlags(&t.forked, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&t.joined, hipEventDisableTiming) != hipSuccess) return nullptr;
-        t.ok = true;
-    }
-    return &t;
-}
-
-struct Overlap {
-    hipStream_t main;
-    SideStream* sd;                       // nullptr: one stream
-    void* obj() const { return sd ? (void*)sd->s : (void*)main; }
-    // fork: the side stream waits for everything issued so far on the caller's stream; join: the reverse
-    int fork() const {
-        if (!sd) return 0;
-        std::lock_guard<std::mutex> lock(g_side_mutex);          // (record + wait as a pair: the events are per device)
-        if (hipEventRecord(sd->forked, main) != hipSuccess || hipStreamWaitEvent(sd->s, sd->forked, 0) != hipSuccess) return 1;
-        return 0;
-    }
-    int join() const {
-        if (!sd) return 0;
-        std::lock_guard<std::mutex> lock(g_side_mutex);
-        if (hipEventRecord(sd->joined, sd->s) != hipSuccess || hipStreamWaitEvent(main, sd->joined, 0) != hipSuccess) return 1;
-        return 0;
-    }
-};
-
-Overlap overlap_for(void* stream, size_t rows, int Kb) {
-    Overlap o{(hipStream_t)stream, nullptr};
-    const char* e = getenv("DURF_OVERLAP_OBJECTS");
-    const bool want = (e == nullptr || !strcmp(e, "auto")) ? rows >= (size_t)2048 * 128 : strcmp(e, "0") != 0;
-    if (Kb > 0 && want) o.sd = side_stream_of_device();
-    return o;
-}
 
 constexpr int ML = DURF_FORWARD_MAX_LEVELS;
 constexpr int OBJ32_NSPLIT = 8;        // ops.objf32_dw_batch's default: same split-K partial order as the Python path
@@ -242,12 +192,13 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     STEP(durf_ray_prologue_pack(stream, B, K, N, f.origins, f.directions, f.pose, f.ext, w.o_s, w.d_s, w.hit, f.zo, f.viewdirs, w.view,
                                 f.near, f.far, f.t_rand, f.lindisp, f.t_vals[0], K > 0 ? a->pose_used : nullptr, a->grad, a->n_params, f.seed_lo, f.seed_hi,
                                 f.draw_noise ? w.u_rand : nullptr, f.bkgd_params, 60, w.wf_bkgd, w.wb_bkgd, Kb, f.obj_params,
-                                f.obj_param_stride, 63, w.wf_obj, w.wb_obj));
+                                f.obj_param_stride, 63, w.wf_obj, w.wb_obj,
+                                // (zero filled on the way: dyn_mask of a model without boxes, or the pose sums)
+                                K == 0 ? (float*)f.dyn_mask : (pose_opt ? w.pose_sums : nullptr),
+                                K == 0 ? (size_t)B : (pose_opt ? (size_t)K * 21 : (size_t)0)));
     if (K > 0)
         STEP(durf_compact_all(stream, B, K, N, w.hit, w.idx_obj, w.count_obj, w.slot_obj, w.idx_cls, w.count_cls, w.slot_cls,
                               f.dyn_mask));
-    else
-        STEP((int)hipMemsetAsync(f.dyn_mask, 0, (size_t)B * 4, hs));
     if (f32o) {
         // the object branch in exact fp32 (MipNerfModel.object_precision, obbpose_model._forward): fp32 view features and
         // weight streams, and the background MLP's ONE evaluation of every box-hit ray redone in fp32 -- the constant
@@ -256,13 +207,12 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         STEP(durf_mlp_f32_pack(stream, 128, 63, K, f.obj_params, f.obj_param_stride, w.obj_ws));
         STEP(durf_bkgd_const_trunk_f32(stream, f.bkgd_params, w.trunk));
         STEP(durf_bkgd_hit_rays_f32(stream, B, w.view27, f.bkgd_params, w.idx_cls + B, w.count_cls + 1, w.trunk, w.raw_tail));
-        if (pose_opt) STEP((int)hipMemsetAsync(w.pose_sums, 0, (size_t)K * 21 * 4, hs));
     }
     const float* raw_obj[ML][DURF_MAX_OBJ];
     for (int l = 0; l < L; l++)
         for (int k = 0; k < K; k++) raw_obj[l][k] = w.obj_raw[l] + (size_t)k * rows * 4;
     const int obj_flags = f.enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER);
-    const Overlap ov = overlap_for(stream, rows, Kb);
+    const durf::Overlap ov = durf::overlap_for(stream, rows, Kb);
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = f.t_vals[lvl];
         if (ov.sd) {              // bf16 objects of a large step: issued first, on the side stream (joined before the composite)

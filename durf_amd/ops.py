@@ -42,6 +42,28 @@ class _Timed:
             TIMERS.setdefault(self.name, []).append((self.e0, self.e1))
 
 
+EVENT_POOL = []          # timing events that exist already (created by a record outside any timed region): _step_timing takes
+                         # them from here first, because handing an event to the C call needs its handle, torch creates the
+                         # handle on the first record, and a record costs the stream 3-6 us (bench.py parks its pre-warm events here)
+
+
+def recycle_timers():
+    """the events of the collected TIMERS go back to EVENT_POOL (call after timer_totals())"""
+    for pairs in (TIMERS or {}).values():
+        for pair in pairs:
+            EVENT_POOL.extend(pair)
+    if TIMERS is not None:
+        TIMERS.clear()
+
+
+def _timing_event():
+    if EVENT_POOL:
+        return EVENT_POOL.pop()
+    e = torch.cuda.Event(enable_timing=True)
+    e.record()                              # (torch creates the underlying event on its first record; the call re-records it)
+    return e
+
+
 def timer_totals():
     """{name: (calls, total_seconds)}; synchronises."""
     torch.cuda.synchronize()
@@ -114,7 +136,7 @@ def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, 
         of = u8(Kp * int(L.durf_wpack_fwd_bytes(W_OBJ_)))
         ob = u8(Kp * int(L.durf_wpack_bwd_bytes(W_OBJ_))) if want_bwd else None
     _lib.check(L.durf_ray_prologue_pack(*common, _p(_f32(bkgd_params)), IN_BKGD, _p(bf), _p(bb), int(Kp),
-                                        _p(obj_params) if Kp else None, int(obj_param_stride), IN_OBJ_, _p(of), _p(ob)),
+                                        _p(obj_params) if Kp else None, int(obj_param_stride), IN_OBJ_, _p(of), _p(ob), None, 0),
                'durf_ray_prologue_pack')
     return out + (((bf, bb), ((of, ob) if Kp else None)),)
 
@@ -1208,9 +1230,7 @@ def _step_timing(num_levels, keep):
         return None
     tm = StepTiming()
     for name, i in slots:
-        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        for e in pair:
-            e.record()                      # (torch creates the underlying event on its first record; the call re-records it)
+        pair = (_timing_event(), _timing_event())
         tm.begin[i], tm.end[i] = pair[0].cuda_event, pair[1].cuda_event
         TIMERS.setdefault(name, []).append(pair)
     keep.append(tm)

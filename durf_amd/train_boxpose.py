@@ -465,9 +465,17 @@ def one_call_refusal(model, variables, update=True):
 
 def best_step_fn(model, variables):
     """the faster host path of a training step for this model: the one C call (durf_train_step -- bit-identical to train_step,
-    1-3 % faster at every measured shape: no interpreter between the launches, two cross-stream hops fewer) wherever it covers
-    the step, else train_step.  bench.py and train_loop use it; the parity tests name the path they mean."""
-    return train_step_one_call if one_call_refusal(model, variables) is None else train_step
+    0-3 % faster at the measured bf16 shapes: no interpreter between the launches, two cross-stream hops fewer) wherever it covers
+    the step and is not the slower one, else train_step.  bench.py and train_loop use it; the parity tests name the path they mean."""
+    if one_call_refusal(model, variables) is not None:
+        return train_step
+    if variables.layout.K and model.object_precision() == 'f32':
+        # the fp32 hit-ray branch (cfg4): train_step starts the background trunk of the box-hit rays -- a function of the
+        # parameters alone, one workgroup, 40-50 us -- on a side stream right behind the previous step's update
+        # (MipNerfModel.prefetch_const_trunk, guarded by the parameters' version counters); the C call cannot know that nobody
+        # touched the parameters between two calls and runs it inside the step (660 vs 648 k rays/s at cfg4)
+        return train_step
+    return train_step_one_call
 
 
 def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, update=True, reduce_stats=True):

@@ -51,8 +51,8 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_ray_prologue.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64, C.c_uint32, C.c_uint32, vp]
     #   (stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count, seed_lo, seed_hi, u_rand_out)
     L.durf_ray_prologue_pack.restype = i32
-    L.durf_ray_prologue_pack.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64, C.c_uint32, C.c_uint32, vp, vp, i32, vp, vp, i32, vp, u64, i32, vp, vp]
-    #   (stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count, seed_lo, seed_hi, u_rand_out, bkgd_params, in_bkgd, bkgd_fwd, bkgd_bwd, K_pack, obj_params, obj_param_stride, in_obj, obj_fwd, obj_bwd)
+    L.durf_ray_prologue_pack.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, u64, C.c_uint32, C.c_uint32, vp, vp, i32, vp, vp, i32, vp, u64, i32, vp, vp, vp, u64]
+    #   (stream, B, K, N, origins, dirs, pose, ext, origins_s, dirs_s, hit, zo, viewdirs, view_bf16, near, far, t_rand, lindisp, t_vals, pose_copy, zero_buf, zero_count, seed_lo, seed_hi, u_rand_out, bkgd_params, in_bkgd, bkgd_fwd, bkgd_bwd, K_pack, obj_params, obj_param_stride, in_obj, obj_fwd, obj_bwd, zero_buf2, zero_count2)
     L.durf_sample_t.restype = i32
     L.durf_sample_t.argtypes = [vp, i32, i32, vp, vp, vp, i32, vp]
     #   (stream, B, N, near, far, t_rand, lindisp, t_vals)

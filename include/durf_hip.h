@@ -137,7 +137,8 @@ int durf_ray_prologue_pack(void* stream, int B, int K, int N, const float* origi
                            float* zero_buf /* nullable */, size_t zero_count, uint32_t seed_lo, uint32_t seed_hi,
                            float* u_rand_out /* nullable */, const float* bkgd_params, int in_bkgd, void* bkgd_fwd,
                            void* bkgd_bwd /* nullable */, int K_pack, const float* obj_params, size_t obj_param_stride,
-                           int in_obj, void* obj_fwd, void* obj_bwd /* nullable */);
+                           int in_obj, void* obj_fwd, void* obj_bwd /* nullable */,
+                           float* zero_buf2 /* nullable: a second, small region to zero fill (4-byte words) */, size_t zero_count2);
 
 /* mip.sample_along_rays t_vals (mip.py:353-368). t_rand nullable (randomized=False). */
 int durf_sample_t(void* stream, int B, int N, const float* near, const float* far,
