@@ -274,6 +274,8 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         STEP(durf_loss_bwd_levels(stream, B, N, K, L, ll, w.slot_obj, w.d_s, a->pixels, a->lossmult, a->gt_depth, a->sky, f.dyn_mask,
                                   f.zo, a->eps, a->box_loss_mult, a->disable_multiscale, a->bg, f.density_bias));
     }
+    STEP(ov.fork());          // (ONE fork for the whole backward: the object launches read d(raw), which the loss launch above wrote
+                              // for every level, and what their own forward left on the side stream)
     for (int lvl = L - 1; lvl >= 0; lvl--) {
         float* rs = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;
         if (f32o) {       // the object branch in fp32: backward (+ d(enc) -> the 21 pose sums per object), all K at once
@@ -285,7 +287,6 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
                                                obj_flags));
         }
         if (K > 0) {
-            STEP(ov.fork());      // (the object backward below reads d(raw) of this level: written by the loss launch on this stream)
             TIMED(DURF_TIMED_BWD + lvl,
                   durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
                                nullptr, w.idx_cls + B, w.count_cls + 1, rs));
