@@ -188,6 +188,9 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
                    const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
                    float* d_enc, int K, const BwdStrides& st, const int32_t* tail_idx = nullptr,
                    const int32_t* tail_count = nullptr, const float* draw_ray_sum = nullptr);
+int launch_mlp_bwd_ms_levels(void* stream, size_t rows, int N, int nlevels, const float* const* draw, const int32_t* ray_idx,
+                             const int32_t* count, const void* wpack_bwd, const void* const* relu_mask, void* const* dz,
+                             void* const* dz_out, int K, const BwdStrides& st);
 int launch_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
                        const int32_t* count, void* out_tile, int K, size_t idx_stride, size_t out_stride,
                        const int32_t* tail_idx = nullptr, const int32_t* tail_count = nullptr);

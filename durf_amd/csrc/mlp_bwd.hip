@@ -317,10 +317,19 @@ constexpr int OFF_G = 2 * X_BYTES;                     // head-gradient fragment
 constexpr int LDS_BYTES = OFF_G + NT * 2 * 1024;
 }  // namespace msb
 
+// the per-level operands of one launch over SEVERAL levels (durf_obj_bwd_batch_levels: every level's d(raw) exists before the
+// first backward launch -- stop_level_grad -- so the object backward of a step is ONE latency-bound round instead of one per level)
+struct MsBwdLevels {
+    const float* draw[DURF_MAX_LEVELS];
+    const uint4* relu_mask[DURF_MAX_LEVELS];
+    bf16x8* dz[DURF_MAX_LEVELS];
+    bf16x8* dz_out[DURF_MAX_LEVELS];
+    int n;
+};
+
 __global__ void __launch_bounds__(256)
-k_mlp_bwd_ms(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx_g,
-             const int32_t* __restrict__ count_g, const char* __restrict__ wpack_g, const uint4* __restrict__ relu_mask_g,
-             bf16x8* __restrict__ dz_g, bf16x8* __restrict__ dz_out_g, BwdStrides bs, int nobj) {
+k_mlp_bwd_ms(size_t rows, int N, MsBwdLevels lv, const int32_t* __restrict__ ray_idx_g,
+             const int32_t* __restrict__ count_g, const char* __restrict__ wpack_g, BwdStrides bs, int nobj) {
     using S = msb::S;
     using BS = msb::B_;
     constexpr int NT = msb::NT;
@@ -340,8 +349,14 @@ k_mlp_bwd_ms(size_t rows, int N, const float* __restrict__ draw, const int32_t* 
     size_t total = 0;
     for (int k = 0; k < nobj; k++) total += pairs_of(k);
 
-    for (size_t item = blockIdx.x; item < total; item += gridDim.x) {
-        size_t k = 0, pair = item;
+    for (size_t item = blockIdx.x; item < total * (size_t)lv.n; item += gridDim.x) {
+        // (level-major: the items of one level are consecutive workgroups)
+        const int level = __builtin_amdgcn_readfirstlane((int)(item / total));
+        const float* __restrict__ draw = lv.draw[level];
+        const uint4* __restrict__ relu_mask_g = lv.relu_mask[level];
+        bf16x8* __restrict__ dz_g = lv.dz[level];
+        bf16x8* __restrict__ dz_out_g = lv.dz_out[level];
+        size_t k = 0, pair = item - (size_t)level * total;
         for (;; k++) {
             const size_t np = pairs_of((int)k);
             if (pair < np) break;
@@ -1265,8 +1280,10 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
     {
         if (width == 128 && ray_idx && count && !d_enc && !tail_idx && obj_msplit(rows)) {
             const size_t items = (size_t)K * durf_cdiv(rows, 64);       // (small batches only; one round of workgroups: launch_mlp_fwd)
-            hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, s, rows, N, draw, ray_idx,
-                               count, (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out, st, K);
+            MsBwdLevels lv{};
+            lv.draw[0] = draw; lv.relu_mask[0] = (const uint4*)relu_mask; lv.dz[0] = (bf16x8*)dz; lv.dz_out[0] = (bf16x8*)dz_out; lv.n = 1;
+            hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, s, rows, N, lv, ray_idx,
+                               count, (const char*)wpack_bwd, st, K);
             DURF_CHECK_LAUNCH("durf_mlp_bwd (M-split)");
             note_dispatch(DURF_DISPATCH_BWD128_MSPLIT);
             return 0;
@@ -1291,6 +1308,26 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
     DURF_CHECK_LAUNCH("durf_mlp_bwd");
     note_dispatch((width == 128 ? DURF_DISPATCH_BWD128_SAMPLE : (half ? DURF_DISPATCH_BWD256_4W : DURF_DISPATCH_BWD256_8W)) |
                   (d_enc ? DURF_DISPATCH_BWD_POSE : 0u));
+    return 0;
+}
+
+// the M-split object backward of SEVERAL levels as one launch (levels x objects x pairs dealt to one 1-D grid); the caller
+// checked obj_msplit(rows)
+int launch_mlp_bwd_ms_levels(void* stream, size_t rows, int N, int nlevels, const float* const* draw, const int32_t* ray_idx,
+                             const int32_t* count, const void* wpack_bwd, const void* const* relu_mask, void* const* dz,
+                             void* const* dz_out, int K, const BwdStrides& st) {
+    DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS && rows % 32 == 0 && ray_idx && count, "1 <= nlevels <= DURF_MAX_LEVELS, compacted rays");
+    if (rows == 0 || K <= 0) return 0;
+    MsBwdLevels lv{};
+    lv.n = nlevels;
+    for (int l = 0; l < nlevels; l++) {
+        lv.draw[l] = draw[l]; lv.relu_mask[l] = (const uint4*)relu_mask[l]; lv.dz[l] = (bf16x8*)dz[l]; lv.dz_out[l] = (bf16x8*)dz_out[l];
+    }
+    const size_t items = (size_t)nlevels * K * durf_cdiv(rows, 64);
+    hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, (hipStream_t)stream, rows, N,
+                       lv, ray_idx, count, (const char*)wpack_bwd, st, K);
+    DURF_CHECK_LAUNCH("durf_obj_bwd_batch_levels (M-split)");
+    note_dispatch(DURF_DISPATCH_BWD128_MSPLIT);
     return 0;
 }
 

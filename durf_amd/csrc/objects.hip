@@ -58,6 +58,25 @@ int durf_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, co
                                 K, st);
 }
 
+int durf_obj_bwd_batch_levels(void* stream, int K, int B, int N, int nlevels, const int32_t* idx, const int32_t* count,
+                              const float* const* draw, const void* wpack_bwd, const void* const* relu_mask, void* const* dz,
+                              void* const* dz_out) {
+    DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
+    const size_t rows = (size_t)B * N;
+    if (!durf::obj_msplit(rows)) {          // large batches: the sample-split kernel, level by level (as durf_obj_bwd_batch)
+        for (int l = 0; l < nlevels; l++) {
+            const int rc = durf_obj_bwd_batch(stream, K, B, N, idx, count, draw[l], wpack_bwd, relu_mask[l], dz[l], dz_out[l], nullptr);
+            if (rc) return rc;
+        }
+        return 0;
+    }
+    BwdStrides st;
+    st.idx = (size_t)B; st.wpack = durf_wpack_bwd_bytes(DURF_W_OBJ); st.mask = durf_mlp_mask_bytes(rows);
+    st.dz = durf_mlp_stash_bytes(DURF_W_OBJ, rows); st.dz_out = durf_obj_dzout_stride(B, N);
+    st.d_enc = rows * DURF_ENC_DIM * sizeof(float);
+    return durf::launch_mlp_bwd_ms_levels(stream, rows, N, nlevels, draw, idx, count, wpack_bwd, relu_mask, dz, dz_out, K, st);
+}
+
 static DwStrides obj_dw_strides(int B, int N) {
     const size_t rows = (size_t)B * N;
     DwStrides st;

@@ -276,6 +276,12 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     }
     STEP(ov.fork());          // (ONE fork for the whole backward: the object launches read d(raw), which the loss launch above wrote
                               // for every level, and what their own forward left on the side stream)
+    if (Kb > 0) {             // the object backward of EVERY level: one launch at small batches (in front of the background's), level
+                              // by level on the side stream, in the shadow of the background backward, at large ones
+        const float* dr[ML]; const void* mk[ML]; void* dzl[ML]; void* dzo[ML];
+        for (int l = 0; l < L; l++) { dr[l] = w.draw[L - 1 - l]; mk[l] = w.obj_mask[L - 1 - l]; dzl[l] = w.obj_dz[L - 1 - l]; dzo[l] = w.obj_dz_out[L - 1 - l]; }
+        STEP(durf_obj_bwd_batch_levels(ov.obj(), K, B, N, L, w.idx_obj, w.count_obj, dr, w.wb_obj, mk, dzl, dzo));
+    }
     for (int lvl = L - 1; lvl >= 0; lvl--) {
         float* rs = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;
         if (f32o) {       // the object branch in fp32: backward (+ d(enc) -> the 21 pose sums per object), all K at once
@@ -290,9 +296,6 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
             TIMED(DURF_TIMED_BWD + lvl,
                   durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
                                nullptr, w.idx_cls + B, w.count_cls + 1, rs));
-            if (!f32o)            // (large step: in the shadow of the background backward just issued; the fork is in front of it)
-                STEP(durf_obj_bwd_batch(ov.obj(), K, B, N, w.idx_obj, w.count_obj, w.draw[lvl], w.wb_obj, w.obj_mask[lvl], w.obj_dz[lvl],
-                                        w.obj_dz_out[lvl], nullptr));
         } else {
             TIMED(DURF_TIMED_BWD + lvl,
                   durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], nullptr, nullptr, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl], nullptr,

@@ -901,6 +901,25 @@ def obj_bwd_batch(slabs, idx, count, draw, wb, want_d_enc=False):
                                         _p(slabs.dz), _p(slabs.dz_out), _p(slabs.d_enc)), 'durf_obj_bwd_batch')
 
 
+def obj_bwd_batch_levels(slabs_levels, idx, count, draws, wb):
+    """obj_bwd_batch (no d(enc)) for every level of a step in one call (durf_obj_bwd_batch_levels: one launch at small batches);
+    slabs_levels / draws: per level, in the order they are to be issued"""
+    L = _lib.lib()
+    s0 = slabs_levels[0]
+    K, B, N = s0.K, s0.B, s0.N
+    nl = len(slabs_levels)
+    dev = draws[0].device
+    for sl in slabs_levels:
+        sl.dz = torch.empty(K * mlp_stash_bytes(W_OBJ_, B * N), dtype=torch.uint8, device=dev)
+        sl.dz_out = torch.empty(K * int(L.durf_obj_dzout_stride(B, N)), dtype=torch.uint8, device=dev)
+        sl.d_enc = None
+    arr = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    with _Timed('obj_bwd_batch'):
+        _lib.check(L.durf_obj_bwd_batch_levels(_stream(), K, B, N, nl, _p(idx), _p(count), arr([_f32(d) for d in draws]), _p(wb),
+                                               arr([s.mask for s in slabs_levels]), arr([s.dz for s in slabs_levels]),
+                                               arr([s.dz_out for s in slabs_levels])), 'durf_obj_bwd_batch_levels')
+
+
 def obj_dw_batch(slabs_levels, view_tile, count, grad_obj, grad_stride, obj_params):
     """weight gradients of all K object MLPs over every level -> grad_obj (flat, K x grad_stride floats);
     obj_params: their fp32 parameters with the same stride"""

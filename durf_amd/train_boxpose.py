@@ -211,6 +211,19 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                   float(config.box_loss_mult), bg, model.density_bias, config.disable_multiscale_loss)
         for lvl in range(L):
             draws[lvl], terms[lvl] = res[lvl]
+    # the object backward of EVERY level in front of the background's (one launch at small batches: durf_obj_bwd_batch_levels)
+    # whenever all the levels' d(raw) exist already and no d(enc) is wanted (the pose gradient behind bf16 objects takes the
+    # per-level kernel with the d(enc) epilogue)
+    obj_bwd_done = bool(Kb) and not pose_opt and not f32 and all(d is not None for d in draws) and all(r is None for r in ready)
+    if obj_bwd_done:
+        obj_side.fork()
+        with obj_side:
+            if obj_side.enabled:
+                for d in draws:
+                    d.record_stream(obj_side.side)
+            order = list(reversed(range(L)))
+            ops.obj_bwd_batch_levels([ctx['levels'][l]['slabs'] for l in order], ctx['idx'], ctx['count'],
+                                     [draws[l] for l in order], ctx['packs']['obj'][1])
     # last level first: its loss kernel also fills that level's rendered outputs (ret[-1]) when the forward deferred them
     for lvl in reversed(range(L)):
         lv = ctx['levels'][lvl]
@@ -242,14 +255,15 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                                          enc_flags=obj_enc_flags)
         if f32:
             continue
-        obj_side.fork()                      # the object backward runs in the shadow of the background backward
+        if not obj_bwd_done:
+            obj_side.fork()                  # the object backward runs in the shadow of the background backward
         if dd is not None:
             dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'], ray_idx=dd['idx'][0],
                                    count=dd['count'][0:1], tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
                                    draw_ray_sum=ray_sums[lvl])
         else:
             dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'])
-        if Kb:                                # all K object MLPs: one call (csrc/objects.hip)
+        if Kb and not obj_bwd_done:           # all K object MLPs: one call (csrc/objects.hip)
             with obj_side:
                 ops.obj_bwd_batch(lv['slabs'], ctx['idx'], ctx['count'], draw, ctx['packs']['obj'][1], want_d_enc=pose_opt)
                 if pose_opt:                            # d(loss)/d(box pose) through the object encoding, all K at once

@@ -229,6 +229,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_obj_bwd_batch.restype = i32
     L.durf_obj_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, K, B, N, idx, count, draw, wpack_bwd, relu_mask, dz, dz_out, d_enc)
+    L.durf_obj_bwd_batch_levels.restype = i32
+    L.durf_obj_bwd_batch_levels.argtypes = [vp, i32, i32, i32, i32, vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    #   (stream, K, B, N, nlevels, idx, count, draw, wpack_bwd, relu_mask, dz, dz_out)
     L.durf_obj_dw_batch.restype = i32
     L.durf_obj_dw_batch.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, vp, u64, vp]
     #   (stream, K, B, N, count, nlevels, enc, view_tile, stash, dz, dz_out, in_dim, part, bpart, grad_mlp, grad_stride, mlp_params)

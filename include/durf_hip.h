@@ -575,6 +575,13 @@ int durf_obj_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx, co
 int durf_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count,
                        const float* draw, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
                        float* d_enc /* nullable */);
+/* The same for EVERY level of a step at once (no d(enc)): stop_level_grad makes each level's d(raw) a function of the forward
+ * alone, so all of them exist before the first backward launch; at small batches (the M-split kernel, < 2048 x 128 sample rows)
+ * the step's object backward is then ONE latency-bound launch instead of one per level.  draw / relu_mask / dz / dz_out: host
+ * arrays [nlevels] of the per-level device buffers durf_obj_bwd_batch takes.  Bit-identical to the per-level calls. */
+int durf_obj_bwd_batch_levels(void* stream, int K, int B, int N, int nlevels, const int32_t* idx, const int32_t* count,
+                              const float* const* draw, const void* wpack_bwd, const void* const* relu_mask, void* const* dz,
+                              void* const* dz_out);
 int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
                       const void* const* enc, const void* const* view_tile, const void* const* stash,
                       const void* const* dz, const void* const* dz_out, int in_dim, float* part, float* bpart,
