@@ -427,7 +427,11 @@ int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
  * f.bkgd_mode 0 / 1 / 2 with bg = 0.5 / 1.0 / 0 (2: Config.rand_bkgd, no background colour).  `f` carries the rays, boxes,
  * draws and -- as outputs -- each level's rendered values; f.bkgd_params / f.obj_params must point into `params`.
  * workspace: durf_train_workspace_bytes_flags(B, N, K, num_levels, n_params, flags) bytes, 256-byte aligned
- * (durf_train_workspace_bytes = flags 0). */
+ * (durf_train_workspace_bytes = flags 0).
+ * Streams: everything is ordered on `stream`, whose device must be the calling thread's current device.  The bf16 object
+ * MLPs of a large step (>= 2048 x 128 sample rows per level) run on a second, non-blocking stream the library creates per
+ * device on first use, forked from / joined to `stream` with events inside the call (DURF_OVERLAP_OBJECTS=0: one stream);
+ * when the call returns, all of its work is ordered before whatever the caller issues to `stream` next. */
 #define DURF_TRAIN_OBJ_FP32 1
 #define DURF_TRAIN_POSE_OPT 2
 /* Live timing of the step's dominant launches for a roofline line (bench.py): hipEvent_t handles (created with timing
