@@ -144,10 +144,9 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     dzs = [None] * L                            # per-level (dz, dz_out) of the bkgd MLP, consumed by ONE dW launch
     dd = ctx.get('dedup')                        # de-duplicated background evaluation (obbpose_model._forward)
     # Side stream (ops.overlap_mode; large batches only -- a fork / join is one more dependency in a latency-bound step): the
-    # object backward / weight gradients, and two things nothing on the critical path waits for: the view-direction tile
-    # (read by the weight-gradient launch only) and the loss kernels of the levels below the last -- stop_level_grad makes
-    # every level's loss gradient a function of the forward alone, so they run beside the last level's instead of between
-    # two persistent backward launches.
+    # object backward / weight gradients and, when the forward did not write it, the view-direction tile (read by the
+    # weight-gradient launch only).  (Until round 5 also the loss launches of the levels below the last: one launch for every
+    # level on this stream measured better -- two cross-stream hops fewer.)
     side = ops.on_side(dev, not f32 and ops.overlap_backward(rows))
     main = torch.cuda.current_stream() if side.enabled else None
     obj_side = side if Kb else ops.on_side(dev, False)
@@ -176,23 +175,15 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
                             model.density_bias, config.disable_multiscale_loss, render_out=out,
                             draw_ray_sum=None if dd is None else ray_sums[lvl], defer_sums=True)
 
-    draws, ready = [None] * L, [None] * L
+    draws = [None] * L
     view_tile, view_ready = ctx.get('view_tile'), None       # (written by the level-0 forward when it encodes its own tiles)
-    if side.enabled:
+    if side.enabled and view_tile is None:                   # (a forward that does not: the tile is made beside the backward)
         side.fork()
         with side:
-            if view_tile is None:
-                view_tile = make_view_tile()
-                view_tile.record_stream(main)
-                view_ready = torch.cuda.Event()
-                view_ready.record(side.side)
-            if prep is not None and L < 2:        # (the fused forward filled every level's normalisers already)
-                for lvl in range(L - 1):
-                    draws[lvl], terms[lvl] = level_loss(lvl)
-                    draws[lvl].record_stream(main)
-                    terms[lvl].record_stream(main)
-                    ready[lvl] = torch.cuda.Event()
-                    ready[lvl].record(side.side)
+            view_tile = make_view_tile()
+            view_tile.record_stream(main)
+            view_ready = torch.cuda.Event()
+            view_ready.record(side.side)
     elif not f32 and view_tile is None:
         view_tile = make_view_tile()
     if prep is not None and L >= 2:
@@ -214,7 +205,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     # the object backward of EVERY level in front of the background's (one launch at small batches: durf_obj_bwd_batch_levels)
     # whenever all the levels' d(raw) exist already and no d(enc) is wanted (the pose gradient behind bf16 objects takes the
     # per-level kernel with the d(enc) epilogue)
-    obj_bwd_done = bool(Kb) and not pose_opt and not f32 and all(d is not None for d in draws) and all(r is None for r in ready)
+    obj_bwd_done = bool(Kb) and not pose_opt and not f32 and all(d is not None for d in draws)
     if obj_bwd_done:
         obj_side.fork()
         with obj_side:
@@ -234,8 +225,6 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             draw, terms[lvl] = level_loss(lvl)
         else:
             draw = draws[lvl]
-            if ready[lvl] is not None:
-                main.wait_event(ready[lvl])
         if obj_side.enabled:
             draw.record_stream(obj_side.side)     # (read by the object backward on the side stream)
         if f32:                               # exact-fp32 parity instrument: per-MLP fp32 backward + weight gradients
