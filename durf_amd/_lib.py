@@ -28,6 +28,10 @@ def lib():
             raise RuntimeError(
                 'libdurf_hip.so not built (%s): the HIP extension is required, there is no '
                 'fallback path.  Run __graft_entry__.build().' % LIB_PATH)
+        # PyTorch first: the process must hold ONE HIP runtime -- the copy torch brings.  Loaded before torch, this library
+        # would bind /opt/rocm's libamdhip64 and torch would then load its own next to it; launches from here then fail with
+        # "no ROCm-capable device is detected" (seen with __graft_entry__.build() followed by smoke() in one process).
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(L, name)
