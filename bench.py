@@ -86,6 +86,8 @@ def parse_args():
     ap.add_argument('--chunk', type=int, default=8192, help='render_image chunk (eval mode)')
     ap.add_argument('--one-call', action='store_true',
                     help='eval mode: every chunk through the single C entry point durf_forward (no per-kernel timers)')
+    ap.add_argument('--c-step', action='store_true',
+                    help='train mode: every step through durf_train_step even where best_step_fn prefers the Python host (A/B)')
     ap.add_argument('--python-step', action='store_true',
                     help='train mode: every step through train_step\'s Python-issued launches instead of the single C entry '
                          'point durf_train_step (bit-identical; the default takes the C call wherever it covers the workload)')
@@ -422,7 +424,8 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     # launches of train_step and 1-3 % faster -- no interpreter between the launches) wherever that entry point covers the
     # workload; its timing hooks (durf_train_args.timing) record the same HIP events around the same launches.  --python-step
     # (and --profile-ops, which times every wrapped op) keeps the Python-issued launches.
-    step_fn = train_boxpose.train_step if (args.python_step or profile_ops) else train_boxpose.best_step_fn(model, state.variables)
+    step_fn = train_boxpose.train_step if (args.python_step or profile_ops) else (
+        train_boxpose.train_step_one_call if args.c_step else train_boxpose.best_step_fn(model, state.variables))
     host_path = 'durf_train_step (one C call)' if step_fn is train_boxpose.train_step_one_call else 'train_step (Python-issued launches)'
     ops.TIMED_NAMES = None if profile_ops else {k_fwd, k_bwd, k_dw, 'encode_bkgd', 'composite_resample'}
     ops.TIMERS = {}

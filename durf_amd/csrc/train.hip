@@ -205,8 +205,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         // trunk once, the view layer + rgb head per ray (the Python path runs these beside the prologue on a side stream)
         STEP(durf_view_enc(stream, B, f.viewdirs, nullptr, w.view27));
         STEP(durf_mlp_f32_pack(stream, 128, 63, K, f.obj_params, f.obj_param_stride, w.obj_ws));
-        STEP(durf_bkgd_const_trunk_f32(stream, f.bkgd_params, w.trunk));
-        STEP(durf_bkgd_hit_rays_f32(stream, B, w.view27, f.bkgd_params, w.idx_cls + B, w.count_cls + 1, w.trunk, w.raw_tail));
+        // (the constant trunk + the box-hit rays' view layer and rgb head: behind the level-0 forward, below)
     }
     const float* raw_obj[ML][DURF_MAX_OBJ];
     for (int l = 0; l < L; l++)
@@ -228,6 +227,20 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
                   durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags | (f32o ? 0 : DURF_FWD_RAW_FULL),
                                    w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, f32o ? w.raw_c[lvl] : w.raw_b[lvl], w.stash[lvl],
                                    w.mask[lvl], w.idx_cls + B, w.count_cls + 1, lvl == 0 ? w.view_tile : nullptr));
+            if (f32o && lvl == 0) {
+                // the background MLP's ONE fp32 evaluation of every box-hit ray (same input at both levels: once per step), HERE,
+                // behind the level-0 forward: a trunk prefetched behind the previous step's update (durf_train_step below) has
+                // had that launch's time to land, and beside the persistent launch these small ones would wait for a CU
+                float* trunk = a->const_trunk ? a->const_trunk : w.trunk;
+                if (a->const_trunk && a->const_trunk_valid) {
+                    durf::SideStream* sd = durf::side_stream_of_device();
+                    DURF_REQUIRE(sd != nullptr, "const_trunk_valid: the side stream the prefetch ran on");
+                    STEP((durf::Overlap{hs, sd}).join());
+                } else {
+                    STEP(durf_bkgd_const_trunk_f32(stream, f.bkgd_params, trunk));
+                }
+                STEP(durf_bkgd_hit_rays_f32(stream, B, w.view27, f.bkgd_params, w.idx_cls + B, w.count_cls + 1, trunk, w.raw_tail));
+            }
             if (f32o) STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], w.raw_tail));
             if (f32o)
                 STEP(durf_objf32_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, nullptr, w.view27, f.obj_params,
@@ -378,7 +391,24 @@ int durf_loss_backward(void* stream, const durf_train_args* a, void* workspace) 
     return loss_backward(stream, a, workspace_of(a, workspace));
 }
 
+static int train_step_body(void* stream, const durf_train_args* a, void* workspace);
+
 int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
+    int rc = train_step_body(stream, a, workspace);
+    if (rc != 0) return rc;
+    if ((a->flags & DURF_TRAIN_OBJ_FP32) && a->f.K > 0 && a->prefetch_const_trunk && a->const_trunk) {
+        // the NEXT step's constant trunk, from the parameters just updated, beside whatever the caller does between the steps
+        durf::SideStream* sd = durf::side_stream_of_device();
+        if (sd != nullptr) {
+            const durf::Overlap ov{(hipStream_t)stream, sd};
+            STEP(ov.fork());
+            STEP(durf_bkgd_const_trunk_f32(ov.obj(), a->f.bkgd_params, a->const_trunk));
+        }
+    }
+    return 0;
+}
+
+static int train_step_body(void* stream, const durf_train_args* a, void* workspace) {
     int rc = check_args(a, workspace);
     if (rc != 0) return rc;
     DURF_REQUIRE(a->adam_m && a->adam_v && a->grad_stats, "Adam moments and grad_stats");

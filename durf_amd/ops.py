@@ -1218,7 +1218,8 @@ class TrainArgs(C.Structure):
                 [('lr', C.c_float), ('max_val', C.c_float), ('max_norm', C.c_float), ('step', C.c_int), ('grad_stats', C.c_void_p),
                  ('flags', C.c_int), ('want_pos', C.c_int), ('want_rot', C.c_int), ('tv_loss_mult', C.c_float),
                  ('comm', C.c_void_p), ('world', C.c_int), ('reduce_stats', C.c_int), ('weight_decay_mult', C.c_float),
-                 ('pose_used', C.c_void_p), ('cls_count', C.c_void_p), ('timing', C.c_void_p)])
+                 ('pose_used', C.c_void_p), ('cls_count', C.c_void_p), ('timing', C.c_void_p),
+                 ('const_trunk', C.c_void_p), ('const_trunk_valid', C.c_int), ('prefetch_const_trunk', C.c_int)])
 
 
 TRAIN_OBJ_FP32, TRAIN_POSE_OPT = 1, 2          # durf_train_args.flags
@@ -1312,12 +1313,14 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
                stat_mults, lr, max_val, max_norm, step, lindisp=False, bkgd_mode=BKGD_GREY, density_bias=-1.0,
                resample_padding=0.01, t_rand=None, u_rand=None, update=True, obj_fp32=False, want_pos=False, want_rot=False,
                tv_loss_mult=0.0, seed=None, comm=None, world=1, reduce_stats=False, density_noise=0.0, density_rand=None,
-               weight_decay_mult=0.0):
+               weight_decay_mult=0.0, const_trunk=None, const_trunk_valid=False):
     """One shard's training step as ONE library call (durf_train_step; update=False: durf_loss_backward, parameters
     untouched) -> (per-level outputs, dyn_mask, zo, grad, stats buffer, grad_stats or None, pose_used [K,6] or None -- the
     poses the step rendered with -- and the class counts [8] int32 or None: [3] = rays that hit two boxes).
     obj_fp32: the object branch on the exact-fp32 kernels; want_pos / want_rot: box-pose optimisation behind it (`pose` must
-    then be a view of this timestep's rows of box_centers inside params_flat)"""
+    then be a view of this timestep's rows of box_centers inside params_flat).  const_trunk [264] (obj_fp32): the caller-kept
+    constant trunk -- used when const_trunk_valid (the caller vouches for the parameters), refilled for the NEXT step behind the
+    update (durf_train_args.prefetch_const_trunk)"""
     if update:
         _bump_generation(params_flat)
     B, K = rays.origins.shape[0], pose.shape[0]
@@ -1357,6 +1360,9 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
     pose_used = torch.empty_like(pose) if K else None
     cls = torch.empty(8, dtype=torch.int32, device=dev) if K else None
     a.pose_used, a.cls_count = _p(pose_used), _p(cls)
+    if const_trunk is not None and K and obj_fp32:
+        assert const_trunk.numel() >= 264 and const_trunk.is_contiguous()
+        a.const_trunk, a.const_trunk_valid, a.prefetch_const_trunk = _p(_f32(const_trunk)), int(bool(const_trunk_valid)), int(bool(update))
     tm = _step_timing(num_levels, keep) if update else None
     a.timing = C.cast(C.pointer(tm), C.c_void_p) if tm is not None else None
     ws = torch.empty(int(L.durf_train_workspace_bytes_flags(B, N, K, num_levels, params_flat.numel(), a.flags)), dtype=torch.uint8,

@@ -468,17 +468,9 @@ def one_call_refusal(model, variables, update=True):
 
 def best_step_fn(model, variables):
     """the faster host path of a training step for this model: the one C call (durf_train_step -- bit-identical to train_step,
-    0-3 % faster at the measured bf16 shapes: no interpreter between the launches, two cross-stream hops fewer) wherever it covers
-    the step and is not the slower one, else train_step.  bench.py and train_loop use it; the parity tests name the path they mean."""
-    if one_call_refusal(model, variables) is not None:
-        return train_step
-    if variables.layout.K and model.object_precision() == 'f32':
-        # the fp32 hit-ray branch (cfg4): train_step starts the background trunk of the box-hit rays -- a function of the
-        # parameters alone, one workgroup, 40-50 us -- on a side stream right behind the previous step's update
-        # (MipNerfModel.prefetch_const_trunk, guarded by the parameters' version counters); the C call cannot know that nobody
-        # touched the parameters between two calls and runs it inside the step (660 vs 648 k rays/s at cfg4)
-        return train_step
-    return train_step_one_call
+    0-3 % faster at the measured shapes: no interpreter between the launches, two cross-stream hops fewer) wherever it covers
+    the step, else train_step.  bench.py and train_loop use it; the parity tests name the path they mean."""
+    return train_step_one_call if one_call_refusal(model, variables) is None else train_step
 
 
 def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, noise=None, update=True, reduce_stats=True):
@@ -522,6 +514,16 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
     assert pose.is_contiguous()
     flags = ((ops.ENC_CONTRACT if model.contraction else 0) | (ops.ENC_NO_INTEGRATION if model.disable_integration else 0) |
              (ops.ENC_CYLINDER if model.ray_shape == 'cylinder' else 0))
+    # The constant trunk of the fp32 hit-ray branch (a function of the parameters alone) across steps: the call refills the
+    # buffer behind its update, on its side stream, and the next call uses it if nothing wrote the parameters in between --
+    # through torch (version counter) or through this library (ops.param_generation), exactly MipNerfModel.prefetch_const_trunk's
+    # guard for the Python-issued launches
+    trunk_buf = trunk_ok = None
+    if obj_fp32:
+        c = getattr(variables, '_c_trunk', None)
+        if c is None or c['buf'].device != dev:
+            c = variables._c_trunk = dict(buf=torch.empty(264, device=dev), key=None)
+        trunk_buf, trunk_ok = c['buf'], c['key'] == (variables.flat._version, ops.param_generation(variables.flat))
     # (pose_used: what the step renders with -- the update is in place; snapshot by the call's first launch, like cls, the
     # ray classes' counts: no launch of their own)
     outs, dyn, zo, grad, out, gs, pose_used, cls = ops.train_call(
@@ -538,7 +540,10 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         update=update, obj_fp32=obj_fp32, want_pos=pose_opt and not model.no_pose_opt, want_rot=pose_opt and not model.no_yaw_opt,
         tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0, seed=seed, comm=comm,
         world=dist.get_world_size() if dist is not None else 1, reduce_stats=dist is not None and reduce_stats,
-        density_noise=dn, density_rand=noise.get('density') if dn else None, weight_decay_mult=config.weight_decay_mult)
+        density_noise=dn, density_rand=noise.get('density') if dn else None, weight_decay_mult=config.weight_decay_mult,
+        const_trunk=trunk_buf, const_trunk_valid=trunk_ok)
+    if obj_fp32:        # (update=True: the buffer now holds the trunk of the updated parameters; update=False: of the unchanged ones)
+        variables._c_trunk['key'] = (variables.flat._version, ops.param_generation(variables.flat))
     if pose_used is None:
         pose_used = pose                                       # K = 0: [0, 6]
     box_rot0 = pose_used[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))

@@ -474,6 +474,14 @@ typedef struct durf_train_args {
     int32_t* cls_count;                                   /* nullable out [8]: durf_compact_all's class counts, kept where the caller can read
                                                              them ([3] = rays that hit two boxes, utils.Stats.multi_hit_rays) instead of in the workspace */
     const durf_step_timing* timing;                       /* nullable: events to record around the dominant launches (above) */
+    float* const_trunk;                                   /* DURF_TRAIN_OBJ_FP32, nullable [264]: the background trunk on the box-hit rays' constant
+                                                             encoding (durf_bkgd_const_trunk_f32: a function of the parameters alone, one workgroup,
+                                                             40-50 us), kept by the CALLER across steps so that it leaves the critical path: */
+    int const_trunk_valid;                                /*   != 0: const_trunk holds the trunk of `params` as they are NOW -- the caller vouches that
+                                                             nothing wrote them since the durf_train_step that prefetched it -- and the step uses it;
+                                                             0: the step computes it (into const_trunk when given) */
+    int prefetch_const_trunk;                             /*   != 0 (durf_train_step): behind the optimizer update the call starts the NEXT step's trunk
+                                                             on its side stream into const_trunk; the next call waits for it before using it */
 } durf_train_args;
 size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params);
 size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, size_t n_params, int flags);

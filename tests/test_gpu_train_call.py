@@ -6,7 +6,7 @@ against the reference's own train_step (tests/test_golden_ref_train.py)."""
 import pytest
 import torch
 
-from durf_amd import obbpose_model, synthetic, train_boxpose, utils
+from durf_amd import obbpose_model, ops as ops_mod, synthetic, train_boxpose, utils
 from tests import helpers as H
 
 pytestmark = pytest.mark.gpu
@@ -172,3 +172,35 @@ def test_timing_hooks_of_the_one_call_step(cuda):
     for name, (n, sec) in totals.items():
         assert 2e-6 < sec / n < 5e-3, (name, sec / n)
     assert totals['mlp_dw_256'][1] / 2 > totals['composite_resample'][1] / 2
+
+
+def test_constant_trunk_kept_across_one_call_steps_follows_the_parameters(cuda):
+    """cfg4's fp32 hit-ray branch through the C call keeps the background trunk of the box-hit rays across steps
+    (durf_train_args.const_trunk: refilled behind the update, used by the next call while the caller vouches for the
+    parameters).  The wrapper's guard -- torch's version counter + the library's generation count -- must drop it when
+    anything else writes the parameters between two steps: here torch does, after step 1, on both paths."""
+    B, K, N = 512, 2, 32
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.density_noise = 0.0\n' % N + POSE +
+                    'Config.randomized = True\nConfig.rand_bkgd = False\nConfig.tv_loss_mult = 0.01\n')
+    config = utils.configured(utils.Config)
+    db = H.device_batch(synthetic.make_batch(B, K, seed=990, noise_boxes=0.2), cuda)
+    prev = db['init'][0:1] + 0.01
+    out = []
+    for fn in (train_boxpose.train_step, train_boxpose.train_step_one_call):
+        model, variables = obbpose_model.construct_mipnerf(3, db, device=cuda)
+        assert model.object_precision() == 'f32'
+        state = train_boxpose.create_train_state(variables)
+        rng = 21
+        for i in range(4):
+            state, stats, rng, _ = fn(model, config, rng, state, db, 5e-4, 0.7, 6.5, prev)
+            if i == 1:
+                state.variables.flat.mul_(1.001)          # someone else writes the parameters: the kept trunk is stale
+            if fn is train_boxpose.train_step_one_call:
+                c = state.variables._c_trunk
+                fresh = c['key'] == (state.variables.flat._version, ops_mod.param_generation(state.variables.flat))
+                assert fresh == (i != 1), 'step %d: the kept trunk is %s' % (i, 'fresh' if fresh else 'stale')
+        torch.cuda.synchronize()
+        out.append((state.variables.flat.clone(), float(stats.loss)))
+    _eq(out[0][0], out[1][0], 'parameters after 4 steps with a foreign write in between')
+    assert out[0][1] == out[1][1]
