@@ -19,15 +19,24 @@ enum { POSE_ROWS = 21 };   // [0..2] sum g_o ; [3..11] sum g_o (x) o ; [12..20] 
 // PRECISE: libm exp / sin / cos (the fp32 object branch and the parity instrument); otherwise the hardware
 // transcendentals (bf16 object branch: |z| < 314.16 after the wrap, where v_sin's z / 2 pi scaling alone loses
 // ~|z| 2^-24 = 2e-5 rad -- two orders below the bf16 rounding of the d(enc) it multiplies).
+// the per-level operands of one launch over several levels (blockIdx.z = level: durf_encode_obj_bwd_levels)
+struct EncBwdLevels {
+    const float* d_enc[DURF_MAX_LEVELS];
+    const float* t_vals[DURF_MAX_LEVELS];
+    float* rows_out[DURF_MAX_LEVELS];      // [21][B] per object, column j = compact ray index
+};
+
 template <int P, bool PRECISE>
 __global__ void __launch_bounds__(256)
 k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const int32_t* __restrict__ count,
-                 const float* __restrict__ d_enc, const float* __restrict__ t_vals,
+                 EncBwdLevels lv,
                  const float* __restrict__ origins_s, const float* __restrict__ dirs_s,
                  const float* __restrict__ radii, const float* __restrict__ origins,
                  const float* __restrict__ dirs, const float* __restrict__ pose, BarfW bw,
-                 float* __restrict__ rows_out /* [21][B] per object, column j = compact ray index */,
                  size_t idx_stride, size_t denc_stride, size_t rows_stride, int enc_flags) {
+    const float* __restrict__ d_enc = lv.d_enc[blockIdx.z];
+    const float* __restrict__ t_vals = lv.t_vals[blockIdx.z];
+    float* __restrict__ rows_out = lv.rows_out[blockIdx.z];
     // MipNerfModel.ray_shape = 'cylinder' (mip.cylinder_to_gaussian, mip.py:133-152) and disable_integration
     // (obbpose_model.py:163-164: the variances are zeroed, so only the means carry a gradient)
     const bool cyl = (enc_flags & DURF_ENC_CYLINDER) != 0, noint = (enc_flags & DURF_ENC_NO_INTEGRATION) != 0;
@@ -148,24 +157,28 @@ k_encode_obj_bwd(int B, int N, int k_obj, const int32_t* __restrict__ idx, const
     }   // rays
 }
 
+// (nlev levels in the order given: each level's row sum is formed and added exactly as a launch of its own would -- the same bits
+// as one launch per level)
 __global__ void __launch_bounds__(1024)
-k_pose_reduce(int n, const int32_t* __restrict__ count, const float* __restrict__ in, float* __restrict__ out) {
+k_pose_reduce(int n, const int32_t* __restrict__ count, EncBwdLevels lv, int nlev, float* __restrict__ out) {
     __shared__ float sh[16];
     const int r = blockIdx.x;
     count += blockIdx.y;                               // batched call: blockIdx.y = object
-    in += (size_t)blockIdx.y * POSE_ROWS * n;
     out += blockIdx.y * POSE_ROWS;
     const int c = *count < n ? *count : n;
-    const float* p = in + (size_t)r * n;
-    float v = 0.0f;
-    for (int i = threadIdx.x; i < c; i += 1024) v += p[i];
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float a = sh[0];
-        for (int w = 1; w < 16; w++) a += sh[w];
-        out[r] += a;                       // accumulates over levels (caller zeroes)
+    for (int l = 0; l < nlev; l++) {
+        const float* p = lv.rows_out[l] + (size_t)blockIdx.y * POSE_ROWS * n + (size_t)r * n;
+        float v = 0.0f;
+        for (int i = threadIdx.x; i < c; i += 1024) v += p[i];
+        v = wave_sum(v);
+        __syncthreads();                   // (sh[] of the previous level has been read)
+        if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float a = sh[0];
+            for (int w = 1; w < 16; w++) a += sh[w];
+            out[r] += a;                   // accumulates over levels (caller zeroes)
+        }
     }
 }
 
@@ -225,23 +238,32 @@ extern "C" {
 static int encode_obj_bwd_launch(void* stream, int K, int B, int N, int k0, const int32_t* idx, const int32_t* count,
                                  const float* d_enc, size_t denc_stride, const float* t_vals, const float* origins_s,
                                  const float* dirs_s, const float* radii, const float* origins, const float* dirs,
-                                 const float* pose, const float* barf_w, float* scratch, float* sums, int precise, int enc_flags) {
+                                 const float* pose, const float* barf_w, float* scratch, float* sums, int precise, int enc_flags,
+                                 int nlev = 1, const float* const* d_enc_l = nullptr, const float* const* t_vals_l = nullptr) {
     DURF_REQUIRE(N >= 1 && N <= 256, "1 <= N <= 256");
+    DURF_REQUIRE(nlev >= 1 && nlev <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
     DURF_REQUIRE((enc_flags & ~(DURF_ENC_CYLINDER | DURF_ENC_NO_INTEGRATION)) == 0, "enc_flags: DURF_ENC_CYLINDER | DURF_ENC_NO_INTEGRATION");
     if (B <= 0 || K <= 0) return 0;
     BarfW bw;
     for (int i = 0; i < 10; i++) bw.w[i] = barf_w[i];
     hipStream_t s = (hipStream_t)stream;
-    dim3 grid(B < 256 ? B : 256, K), block(256);
+    // (levels: scratch holds nlev blocks of K * 21 * B floats)
+    EncBwdLevels lv{};
+    for (int l = 0; l < nlev; l++) {
+        lv.d_enc[l] = d_enc_l ? d_enc_l[l] : d_enc;
+        lv.t_vals[l] = t_vals_l ? t_vals_l[l] : t_vals;
+        lv.rows_out[l] = scratch + (size_t)l * K * POSE_ROWS * B;
+    }
+    dim3 grid(B < 256 ? B : 256, K, nlev), block(256);
 #define LAUNCH_E2(P, PR)                                                                                  \
-    hipLaunchKernelGGL((k_encode_obj_bwd<P, PR>), grid, block, 0, s, B, N, k0, idx, count, d_enc, t_vals, \
-                       origins_s, dirs_s, radii, origins, dirs, pose, bw, scratch, (size_t)B, denc_stride, \
+    hipLaunchKernelGGL((k_encode_obj_bwd<P, PR>), grid, block, 0, s, B, N, k0, idx, count, lv,            \
+                       origins_s, dirs_s, radii, origins, dirs, pose, bw, (size_t)B, denc_stride,          \
                        (size_t)POSE_ROWS * B, enc_flags)
 #define LAUNCH_E(P) { if (precise) LAUNCH_E2(P, true); else LAUNCH_E2(P, false); }
     if (N <= 64) LAUNCH_E(1) else if (N <= 128) LAUNCH_E(2) else LAUNCH_E(4)
 #undef LAUNCH_E2
 #undef LAUNCH_E
-    hipLaunchKernelGGL(k_pose_reduce, dim3(POSE_ROWS, K), dim3(1024), 0, s, B, count, scratch, sums + k0 * POSE_ROWS);
+    hipLaunchKernelGGL(k_pose_reduce, dim3(POSE_ROWS, K), dim3(1024), 0, s, B, count, lv, nlev, sums + k0 * POSE_ROWS);
     DURF_CHECK_LAUNCH("durf_encode_obj_bwd");
     return 0;
 }
@@ -260,6 +282,14 @@ int durf_encode_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* 
                               const float* pose, const float* barf_w, float* scratch, float* sums, int precise, int enc_flags) {
     return encode_obj_bwd_launch(stream, K, B, N, 0, idx, count, d_enc, (size_t)B * N * DURF_ENC_DIM, t_vals, origins_s,
                                  dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise, enc_flags);
+}
+
+int durf_encode_obj_bwd_levels(void* stream, int K, int B, int N, int nlevels, const int32_t* idx, const int32_t* count,
+                               const float* const* d_enc, const float* const* t_vals, const float* origins_s,
+                               const float* dirs_s, const float* radii, const float* origins, const float* dirs,
+                               const float* pose, const float* barf_w, float* scratch, float* sums, int precise, int enc_flags) {
+    return encode_obj_bwd_launch(stream, K, B, N, 0, idx, count, nullptr, (size_t)B * N * DURF_ENC_DIM, nullptr, origins_s,
+                                 dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise, enc_flags, nlevels, d_enc, t_vals);
 }
 
 // sums [K,21] (all levels accumulated) -> adds d(loss)/d(box_centers[ts]) into grad6 [K,6]

@@ -118,7 +118,7 @@ TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params, int 
         w.obj_ws = (float*)c.take((size_t)K * durf_mlp_f32_wstream_floats(128) * 4);
         w.dw32_scratch = (float*)c.take((size_t)K * durf_mlp_f32_dw_scratch_floats(128, 63, OBJ32_NSPLIT) * 4);
         w.pose_sums = (float*)c.take((size_t)K * 21 * 4);
-        w.pose_scratch = (float*)c.take(pose ? (size_t)K * 21 * B * 4 : 0);
+        w.pose_scratch = (float*)c.take(pose ? (size_t)L * K * 21 * B * 4 : 0);      // (every level's rows: one launch pair)
     }
     w.total = (c.off + 255) & ~(size_t)255;
     return w;
@@ -295,16 +295,20 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         for (int l = 0; l < L; l++) { dr[l] = w.draw[L - 1 - l]; mk[l] = w.obj_mask[L - 1 - l]; dzl[l] = w.obj_dz[L - 1 - l]; dzo[l] = w.obj_dz_out[L - 1 - l]; }
         STEP(durf_obj_bwd_batch_levels(ov.obj(), K, B, N, L, w.idx_obj, w.count_obj, dr, w.wb_obj, mk, dzl, dzo));
     }
-    for (int lvl = L - 1; lvl >= 0; lvl--) {
-        float* rs = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;
-        if (f32o) {       // the object branch in fp32: backward (+ d(enc) -> the 21 pose sums per object), all K at once
+    if (f32o) {           // the object branch in fp32: backward of every level, all K at once; then d(enc) -> the 21 pose sums per
+                          // object for EVERY level as one launch pair (levels added last level first, as one pair per level would)
+        const float *de[ML], *tv[ML];
+        for (int lvl = L - 1; lvl >= 0; lvl--) {
             STEP(durf_objf32_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw[lvl], f.obj_params, f.obj_param_stride, w.obj_ws,
                                        w.act32[lvl], w.dz32[lvl], pose_opt ? w.d_enc32[lvl] : nullptr));
-            if (pose_opt)
-                STEP(durf_encode_obj_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.d_enc32[lvl], f.t_vals[lvl], w.o_s, w.d_s,
-                                               f.radii, f.origins, f.directions, f.pose, f.barf_w, w.pose_scratch, w.pose_sums, 1,
-                                               obj_flags));
+            de[L - 1 - lvl] = w.d_enc32[lvl]; tv[L - 1 - lvl] = f.t_vals[lvl];
         }
+        if (pose_opt)
+            STEP(durf_encode_obj_bwd_levels(stream, K, B, N, L, w.idx_obj, w.count_obj, de, tv, w.o_s, w.d_s, f.radii, f.origins,
+                                            f.directions, f.pose, f.barf_w, w.pose_scratch, w.pose_sums, 1, obj_flags));
+    }
+    for (int lvl = L - 1; lvl >= 0; lvl--) {
+        float* rs = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;
         if (K > 0) {
             TIMED(DURF_TIMED_BWD + lvl,
                   durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],

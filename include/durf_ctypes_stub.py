@@ -247,6 +247,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_encode_obj_bwd_batch.restype = i32
     L.durf_encode_obj_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp, i32, i32]
     #   (stream, K, B, N, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise, enc_flags)
+    L.durf_encode_obj_bwd_levels.restype = i32
+    L.durf_encode_obj_bwd_levels.argtypes = [vp, i32, i32, i32, i32, vp, vp, C.POINTER(vp), C.POINTER(vp), vp, vp, vp, vp, vp, vp, C.POINTER(f32), vp, vp, i32, i32]
+    #   (stream, K, B, N, nlevels, idx, count, d_enc, t_vals, origins_s, dirs_s, radii, origins, dirs, pose, barf_w, scratch, sums, precise, enc_flags)
     L.durf_pose_finish.restype = i32
     L.durf_pose_finish.argtypes = [vp, i32, vp, vp, i32, i32, vp]
     #   (stream, K, pose, sums, want_pos, want_rot, grad6)

@@ -630,6 +630,14 @@ int durf_encode_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* 
                               const float* dirs_s, const float* radii, const float* origins, const float* dirs,
                               const float* pose, const float* barf_w /* host float[10] */, float* scratch, float* sums,
                               int precise, int enc_flags);
+/* ... and for EVERY level of a step in one launch pair (blockIdx.z = level; the reduction adds the levels' row sums in the
+ * order given, the bits of one call per level): d_enc / t_vals host arrays [nlevels] of the per-level device buffers,
+ * scratch nlevels * K*21*B floats. */
+int durf_encode_obj_bwd_levels(void* stream, int K, int B, int N, int nlevels, const int32_t* idx, const int32_t* count,
+                               const float* const* d_enc, const float* const* t_vals, const float* origins_s,
+                               const float* dirs_s, const float* radii, const float* origins, const float* dirs,
+                               const float* pose, const float* barf_w /* host float[10] */, float* scratch, float* sums,
+                               int precise, int enc_flags);
 int durf_pose_finish(void* stream, int K, const float* pose, const float* sums, int want_pos, int want_rot,
                      float* grad6);
 
