@@ -1301,11 +1301,25 @@ def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, 
     _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
                        bkgd_mode, density_bias, resample_padding, t_rand, u_rand, outs, dyn, zo, keep, seed=seed,
                        density_noise=density_noise, density_rand=density_rand)
-    ws = torch.empty(int(L.durf_forward_workspace_bytes(B, N, K)), dtype=torch.uint8, device=dev)
-    assert ws.data_ptr() % 256 == 0
+    ws = _workspace(dev, int(L.durf_forward_workspace_bytes(B, N, K)))
     with _Timed('forward_call'):
         _lib.check(L.durf_forward(_stream(), C.byref(a), _p(ws)), 'durf_forward')
     return outs, dyn, zo
+
+
+_WORKSPACE = {}
+
+
+def _workspace(dev, nbytes):
+    """the one-call entry points' workspace: ONE buffer per device, kept across calls and grown when a call needs more (a
+    fresh torch.empty of several hundred MB per step leaves it to the caching allocator to hand the same block back; when it
+    does not, the step stalls on a device allocation -- seen as one 0.5 ms step in ~8 passes of a 0.4 ms workload)"""
+    key = (dev.type, dev.index)
+    ws = _WORKSPACE.get(key)
+    if ws is None or ws.numel() < nbytes:
+        _WORKSPACE[key] = ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        assert ws.data_ptr() % 256 == 0
+    return ws
 
 
 def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_floats, N, num_levels, alpha, enc_flags,
@@ -1365,9 +1379,7 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
         a.const_trunk, a.const_trunk_valid, a.prefetch_const_trunk = _p(_f32(const_trunk)), int(bool(const_trunk_valid)), int(bool(update))
     tm = _step_timing(num_levels, keep) if update else None
     a.timing = C.cast(C.pointer(tm), C.c_void_p) if tm is not None else None
-    ws = torch.empty(int(L.durf_train_workspace_bytes_flags(B, N, K, num_levels, params_flat.numel(), a.flags)), dtype=torch.uint8,
-                     device=dev)
-    assert ws.data_ptr() % 256 == 0
+    ws = _workspace(dev, int(L.durf_train_workspace_bytes_flags(B, N, K, num_levels, params_flat.numel(), a.flags)))
     with _Timed('train_call'):
         fn = L.durf_train_step if update else L.durf_loss_backward
         _lib.check(fn(_stream(), C.byref(a), _p(ws)), 'durf_train_step' if update else 'durf_loss_backward')

@@ -468,8 +468,8 @@ def one_call_refusal(model, variables, update=True):
 
 def best_step_fn(model, variables):
     """the faster host path of a training step for this model: the one C call (durf_train_step -- bit-identical to train_step,
-    0-3 % faster at the measured shapes: no interpreter between the launches, two cross-stream hops fewer) wherever it covers
-    the step, else train_step.  bench.py and train_loop use it; the parity tests name the path they mean."""
+    within +-1.5 % of it at every measured shape, +0.3-0.8 % at the 4096-ray headline: no interpreter between the launches, two
+    cross-stream hops fewer; profiles/r05_ab_host_path.txt) wherever it covers the step, else train_step.  bench.py and train_loop use it; the parity tests name the path they mean."""
     return train_step_one_call if one_call_refusal(model, variables) is None else train_step
 
 
