@@ -59,7 +59,7 @@ extern "C" {
 
 size_t durf_forward_workspace_bytes(int B, int N, int K) { return carve(nullptr, B, N, K).total; }
 
-int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
+int durf_forward(void* stream, const durf_forward_args* a, void* workspace, size_t workspace_bytes) {
     DURF_REQUIRE(a != nullptr && workspace != nullptr, "arguments and workspace");
     const int B = a->B, N = a->N, K = a->K, L = a->num_levels;
     DURF_REQUIRE(B > 0 && N % 32 == 0 && N >= 32 && N <= 256, "B > 0, num_samples a multiple of 32 in [32, 256]");
@@ -70,6 +70,10 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace) {
     for (int l = 0; l < L && a->density_noise != 0.0f; l++)
         DURF_REQUIRE(a->density_rand[l] != nullptr || a->draw_noise, "density_noise: density_rand[level] or draw_noise");
     const FwdWs w = carve(workspace, B, N, K);
+    if (workspace_bytes < w.total) {
+        durf_set_error("durf_forward: workspace of %zu bytes, durf_forward_workspace_bytes(%d, %d, %d) = %zu", workspace_bytes, B, N, K, w.total);
+        return -1;
+    }
     const size_t rows = (size_t)B * N;
     int rc;
 #define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)

@@ -1181,10 +1181,6 @@ size_t durf_wpack_bwd_bytes(int width) {
     return (size_t)(width == 256 ? BwdSpec<256>::TOTAL_CHUNKS : BwdSpec<128>::TOTAL_CHUNKS) * 1024;
 }
 
-int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_bwd) {
-    return durf::launch_pack(stream, width, in_dim, 1, mlp_params, 0, nullptr, wpack_bwd);
-}
-
 int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw, const int32_t* ray_idx,
                  const int32_t* count, const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out,
                  float* d_enc, const int32_t* tail_idx, const int32_t* tail_count, const float* draw_ray_sum) {

@@ -796,13 +796,6 @@ size_t durf_mlp_stash_bytes(int width, size_t rows) {
     return ((rows + 31) / 32) * kb * 1024;
 }
 
-int durf_pack_weights_bwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_bwd);
-size_t durf_wpack_bwd_bytes(int width);
-
-int durf_pack_weights_fwd(void* stream, int width, int in_dim, const float* mlp_params, void* wpack_fwd) {
-    return durf::launch_pack(stream, width, in_dim, 1, mlp_params, 0, wpack_fwd, nullptr);
-}
-
 int durf_pack_weights_all(void* stream, const float* bkgd_params, int in_bkgd, void* bkgd_fwd, void* bkgd_bwd, int K,
                           const float* obj_params, size_t obj_param_stride, int in_obj, void* obj_fwd, void* obj_bwd) {
     DURF_REQUIRE(bkgd_params == nullptr || (bkgd_fwd != nullptr && in_bkgd > 0 && in_bkgd <= DURF_ENC_DIM),

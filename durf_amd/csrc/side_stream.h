@@ -13,15 +13,18 @@ namespace durf {
 // BEFORE the persistent background launch takes every CU, the object backward runs in its shadow, the objects' weight
 // gradients (their own split-K launch + finalize) beside the background's.  One side stream + two events per device,
 // created on first use; DURF_OVERLAP_OBJECTS=0 keeps everything on the caller's stream.  No result depends on it (no atomics).
-struct SideStream { hipStream_t s; hipEvent_t forked, joined; bool ok; };
+// pending_trunk: the buffer an outstanding cross-step prefetch (durf_train_step: prefetch_const_trunk) is writing on this stream
+// -- it also READS the parameters -- or nullptr; whoever uses, recomputes or is asked about that buffer joins first (join_prefetch).
+struct SideStream { hipStream_t s; hipEvent_t forked, joined; bool ok; void* pending_trunk; };
 inline std::mutex& side_mutex() { static std::mutex m; return m; }
 
-inline SideStream* side_stream_of_device() {      // (inline: ONE table for the library, whichever file asks)
+inline SideStream* side_stream_of_device(bool create = true) {      // (inline: ONE table for the library, whichever file asks)
     static SideStream tab[64] = {};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
     std::lock_guard<std::mutex> lock(side_mutex());
     SideStream& t = tab[dev];
+    if (!t.ok && !create) return nullptr;
     if (!t.ok) {
         if (hipStreamCreateWithFlags(&t.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
         if (hipEventCreateWithFlags(&t.forked, hipEventDisableTiming) != hipSuccess ||
@@ -49,6 +52,22 @@ struct Overlap {
         return 0;
     }
 };
+
+// Orders `stream` behind an outstanding prefetch of this device, if there is one (no stream is created for the question).
+inline int join_prefetch(void* stream) {
+    SideStream* sd = side_stream_of_device(false);
+    if (sd == nullptr) return 0;
+    {
+        std::lock_guard<std::mutex> lock(side_mutex());
+        if (sd->pending_trunk == nullptr) return 0;
+        sd->pending_trunk = nullptr;
+    }
+    return (Overlap{(hipStream_t)stream, sd}).join();
+}
+inline void note_prefetch(SideStream* sd, void* dst) {
+    std::lock_guard<std::mutex> lock(side_mutex());
+    sd->pending_trunk = dst;
+}
 
 inline Overlap overlap_for(void* stream, size_t rows, int Kb) {
     Overlap o{(hipStream_t)stream, nullptr};

@@ -131,6 +131,14 @@ TrainWs workspace_of(const durf_train_args* a, void* workspace) {
     return w;
 }
 
+// a workspace the caller sized for another shape is refused, not overrun (the intermediates of a step are up to ~10 GB)
+int check_workspace(const char* who, const durf_train_args* a, const TrainWs& w, size_t workspace_bytes) {
+    if (workspace_bytes >= w.total) return 0;
+    durf_set_error("%s: workspace of %zu bytes, durf_train_workspace_bytes_flags(%d, %d, %d, %d, %zu, %d) = %zu", who, workspace_bytes,
+                   a->f.B, a->f.N, a->f.K, a->f.num_levels, a->n_params, a->flags, w.total);
+    return -1;
+}
+
 int check_args(const durf_train_args* a, void* workspace) {
     DURF_REQUIRE(a != nullptr && workspace != nullptr, "arguments and workspace");
     const durf_forward_args& f = a->f;
@@ -232,13 +240,12 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
                 // behind the level-0 forward: a trunk prefetched behind the previous step's update (durf_train_step below) has
                 // had that launch's time to land, and beside the persistent launch these small ones would wait for a CU
                 float* trunk = a->const_trunk ? a->const_trunk : w.trunk;
-                if (a->const_trunk && a->const_trunk_valid) {
-                    durf::SideStream* sd = durf::side_stream_of_device();
-                    DURF_REQUIRE(sd != nullptr, "const_trunk_valid: the side stream the prefetch ran on");
-                    STEP((durf::Overlap{hs, sd}).join());
-                } else {
+                // A prefetch the previous durf_train_step left running on the side stream (it reads the parameters and writes the
+                // caller's const_trunk) is joined HERE whatever this call was told about the buffer: a recomputation into the same
+                // buffer must not race with it, and this step's optimizer must not update parameters it is still reading.
+                STEP(durf::join_prefetch(stream));
+                if (!(a->const_trunk && a->const_trunk_valid))
                     STEP(durf_bkgd_const_trunk_f32(stream, f.bkgd_params, trunk));
-                }
                 STEP(durf_bkgd_hit_rays_f32(stream, B, w.view27, f.bkgd_params, w.idx_cls + B, w.count_cls + 1, trunk, w.raw_tail));
             }
             if (f32o) STEP(durf_expand_raw(stream, B, N, w.raw_c[lvl], w.count_cls, w.slot_cls, w.raw_b[lvl], w.raw_tail));
@@ -364,6 +371,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         if (a->want_pos && a->tv_loss_mult != 0.0f) {
             const float c = (float)((double)a->tv_loss_mult * (1.0 + 0.1 * (double)(L - 1)) * 2.0);
             hipLaunchKernelGGL(k_tv_rows, dim3(1), dim3(64), 0, hs, K, f.pose, a->prev6, c, g_rows);
+            DURF_CHECK_LAUNCH("durf_loss_backward (TV prior rows)");
         }
     }
     if (!tail) return 0;
@@ -389,16 +397,18 @@ size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, siz
     return carve(nullptr, B, N, K, num_levels, n_params, flags).total;
 }
 
-int durf_loss_backward(void* stream, const durf_train_args* a, void* workspace) {
+int durf_loss_backward(void* stream, const durf_train_args* a, void* workspace, size_t workspace_bytes) {
     int rc = check_args(a, workspace);
     if (rc != 0) return rc;
-    return loss_backward(stream, a, workspace_of(a, workspace));
+    const TrainWs w = workspace_of(a, workspace);
+    STEP(check_workspace("durf_loss_backward", a, w, workspace_bytes));
+    return loss_backward(stream, a, w);
 }
 
-static int train_step_body(void* stream, const durf_train_args* a, void* workspace);
+static int train_step_body(void* stream, const durf_train_args* a, void* workspace, size_t workspace_bytes);
 
-int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
-    int rc = train_step_body(stream, a, workspace);
+int durf_train_step(void* stream, const durf_train_args* a, void* workspace, size_t workspace_bytes) {
+    int rc = train_step_body(stream, a, workspace, workspace_bytes);
     if (rc != 0) return rc;
     if ((a->flags & DURF_TRAIN_OBJ_FP32) && a->f.K > 0 && a->prefetch_const_trunk && a->const_trunk) {
         // the NEXT step's constant trunk, from the parameters just updated, beside whatever the caller does between the steps
@@ -407,17 +417,20 @@ int durf_train_step(void* stream, const durf_train_args* a, void* workspace) {
             const durf::Overlap ov{(hipStream_t)stream, sd};
             STEP(ov.fork());
             STEP(durf_bkgd_const_trunk_f32(ov.obj(), a->f.bkgd_params, a->const_trunk));
+            durf::note_prefetch(sd, a->const_trunk);
         }
     }
     return 0;
 }
 
-static int train_step_body(void* stream, const durf_train_args* a, void* workspace) {
+static int train_step_body(void* stream, const durf_train_args* a, void* workspace, size_t workspace_bytes) {
     int rc = check_args(a, workspace);
     if (rc != 0) return rc;
     DURF_REQUIRE(a->adam_m && a->adam_v && a->grad_stats, "Adam moments and grad_stats");
     const TrainWs w = workspace_of(a, workspace);
+    STEP(check_workspace("durf_train_step", a, w, workspace_bytes));
     STEP(loss_backward(stream, a, w, false));
+    STEP(durf::join_prefetch(stream));       // (a step without the fp32 object branch behind one with it: nothing has joined yet)
     if (a->comm != nullptr) {
         // One rank's share of a data-parallel step (train_boxpose.py:253-255; durf_amd/train_boxpose.py train_step): the
         // multi-hit NaNs have to exist BEFORE the exchange (the reference's pmean sees them), then ONE all-reduce of the flat
@@ -446,6 +459,7 @@ static int train_step_body(void* stream, const durf_train_args* a, void* workspa
                               K ? a->target6 : nullptr, tv, a->stat_mults, 1, a->stats, terms, f.B));
         STEP(durf_allreduce_sum(stream, a->comm, a->stats, (size_t)ns));
         hipLaunchKernelGGL(k_scale, dim3(1), dim3(256), 0, (hipStream_t)stream, ns, a->stats, inv_world);
+        DURF_CHECK_LAUNCH("durf_train_step (pmean of the logged scalars)");
         STEP(durf_train_stats(stream, L, K, f.N, w.norms, w.sums, nullptr, nullptr, nullptr, nullptr, tv, a->stat_mults, 2, a->stats,
                               nullptr, 0));
         return durf_clip_adam(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, inv_world, a->max_val, a->max_norm,
@@ -465,5 +479,7 @@ static int train_step_body(void* stream, const durf_train_args* a, void* workspa
     return durf_adam_apply(stream, a->n_params, a->params, a->adam_m, a->adam_v, a->grad, a->max_norm, a->lr, a->step, w.scratch,
                            a->grad_stats);
 }
+
+int durf_prefetch_join(void* stream) { return durf::join_prefetch(stream); }
 
 }  // extern "C"

@@ -1303,7 +1303,7 @@ def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, 
                        density_noise=density_noise, density_rand=density_rand)
     ws = _workspace(dev, int(L.durf_forward_workspace_bytes(B, N, K)))
     with _Timed('forward_call'):
-        _lib.check(L.durf_forward(_stream(), C.byref(a), _p(ws)), 'durf_forward')
+        _lib.check(L.durf_forward(_stream(), C.byref(a), _p(ws), ws.numel()), 'durf_forward')
     return outs, dyn, zo
 
 
@@ -1382,5 +1382,5 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
     ws = _workspace(dev, int(L.durf_train_workspace_bytes_flags(B, N, K, num_levels, params_flat.numel(), a.flags)))
     with _Timed('train_call'):
         fn = L.durf_train_step if update else L.durf_loss_backward
-        _lib.check(fn(_stream(), C.byref(a), _p(ws)), 'durf_train_step' if update else 'durf_loss_backward')
+        _lib.check(fn(_stream(), C.byref(a), _p(ws), ws.numel()), 'durf_train_step' if update else 'durf_loss_backward')
     return outs, dyn, zo, grad, stats, (gstats if update else None), pose_used, cls

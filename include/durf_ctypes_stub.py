@@ -135,20 +135,23 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_forward_workspace_bytes.argtypes = [i32, i32, i32]
     #   (B, N, K)
     L.durf_forward.restype = i32
-    L.durf_forward.argtypes = [vp, vp, vp]
-    #   (stream, args, workspace)
+    L.durf_forward.argtypes = [vp, vp, vp, u64]
+    #   (stream, args, workspace, workspace_bytes)
     L.durf_train_workspace_bytes.restype = u64
     L.durf_train_workspace_bytes.argtypes = [i32, i32, i32, i32, u64]
     #   (B, N, K, num_levels, n_params)
     L.durf_train_workspace_bytes_flags.restype = u64
     L.durf_train_workspace_bytes_flags.argtypes = [i32, i32, i32, i32, u64, i32]
     #   (B, N, K, num_levels, n_params, flags)
+    L.durf_prefetch_join.restype = i32
+    L.durf_prefetch_join.argtypes = [vp]
+    #   (stream)
     L.durf_loss_backward.restype = i32
-    L.durf_loss_backward.argtypes = [vp, vp, vp]
-    #   (stream, args, workspace)
+    L.durf_loss_backward.argtypes = [vp, vp, vp, u64]
+    #   (stream, args, workspace, workspace_bytes)
     L.durf_train_step.restype = i32
-    L.durf_train_step.argtypes = [vp, vp, vp]
-    #   (stream, args, workspace)
+    L.durf_train_step.argtypes = [vp, vp, vp, u64]
+    #   (stream, args, workspace, workspace_bytes)
     L.durf_comm_available.restype = i32
     L.durf_comm_available.argtypes = []
     L.durf_comm_unique_id.restype = i32

@@ -408,7 +408,10 @@ typedef struct durf_forward_args {
                                                                under (seed_lo, seed_hi) */
 } durf_forward_args;
 size_t durf_forward_workspace_bytes(int B, int N, int K);
-int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
+/* workspace_bytes: the size of the buffer `workspace` points to.  The call refuses (-1, durf_last_error names both sizes)
+ * a buffer smaller than durf_forward_workspace_bytes(B, N, K) instead of carving its intermediates out of memory the
+ * caller does not own. */
+int durf_forward(void* stream, const durf_forward_args* args, void* workspace, size_t workspace_bytes);
 
 /* ---- one shard's training step as ONE call (csrc/train.hip) ------------------------------------------------
  * durf_loss_backward: value_and_grad(loss_fn) of train_step (train_boxpose.py:67-252) -- the forward with activations
@@ -431,7 +434,15 @@ int durf_forward(void* stream, const durf_forward_args* args, void* workspace);
  * Streams: everything is ordered on `stream`, whose device must be the calling thread's current device.  The bf16 object
  * MLPs of a large step (>= 2048 x 128 sample rows per level) run on a second, non-blocking stream the library creates per
  * device on first use, forked from / joined to `stream` with events inside the call (DURF_OVERLAP_OBJECTS=0: one stream);
- * when the call returns, all of its work is ordered before whatever the caller issues to `stream` next. */
+ * when the call returns, all of its work is ordered before whatever the caller issues to `stream` next -- with ONE exception,
+ * prefetch_const_trunk (below): that launch is left running on the side stream, reading `params` and writing const_trunk.  The
+ * next durf_train_step / durf_loss_backward on the device joins it before it uses or recomputes a trunk and before its own
+ * optimizer update; a caller that overwrites or frees `params` or `const_trunk` between two steps calls
+ * durf_prefetch_join(stream) first.
+ * Threading: the side stream and its two events are ONE set per DEVICE for the whole process (created on first use, never
+ * destroyed).  Calls for two models on one device from two host threads are correct -- fork / join pairs are issued under a
+ * mutex -- but each join waits for everything on the shared side stream, i.e. the two models' object launches serialise;
+ * the entry points themselves keep no other state between calls (durf_last_error is thread-local). */
 #define DURF_TRAIN_OBJ_FP32 1
 #define DURF_TRAIN_POSE_OPT 2
 /* Live timing of the step's dominant launches for a roofline line (bench.py): hipEvent_t handles (created with timing
@@ -485,8 +496,13 @@ typedef struct durf_train_args {
 } durf_train_args;
 size_t durf_train_workspace_bytes(int B, int N, int K, int num_levels, size_t n_params);
 size_t durf_train_workspace_bytes_flags(int B, int N, int K, int num_levels, size_t n_params, int flags);
-int durf_loss_backward(void* stream, const durf_train_args* args, void* workspace);
-int durf_train_step(void* stream, const durf_train_args* args, void* workspace);
+/* workspace_bytes: the size of the buffer behind `workspace`; a buffer smaller than
+ * durf_train_workspace_bytes_flags(f.B, f.N, f.K, f.num_levels, n_params, flags) is refused (-1, durf_last_error). */
+/* durf_prefetch_join: orders `stream` behind a prefetch_const_trunk launch still outstanding on this device's side stream
+ * (no-op when there is none). */
+int durf_prefetch_join(void* stream);
+int durf_loss_backward(void* stream, const durf_train_args* args, void* workspace, size_t workspace_bytes);
+int durf_train_step(void* stream, const durf_train_args* args, void* workspace, size_t workspace_bytes);
 
 /* ---- the data-parallel exchange on the caller's stream (csrc/comm.hip) -------------------------------------
  * jax.lax.pmean(grad, 'batch') (train_boxpose.py:253) as ONE in-place RCCL all-reduce (sum; durf_clip_adam / durf_stats_scrub

@@ -114,5 +114,36 @@ def test_workspace_size_and_argument_checks(cuda):
     a.B, a.N, a.K, a.num_levels = 16, 48, 0, 2                   # num_samples not a multiple of 32
     ws = torch.empty(1 << 20, dtype=torch.uint8, device=cuda)
     import ctypes
-    assert L.durf_forward(None, ctypes.byref(a), ws.data_ptr()) != 0
+    assert L.durf_forward(None, ctypes.byref(a), ws.data_ptr(), ws.numel()) != 0
     assert b'num_samples' in L.durf_last_error()
+
+
+def test_an_undersized_workspace_is_refused(cuda, monkeypatch):
+    """The one-call entry points carve up to ~10 GB of intermediates out of the caller's buffer: a buffer sized for another
+    shape has to be refused with a message naming both sizes, not overrun (SURVEY 8b's durf_workspace_bytes; the reference
+    raises on a bad batch shape, train_boxpose.py:332-333) -- and before the first launch: the parameters stay untouched."""
+    from durf_amd import train_boxpose
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = 32\nMipNerfModel.density_noise = 0.0\nMipNerfModel.no_pose_opt = True\n'
+                    'MipNerfModel.no_yaw_opt = True\nConfig.randomized = False\n')
+    config = utils.configured(utils.Config)
+    b = synthetic.make_batch(64, 2, seed=3)
+    db = H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(0, db, device=cuda)
+    args = (variables, 0, db['rays'], db['init'], db['ext'], b['ts'])
+    kw = dict(randomized=False, rand_bkgd=False, white_bkgd=False, alpha=10.0)
+    good = model.apply_one_call(*args, **kw)
+    real = ops._workspace
+    monkeypatch.setattr(ops, '_workspace', lambda dev, n: real(dev, n)[:n - 256])        # same pointer, 256 bytes short
+    need = int(ops._lib.lib().durf_forward_workspace_bytes(64, 32, 2))
+    with pytest.raises(ops._lib.DurfError, match=r'durf_forward: workspace of %d bytes.* = %d' % (need - 256, need)):
+        model.apply_one_call(*args, **kw)
+    state = train_boxpose.create_train_state(variables)
+    before = variables.flat.clone()
+    for update, who in ((True, 'durf_train_step'), (False, 'durf_loss_backward')):
+        with pytest.raises(ops._lib.DurfError, match=who + ': workspace of'):
+            train_boxpose.train_step_one_call(model, config, 0, state, db, 5e-4, 3.0, 10.0, db['init'][0:1], update=update)
+    torch.cuda.synchronize()
+    assert torch.equal(variables.flat, before), 'refused before the first launch'
+    monkeypatch.setattr(ops, '_workspace', real)
+    _same(model.apply_one_call(*args, **kw), good, 'the right size is accepted')

@@ -92,6 +92,13 @@ def test_library_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), 'libdurf_hip.so does not export %s' % name
     assert declared == set(_lib.symbols()), declared ^ set(_lib.symbols())
+    # ... and nothing else: the dynamic symbol table of the shared object == the header (an exported entry point the header
+    # does not declare is outside the stub, the binding table and this drift test)
+    import subprocess
+    out = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ' T ' in ln and ln.split()[-1].startswith('durf_')}
+    assert exported == declared, 'exported but not declared: %s; declared but not exported: %s' % (
+        sorted(exported - declared), sorted(declared - exported))
     assert L.durf_version() >= 1
     assert L.durf_mlp_param_count(256, 60) == 594308
     assert L.durf_mlp_param_count(128, 63) == 168836
