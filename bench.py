@@ -591,11 +591,13 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
                            # object MLP launches on a side HIP stream (ops.py DURF_OVERLAP_OBJECTS): with '2' the timed
                            # background kernels' durations include what runs beside them
                            object_streams=(ops.overlap_mode(B * NS) if K_OBJ and model.object_precision() == 'bf16' else None),
-                           collective=('%s all-reduce, world size %d%s%s' % (
-                               'gloo' if shared_gpu else 'rccl', world, ' (forced)' if args.force_dist else '',
-                               ', issued in the compute stream by the library (DURF_INSTREAM_ALLREDUCE)'
-                               if train_boxpose._INSTREAM.get('comm') is not None else ''))
-                           if (world > 1 or args.force_dist) else None),
+                           # the data-parallel exchange as it actually ran: the route the init-time self-check chose
+                           # (train_boxpose._instream_comm) and the number of ranks the collective itself saw
+                           # (`ranks_seen`, from the all-reduced self-check vector: sum(rank + 1) = w (w + 1) / 2)
+                           collective=(dict(summary='%s all-reduce, world size %d%s' % (
+                                                'gloo' if shared_gpu else 'rccl', world, ' (forced)' if args.force_dist else ''),
+                                            **train_boxpose.COLLECTIVE_INFO)
+                                       if (world > 1 or args.force_dist) else None)),
                loss=float(stats.loss), psnr=float(stats.psnr), roofline=roof, cpu_baseline=cb,
                # distribution of the individual steps' GPU time: ms_per_step is the mean over the timed region and
                # includes any stall (a step far above the median is the host or the runtime, not the kernels)

@@ -8,6 +8,7 @@
 // librccl in memory: the communicator and the calls must come from ONE copy), then librccl.so.1 / librccl.so.  No link-time
 // dependency: a single-GPU host never needs it, and a missing library is a clear error from durf_comm_init.
 #include <dlfcn.h>
+#include <link.h>
 #include <string.h>
 #include <rccl/rccl.h>
 #include "durf_common.h"
@@ -24,15 +25,42 @@ struct Rccl {
     bool ok;
 };
 
+// how many distinct loaded objects are called like `stem` (libamdhip64 / librccl), and the path of the first
+struct Loaded { const char* stem; int n; char first[512]; };
+int count_loaded(struct dl_phdr_info* info, size_t, void* data) {
+    Loaded* L = (Loaded*)data;
+    const char* base = info->dlpi_name ? strrchr(info->dlpi_name, '/') : nullptr;
+    base = base ? base + 1 : (info->dlpi_name ? info->dlpi_name : "");
+    if (strncmp(base, L->stem, strlen(L->stem)) == 0) {
+        if (L->n == 0) { strncpy(L->first, info->dlpi_name, sizeof(L->first) - 1); L->first[sizeof(L->first) - 1] = 0; }
+        L->n++;
+    }
+    return 0;
+}
+
 const Rccl& rccl() {
     static const Rccl r = [] {
         Rccl x{};
         void* h = RTLD_DEFAULT;
         if (!dlsym(h, "ncclAllReduce")) {
-            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+            // A host that loaded its RCCL privately (Python imports are RTLD_LOCAL: a PyTorch process has librccl in memory but
+            // not in the global scope): take THAT object, by the path it was loaded from -- the communicator, the collective
+            // and the streams they are handed must all belong to the one HIP runtime the process runs on
+            Loaded have{"librccl", 0, ""};
+            dl_iterate_phdr(count_loaded, &have);
+            h = have.n > 0 ? dlopen(have.first, RTLD_NOW | RTLD_NOLOAD) : nullptr;
+            if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);      // (by soname: a copy already loaded under it is returned)
             if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         }
         if (!h && !dlsym(RTLD_DEFAULT, "ncclAllReduce")) return x;
+        // ... and refuse when resolving it brought a SECOND HIP runtime into the process (an RCCL bound to another
+        // libamdhip64 than the host's: its calls would be handed streams of a foreign runtime)
+        Loaded hip{"libamdhip64", 0, ""};
+        dl_iterate_phdr(count_loaded, &hip);
+        if (hip.n > 1) {
+            durf_set_error("durf_comm: %d HIP runtimes are loaded (first: %s): the RCCL found does not share the host's", hip.n, hip.first);
+            return x;
+        }
         x.get_unique_id = (decltype(x.get_unique_id))dlsym(h, "ncclGetUniqueId");
         x.comm_init_rank = (decltype(x.comm_init_rank))dlsym(h, "ncclCommInitRank");
         x.comm_destroy = (decltype(x.comm_destroy))dlsym(h, "ncclCommDestroy");

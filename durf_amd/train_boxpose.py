@@ -59,25 +59,78 @@ def _bucketed():
     return os.environ.get('DURF_BUCKET_ALLREDUCE', '0') != '0'
 
 
-# DURF_INSTREAM_ALLREDUCE=1 (nccl backend): the gradient all-reduce is issued by the library itself IN the compute stream
-# (csrc/comm.hip: its own RCCL communicator, the unique id handed round through torch.distributed's store) instead of by
-# torch.distributed on its communication stream -- no event hop there and back (~22 us of idle GPU per step measured on a
-# world-size-1 group, profiles/r05_rccl_instream.txt), and the same call sequence a host that is not Python gets from
-# durf_train_step(args.comm).  Off by default: torch.distributed's path is the one the multi-GPU tests have exercised.
+# The gradient all-reduce of a multi-rank step (lax.pmean(grad), train_boxpose.py:253-255,370-374) is issued by the library
+# itself IN the compute stream (csrc/comm.hip: its own RCCL communicator, the unique id handed round through
+# torch.distributed's store) instead of by torch.distributed on its communication stream -- no event hop there and back
+# (~22 us of idle GPU per step on a world-size-1 group, profiles/r05_rccl_instream.txt: 3.3 % of cfg5's per-rank step) --
+# and the step then runs as the ONE C call durf_train_step(args.comm), the sequence a host that is not Python gets.
+# Round 6: this is the DEFAULT route of an `nccl` process group, SELF-VERIFIED when the communicator is created: a known
+# vector (rank + 1, and a rank-dependent ramp) is all-reduced through the library's communicator AND through c10d, both are
+# compared with the closed form and with each other, and the ranks agree on the verdict (a MIN all-reduce through c10d): any
+# failure on any rank -> every rank logs once and stays on the c10d route, in the same process.  DURF_INSTREAM_ALLREDUCE=0
+# opts out.  COLLECTIVE_INFO records what happened (bench.py prints it in its JSON line: `collective.route`, `ranks_seen`).
 _INSTREAM = {}
+COLLECTIVE_INFO = {}
+
+
+def _selfcheck_vector(rank, n, dev):
+    return (rank + 1) + torch.arange(n, device=dev, dtype=torch.float32) * (rank + 1) / 1024.0
 
 
 def _instream_comm(dist):
     import os
-    if os.environ.get('DURF_INSTREAM_ALLREDUCE', '0') == '0' or dist.get_backend() != 'nccl' or not ops.comm_available():
+    if 'comm' in _INSTREAM:
+        return _INSTREAM['comm']
+    _INSTREAM['comm'] = None
+    info = COLLECTIVE_INFO
+    info.update(backend=dist.get_backend(), world=dist.get_world_size(), route='torch.distributed (c10d) all-reduce on its own stream')
+    if os.environ.get('DURF_INSTREAM_ALLREDUCE', '1') == '0':
+        info['why'] = 'DURF_INSTREAM_ALLREDUCE=0'
         return None
-    if 'comm' not in _INSTREAM:
+    if dist.get_backend() != 'nccl':
+        info['why'] = 'backend %s: the in-stream route is RCCL only' % dist.get_backend()
+        return None
+    rank, world = dist.get_rank(), dist.get_world_size()
+    dev = torch.device('cuda', torch.cuda.current_device())
+    comm, err = None, None
+    try:
+        if not ops.comm_available():
+            raise RuntimeError('no RCCL resolvable by the library: ' + ops._lib.lib().durf_last_error().decode())
         store = dist.distributed_c10d._get_default_store()
-        rank, world = dist.get_rank(), dist.get_world_size()
         if rank == 0:
             store.set('durf_rccl_unique_id', ops.comm_unique_id())
-        _INSTREAM['comm'] = ops.Comm(world, rank, store.get('durf_rccl_unique_id'))
-    return _INSTREAM['comm']
+        comm = ops.Comm(world, rank, store.get('durf_rccl_unique_id'))
+        n = 4096
+        mine = _selfcheck_vector(rank, n, dev)
+        a, b = mine.clone(), mine.clone()
+        comm.all_reduce_sum(a)                      # the library's communicator, in the compute stream
+        dist.all_reduce(b)                          # c10d
+        want = sum(_selfcheck_vector(r, n, dev).double() for r in range(world))
+        torch.cuda.synchronize()
+        tol = 1e-6 * float(want.abs().max())
+        if not (torch.equal(a, b) or float((a - b).abs().max()) <= tol):
+            raise RuntimeError('the library\'s all-reduce and c10d\'s disagree (max |diff| %g)' % float((a - b).abs().max()))
+        if float((a.double() - want).abs().max()) > tol:
+            raise RuntimeError('the all-reduced self-check vector is not the sum over %d ranks' % world)
+        info['ranks_seen'] = int(round(float(a[0]) * 2.0 / (world + 1))) if world > 0 else 0      # sum(rank + 1) = w (w + 1) / 2
+    except Exception as e:                          # noqa: BLE001 -- whatever went wrong, the c10d route still works
+        err = '%s: %s' % (type(e).__name__, e)
+    ok = torch.tensor([0.0 if err else 1.0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)       # every rank takes the same route
+    if float(ok) < 1.0:
+        info['why'] = err or 'another rank failed the self-check'
+        if comm is not None:
+            try:
+                comm.destroy()
+            except Exception:                       # noqa: BLE001
+                pass
+        if rank == 0 or err:
+            import sys
+            print('durf: in-stream all-reduce not used (%s); staying on torch.distributed' % info['why'], file=sys.stderr)
+        return None
+    info['route'] = 'in-stream RCCL all-reduce issued by libdurf_hip.so (self-verified against c10d at init)'
+    _INSTREAM['comm'] = comm
+    return comm
 
 
 def shutdown_instream():
@@ -86,6 +139,53 @@ def shutdown_instream():
     if c is not None:
         torch.cuda.synchronize()
         c.destroy()
+
+
+def _cpus_near_gpu(local, n_local, avail, sysfs='/sys/class/drm'):
+    """the host cores rank `local` of `n_local` ranks on this node should run on: the cores sysfs lists as local to its GPU
+    (the local_cpulist of the local-th AMD render device by PCI address), shared out among the ranks that list the same
+    cores; without that information an even split of the cores the process may use.  Pure function of its arguments + sysfs."""
+    import os
+    avail = sorted(avail)
+    lists = []
+    try:
+        devs = []
+        for c in sorted(os.listdir(sysfs)):
+            d = os.path.join(sysfs, c, 'device')
+            if not c.startswith('renderD') or not os.path.exists(os.path.join(d, 'vendor')):
+                continue
+            if open(os.path.join(d, 'vendor')).read().strip() != '0x1002':
+                continue
+            devs.append((os.path.basename(os.path.realpath(d)), open(os.path.join(d, 'local_cpulist')).read().strip()))
+        for _, txt in sorted(devs):
+            cpus = set()
+            for part in filter(None, txt.split(',')):
+                lo, _, hi = part.partition('-')
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            lists.append(sorted(cpus & set(avail)))
+    except (OSError, ValueError):
+        lists = []
+    if len(lists) >= n_local and lists[local]:
+        mates = [r for r in range(n_local) if lists[r] == lists[local]]
+        mine = lists[local]
+        k, per = mates.index(local), max(len(mine) // len(mates), 1)
+        return mine[k * per:(k + 1) * per] or mine
+    per = max(len(avail) // max(n_local, 1), 1)
+    return avail[local * per:(local + 1) * per] or avail
+
+
+def pin_host_thread(local, n_local):
+    """os.sched_setaffinity for this rank, before its first GPU call (DURF_PIN_CPUS=0: leave the affinity alone)"""
+    import os
+    if n_local <= 1 or os.environ.get('DURF_PIN_CPUS', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        return None
+    try:
+        cpus = _cpus_near_gpu(local, n_local, os.sched_getaffinity(0))
+        os.sched_setaffinity(0, cpus)
+        COLLECTIVE_INFO['host_cpus'] = '%d-%d (%d)' % (cpus[0], cpus[-1], len(cpus))
+        return cpus
+    except OSError:
+        return None
 
 
 def level_multipliers(config, level, num_levels):
@@ -417,7 +517,7 @@ def train_step(model, config, rng, state, batch, lr, eps, alpha, prev, noise=Non
             comm.all_reduce_sum(out)
         else:
             dist.all_reduce(out)
-        out /= world
+        out *= 1.0 / world                                  # (the C step's k_scale multiplies by the same float)
         ops.train_stats(raw['norms'], raw['sums'], None, None, None, None, [r[4] for r in raw['ret']],
                         _stat_mults(config), ops.STATS_PSNR, out=out)
     for work in pending:
@@ -458,7 +558,7 @@ def one_call_refusal(model, variables, update=True):
         return 'durf_train_step covers the step with a bf16 background MLP (12-Dense tree), dynamic boxes and >= 2 levels'
     if dist is not None and (_instream_comm(dist) is None or not update):
         return ('durf_train_step is data-parallel only through the library\'s own in-stream all-reduce '
-                '(DURF_INSTREAM_ALLREDUCE=1; see csrc/train.hip, csrc/comm.hip)')
+                '(nccl backend, self-check passed, DURF_INSTREAM_ALLREDUCE != 0; see csrc/train.hip, csrc/comm.hip)')
     if bool(K) and not (model.no_pose_opt and model.no_yaw_opt) and model.object_precision() != 'f32':
         # (train_step runs this combination -- obj_precision='bf16' forced under pose optimisation -- on the bf16 object
         # kernels; the C entry point only has the fp32 hit-ray branch behind the pose gradient)
@@ -576,6 +676,8 @@ def init_distributed(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1:               # before anything touches the GPU: this rank's host thread on the cores near its device
+        pin_host_thread(local, int(os.environ.get('LOCAL_WORLD_SIZE', world)))
     if torch.cuda.is_available():
         local = local % max(torch.cuda.device_count(), 1)     # several ranks may share a GPU in tests (gloo)
     if (world > 1 or _force_dist()) and not dist.is_initialized():
@@ -669,6 +771,11 @@ def train_loop(model, config, state, dataset, test_dataset=None, train_dir=None,
     import time
     from . import checkpoints
     step_fn = step_fn or best_step_fn(model, state.variables)       # (the one C call wherever it covers the step)
+    if isinstance(rng, int) and world > 1:
+        # every rank draws its OWN stratified-sampling / resampling / density noise for its own rays, as the reference's keys
+        # differ per device (train_boxpose.py:415 `keys = random.split(rng, jax.local_device_count())`, one per pmap replica):
+        # the rank is the high word of the in-kernel Philox key (ops.split_seed), the step counter stays in the low word
+        rng = (int(rng) & 0xFFFFFFFF) | (int(rank) << 32)
     lr_fn, eps_fn, alpha_fn = make_schedules(config)
     if train_dir is not None:
         state = checkpoints.restore_checkpoint(train_dir, state)                         # :404
@@ -855,6 +962,7 @@ def main(argv=None):
     if world > 1:
         import torch.distributed as dist
         dist.barrier()
+        shutdown_instream()                 # the library's communicator goes before the process group it was built through
         dist.destroy_process_group()
     return history
 

@@ -122,7 +122,10 @@ def _rccl_worker(_i, out_dir, force, bucket, pose_opt, instream=0, one_call=Fals
         os.environ.pop(k, None)
     os.environ['DURF_FORCE_DIST'] = '1' if force else '0'
     os.environ['DURF_BUCKET_ALLREDUCE'] = '1' if bucket else '0'
-    os.environ['DURF_INSTREAM_ALLREDUCE'] = '1' if instream else '0'
+    if instream == 2:       # the DEFAULT: no switch set -- the self-verified in-stream route must be what an nccl group takes
+        os.environ.pop('DURF_INSTREAM_ALLREDUCE', None)
+    else:
+        os.environ['DURF_INSTREAM_ALLREDUCE'] = '1' if instream else '0'
     sys.path.insert(0, ROOT)
     import bench
     from durf_amd import train_boxpose
@@ -136,6 +139,11 @@ def _rccl_worker(_i, out_dir, force, bucket, pose_opt, instream=0, one_call=Fals
     state, losses = wl['state'], []
     rng = 0
     step = train_boxpose.train_step_one_call if one_call else train_boxpose.train_step
+    if instream == 2:       # what bench.py and train_loop run: the fast host path, chosen by the init-time self-check
+        step = train_boxpose.best_step_fn(wl['model'], state.variables)
+        assert step is train_boxpose.train_step_one_call, train_boxpose.COLLECTIVE_INFO
+        info = train_boxpose.COLLECTIVE_INFO
+        assert info['route'].startswith('in-stream RCCL') and info['ranks_seen'] == 1 and info['world'] == 1, info
     for i in range(3):
         state, stats, rng, _ = step(wl['model'], wl['config'], rng, state, wl['batch'], 5e-4, 3.0,
                                     wl['alpha'], wl['prev'], reduce_stats=(i == 2))
@@ -143,6 +151,8 @@ def _rccl_worker(_i, out_dir, force, bucket, pose_opt, instream=0, one_call=Fals
     torch.cuda.synchronize()
     if instream:
         assert train_boxpose._INSTREAM.get('comm') is not None, 'the in-stream communicator was not created'
+    elif force:
+        assert train_boxpose._INSTREAM.get('comm') is None and 'c10d' in train_boxpose.COLLECTIVE_INFO['route']
     torch.save(dict(flat=state.variables.flat.cpu(), m=state.m.cpu(), losses=losses),
                os.path.join(out_dir, 'rccl_%d_%d_%d_%d.pt' % (force, bucket, instream, one_call)))
     if force:
@@ -162,10 +172,11 @@ def test_train_step_through_rccl_world_size_one(cuda, tmp_path, pose_opt):
     communicator from a unique id passed through the store), and with the whole step as ONE C call on that communicator
     (durf_train_step with args.comm: what a host that is not Python would run per rank)."""
     for force, bucket, instream, one_call in ((0, 0, 0, False), (1, 0, 0, False), (1, 1, 0, False), (1, 0, 1, False),
-                                              (1, 0, 1, True)):
+                                              (1, 0, 1, True), (1, 0, 2, False)):
         mp.spawn(_rccl_worker, args=(str(tmp_path), force, bucket, pose_opt, instream, one_call), nprocs=1, join=True)
     base = torch.load(os.path.join(str(tmp_path), 'rccl_0_0_0_0.pt'))
-    for tag in ('rccl_1_0_0_0.pt', 'rccl_1_1_0_0.pt', 'rccl_1_0_1_0.pt', 'rccl_1_0_1_1.pt'):
+    # (rccl_1_0_2_0: round 6's default -- no switch set, the route picked by the self-check at communicator creation)
+    for tag in ('rccl_1_0_0_0.pt', 'rccl_1_1_0_0.pt', 'rccl_1_0_1_0.pt', 'rccl_1_0_1_1.pt', 'rccl_1_0_2_0.pt'):
         got = torch.load(os.path.join(str(tmp_path), tag))
         assert torch.equal(got['flat'], base['flat']) and torch.equal(got['m'], base['m']), tag
         assert got['losses'] == base['losses'], tag
@@ -243,7 +254,9 @@ def test_bench_gpus_2_end_to_end_on_one_gpu(cuda):
     assert out['n_gpus'] == 2 and out['steps'] == 4 and out['warmup'] == 2 and out['scaling'] == 'weak'
     c = out['config']
     assert c['rays_per_gpu'] == 512 and c['global_batch'] == 1024 and c['parallelism'] == 'dp2' and c['name'] == 'cfg3'
-    assert c['collective'] == 'gloo all-reduce, world size 2'
+    col = c['collective']
+    assert col['summary'] == 'gloo all-reduce, world size 2' and col['world'] == 2 and col['backend'] == 'gloo'
+    assert 'c10d' in col['route'] and 'gloo' in col['why']       # the decision path ran and said why it stayed on c10d
     assert out['cpu_baseline'] is None                          # rank 0 at N = 1 only
     assert abs(out['value'] - 1024 * 4 / (out['ms_per_step'] * 4e-3)) <= 1e-6 * out['value']    # whole-job rays / max-over-ranks time
     r = out['roofline']

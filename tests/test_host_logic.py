@@ -249,3 +249,33 @@ def test_argument_structs_match_the_header(tmp_path):
         assert int(got[cname]) == ctypes.sizeof(cls), cname
         for name, _ in cls._fields_:
             assert int(got['%s.%s' % (cname, name)]) == getattr(cls, name).offset, (cname, name)
+
+
+def test_host_thread_pinning_picks_the_cores_near_the_gpu(tmp_path):
+    """train_boxpose._cpus_near_gpu: each rank of a multi-rank run is pinned (os.sched_setaffinity, before its first GPU
+    call) to the cores sysfs lists as local to its GPU, shared out among the ranks that list the same cores; without sysfs
+    information an even split of the cores the process may use"""
+    from durf_amd import train_boxpose as tb
+    avail = set(range(16))
+    # no sysfs: even split
+    assert tb._cpus_near_gpu(0, 2, avail, sysfs=str(tmp_path / 'none')) == list(range(0, 8))
+    assert tb._cpus_near_gpu(1, 2, avail, sysfs=str(tmp_path / 'none')) == list(range(8, 16))
+    assert tb._cpus_near_gpu(3, 4, set(range(8)), sysfs=str(tmp_path / 'none')) == [6, 7]
+    # four AMD render devices, two per NUMA node, and one device of another vendor that must not shift the numbering
+    sysfs = tmp_path / 'drm'
+    for i, (pci, vendor, cpus) in enumerate([('0000:05:00.0', '0x1002', '0-7'), ('0000:15:00.0', '0x1002', '0-7'),
+                                             ('0000:10:00.0', '0x10de', '0-15'), ('0000:85:00.0', '0x1002', '8-15'),
+                                             ('0000:95:00.0', '0x1002', '8-11,12-15')]):
+        real = tmp_path / 'pci' / pci
+        real.mkdir(parents=True)
+        (real / 'vendor').write_text(vendor + '\n')
+        (real / 'local_cpulist').write_text(cpus + '\n')
+        d = sysfs / ('renderD%d' % (128 + i))
+        d.mkdir(parents=True)
+        os.symlink(str(real), str(d / 'device'))
+    got = [tb._cpus_near_gpu(r, 4, avail, sysfs=str(sysfs)) for r in range(4)]
+    assert got == [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]], got
+    # cores outside the process's own affinity mask are never chosen
+    assert tb._cpus_near_gpu(0, 4, {2, 3, 9}, sysfs=str(sysfs)) == [2]
+    # one rank per node: nothing to do
+    assert tb.pin_host_thread(0, 1) is None
