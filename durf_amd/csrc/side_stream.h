@@ -69,6 +69,10 @@ inline void note_prefetch(SideStream* sd, void* dst) {
     sd->pending_trunk = dst;
 }
 
+// DURF_OVERLAP_OBJECTS as the one-call entry points read it: unset / "auto" = by size, "0" = one stream, anything else = "2"
+// (forward, backward and weight gradients of the objects on the side stream).  The Python-issued path's experiment modes "1"
+// (forward only) and "3" (forward + backward) exist there only (ops.overlap_mode): an A/B of those through the C call measures
+// mode 2.  Read per call (the tests toggle it); the host must not call setenv concurrently with a step.
 inline Overlap overlap_for(void* stream, size_t rows, int Kb) {
     Overlap o{(hipStream_t)stream, nullptr};
     const char* e = getenv("DURF_OVERLAP_OBJECTS");

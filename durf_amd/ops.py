@@ -398,7 +398,8 @@ OVERLAP_MIN_ROWS = 2048 * 128
 
 
 def set_overlap_mode(mode):
-    """'auto' / '0' .. '3' for the Python-issued launches AND for the one-call C step (which reads DURF_OVERLAP_OBJECTS per call)"""
+    """'auto' / '0' .. '3' for the Python-issued launches; the one-call C step reads DURF_OVERLAP_OBJECTS per call and knows
+    'auto', '0' and '2' only -- it runs '1' and '3' (experiment modes of this file) as '2' (csrc/side_stream.h)"""
     global _MODE
     _MODE = mode
     os.environ['DURF_OVERLAP_OBJECTS'] = mode
@@ -1314,12 +1315,20 @@ def _workspace(dev, nbytes):
     """the one-call entry points' workspace: ONE buffer per device, kept across calls and grown when a call needs more (a
     fresh torch.empty of several hundred MB per step leaves it to the caching allocator to hand the same block back; when it
     does not, the step stalls on a device allocation -- seen as one 0.5 ms step in ~8 passes of a 0.4 ms workload)"""
-    key = (dev.type, dev.index)
+    # (per device AND per stream: two one-call entry points issued on different streams of one device -- an eval render beside
+    # training, a second model -- must not share intermediates; calls on one stream are ordered and may)
+    key = (dev.type, dev.index, torch.cuda.current_stream(dev).cuda_stream if dev.type == 'cuda' else 0)
     ws = _WORKSPACE.get(key)
     if ws is None or ws.numel() < nbytes:
         _WORKSPACE[key] = ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         assert ws.data_ptr() % 256 == 0
     return ws
+
+
+def release_workspace():
+    """drop the cached workspaces of the one-call entry points (a large render chunk otherwise pins its buffer -- hundreds
+    of MB -- for the life of the process); the next call allocates afresh"""
+    _WORKSPACE.clear()
 
 
 def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_floats, N, num_levels, alpha, enc_flags,

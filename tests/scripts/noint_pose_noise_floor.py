@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """How far the fp32 ORACLE is from the float64 oracle on the box-pose gradient (CPU only, ~1 min):
-    python tools/experiments/noint_pose_noise_floor.py > profiles/r05_noint_pose_noise_floor.txt
+    python tests/scripts/noint_pose_noise_floor.py > profiles/r05_noint_pose_noise_floor.txt
 With disable_integration (obbpose_model.py:163-164) and the full BARF window (alpha = 10) every frequency of the object encoding
 is on and none is damped: sin(2^9 x) enters at full weight, and the pose gradient -- a sum over the box-hit rays that cancels
 to ~1 % of its summed magnitudes -- is then limited by fp32 itself.  This is the reason tests/test_gpu_train.py holds that one

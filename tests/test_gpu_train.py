@@ -227,7 +227,7 @@ def test_box_pose_gradients(cuda, K, alpha, tv, knobs):
     b = synthetic.make_batch(B, K, seed=77 + K, noise_boxes=0.05)
     # un-integrated encodings are undamped (sin(2^deg x) at full weight) and fp32 itself becomes the limit of this gradient:
     # the ORACLE in fp32 is 2-11 % away from the oracle in float64 on these batches (profiles/r05_noint_pose_noise_floor.txt,
-    # tools/experiments/noint_pose_noise_floor.py), against 1e-6 with integration -- so those cases are held to the float64
+    # tests/scripts/noint_pose_noise_floor.py), against 1e-6 with integration -- so those cases are held to the float64
     # oracle at 0.15 (measured <= 0.05)
     undamped = bool(knobs.get('disable_integration'))
     odt, tol = (torch.float64, 0.15) if undamped else (torch.float32, 5e-2)
