@@ -94,6 +94,8 @@ def parse_args():
     ap.add_argument('--force-dist', action='store_true',
                     help='one rank, but through the data-parallel path: a world-size-1 RCCL group (DURF_FORCE_DIST=1), so the '
                          'gradient all-reduce + stream wait run and their per-step cost shows against a plain run')
+    ap.add_argument('--image-call', action='store_true',
+                    help='eval mode: the whole image as ONE C call (durf_render_image: the chunk loop in C)')
     ap.add_argument('--selftest-launch', action='store_true',
                     help='CPU/gloo check of the spawn + rendezvous + shard + all-reduce plumbing (no HIP kernels)')
     return ap.parse_args()
@@ -266,30 +268,41 @@ def selftest_launch(args):
 
 
 def eval_main(args):
+    import torch
+    dev = torch.device('cuda', 0)
+    torch.cuda.set_device(dev)
+    print(json.dumps(run_eval(args, dev, args.config, args.steps, args.warmup, image_call=args.image_call, one_call=args.one_call)))
+
+
+def run_eval(args, dev, cfg_name, steps, warmup, image_call=False, one_call=False):
     """--mode eval: the inference path the reference times at every test render (train_boxpose.py:548-568,
     obbpose_model.py:421-479): render_image over a full 320 x 480 image in chunks of 8192 rays, deterministic sampling.
     A step = one image.  value = rendered rays per second; roofline = the fused background-MLP forward (inference
-    form: no stash), algorithmic FLOPs per launch / live HIP-event time / 2.5 PFLOP/s."""
+    form: no stash), algorithmic FLOPs per launch / live HIP-event time / 2.5 PFLOP/s.
+    image_call: the whole image as ONE C call (durf_render_image: the chunk loop in C, round 6); one_call: one durf_forward per
+    chunk; neither: the Python-issued launches with per-kernel timers."""
     import torch
     from durf_amd import obbpose_model, ops, synthetic, train_boxpose, utils
-    dev = torch.device('cuda', 0)
-    torch.cuda.set_device(dev)
-    w = setup_workload(args.config, dev, rays=args.rays, objects=args.objects)
+    w = setup_workload(cfg_name, dev, rays=args.rays, objects=args.objects)
     config, model, state = w['config'], w['model'], w['state']
     H, W = 320, 480
     b = synthetic.make_batch(H * W, w['K'], seed=7, far=w['far'])
     db = synthetic.device_batch(b, dev)
     rays = utils.namedtuple_map(lambda r: r.reshape(H, W, -1), db['rays'])
-    fn = train_boxpose.make_render_fn(model, config, state.variables, one_call=args.one_call)
-    render = lambda: obbpose_model.render_image(fn, rays, db['init'], db['ext'], b['ts'], 0, w['alpha'], chunk=args.chunk)
-    ops.TIMED_NAMES = {'mlp_fwd_256', 'encode_bkgd', 'composite_fwd', 'forward_call'}
+    fn = train_boxpose.make_render_fn(model, config, state.variables, one_call=one_call)
+    if image_call:
+        render = lambda: model.render_image_one_call(state.variables, rays, db['init'], db['ext'], b['ts'], config.white_bkgd,
+                                                     w['alpha'], chunk=args.chunk)
+    else:
+        render = lambda: obbpose_model.render_image(fn, rays, db['init'], db['ext'], b['ts'], 0, w['alpha'], chunk=args.chunk)
+    ops.TIMED_NAMES = {'mlp_fwd_256', 'encode_bkgd', 'composite_fwd', 'forward_call', 'render_image_call'}
     ops.TIMERS = {}
     prewarm = [torch.cuda.Event(enable_timing=True) for _ in range(args.prewarm_events)]
     for e in prewarm:
         e.record()
     # (the event records on every `every`-th image only: see run_train)
-    every = args.time_every if args.time_every > 0 else max(1, min(8, args.steps // 5))
-    for i in range(max(args.warmup, 2)):
+    every = args.time_every if args.time_every > 0 else max(1, min(8, steps // 5))
+    for i in range(max(warmup, 2)):
         ops.TIMERS_ACTIVE = i % every == 0
         render()
     torch.cuda.synchronize()
@@ -298,7 +311,7 @@ def eval_main(args):
     t0 = time.perf_counter()
     e0.record()
     sampled = 0
-    for i in range(args.steps):
+    for i in range(steps):
         ops.TIMERS_ACTIVE = i % every == 0
         sampled += int(ops.TIMERS_ACTIVE)
         rgb, dist_, acc = render()
@@ -311,20 +324,21 @@ def eval_main(args):
     ops.TIMERS_ACTIVE = True
     NS = w['N']
     nchunks = (H * W + args.chunk - 1) // args.chunk
-    if args.one_call:                                    # the kernels are launched from C: only the whole call is timed
-        n, sec = totals['forward_call']
+    if image_call or one_call:                           # the kernels are launched from C: only the whole call is timed
+        n, sec = totals['render_image_call' if image_call else 'forward_call']
         fl = N_LEVELS * 2.0 * MAC_BKGD * H * W * NS
-        out = dict(metric='eval_rays_per_sec', value=H * W * args.steps / dt, unit='rays/s', n_gpus=1, steps=args.steps,
-                   warmup=max(args.warmup, 2), ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
+        out = dict(metric='eval_rays_per_sec', value=H * W * steps / dt, unit='rays/s', n_gpus=1, steps=steps,
+                   warmup=max(warmup, 2), ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling='weak',
                    vs_baseline=None, dtype='bf16', data='synthetic',
-                   config=dict(workload=w['label'] + ', render_image, every chunk of %d rays ONE durf_forward call' % args.chunk,
-                               name=args.config, mode='eval', one_call=True, image=[H, W], chunk=args.chunk, num_samples=NS,
-                               objects=w['K']),
-                   roofline=dict(bound='mfma', kernel='durf_forward (whole chunk)', achieved=fl / (sec / sampled) / 1e12,
+                   config=dict(workload=w['label'] + (', render_image of one %dx%d image as ONE durf_render_image call (chunks of %d rays in C)' % (H, W, args.chunk)
+                                                      if image_call else ', render_image, every chunk of %d rays ONE durf_forward call' % args.chunk),
+                               name=cfg_name, mode='eval', one_call=not image_call, image_call=image_call, image=[H, W], chunk=args.chunk,
+                               num_samples=NS, objects=w['K']),
+                   roofline=dict(bound='mfma', kernel='durf_render_image (whole image)' if image_call else 'durf_forward (whole chunk)',
+                                 achieved=fl / (sec / sampled) / 1e12,
                                  peak=PEAK_BF16 / 1e12, unit='TFLOP/s', frac=fl / (sec / sampled) / PEAK_BF16, traffic=None,
                                  launch_us=sec / n * 1e6), cpu_baseline=None)
-        print(json.dumps(out))
-        return
+        return out
     n, sec = totals['mlp_fwd_256']
     rows = H * W * NS                                    # per level, all chunks of one image
     per_image = sec / sampled                         # the background forward of both levels, all chunks
@@ -332,22 +346,22 @@ def eval_main(args):
     busy = sum(s_ for _, s_ in totals.values()) / sampled
     roof = dict(bound='mfma', kernel='mlp_fwd_256 (inference)', achieved=fl / per_image / 1e12, peak=PEAK_BF16 / 1e12,
                 unit='TFLOP/s', frac=fl / per_image / PEAK_BF16, traffic=None, launch_us=sec / n * 1e6,
-                launches_per_image=n // sampled, timed_images='%d of %d (every %d)' % (sampled, args.steps, every),
+                launches_per_image=n // sampled, timed_images='%d of %d (every %d)' % (sampled, steps, every),
                 timed_kernels_ms_per_image={k: v[1] / sampled * 1e3 for k, v in totals.items()},
                 # GPU time of an image outside the three timed kernels (object MLPs, per-ray launches, idle gaps)
-                other_ms_per_image=(e0.elapsed_time(e1) / args.steps) - busy * 1e3)
-    out = dict(metric='eval_rays_per_sec', value=H * W * args.steps / dt, unit='rays/s', n_gpus=1, steps=args.steps,
-               warmup=max(args.warmup, 2), ms_per_step=dt / args.steps * 1e3, higher_is_better=True, scaling='weak',
+                other_ms_per_image=(e0.elapsed_time(e1) / steps) - busy * 1e3)
+    out = dict(metric='eval_rays_per_sec', value=H * W * steps / dt, unit='rays/s', n_gpus=1, steps=steps,
+               warmup=max(warmup, 2), ms_per_step=dt / steps * 1e3, higher_is_better=True, scaling='weak',
                vs_baseline=None, dtype='bf16', data='synthetic',
                config=dict(workload=w['label'] + ', render_image of one %dx%d image (%d rays) in %d chunks of %d, %d samples/ray '
                                                  'x 2 levels, deterministic sampling' % (H, W, H * W, nchunks, args.chunk, NS),
-                           name=args.config, mode='eval', image=[H, W], chunk=args.chunk, num_samples=NS, objects=w['K'],
+                           name=cfg_name, mode='eval', image=[H, W], chunk=args.chunk, num_samples=NS, objects=w['K'],
                            hit_fraction=float(b['hit_fraction'])),
                roofline=roof, cpu_baseline=None,
                # (pixels of rays that hit two boxes are non-finite, as in the reference: obbpose_model.py:120-122)
                checksum=dict(rgb_mean=float(torch.nanmean(rgb)), acc_mean=float(torch.nanmean(acc)),
                              nonfinite_pixels=int((~torch.isfinite(rgb).all(-1)).sum())))
-    print(json.dumps(out))
+    return out
 
 
 def flush_c_stdio():
@@ -692,6 +706,13 @@ def main():
                 extra[name] = summarize_workload(o)
             except Exception as e:                       # the headline stands whatever happens to a side pass
                 extra[name] = dict(error='%s: %s' % (type(e).__name__, e))
+        try:        # the inference path (render_image, obbpose_model.py:421-479): one 320 x 480 image per step, one C call per image
+            o = run_eval(args, dev, 'cfg3', 20, 3, image_call=True)
+            extra['eval'] = dict(rays_per_s=o['value'], ms_per_step=o['ms_per_step'], steps=o['steps'], metric=o['metric'],
+                                 image=o['config']['image'], chunk=o['config']['chunk'], host_path=o['roofline']['kernel'],
+                                 frac=o['roofline']['frac'], bound='mfma', dtype=o['dtype'])
+        except Exception as e:
+            extra['eval'] = dict(error='%s: %s' % (type(e).__name__, e))
         out['workloads'] = extra
     if dist.is_initialized():
         dist.barrier()

@@ -17,7 +17,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define DURF_WAVE 64
 
 void durf_set_error(const char* fmt, ...);
-namespace durf { void note_dispatch(unsigned bits); }      // durf_dispatch_seen() (include/durf_hip.h, csrc/api.hip)
+namespace durf {
+void note_dispatch(unsigned bits);       // durf_dispatch_seen() (include/durf_hip.h, csrc/api.hip)
+int* next_ticket();                      // a zeroed device int for one mixed launch (csrc/api.hip); nullptr: none to be had
+}
 
 #define DURF_CHECK_LAUNCH(name)                                              \
     do {                                                                     \
@@ -142,6 +145,29 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
     }
 }
 
+// A by-value kernel argument read from the kernarg segment where it is needed -- dword by dword through a constant-address-
+// space pointer, i.e. scalar loads -- instead of at kernel entry (the mixed launches: their object arguments must not live in
+// scalar registers across the background loop)
+template <class T>
+__device__ __forceinline__ void load_kernarg(T& dst, const __attribute__((address_space(4))) char* src) {
+    static_assert(sizeof(T) % 4 == 0, "whole dwords");
+    unsigned* d = (unsigned*)&dst;
+    const __attribute__((address_space(4))) unsigned* s = (const __attribute__((address_space(4))) unsigned*)src;
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(T) / 4); i++) d[i] = s[i];
+}
+
+// A device-memory pointer the compiler cannot trace to a kernel argument (read from the kernarg segment by hand, or a field of
+// a struct passed to a real call) is GENERIC to it, and flat loads / stores count on lgkmcnt as well as vmcnt: every ms_barrier
+// would wait for the stores in flight.  Told that it is neither an LDS nor a scratch address, the compiler emits global accesses.
+template <class T>
+__device__ __forceinline__ T* as_global(T* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_assume(!__builtin_amdgcn_is_shared((const void*)p) && !__builtin_amdgcn_is_private((const void*)p));
+#endif
+    return p;
+}
+
 // Workgroup barrier of the M-split kernels: this wave's LDS writes have landed (lgkmcnt), then the raw barrier.  __syncthreads()
 // also waits for vmcnt(0) -- every global store and every prefetched weight load the wave has in flight -- which made each of
 // the 11-13 stages of a tile pay a full HBM round trip (k_mlp_fwd_ms 46 -> 2x us at K = 8).  Nothing the other waves read
@@ -154,7 +180,10 @@ __device__ __forceinline__ void ms_barrier() {
 // 16-byte store of a streamed-once tensor (activation stash, dz): non-temporal, so the stream does
 // not compete with the packed weights for L2 (measured on the fused forward / backward: nt 784 / 643 us,
 // plain 826 / 700, sc1 816 / 747, sc0 sc1 807 / 745)
-#define STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (bf16x8*)(ptr))
+// (an explicitly GLOBAL pointer: a generic one the compiler cannot trace to a kernel argument would make it a flat store,
+// which counts on lgkmcnt too -- see as_global)
+#define DURF_G(T) __attribute__((address_space(1))) T
+#define STREAM_STORE(ptr, val) __builtin_nontemporal_store((val), (DURF_G(bf16x8)*)(ptr))
 
 // ---- batched (per-object) launches ---------------------------------------------------------
 // The K object MLPs use [K, ...] slabs with uniform strides (include/durf_hip.h, durf_obj_*): the

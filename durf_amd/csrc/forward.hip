@@ -59,7 +59,7 @@ extern "C" {
 
 size_t durf_forward_workspace_bytes(int B, int N, int K) { return carve(nullptr, B, N, K).total; }
 
-int durf_forward(void* stream, const durf_forward_args* a, void* workspace, size_t workspace_bytes) {
+static int check_forward_args(const durf_forward_args* a, void* workspace) {
     DURF_REQUIRE(a != nullptr && workspace != nullptr, "arguments and workspace");
     const int B = a->B, N = a->N, K = a->K, L = a->num_levels;
     DURF_REQUIRE(B > 0 && N % 32 == 0 && N >= 32 && N <= 256, "B > 0, num_samples a multiple of 32 in [32, 256]");
@@ -69,11 +69,12 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace, size
     DURF_REQUIRE(!a->draw_noise || (a->t_rand == nullptr && a->u_rand == nullptr), "draw_noise: the library makes the draws");
     for (int l = 0; l < L && a->density_noise != 0.0f; l++)
         DURF_REQUIRE(a->density_rand[l] != nullptr || a->draw_noise, "density_noise: density_rand[level] or draw_noise");
-    const FwdWs w = carve(workspace, B, N, K);
-    if (workspace_bytes < w.total) {
-        durf_set_error("durf_forward: workspace of %zu bytes, durf_forward_workspace_bytes(%d, %d, %d) = %zu", workspace_bytes, B, N, K, w.total);
-        return -1;
-    }
+    return 0;
+}
+
+// the launches of one chunk (arguments checked, workspace carved by the caller)
+static int forward_launches(void* stream, const durf_forward_args* a, const FwdWs& w) {
+    const int B = a->B, N = a->N, K = a->K, L = a->num_levels;
     const size_t rows = (size_t)B * N;
     int rc;
 #define STEP(call) do { rc = (call); if (rc != 0) return rc; } while (0)
@@ -117,6 +118,81 @@ int durf_forward(void* stream, const durf_forward_args* a, void* workspace, size
             STEP(durf_resample(stream, B, N, t_vals, a->weights[lvl], a->resample_padding, a->draw_noise ? w.u_rand : a->u_rand, a->t_vals[lvl + 1]));
     }
 #undef STEP
+    return 0;
+}
+
+int durf_forward(void* stream, const durf_forward_args* a, void* workspace, size_t workspace_bytes) {
+    int rc = check_forward_args(a, workspace);
+    if (rc != 0) return rc;
+    const FwdWs w = carve(workspace, a->B, a->N, a->K);
+    if (workspace_bytes < w.total) {
+        durf_set_error("durf_forward: workspace of %zu bytes, durf_forward_workspace_bytes(%d, %d, %d) = %zu", workspace_bytes, a->B, a->N,
+                       a->K, w.total);
+        return -1;
+    }
+    return forward_launches(stream, a, w);
+}
+
+// ---- one C call per IMAGE (obbpose_model.py:421-479 render_image on one device) --------------------------------------
+// The reference walks the image in chunks from Python, one pmapped call and one host round trip per chunk; here the chunk
+// loop is this function: the rays of the whole image stay where they are on the device, every chunk runs durf_forward's
+// launch sequence on slices of them, the levels' per-chunk outputs live in the workspace, and the LAST level's rgb /
+// distance / acc land in the image planes in place -- what render_image returns (:476-479).
+namespace {
+struct ImgWs { FwdWs f; float *rgb[DURF_FORWARD_MAX_LEVELS], *depth[DURF_FORWARD_MAX_LEVELS], *acc[DURF_FORWARD_MAX_LEVELS],
+               *weights[DURF_FORWARD_MAX_LEVELS], *t_vals[DURF_FORWARD_MAX_LEVELS], *t_mids[DURF_FORWARD_MAX_LEVELS],
+               *t_dists[DURF_FORWARD_MAX_LEVELS], *zo; int32_t* dyn; size_t total; };
+ImgWs carve_image(void* workspace, int chunk, int N, int K, int L) {
+    ImgWs w{};
+    w.f = carve(workspace, chunk, N, K);
+    Carver c{(char*)workspace, w.f.total};
+    for (int l = 0; l < L; l++) {
+        w.rgb[l] = (float*)c.take((size_t)chunk * 3 * 4); w.depth[l] = (float*)c.take((size_t)chunk * 4);
+        w.acc[l] = (float*)c.take((size_t)chunk * 4); w.weights[l] = (float*)c.take((size_t)chunk * N * 4);
+        w.t_vals[l] = (float*)c.take((size_t)chunk * (N + 1) * 4); w.t_mids[l] = (float*)c.take((size_t)chunk * N * 4);
+        w.t_dists[l] = (float*)c.take((size_t)chunk * N * 4);
+    }
+    w.zo = (float*)c.take((size_t)chunk * 4);
+    w.dyn = (int32_t*)c.take((size_t)chunk * 4);
+    w.total = (c.off + 255) & ~(size_t)255;
+    return w;
+}
+}  // namespace
+
+size_t durf_render_image_workspace_bytes(int chunk, int N, int K, int num_levels) {
+    return carve_image(nullptr, chunk, N, K, num_levels).total;
+}
+
+int durf_render_image(void* stream, const durf_forward_args* a, size_t n_rays, int chunk, float* rgb, float* distance, float* acc,
+                      void* workspace, size_t workspace_bytes) {
+    DURF_REQUIRE(a != nullptr && rgb && distance && acc, "arguments and the three image planes");
+    DURF_REQUIRE(chunk > 0 && n_rays > 0, "chunk > 0, n_rays > 0");
+    DURF_REQUIRE(a->t_rand == nullptr && a->u_rand == nullptr && !a->draw_noise && a->density_noise == 0.0f,
+                 "render_image is test mode: randomized = False (obbpose_model.py:421-479)");
+    const int L = a->num_levels;
+    DURF_REQUIRE(L >= 1 && L <= DURF_FORWARD_MAX_LEVELS, "1 <= num_levels <= DURF_FORWARD_MAX_LEVELS");
+    const ImgWs w = carve_image(workspace, chunk, a->N, a->K, L);
+    if (workspace_bytes < w.total) {
+        durf_set_error("durf_render_image: workspace of %zu bytes, durf_render_image_workspace_bytes(%d, %d, %d, %d) = %zu",
+                       workspace_bytes, chunk, a->N, a->K, L, w.total);
+        return -1;
+    }
+    for (size_t i = 0; i < n_rays; i += (size_t)chunk) {
+        durf_forward_args c = *a;
+        c.B = (int)(n_rays - i < (size_t)chunk ? n_rays - i : (size_t)chunk);        // (the last chunk is the remainder, :451-453)
+        c.origins = a->origins + i * 3; c.directions = a->directions + i * 3; c.viewdirs = a->viewdirs + i * 3;
+        c.radii = a->radii + i; c.near = a->near + i; c.far = a->far + i;
+        for (int l = 0; l < L; l++) {
+            const bool last = l == L - 1;
+            c.rgb[l] = last ? rgb + i * 3 : w.rgb[l]; c.depth[l] = last ? distance + i : w.depth[l]; c.acc[l] = last ? acc + i : w.acc[l];
+            c.weights[l] = w.weights[l]; c.t_vals[l] = w.t_vals[l]; c.t_mids[l] = w.t_mids[l]; c.t_dists[l] = w.t_dists[l];
+        }
+        c.zo = w.zo; c.dyn_mask = w.dyn;
+        int rc = check_forward_args(&c, workspace);
+        if (rc != 0) return rc;
+        rc = forward_launches(stream, &c, w.f);
+        if (rc != 0) return rc;
+    }
     return 0;
 }
 

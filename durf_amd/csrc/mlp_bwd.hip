@@ -12,6 +12,7 @@
 //      workgroups with fp32 partials, summed in a fixed order by k_dw_finalize
 //      (deterministic; no atomics).  HBM-bound: 1 KB read per sample per 256x256 layer.
 #include <stdlib.h>
+#include <cstddef>
 #include "mlp_pack.h"
 
 
@@ -172,13 +173,299 @@ __device__ __forceinline__ void run_enc_stage(BPipe& p, const bf16x8* in, f32x16
     }
 }
 
-template <int W, bool POSE, int NWV = 8>
+// ---------------------------------------------------------------------------
+// M-split backward for the object MLPs (W = 128): the counterpart of k_mlp_fwd_ms (mlp_fwd.hip).  A workgroup is 4 waves x
+// 64 samples; wave w owns input-feature tile w of every stage, gradients are exchanged through LDS as the next stage's B
+// fragments, the transposed weight tiles come straight from L2, one barrier per stage.  Same MFMA instruction, operands and
+// k order per output as k_mlp_bwd<128, false>: dz / dz_out are BIT-identical.  (The box-pose variant -- d(enc) -- stays on
+// k_mlp_bwd<128, true>.)
+// ---------------------------------------------------------------------------
+namespace msb {
+using S = MlpSpec<128>;
+using B_ = BwdSpec<128>;
+constexpr int NT = 2;
+constexpr int X_BYTES = NT * S::KW * 1024;
+constexpr int OFF_X = 0;                               // two gradient fragment buffers [tile][k-step][lane][16 B]
+constexpr int OFF_G = 2 * X_BYTES;                     // head-gradient fragments [tile][2: rgb, density][lane][16 B]
+constexpr int LDS_BYTES = OFF_G + NT * 2 * 1024;
+}  // namespace msb
+
+// the per-level operands of one launch over SEVERAL levels (durf_obj_bwd_batch_levels: every level's d(raw) exists before the
+// first backward launch -- stop_level_grad -- so the object backward of a step is ONE latency-bound round instead of one per level)
+struct MsBwdLevels {
+    const float* draw[DURF_MAX_LEVELS];
+    const uint4* relu_mask[DURF_MAX_LEVELS];
+    bf16x8* dz[DURF_MAX_LEVELS];
+    bf16x8* dz_out[DURF_MAX_LEVELS];
+    int n;
+};
+
+// arguments of the M-split object backward (k_mlp_bwd_ms; the object items of the mixed launch k_mlp_bwd<.., MIX>)
+struct MsBwd {
+    size_t rows; int N; MsBwdLevels lv; const int32_t* ray_idx; const int32_t* count; const char* wpack; BwdStrides bs; int nobj;
+    int* ticket;         // mixed launch only (durf::next_ticket)
+};
+__device__ __forceinline__ size_t msb_pairs_of(const MsBwd& A, int k) {
+    const size_t c = (size_t)as_global(A.count)[k] * (size_t)A.N;
+    return ((c < A.rows ? c : A.rows) + 32 * msb::NT - 1) / (32 * msb::NT);
+}
+// item -> (level, object, pair) -- level-major: the items of one level are consecutive; false when item >= total * levels
+__device__ __forceinline__ bool msb_item(const MsBwd& A, size_t total, size_t item, int& level_out, size_t& k_out, size_t& pair_out) {
+    const bool ok = total > 0 && item < total * (size_t)A.lv.n;
+    const size_t it = ok ? item : 0;
+    const int level = total ? (int)(it / total) : 0;
+    size_t k = 0, pair = it - (size_t)level * total;
+    for (; k + 1 < (size_t)A.nobj; k++) {
+        const size_t np = msb_pairs_of(A, (int)k);
+        if (pair < np) break;
+        pair -= np;
+    }
+    level_out = __builtin_amdgcn_readfirstlane(level);
+    k_out = (size_t)__builtin_amdgcn_readfirstlane((unsigned)k);
+    pair_out = pair;
+    return ok;
+}
+
+// One (level, object, tile pair) item on FOUR waves and msb::LDS_BYTES of LDS at `smem` (every barrier inside is the workgroup's)
+// (the level's operands are resolved by the caller: draw [B*N,4], relu_mask / dz / dz_out [K, ...] slabs of that level)
+__device__ __forceinline__ void msb_bwd_pair(const MsBwd& A, const float* __restrict__ draw, const uint4* relu_mask_g, bf16x8* dz_g,
+                                             bf16x8* dz_out_g, char* smem, int lane, int wave, bool live, size_t k, size_t pair) {
+    using S = msb::S;
+    using BS = msb::B_;
+    constexpr int NT = msb::NT;
+    const int n = lane & 31;
+    const size_t ntile32 = A.rows >> 5;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    char* const X0 = smem + msb::OFF_X;
+    char* const G = smem + msb::OFF_G;
+    const size_t rows = A.rows;
+    const int N = A.N;
+    draw = as_global(draw);
+    const int32_t* __restrict__ ray_idx = as_global(A.ray_idx + k * A.bs.idx);
+    const char* __restrict__ wpack = A.wpack + k * A.bs.wpack;
+    const uint4* __restrict__ relu_mask = as_global((const uint4*)((const char*)relu_mask_g + k * A.bs.mask));
+    bf16x8* __restrict__ dz = as_global((bf16x8*)((char*)dz_g + k * A.bs.dz));
+    bf16x8* __restrict__ dz_out = as_global((bf16x8*)((char*)dz_out_g + k * A.bs.dz_out));
+    const size_t c = (size_t)as_global(A.count)[k] * (size_t)N;
+    const size_t nrows = c < rows ? c : rows;
+    const size_t t32[NT] = {pair * NT, pair * NT + 1};
+    // (live == false: the other group of a mixed workgroup still has an item -- same stages on zeros, every global access off)
+    const bool tv[NT] = {live, live && t32[1] * 32 < nrows};
+    ms_barrier();
+    // head gradients (fp32 [*,4]: d raw_rgb[3], d raw_density), gathered by ray: waves 0 / 1 build tile 0 / 1's fragments
+    if (wave < NT) {
+        const int t = wave;
+        f32x4 dr = {0.f, 0.f, 0.f, 0.f};
+        if (tv[t] && lane < 32) {
+            const size_t row = t32[t] * 32 + n;
+            const size_t src = (size_t)ray_idx[row / (size_t)N] * (size_t)N + row % (size_t)N;
+            dr = *(const f32x4*)(draw + src * 4);
+        }
+        bf16x8 g10 = zero8, gd = zero8, gout = zero8;
+        if (lane < 32) {
+            g10[0] = (__bf16)dr[0]; g10[1] = (__bf16)dr[1]; g10[2] = (__bf16)dr[2];
+            gd[0] = (__bf16)dr[3];
+            gout = g10; gout[3] = gd[0];
+        }
+        *(bf16x8*)(G + (t * 2 + 0) * 1024 + lane * 16) = g10;
+        *(bf16x8*)(G + (t * 2 + 1) * 1024 + lane * 16) = gd;
+        if (tv[t]) *(DURF_G(bf16x8)*)(dz_out + t32[t] * 64 + lane) = gout;         // [rows,16] tile: slots 0-2 rgb, 3 density
+    }
+    f32x16 acc[NT];
+    // Weights of (backward stage b, this wave's tile): requested ONE STAGE AHEAD into one of two alternating register sets
+    struct WSet { bf16x8 A[S::KW + 1]; };
+    auto load_w = [&](auto b_, WSet& w) {
+        constexpr int b = decltype(b_)::value, T = BS::n_ks(b);
+        typedef const __attribute__((address_space(1))) char* gptr_t;        // (global by type: see k_mlp_fwd_ms)
+        gptr_t wt = (gptr_t)(wpack + (size_t)(BS::chunk_base(b) + wave * T) * 1024);
+        asm volatile("" : "+s"(wt));               // (see k_mlp_fwd_ms: keeps later stages' weight loads below the barriers)
+#pragma unroll
+        for (int k = 0; k < T; k++) w.A[k] = *(const __attribute__((address_space(1))) bf16x8*)(wt + k * 1024 + lane * 16);
+    };
+    // this wave's tile of backward stage b: NX k-steps from Xin, then NG head-gradient fragments (g: 0 rgb, 1 density)
+    unsigned mword[NT] = {0u, 0u};                 // this stage's ReLU flags (requested before its MFMAs, used in its epilogue)
+    auto load_mask = [&](int jm) {
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+            mword[t] = tv[t] ? ((const unsigned*)((const char*)relu_mask + ((size_t)jm * ntile32 + t32[t]) * 1024 + lane * 16))[wave >> 1] : 0u;
+    };
+    auto stage_mma = [&](auto b_, const WSet& w, auto nx_, auto ng_, int g, const char* Xin) {
+        constexpr int b = decltype(b_)::value, NX = decltype(nx_)::value, NG = decltype(ng_)::value, T = NX + NG;
+        static_assert(T == BS::n_ks(b), "k-steps of the backward stage");
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < T; k++) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const char* src = k < NX ? Xin + (t * S::KW + k) * 1024 : G + (t * 2 + g) * 1024;
+                const bf16x8 bv = *(const bf16x8*)(src + lane * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], bv, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    // mask with the forward's ReLU flags of stash region jm (this wave's tile: word wave / 2, parity wave % 2), hand the
+    // fragments over, store dz region jd (jd < 0: not stored -- the linear bottleneck's gradient)
+    auto hand_over = [&](auto mask_, int /*jm*/, int jd, char* Xout) {
+        constexpr bool MASK = decltype(mask_)::value;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const unsigned word = MASK ? mword[t] : 0u;
+            bf16x8 o0, o1;
+            if (wave & 1) bpack_tile<MASK>(acc[t], word, 1, o0, o1);
+            else bpack_tile<MASK>(acc[t], word, 0, o0, o1);
+            *(bf16x8*)(Xout + (t * S::KW + 2 * wave) * 1024 + lane * 16) = o0;
+            *(bf16x8*)(Xout + (t * S::KW + 2 * wave + 1) * 1024 + lane * 16) = o1;
+            if (jd >= 0 && tv[t]) {
+                char* dd = (char*)dz + ((size_t)S::stash_ks_before(jd) * ntile32 + t32[t] * S::stash_ks(jd)) * 1024;
+                STREAM_STORE(dd + (2 * wave) * 1024 + lane * 16, o0);
+                STREAM_STORE(dd + (2 * wave + 1) * 1024 + lane * 16, o1);
+            }
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using IW = std::integral_constant<int, S::KW>;
+    char* Xa = X0;
+    char* Xb = X0 + msb::X_BYTES;
+    WSet w0, w1;
+    load_w(std::integral_constant<int, 0>{}, w0);
+    ms_barrier();                               // head-gradient fragments in place
+    // bwd of stage 10 (rgb head): d rgb -> d A9, masked by A9 (mask region 8) -> dz region 9
+    load_w(std::integral_constant<int, 1>{}, w1);
+    load_mask(8);
+    stage_mma(std::integral_constant<int, 0>{}, w0, I0{}, I1{}, 0, Xa);
+    hand_over(std::true_type{}, 8, 9, Xa);
+    ms_barrier();
+    // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear; not stored)
+    load_w(std::integral_constant<int, 2>{}, w0);
+    stage_mma(std::integral_constant<int, 1>{}, w1, std::integral_constant<int, S::KC>{}, I0{}, 0, Xa);
+    hand_over(std::false_type{}, 0, -1, Xb);
+    ms_barrier();
+    // bwd of stage 8 (bottleneck + density head): -> d A7 (mask region 7, dz region 7)
+    load_w(std::integral_constant<int, 3>{}, w1);
+    load_mask(7);
+    stage_mma(std::integral_constant<int, 2>{}, w0, IW{}, I1{}, 1, Xb);
+    hand_over(std::true_type{}, 7, 7, Xa);
+    ms_barrier();
+    // bwd of stages 7, 6, 5 (trunk rows) -> d Z6, d Z5, d Z4
+    load_w(std::integral_constant<int, 4>{}, w0);
+    load_mask(6);
+    stage_mma(std::integral_constant<int, 3>{}, w1, IW{}, I0{}, 0, Xa);
+    hand_over(std::true_type{}, 6, 6, Xb);
+    ms_barrier();
+    load_w(std::integral_constant<int, 5>{}, w1);
+    load_mask(5);
+    stage_mma(std::integral_constant<int, 4>{}, w0, IW{}, I0{}, 0, Xb);
+    hand_over(std::true_type{}, 5, 5, Xa);
+    ms_barrier();
+    load_w(std::integral_constant<int, 7>{}, w0);
+    load_mask(4);
+    stage_mma(std::integral_constant<int, 5>{}, w1, IW{}, I0{}, 0, Xa);
+    hand_over(std::true_type{}, 4, 4, Xb);
+    ms_barrier();
+    // bwd of stages 4..1 -> d Z3 .. d Z0
+    load_w(std::integral_constant<int, 8>{}, w1);
+    load_mask(3);
+    stage_mma(std::integral_constant<int, 7>{}, w0, IW{}, I0{}, 0, Xb);
+    hand_over(std::true_type{}, 3, 3, Xa);
+    ms_barrier();
+    load_w(std::integral_constant<int, 9>{}, w0);
+    load_mask(2);
+    stage_mma(std::integral_constant<int, 8>{}, w1, IW{}, I0{}, 0, Xa);
+    hand_over(std::true_type{}, 2, 2, Xb);
+    ms_barrier();
+    load_w(std::integral_constant<int, 10>{}, w1);
+    load_mask(1);
+    stage_mma(std::integral_constant<int, 9>{}, w0, IW{}, I0{}, 0, Xb);
+    hand_over(std::true_type{}, 1, 1, Xa);
+    ms_barrier();
+    load_mask(0);
+    stage_mma(std::integral_constant<int, 10>{}, w1, IW{}, I0{}, 0, Xa);
+    hand_over(std::true_type{}, 0, 0, Xb);
+}
+
+__global__ void __launch_bounds__(256)
+k_mlp_bwd_ms(MsBwd A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // (object, pair) items dealt to a 1-D grid by the device-side hit counts: see k_mlp_fwd_ms
+    size_t total = 0;
+    for (int k = 0; k < A.nobj; k++) total += msb_pairs_of(A, k);
+    for (size_t item = blockIdx.x; item < total * (size_t)A.lv.n; item += gridDim.x) {
+        int level; size_t k, pair;
+        msb_item(A, total, item, level, k, pair);
+        msb_bwd_pair(A, A.lv.draw[level], A.lv.relu_mask[level], A.lv.dz[level], A.lv.dz_out[level], smem, lane, wave, true, k, pair);
+    }
+}
+
+// (the kernel's explicit arguments as the kernarg segment lays them out; see FwdKernArgs in mlp_fwd.hip)
+struct BwdKernArgs {
+    size_t rows; int N; const float* draw; const int32_t* ray_idx; const int32_t* count; const char* wpack; const uint4* relu_mask;
+    bf16x8* dz; bf16x8* dz_out; float* d_enc; BwdStrides bs; const int32_t* tail_idx; const int32_t* tail_count;
+    const float* draw_ray_sum; MsBwd ow;
+};
+// The object phase of a mixed backward workgroup (k_mlp_bwd<.., MIX>): two groups of four waves take (level, object, tile
+// pair) items off the ticket counter.  Not inlined, arguments from the kernarg segment: see mix_object_items in mlp_fwd.hip.
+__device__ __attribute__((noinline)) void mix_object_items_bwd(unsigned smem_lds, int wave_v, int nwg_v, unsigned ka_lo, unsigned ka_hi) {
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v), nwg = __builtin_amdgcn_readfirstlane(nwg_v);
+    char* const smem = (char*)(__attribute__((address_space(3))) char*)(size_t)__builtin_amdgcn_readfirstlane(smem_lds);
+    typedef const __attribute__((address_space(4))) char* kptr_t;
+    // (the kernarg segment pointer comes from the KERNEL: in a callee __builtin_amdgcn_kernarg_segment_ptr() is lowered to null)
+    kptr_t ka = (kptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_hi) << 32) |
+                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_lo));
+    MsBwd ow;
+    load_kernarg(ow, ka + offsetof(BwdKernArgs, ow));
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool first = wave == 0 && lane == 0;
+    const int half = wave >> 2, w4 = wave & 3;
+    char* const lds = smem + half * msb::LDS_BYTES;
+    volatile __attribute__((address_space(3))) int* const tk =
+        (volatile __attribute__((address_space(3))) int*)(size_t)(__builtin_amdgcn_readfirstlane(smem_lds) + 2u * msb::LDS_BYTES);
+    size_t total = 0;
+    for (int k = 0; k < ow.nobj; k++) total += msb_pairs_of(ow, k);
+    const size_t items = total * (size_t)ow.lv.n;
+    const int last = 2 * (int)((items + 1) / 2 + nwg - 1);            // the value the LAST request of the launch returns
+    int t = 0;
+    // (a GLOBAL atomic: a flat one counts on lgkmcnt, and the first barrier of the item would wait for the request under way)
+    DURF_G(int)* const ticket = (DURF_G(int)*)ow.ticket;
+    if (first) { t = __hip_atomic_fetch_add(ticket, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *tk = t; }
+    ms_barrier();
+    t = __builtin_amdgcn_readfirstlane(*tk);
+    while ((size_t)t < items) {
+        int tn = 0;
+        if (first) tn = __hip_atomic_fetch_add(ticket, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next request is under way while this item runs
+        int level; size_t k, pair;
+        const bool live = msb_item(ow, total, (size_t)t + (size_t)half, level, k, pair);
+        // (this level's operands straight from the kernarg segment: a dynamically indexed copy would live in scratch)
+        const __attribute__((address_space(4))) MsBwd* kp = (const __attribute__((address_space(4))) MsBwd*)(ka + offsetof(BwdKernArgs, ow));
+        const float* draw = kp->lv.draw[level];
+        const uint4* mk = kp->lv.relu_mask[level];
+        bf16x8* dzl = kp->lv.dz[level];
+        bf16x8* dzo = kp->lv.dz_out[level];
+        msb_bwd_pair(ow, draw, mk, dzl, dzo, lds, lane, w4, live, k, pair);
+        if (first) *tk = tn;
+        ms_barrier();
+        t = __builtin_amdgcn_readfirstlane(*tk);
+    }
+    if (first && t == last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every other workgroup has made its last request
+}
+
+// MIX (W = 256, 8 waves; round 6): the background blocks, then the object MLPs' backward items on two 4-wave groups per
+// workgroup -- the counterpart of k_mlp_fwd<.., MIX> (mlp_fwd.hip), dz / dz_out of both classes bit-identical to the launches
+// of their own.
+template <int W, bool POSE, int NWV = 8, bool MIX = false>
 __global__ void __launch_bounds__(512, 2)
 k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
           const int32_t* __restrict__ count, const char* __restrict__ wpack,
           const uint4* __restrict__ relu_mask, bf16x8* __restrict__ dz, bf16x8* __restrict__ dz_out,
           float* __restrict__ d_enc, BwdStrides bs, const int32_t* __restrict__ tail_idx,
-          const int32_t* __restrict__ tail_count, const float* __restrict__ draw_ray_sum) {
+          const int32_t* __restrict__ tail_count, const float* __restrict__ draw_ray_sum, MsBwd ow_arg) {
+    static_assert(!MIX || (W == 256 && NWV == 8 && !POSE), "the mixed launch: background blocks of 8 waves + object items on 2 x 4");
+    (void)ow_arg;      // (read from the kernarg segment behind the background loop: mix_object_items_bwd)
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gridDim.y > 1) {                             // batched object MLPs: this workgroup's object slab
@@ -201,10 +488,11 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
         const size_t t = nrows_c + (size_t)(*tail_count);
         nrows = t < rows ? t : rows;
     }
-    if ((size_t)blockIdx.x * (32 * NWV) >= nrows) return;
+    const bool has_block = (size_t)blockIdx.x * (32 * NWV) < nrows;
+    if (!MIX && !has_block) return;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);     // stagger SIMD partners (see mlp_fwd.hip)
+    if (wave >= 4 && has_block) __builtin_amdgcn_s_setprio(1);     // stagger SIMD partners (see mlp_fwd.hip)
     const size_t ntile32 = rows >> 5;
     const size_t nblk = (nrows + 32 * NWV - 1) / (32 * NWV);
 
@@ -215,7 +503,7 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
     p.lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     p.wave = wave; p.lane = lane; p.nw = NWV;
     constexpr int GB0 = bgroup_tiles(S::CT, 1, SLOT) * 1;                 // all tiles of the rgb-head stage
-    p.issue(0, GB0);
+    if (!MIX || has_block) p.issue(0, GB0);
 
   // persistent workgroup (see mlp_fwd.hip): loop over this CU's 256-sample blocks
   for (size_t blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
@@ -298,214 +586,12 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
         }
     }
   }
-}
-
-// ---------------------------------------------------------------------------
-// M-split backward for the object MLPs (W = 128): the counterpart of k_mlp_fwd_ms (mlp_fwd.hip).  A workgroup is 4 waves x
-// 64 samples; wave w owns input-feature tile w of every stage, gradients are exchanged through LDS as the next stage's B
-// fragments, the transposed weight tiles come straight from L2, one barrier per stage.  Same MFMA instruction, operands and
-// k order per output as k_mlp_bwd<128, false>: dz / dz_out are BIT-identical.  (The box-pose variant -- d(enc) -- stays on
-// k_mlp_bwd<128, true>.)
-// ---------------------------------------------------------------------------
-namespace msb {
-using S = MlpSpec<128>;
-using B_ = BwdSpec<128>;
-constexpr int NT = 2;
-constexpr int X_BYTES = NT * S::KW * 1024;
-constexpr int OFF_X = 0;                               // two gradient fragment buffers [tile][k-step][lane][16 B]
-constexpr int OFF_G = 2 * X_BYTES;                     // head-gradient fragments [tile][2: rgb, density][lane][16 B]
-constexpr int LDS_BYTES = OFF_G + NT * 2 * 1024;
-}  // namespace msb
-
-// the per-level operands of one launch over SEVERAL levels (durf_obj_bwd_batch_levels: every level's d(raw) exists before the
-// first backward launch -- stop_level_grad -- so the object backward of a step is ONE latency-bound round instead of one per level)
-struct MsBwdLevels {
-    const float* draw[DURF_MAX_LEVELS];
-    const uint4* relu_mask[DURF_MAX_LEVELS];
-    bf16x8* dz[DURF_MAX_LEVELS];
-    bf16x8* dz_out[DURF_MAX_LEVELS];
-    int n;
-};
-
-__global__ void __launch_bounds__(256)
-k_mlp_bwd_ms(size_t rows, int N, MsBwdLevels lv, const int32_t* __restrict__ ray_idx_g,
-             const int32_t* __restrict__ count_g, const char* __restrict__ wpack_g, BwdStrides bs, int nobj) {
-    using S = msb::S;
-    using BS = msb::B_;
-    constexpr int NT = msb::NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31;
-    const size_t ntile32 = rows >> 5;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    char* const X0 = smem + msb::OFF_X;
-    char* const G = smem + msb::OFF_G;
-    // (object, pair) items dealt to a 1-D grid by the device-side hit counts: see k_mlp_fwd_ms
-    auto pairs_of = [&](int k) -> size_t {
-        const size_t c = (size_t)count_g[k] * (size_t)N;
-        return ((c < rows ? c : rows) + 32 * NT - 1) / (32 * NT);
-    };
-    size_t total = 0;
-    for (int k = 0; k < nobj; k++) total += pairs_of(k);
-
-    for (size_t item = blockIdx.x; item < total * (size_t)lv.n; item += gridDim.x) {
-        // (level-major: the items of one level are consecutive workgroups)
-        const int level = __builtin_amdgcn_readfirstlane((int)(item / total));
-        const float* __restrict__ draw = lv.draw[level];
-        const uint4* __restrict__ relu_mask_g = lv.relu_mask[level];
-        bf16x8* __restrict__ dz_g = lv.dz[level];
-        bf16x8* __restrict__ dz_out_g = lv.dz_out[level];
-        size_t k = 0, pair = item - (size_t)level * total;
-        for (;; k++) {
-            const size_t np = pairs_of((int)k);
-            if (pair < np) break;
-            pair -= np;
-        }
-        k = (size_t)__builtin_amdgcn_readfirstlane((unsigned)k);
-        const int32_t* __restrict__ ray_idx = ray_idx_g + k * bs.idx;
-        const char* __restrict__ wpack = wpack_g + k * bs.wpack;
-        const uint4* __restrict__ relu_mask = (const uint4*)((const char*)relu_mask_g + k * bs.mask);
-        bf16x8* __restrict__ dz = (bf16x8*)((char*)dz_g + k * bs.dz);
-        bf16x8* __restrict__ dz_out = (bf16x8*)((char*)dz_out_g + k * bs.dz_out);
-        const size_t c = (size_t)count_g[k] * (size_t)N;
-        const size_t nrows = c < rows ? c : rows;
-        const size_t t32[NT] = {pair * NT, pair * NT + 1};
-        const bool tv[NT] = {true, t32[1] * 32 < nrows};
-        ms_barrier();
-        // head gradients (fp32 [*,4]: d raw_rgb[3], d raw_density), gathered by ray: waves 0 / 1 build tile 0 / 1's fragments
-        if (wave < NT) {
-            const int t = wave;
-            f32x4 dr = {0.f, 0.f, 0.f, 0.f};
-            if (tv[t] && lane < 32) {
-                const size_t row = t32[t] * 32 + n;
-                const size_t src = (size_t)ray_idx[row / (size_t)N] * (size_t)N + row % (size_t)N;
-                dr = *(const f32x4*)(draw + src * 4);
-            }
-            bf16x8 g10 = zero8, gd = zero8, gout = zero8;
-            if (lane < 32) {
-                g10[0] = (__bf16)dr[0]; g10[1] = (__bf16)dr[1]; g10[2] = (__bf16)dr[2];
-                gd[0] = (__bf16)dr[3];
-                gout = g10; gout[3] = gd[0];
-            }
-            *(bf16x8*)(G + (t * 2 + 0) * 1024 + lane * 16) = g10;
-            *(bf16x8*)(G + (t * 2 + 1) * 1024 + lane * 16) = gd;
-            if (tv[t]) dz_out[t32[t] * 64 + lane] = gout;         // [rows,16] tile: slots 0-2 rgb, 3 density
-        }
-        f32x16 acc[NT];
-        // Weights of (backward stage b, this wave's tile): requested ONE STAGE AHEAD into one of two alternating register sets
-        struct WSet { bf16x8 A[S::KW + 1]; };
-        auto load_w = [&](auto b_, WSet& w) {
-            constexpr int b = decltype(b_)::value, T = BS::n_ks(b);
-            const char* wt = wpack + (size_t)(BS::chunk_base(b) + wave * T) * 1024;
-            asm volatile("" : "+s"(wt));               // (see k_mlp_fwd_ms: keeps later stages' weight loads below the barriers)
-#pragma unroll
-            for (int k = 0; k < T; k++) w.A[k] = *(const bf16x8*)(wt + k * 1024 + lane * 16);
-        };
-        // this wave's tile of backward stage b: NX k-steps from Xin, then NG head-gradient fragments (g: 0 rgb, 1 density)
-        unsigned mword[NT] = {0u, 0u};                 // this stage's ReLU flags (requested before its MFMAs, used in its epilogue)
-        auto load_mask = [&](int jm) {
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-                mword[t] = tv[t] ? ((const unsigned*)((const char*)relu_mask + ((size_t)jm * ntile32 + t32[t]) * 1024 + lane * 16))[wave >> 1] : 0u;
-        };
-        auto stage_mma = [&](auto b_, const WSet& w, auto nx_, auto ng_, int g, const char* Xin) {
-            constexpr int b = decltype(b_)::value, NX = decltype(nx_)::value, NG = decltype(ng_)::value, T = NX + NG;
-            static_assert(T == BS::n_ks(b), "k-steps of the backward stage");
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-#pragma unroll
-                for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
-#pragma unroll
-            for (int k = 0; k < T; k++) {
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const char* src = k < NX ? Xin + (t * S::KW + k) * 1024 : G + (t * 2 + g) * 1024;
-                    const bf16x8 bv = *(const bf16x8*)(src + lane * 16);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], bv, acc[t], 0, 0, 0);
-                }
-            }
-        };
-        // mask with the forward's ReLU flags of stash region jm (this wave's tile: word wave / 2, parity wave % 2), hand the
-        // fragments over, store dz region jd (jd < 0: not stored -- the linear bottleneck's gradient)
-        auto hand_over = [&](auto mask_, int /*jm*/, int jd, char* Xout) {
-            constexpr bool MASK = decltype(mask_)::value;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const unsigned word = MASK ? mword[t] : 0u;
-                bf16x8 o0, o1;
-                if (wave & 1) bpack_tile<MASK>(acc[t], word, 1, o0, o1);
-                else bpack_tile<MASK>(acc[t], word, 0, o0, o1);
-                *(bf16x8*)(Xout + (t * S::KW + 2 * wave) * 1024 + lane * 16) = o0;
-                *(bf16x8*)(Xout + (t * S::KW + 2 * wave + 1) * 1024 + lane * 16) = o1;
-                if (jd >= 0 && tv[t]) {
-                    char* dd = (char*)dz + ((size_t)S::stash_ks_before(jd) * ntile32 + t32[t] * S::stash_ks(jd)) * 1024;
-                    STREAM_STORE(dd + (2 * wave) * 1024 + lane * 16, o0);
-                    STREAM_STORE(dd + (2 * wave + 1) * 1024 + lane * 16, o1);
-                }
-            }
-        };
-        using I0 = std::integral_constant<int, 0>;
-        using I1 = std::integral_constant<int, 1>;
-        using IW = std::integral_constant<int, S::KW>;
-        char* Xa = X0;
-        char* Xb = X0 + msb::X_BYTES;
-        WSet w0, w1;
-        load_w(std::integral_constant<int, 0>{}, w0);
-        ms_barrier();                               // head-gradient fragments in place
-        // bwd of stage 10 (rgb head): d rgb -> d A9, masked by A9 (mask region 8) -> dz region 9
-        load_w(std::integral_constant<int, 1>{}, w1);
-        load_mask(8);
-        stage_mma(std::integral_constant<int, 0>{}, w0, I0{}, I1{}, 0, Xa);
-        hand_over(std::true_type{}, 8, 9, Xa);
-        ms_barrier();
-        // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear; not stored)
-        load_w(std::integral_constant<int, 2>{}, w0);
-        stage_mma(std::integral_constant<int, 1>{}, w1, std::integral_constant<int, S::KC>{}, I0{}, 0, Xa);
-        hand_over(std::false_type{}, 0, -1, Xb);
-        ms_barrier();
-        // bwd of stage 8 (bottleneck + density head): -> d A7 (mask region 7, dz region 7)
-        load_w(std::integral_constant<int, 3>{}, w1);
-        load_mask(7);
-        stage_mma(std::integral_constant<int, 2>{}, w0, IW{}, I1{}, 1, Xb);
-        hand_over(std::true_type{}, 7, 7, Xa);
-        ms_barrier();
-        // bwd of stages 7, 6, 5 (trunk rows) -> d Z6, d Z5, d Z4
-        load_w(std::integral_constant<int, 4>{}, w0);
-        load_mask(6);
-        stage_mma(std::integral_constant<int, 3>{}, w1, IW{}, I0{}, 0, Xa);
-        hand_over(std::true_type{}, 6, 6, Xb);
-        ms_barrier();
-        load_w(std::integral_constant<int, 5>{}, w1);
-        load_mask(5);
-        stage_mma(std::integral_constant<int, 4>{}, w0, IW{}, I0{}, 0, Xb);
-        hand_over(std::true_type{}, 5, 5, Xa);
-        ms_barrier();
-        load_w(std::integral_constant<int, 7>{}, w0);
-        load_mask(4);
-        stage_mma(std::integral_constant<int, 5>{}, w1, IW{}, I0{}, 0, Xa);
-        hand_over(std::true_type{}, 4, 4, Xb);
-        ms_barrier();
-        // bwd of stages 4..1 -> d Z3 .. d Z0
-        load_w(std::integral_constant<int, 8>{}, w1);
-        load_mask(3);
-        stage_mma(std::integral_constant<int, 7>{}, w0, IW{}, I0{}, 0, Xb);
-        hand_over(std::true_type{}, 3, 3, Xa);
-        ms_barrier();
-        load_w(std::integral_constant<int, 9>{}, w0);
-        load_mask(2);
-        stage_mma(std::integral_constant<int, 8>{}, w1, IW{}, I0{}, 0, Xa);
-        hand_over(std::true_type{}, 2, 2, Xb);
-        ms_barrier();
-        load_w(std::integral_constant<int, 10>{}, w1);
-        load_mask(1);
-        stage_mma(std::integral_constant<int, 9>{}, w0, IW{}, I0{}, 0, Xb);
-        hand_over(std::true_type{}, 1, 1, Xa);
-        ms_barrier();
-        load_mask(0);
-        stage_mma(std::integral_constant<int, 10>{}, w1, IW{}, I0{}, 0, Xa);
-        hand_over(std::true_type{}, 0, 0, Xb);
-    }
+  if constexpr (MIX) {
+    if (has_block) __builtin_amdgcn_s_setprio(0);
+    ms_barrier();                  // every wave is past its last weight read; no DMA is in flight (the last block prefetches none)
+    const unsigned long long ka = (unsigned long long)(const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    mix_object_items_bwd(lds_addr_of(smem), wave, (int)gridDim.x, (unsigned)ka, (unsigned)(ka >> 32));
+  }
 }
 
 // view-direction features expanded per sample into tile layout [rows, 32] (dW of Dense_10)
@@ -1191,6 +1277,60 @@ int durf_mlp_bwd(void* stream, int width, size_t rows, int N, const float* draw,
                                 1, BwdStrides{}, tail_idx, tail_count, draw_ray_sum);
 }
 
+// durf_mlp_bwd (the background MLP) + durf_obj_bwd_batch_levels (the K object MLPs over `nlevels` levels) as ONE launch where
+// that pays (include/durf_hip.h), else as the two launches
+int durf_obj_bwd_batch_levels(void* stream, int K, int B, int N, int nlevels, const int32_t* idx, const int32_t* count,
+                              const float* const* draw, const void* wpack_bwd, const void* const* relu_mask, void* const* dz,
+                              void* const* dz_out);
+int durf_mlp_bwd_obj(void* stream, size_t rows, int N, const float* draw, const int32_t* ray_idx, const int32_t* count,
+                     const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out, const int32_t* tail_idx,
+                     const int32_t* tail_count, const float* draw_ray_sum, int K, int B, int nlevels, const int32_t* obj_idx,
+                     const int32_t* obj_count, const float* const* obj_draw, const void* obj_wpack_bwd,
+                     const void* const* obj_relu_mask, void* const* obj_dz, void* const* obj_dz_out) {
+    DURF_REQUIRE(K > 0 && B > 0 && (size_t)B * N == rows, "K object MLPs over rows = B * N sample rows");
+    DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
+    DURF_REQUIRE(obj_idx && obj_count && obj_draw && obj_wpack_bwd && obj_relu_mask && obj_dz && obj_dz_out, "the object launch's buffers");
+    const char* e = getenv("DURF_OBJ_MIX");
+    const bool mix = !(e && e[0] == '0') && durf::obj_msplit(rows) && N % 32 == 0 && ray_idx != nullptr && count != nullptr;
+    if (!mix) {
+        int rc = durf_mlp_bwd(stream, 256, rows, N, draw, ray_idx, count, wpack_bwd, relu_mask, dz, dz_out, nullptr, tail_idx, tail_count,
+                              draw_ray_sum);
+        if (rc) return rc;
+        return durf_obj_bwd_batch_levels(stream, K, B, N, nlevels, obj_idx, obj_count, obj_draw, obj_wpack_bwd, obj_relu_mask, obj_dz,
+                                         obj_dz_out);
+    }
+    DURF_REQUIRE((tail_idx == nullptr) == (tail_count == nullptr) && (tail_idx == nullptr) == (draw_ray_sum == nullptr),
+                 "tail_idx, tail_count and draw_ray_sum go together");
+    DURF_REQUIRE(rows % 32 == 0, "rows must be a multiple of 32");
+    MsBwd ow{};
+    ow.rows = rows; ow.N = N; ow.ray_idx = obj_idx; ow.count = obj_count; ow.wpack = (const char*)obj_wpack_bwd; ow.nobj = K;
+    ow.lv.n = nlevels;
+    for (int l = 0; l < nlevels; l++) {
+        ow.lv.draw[l] = obj_draw[l]; ow.lv.relu_mask[l] = (const uint4*)obj_relu_mask[l]; ow.lv.dz[l] = (bf16x8*)obj_dz[l];
+        ow.lv.dz_out[l] = (bf16x8*)obj_dz_out[l];
+    }
+    ow.bs.idx = (size_t)B; ow.bs.wpack = durf_wpack_bwd_bytes(DURF_W_OBJ); ow.bs.mask = durf_mlp_mask_bytes(rows);
+    ow.bs.dz = durf_mlp_stash_bytes(DURF_W_OBJ, rows); ow.bs.dz_out = durf_obj_dzout_stride(B, N);
+    ow.bs.d_enc = rows * DURF_ENC_DIM * sizeof(float);
+    ow.ticket = durf::next_ticket();
+    DURF_REQUIRE(ow.ticket != nullptr, "no item counter for the mixed launch (device allocation failed)");
+    const unsigned nblk = durf_cdiv(rows, 256), nobj = durf_cdiv((size_t)nlevels * K * durf_cdiv(rows, 64), 2);
+    const unsigned g = nblk + nobj < 256u ? nblk + nobj : 256u;
+    constexpr int lds = 2 * 4 * (MlpSpec<256>::KW + 1) * 1024;
+    static_assert(2 * msb::LDS_BYTES + 16 <= lds, "two object groups fit the background block's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_mlp_bwd<256, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_mlp_bwd<256, false, 8, true>), dim3(g), dim3(512), lds, (hipStream_t)stream, rows, N, draw, ray_idx, count,
+                       (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out, (float*)nullptr, BwdStrides{},
+                       tail_idx, tail_count, draw_ray_sum, ow);
+    DURF_CHECK_LAUNCH("durf_mlp_bwd_obj");
+    durf::note_dispatch(DURF_DISPATCH_BWD256_8W | DURF_DISPATCH_BWD_MIX);
+    return 0;
+}
+
 int durf_expand_view(void* stream, size_t rows, int N, const void* view_bf16, const int32_t* ray_idx,
                      const int32_t* count, void* out_tile, const int32_t* tail_idx, const int32_t* tail_count) {
     DURF_REQUIRE((tail_idx == nullptr) == (tail_count == nullptr), "tail_idx and tail_count go together");
@@ -1278,8 +1418,8 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
             const size_t items = (size_t)K * durf_cdiv(rows, 64);       // (small batches only; one round of workgroups: launch_mlp_fwd)
             MsBwdLevels lv{};
             lv.draw[0] = draw; lv.relu_mask[0] = (const uint4*)relu_mask; lv.dz[0] = (bf16x8*)dz; lv.dz_out[0] = (bf16x8*)dz_out; lv.n = 1;
-            hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, s, rows, N, lv, ray_idx,
-                               count, (const char*)wpack_bwd, st, K);
+            const MsBwd A{rows, N, lv, ray_idx, count, (const char*)wpack_bwd, st, K, nullptr};
+            hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, s, A);
             DURF_CHECK_LAUNCH("durf_mlp_bwd (M-split)");
             note_dispatch(DURF_DISPATCH_BWD128_MSPLIT);
             return 0;
@@ -1295,7 +1435,7 @@ int launch_mlp_bwd(void* stream, int width, size_t rows, int N, const float* dra
         (void)hipFuncSetAttribute((const void*)k_mlp_bwd<WW, PP, NWV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((k_mlp_bwd<WW, PP, NWV>), grid, block, lds, s, rows, N, draw, ray_idx, count,    \
                            (const char*)wpack_bwd, (const uint4*)relu_mask, (bf16x8*)dz, (bf16x8*)dz_out,  \
-                           d_enc, st, tail_idx, tail_count, draw_ray_sum);                                 \
+                           d_enc, st, tail_idx, tail_count, draw_ray_sum, MsBwd{});                        \
     }
     if (half) LAUNCH_B(256, false, 4)
     else if (width == 256) { if (d_enc) LAUNCH_B(256, true, 8) else LAUNCH_B(256, false, 8) }
@@ -1320,8 +1460,8 @@ int launch_mlp_bwd_ms_levels(void* stream, size_t rows, int N, int nlevels, cons
         lv.draw[l] = draw[l]; lv.relu_mask[l] = (const uint4*)relu_mask[l]; lv.dz[l] = (bf16x8*)dz[l]; lv.dz_out[l] = (bf16x8*)dz_out[l];
     }
     const size_t items = (size_t)nlevels * K * durf_cdiv(rows, 64);
-    hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, (hipStream_t)stream, rows, N,
-                       lv, ray_idx, count, (const char*)wpack_bwd, st, K);
+    const MsBwd A{rows, N, lv, ray_idx, count, (const char*)wpack_bwd, st, K, nullptr};
+    hipLaunchKernelGGL(k_mlp_bwd_ms, dim3((unsigned)(items < 256 ? items : 256)), dim3(256), msb::LDS_BYTES, (hipStream_t)stream, A);
     DURF_CHECK_LAUNCH("durf_obj_bwd_batch_levels (M-split)");
     note_dispatch(DURF_DISPATCH_BWD128_MSPLIT);
     return 0;

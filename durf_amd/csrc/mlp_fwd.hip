@@ -7,6 +7,7 @@
 // ds_read_b128 is conflict-free), double buffered per output M-tile, one barrier per tile.
 // MFMA-bound: 2*606 208 padded MAC per sample (591 872 algorithmic) for W=256.
 #include <stdlib.h>
+#include <cstddef>
 #include "mlp_pack.h"
 #include "enc_lane.h"
 
@@ -220,18 +221,416 @@ __device__ __forceinline__ void run_stage(WPipe& p, const bf16x8* inA, const bf1
 }
 
 
+// ---------------------------------------------------------------------------
+// M-split forward for the object MLPs (W = 128): latency per tile instead of work per wave.
+//
+// k_mlp_fwd gives every wave 32 samples and ALL output tiles of a layer: a block is a chain of 11 stages x 32 MFMAs per
+// wave behind a workgroup barrier and a weight DMA each, ~2.3 us per stage whatever the occupancy -- and the object launches
+// of a step are one round of a few dozen such blocks, i.e. pure latency (25-45 us per launch at the reference's 512-ray
+// batch and at K = 8).  Here a workgroup is 4 waves x 64 samples (two 32-sample MFMA tiles); wave w owns output tile w of
+// every layer, so a stage is 8-12 k-steps x 2 independent accumulators per wave.  Activations are exchanged through LDS
+// as the very fragments the next stage's MFMAs read (the C-layout of tile w IS k-steps 2w, 2w+1 of the next B operand:
+// mlp_spec.h), weights come straight from L2 (each wave reads only its own tile's 9-13 KB per stage: no LDS staging, no
+// DMA waits), one barrier per stage.  Same MFMA instruction, same operands, same k order per output as k_mlp_fwd<128>:
+// raw, encoding tile, stash, masks and view tile are BIT-identical (tests/test_gpu_fused_encode.py).
+// ---------------------------------------------------------------------------
+namespace ms {
+using S = MlpSpec<128>;
+constexpr int NT = 2;                                  // 32-sample tiles per workgroup
+constexpr int X_BYTES = NT * S::KW * 1024;             // one activation fragment buffer: [tile][k-step][lane][16 B]
+constexpr int OFF_X = 0;                               // two of them (written by stage s, read by stage s + 1)
+constexpr int OFF_E = 2 * X_BYTES;                     // encoding fragments [tile][KE][lane][16 B] (natural order)
+constexpr int OFF_V = OFF_E + NT * S::KE * 1024;       // view fragments     [tile][KV][lane][16 B]
+constexpr int OFF_M = OFF_V + NT * S::KV * 1024;       // ReLU-flag pieces   [2][tile][wave][lane] u32
+constexpr int LDS_BYTES = OFF_M + 2 * NT * 4 * 64 * 4;
+}  // namespace ms
+
+// One (object, pair of 32-sample tiles) item of the M-split forward on FOUR waves (wave = 0..3 within the group) and ms::LDS_BYTES
+// of LDS at `smem`: the body of k_mlp_fwd_ms, and of the object half-workgroups of the mixed launch (k_mlp_fwd<.., MIX>).
+// Every barrier inside is the WORKGROUP barrier: all groups of a workgroup call this function the same number of times.
+struct MsFwd {
+    size_t rows; int N; const bf16x8* enc; const bf16x8* view; const int32_t* ray_idx; const int32_t* count; const char* wpack;
+    float* raw; bf16x8* stash; uint4* relu_mask; FwdStrides bs; EncIn ei; int nobj;
+    int* ticket;         // mixed launch only: the item counter (durf::next_ticket)
+};
+__device__ __forceinline__ size_t ms_pairs_of(const MsFwd& A, int k) {
+    const size_t c = (size_t)as_global(A.count)[k] * (size_t)A.N;
+    return ((c < A.rows ? c : A.rows) + 32 * ms::NT - 1) / (32 * ms::NT);
+}
+// item -> (object, pair); false when item >= total
+__device__ __forceinline__ bool ms_item(const MsFwd& A, size_t item, size_t& k_out, size_t& pair_out) {
+    size_t k = 0, pair = item;
+    for (; k < (size_t)A.nobj; k++) {
+        const size_t np = ms_pairs_of(A, (int)k);
+        if (pair < np) break;
+        pair -= np;
+    }
+    const bool ok = k < (size_t)A.nobj;
+    k_out = (size_t)__builtin_amdgcn_readfirstlane((unsigned)(ok ? k : 0));
+    pair_out = ok ? pair : 0;
+    return ok;
+}
+
+template <bool TRAIN>
+__device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane, int wave, bool live, size_t k, size_t pair) {
+    using S = ms::S;
+    constexpr int NT = ms::NT;
+    const int n = lane & 31, hi = lane >> 5;
+    const size_t ntile32 = A.rows >> 5;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    char* const X0 = smem + ms::OFF_X;
+    char* const E = smem + ms::OFF_E;
+    char* const V = smem + ms::OFF_V;
+    unsigned* const M = (unsigned*)(smem + ms::OFF_M);
+    // this object's slabs (0 strides for a single MLP)
+    const size_t rows = A.rows;
+    const int N = A.N;
+    const bf16x8* __restrict__ view = as_global(A.view);
+    const bf16x8* __restrict__ enc = as_global((const bf16x8*)((const char*)A.enc + k * A.bs.enc));
+    const int32_t* __restrict__ ray_idx = as_global(A.ray_idx + k * A.bs.idx);
+    const char* __restrict__ wpack = A.wpack + k * A.bs.wpack;
+    float* __restrict__ raw = as_global((float*)((char*)A.raw + k * A.bs.raw));
+    EncIn ei = A.ei;
+    ei.t_vals = as_global(ei.t_vals); ei.origins_s = as_global(ei.origins_s); ei.dirs_s = as_global(ei.dirs_s); ei.radii = as_global(ei.radii);
+    if (ei.view_tile) ei.view_tile = as_global((char*)ei.view_tile + k * ei.view_stride);
+    bf16x8* __restrict__ stash = TRAIN ? as_global((bf16x8*)((char*)A.stash + k * A.bs.stash)) : nullptr;
+    uint4* __restrict__ relu_mask = TRAIN ? as_global((uint4*)((char*)A.relu_mask + k * A.bs.mask)) : nullptr;
+    const size_t c = (size_t)as_global(A.count)[k] * (size_t)N;
+    const size_t nrows = c < rows ? c : rows;          // a multiple of 32 (N % 32 == 0)
+    const size_t t32[NT] = {pair * NT, pair * NT + 1};
+    // (a group without an item -- live == false: the other half of a mixed workgroup still has one -- runs the same stages
+    // on zeros with every global load / store predicated off by these flags, so that both halves meet at every barrier)
+    const bool tv[NT] = {live, live && t32[1] * 32 < nrows};
+    ms_barrier();                               // the previous pair is done with the LDS
+    // ---- inputs: the tiles' encodings (computed here or read), view directions ----
+    if (ei.obj) {
+        if (wave == 0) {                           // lane = sample: 64 lanes = both tiles; the stand-alone encoder's body
+            const int t = lane >> 5;
+            const size_t row = t32[t] * 32 + n;
+            if (tv[t]) {
+                const int j = (int)(row / (size_t)N), nn = (int)(row % (size_t)N);
+                const int b = ray_idx[j];
+                const float t0 = ei.t_vals[(size_t)b * (N + 1) + nn], t1 = ei.t_vals[(size_t)b * (N + 1) + nn + 1];
+                float o[3] = {ei.origins_s[b * 3], ei.origins_s[b * 3 + 1], ei.origins_s[b * 3 + 2]};
+                float d[3] = {ei.dirs_s[b * 3], ei.dirs_s[b * 3 + 1], ei.dirs_s[b * 3 + 2]};
+                Gauss g = frustum_gaussian(t0, t1, o, d, ei.radii[b], (ei.flags & DURF_ENC_CYLINDER) != 0);
+                if (ei.flags & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
+                BarfW bw;
+#pragma unroll
+                for (int i = 0; i < 10; i++) bw.w[i] = ei.w[i];
+                char* const eg = (char*)enc + t32[t] * (S::KE * 1024);
+                lane_features<true>(g, bw, [&](auto q_, const bf16x8& o8) {
+                    constexpr int q = decltype(q_)::value;             // features [8 q, 8 q + 8): k-step q / 2, half q % 2
+                    const int off = (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16;
+                    *(bf16x8*)(E + t * (S::KE * 1024) + off) = o8;
+                    *(DURF_G(bf16x8)*)(eg + off) = o8;      // the encoding tile the weight-gradient GEMMs of Dense_0 / Dense_5 read
+                });
+            } else {
+#pragma unroll
+                for (int q = 0; q < 8; q++) *(bf16x8*)(E + t * (S::KE * 1024) + (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16) = zero8;
+            }
+        }
+    } else {
+        for (int ch = wave; ch < NT * S::KE; ch += 4) {                // chunk = (tile, k-step)
+            const int t = ch / S::KE, k = ch % S::KE;
+            *(bf16x8*)(E + ch * 1024 + lane * 16) =
+                tv[t] ? *(const bf16x8*)((const char*)enc + t32[t] * (S::KE * 1024) + k * 1024 + lane * 16) : zero8;
+        }
+    }
+    if (wave >= 2) {                               // waves 2, 3: the view-direction fragments of tile 0, 1
+        const int t = wave - 2;
+        const size_t row = t32[t] * 32 + n;
+        size_t ray = 0;
+        if (tv[t]) ray = (size_t)ray_idx[row / (size_t)N];
+#pragma unroll
+        for (int k = 0; k < S::KV; k++) {
+            const bf16x8 v = tv[t] ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + hi] : zero8;
+            *(bf16x8*)(V + (t * S::KV + k) * 1024 + lane * 16) = v;
+            if (TRAIN && ei.view_tile && tv[t]) *(DURF_G(bf16x8)*)((char*)ei.view_tile + (t32[t] * S::KV + k) * 1024 + lane * 16) = v;
+        }
+    }
+
+    // ---- one stage: this wave's output tile `mo` of forward stage s for both sample tiles ----
+    // B operands: NX k-steps from the activation buffer Xin, then NE from the encoding, then NV from the view fragments
+    f32x16 acc[NT];
+    // Weights of (stage s, output tile mo): T A-fragments + the 16 bias values of this lane, straight from L2 into registers.
+    // They are requested ONE STAGE AHEAD (two register sets, alternating), so a stage never waits for its own loads.
+    struct WSet { bf16x8 A[S::KW + S::KE]; f32x4 b[4]; };         // stages 5 and 9 (12 / 10 k-steps) use the odd set
+    struct WSet8 { bf16x8 A[S::KW]; f32x4 b[4]; };                // the even stages have at most KW k-steps
+    auto load_w = [&](auto s_, int mo, auto& w) {
+        constexpr int s = decltype(s_)::value, T = S::n_ks(s);
+        // (a GLOBAL pointer by type, round 6: behind the opaque asm a generic pointer made these FLAT loads, which count on
+        // lgkmcnt as well -- every ms_barrier then waited for the next stage's weights it was meant to leave in flight)
+        typedef const __attribute__((address_space(1))) char* gptr_t;
+        gptr_t wt = (gptr_t)(wpack + (size_t)(S::stage_chunk_base(s) + mo * S::tile_chunks(s)) * 1024);     // wave-uniform
+        // (opaque: the stream is read-only, so hipcc would otherwise hoist EVERY later stage's loads above the barriers in
+        // between -- the inference instantiation needed all 512 registers and still spilled)
+        asm volatile("" : "+s"(wt));
+#pragma unroll
+        for (int k = 0; k < T; k++) w.A[k] = *(const __attribute__((address_space(1))) bf16x8*)(wt + k * 1024 + lane * 16);
+        const __attribute__((address_space(1))) f32x4* bp = (const __attribute__((address_space(1))) f32x4*)(wt + T * 1024 + hi * 64);     // the bias rows: the initial accumulators
+#pragma unroll
+        for (int g = 0; g < 4; g++) w.b[g] = bp[g];
+    };
+    auto stage_mma = [&](auto s_, const auto& w, auto nx_, auto ne_, auto nv_, const char* Xin) {
+        constexpr int s = decltype(s_)::value, NX = decltype(nx_)::value, NE = decltype(ne_)::value, NV = decltype(nv_)::value;
+        constexpr int T = NX + NE + NV;
+        static_assert(T == S::n_ks(s), "k-steps of the stage");
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) { acc[t][4 * g] = w.b[g][0]; acc[t][4 * g + 1] = w.b[g][1]; acc[t][4 * g + 2] = w.b[g][2]; acc[t][4 * g + 3] = w.b[g][3]; }
+        }
+#pragma unroll
+        for (int k = 0; k < T; k++) {
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                const char* src = k < NX ? Xin + (t * S::KW + k) * 1024
+                                         : (k < NX + NE ? E + (t * S::KE + (k - NX)) * 1024 : V + (t * S::KV + (k - NX - NE)) * 1024);
+                const bf16x8 b = *(const bf16x8*)(src + lane * 16);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], b, acc[t], 0, 0, 0);
+            }
+        }
+    };
+    // epilogue of a stashed ReLU stage: fragments 2 mo, 2 mo + 1 of the next stage's input, the stash, the flag pieces
+    auto hand_over = [&](auto relu_, int mo, char* Xout, int jstash, unsigned* Mbuf) {
+        constexpr bool RELU = decltype(relu_)::value;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            bf16x8 o0, o1;
+            const unsigned bits = pack_tile<RELU, TRAIN && RELU>(acc[t], o0, o1);
+            *(bf16x8*)(Xout + (t * S::KW + 2 * mo) * 1024 + lane * 16) = o0;
+            *(bf16x8*)(Xout + (t * S::KW + 2 * mo + 1) * 1024 + lane * 16) = o1;
+            if (TRAIN && RELU && tv[t]) {
+                char* sd = (char*)stash + ((size_t)S::stash_ks_before(jstash) * ntile32 + t32[t] * S::stash_ks(jstash)) * 1024;
+                STREAM_STORE(sd + (2 * mo) * 1024 + lane * 16, o0);
+                STREAM_STORE(sd + (2 * mo + 1) * 1024 + lane * 16, o1);
+                Mbuf[(t * 4 + mo) * 64 + lane] = bits << (8 * (mo & 1));
+            }
+        }
+    };
+    // waves 0 / 1 assemble the previous stage's flags of tile 0 / 1 into k_mlp_fwd's layout (one uint4 per lane: words
+    // 0, 1 = tile pairs (0,1), (2,3)) -- after the barrier that made every wave's piece visible
+    auto flush_mask = [&](int jmask, const unsigned* Mbuf) {
+        if (TRAIN && wave < NT && tv[wave]) {
+            const unsigned* m = Mbuf + (wave * 4) * 64 + lane;
+            const uint4 w4 = make_uint4(m[0] | m[64], m[128] | m[192], 0u, 0u);
+            typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+            const u32x4_ w4v = {w4.x, w4.y, w4.z, w4.w};
+            *(DURF_G(u32x4_)*)((char*)relu_mask + ((size_t)jmask * ntile32 + t32[wave]) * 1024 + lane * 16) = w4v;
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    char* Xa = X0;
+    char* Xb = X0 + ms::X_BYTES;
+    unsigned* Ma = M;
+    unsigned* Mb = M + NT * 4 * 64;
+    WSet8 w0;                                      // two alternating weight sets
+    WSet w1;
+    load_w(std::integral_constant<int, 0>{}, wave, w0);
+    ms_barrier();                               // encodings and view fragments are in place
+    using IE = std::integral_constant<int, S::KE>;
+    using IW = std::integral_constant<int, S::KW>;
+    auto swap = [&]() { char* tx = Xa; Xa = Xb; Xb = tx; unsigned* tm = Ma; Ma = Mb; Mb = tm; };
+    // stage 0: enc -> Xa
+    load_w(std::integral_constant<int, 1>{}, wave, w1);
+    stage_mma(std::integral_constant<int, 0>{}, w0, I0{}, IE{}, I0{}, Xa);
+    hand_over(std::true_type{}, wave, Xa, 0, Ma);
+    ms_barrier();
+    // stages 1-4 (the next stage's weights are requested before this stage's MFMAs)
+    flush_mask(0, Ma);
+    load_w(std::integral_constant<int, 2>{}, wave, w0);
+    stage_mma(std::integral_constant<int, 1>{}, w1, IW{}, I0{}, I0{}, Xa);
+    hand_over(std::true_type{}, wave, Xb, 1, Mb);
+    ms_barrier();
+    swap();
+    flush_mask(1, Ma);
+    load_w(std::integral_constant<int, 3>{}, wave, w1);
+    stage_mma(std::integral_constant<int, 2>{}, w0, IW{}, I0{}, I0{}, Xa);
+    hand_over(std::true_type{}, wave, Xb, 2, Mb);
+    ms_barrier();
+    swap();
+    flush_mask(2, Ma);
+    load_w(std::integral_constant<int, 4>{}, wave, w0);
+    stage_mma(std::integral_constant<int, 3>{}, w1, IW{}, I0{}, I0{}, Xa);
+    hand_over(std::true_type{}, wave, Xb, 3, Mb);
+    ms_barrier();
+    swap();
+    flush_mask(3, Ma);
+    load_w(std::integral_constant<int, 5>{}, wave, w1);
+    stage_mma(std::integral_constant<int, 4>{}, w0, IW{}, I0{}, I0{}, Xa);
+    hand_over(std::true_type{}, wave, Xb, 4, Mb);
+    ms_barrier();
+    swap();
+    // stage 5: [h4, enc] (obbpose_model.py:333-334)
+    flush_mask(4, Ma);
+    load_w(std::integral_constant<int, 6>{}, wave, w0);
+    stage_mma(std::integral_constant<int, 5>{}, w1, IW{}, IE{}, I0{}, Xa);
+    hand_over(std::true_type{}, wave, Xb, 5, Mb);
+    ms_barrier();
+    swap();
+    // stages 6, 7
+    flush_mask(5, Ma);
+    load_w(std::integral_constant<int, 7>{}, wave, w1);
+    stage_mma(std::integral_constant<int, 6>{}, w0, IW{}, I0{}, I0{}, Xa);
+    hand_over(std::true_type{}, wave, Xb, 6, Mb);
+    ms_barrier();
+    swap();
+    flush_mask(6, Ma);
+    load_w(std::integral_constant<int, 8>{}, wave, w0);
+    stage_mma(std::integral_constant<int, 7>{}, w1, IW{}, I0{}, I0{}, Xa);
+    hand_over(std::true_type{}, wave, Xb, 7, Mb);
+    ms_barrier();
+    swap();
+    // stage 8: h7 -> bottleneck (linear, tile `wave`) and, wave 0, the density head (tile WT)
+    flush_mask(7, Ma);
+    float dens[NT] = {0.0f, 0.0f};
+    if (wave == 0) {
+        // Wave 0 also owns the density head's tile (WT).  Its weights take the ODD set's registers for this stage and stage
+        // 9's follow behind them (round 6; until then a third set, requested two stages ahead, stayed live across three
+        // stages: 302 registers -- with two sets the body needs 182-220, which is what lets it run as the object half of a
+        // mixed workgroup beside the persistent background body's 256, k_mlp_fwd<.., MIX>).  Same MFMAs, same operands.
+        load_w(std::integral_constant<int, 8>{}, S::WT, w1);
+        stage_mma(std::integral_constant<int, 8>{}, w0, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::false_type{}, wave, Xb, 8, Mb);
+        stage_mma(std::integral_constant<int, 8>{}, w1, IW{}, I0{}, I0{}, Xa);
+#pragma unroll
+        for (int t = 0; t < NT; t++) dens[t] = acc[t][0];
+        load_w(std::integral_constant<int, 9>{}, wave, w1);
+    } else {
+        load_w(std::integral_constant<int, 9>{}, wave, w1);
+        stage_mma(std::integral_constant<int, 8>{}, w0, IW{}, I0{}, I0{}, Xa);
+        hand_over(std::false_type{}, wave, Xb, 8, Mb);
+    }
+    ms_barrier();
+    { char* tx = Xa; Xa = Xb; Xb = tx; }
+    // stage 9: [bottleneck, view] -> hc (128, relu); its flags go to mask region 8
+    if (wave == 0) load_w(std::integral_constant<int, 10>{}, 0, w0);
+    stage_mma(std::integral_constant<int, 9>{}, w1, IW{}, I0{}, std::integral_constant<int, S::KV>{}, Xa);
+    hand_over(std::true_type{}, wave, Xb, 9, Mb);
+    ms_barrier();
+    flush_mask(8, Mb);
+    // stage 10: hc -> rgb (wave 0), raw = (rgb, density)
+    if (wave == 0) {
+        // jnp.maximum propagates NaN, v_max_f32 does not: a non-finite encoding poisons the sample's output (as k_mlp_fwd:
+        // the lane's 8 features of each k-step, then the sample's other half)
+        bool bad[NT] = {false, false};
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int k = 0; k < S::KE; k++) {
+                const bf16x8 e8 = *(const bf16x8*)(E + (t * S::KE + k) * 1024 + lane * 16);
+#pragma unroll
+                for (int e = 0; e < 8; e++) bad[t] |= !(fabsf((float)e8[e]) <= 3.0e38f);
+            }
+#pragma unroll
+        for (int t = 0; t < NT; t++) bad[t] |= (__shfl_xor((int)bad[t], 32, 64) != 0);
+        stage_mma(std::integral_constant<int, 10>{}, w0, std::integral_constant<int, S::KC>{}, I0{}, I0{}, Xb);
+        if (lane < 32) {
+            const float qn = __builtin_nanf("");
+#pragma unroll
+            for (int t = 0; t < NT; t++) {
+                if (!tv[t]) continue;
+                const f32x4 o = {bad[t] ? qn : acc[t][0], bad[t] ? qn : acc[t][1], bad[t] ? qn : acc[t][2], bad[t] ? qn : dens[t]};
+                *(DURF_G(f32x4)*)(raw + (t32[t] * 32 + n) * 4) = o;
+            }
+        }
+    }
+}
+
+template <bool TRAIN>
+__global__ void __launch_bounds__(256)      // one wave per SIMD: the register file is this workgroup's (latency, not occupancy)
+k_mlp_fwd_ms(MsFwd A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // The work items are (object, pair of 32-sample tiles); the hit counts live on the device.  A 1-D grid deals them in
+    // order -- object 0's pairs, object 1's, ... -- so the workgroups that find work are exactly the first sum(pairs) of the
+    // grid.  (With a (object, pair) grid the first 256 workgroups dispatched covered only pairs < 256 / K of every object: at
+    // K = 8 an object with more than 32 pairs waited for a second round of CUs although fewer than 256 workgroups had work --
+    // 47 us a launch for 26 us of work.)
+    size_t total = 0;
+    for (int k = 0; k < A.nobj; k++) total += ms_pairs_of(A, k);
+    for (size_t item = blockIdx.x; item < total; item += gridDim.x) {
+        size_t k, pair;
+        ms_item(A, item, k, pair);
+        ms_fwd_pair<TRAIN>(A, smem, lane, wave, true, k, pair);
+    }
+}
+
+
 // ENC (W = 256): the workgroup ENCODES its own tiles -- each lane computes its sample's 60 features from the ray data
 // (enc_lane.h, the body of k_encode_lane<false>: bit-identical features), keeps the half its MFMA fragment holds and
 // writes the tile to `enc`, where stage 5 (the skip connection) and the weight-gradient GEMMs of Dense_0 / Dense_5 read
 // it.  Replaces the durf_encode_bkgd launch in front of every forward: one launch, one 64 MB write + read and ~30 us of
 // launch gaps less per level at 4096 rays.
-template <int W, bool TRAIN, int NWV = 8, bool ENC = false>
+// MIX (W = 256, 8 waves; round 6): ONE heterogeneous persistent launch for a small step -- every workgroup first walks its
+// background blocks as before, then turns into TWO 4-wave groups that take (object, tile pair) items of the K object MLPs
+// (ms_fwd_pair: the body of k_mlp_fwd_ms, bit-identical outputs) off an atomic ticket counter until none is left.  At the
+// reference's 512-ray batch the de-duplicated background grid leaves ~24 of the 256 workgroups without a block: they start
+// on the object items at once and are done with them inside the background blocks' 77 us (a launch of their own behind
+// the background's cost 22 us per level; on a second stream the early object workgroups delayed the persistent
+// background workgroups that wanted their CUs); at 1024 rays x K = 8 the workgroups with one block instead of two pick
+// them up.  `ow.ticket`: a zeroed int the launch leaves zeroed (the workgroup that draws the last ticket resets it).
+// (the kernel's explicit arguments as the kernarg segment lays them out -- in order, naturally aligned: the mixed launch reads
+// its object arguments from the segment itself, see below)
+struct FwdKernArgs {
+    size_t rows; int N; const bf16x8* enc; const bf16x8* view; const int32_t* ray_idx; const int32_t* count; const char* wpack;
+    float* raw; bf16x8* stash; uint4* relu_mask; FwdStrides bs; const int32_t* tail_idx; const int32_t* tail_count; EncIn ei;
+    MsFwd ow;
+};
+// The object phase of a mixed workgroup.  NOT inlined: it is compiled with a register allocation of its own -- inlined behind
+// the background loop its scalar-register spills reserved a third vector register throughout the kernel, and the loop,
+// which sits at the 256-register cap, spilled three more of its own values (a scratch reload drains the weight prefetch).
+// Nothing of the caller is live across the call.  The object arguments are fetched from the kernarg segment here.
+template <bool TRAIN>
+__device__ __attribute__((noinline)) void mix_object_items(unsigned smem_lds, int wave_v, int nwg_v, unsigned ka_lo, unsigned ka_hi) {
+    // (arguments of a real call arrive in vector registers: make the wave-uniform ones scalar again)
+    const int wave = __builtin_amdgcn_readfirstlane(wave_v), nwg = __builtin_amdgcn_readfirstlane(nwg_v);
+    char* const smem = (char*)(__attribute__((address_space(3))) char*)(size_t)__builtin_amdgcn_readfirstlane(smem_lds);
+    typedef const __attribute__((address_space(4))) char* kptr_t;
+    // (the kernarg segment pointer comes from the KERNEL: in a callee __builtin_amdgcn_kernarg_segment_ptr() is lowered to null)
+    kptr_t ka = (kptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_hi) << 32) |
+                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_lo));
+    MsFwd ow;
+    load_kernarg(ow, ka + offsetof(FwdKernArgs, ow));      // (scalar loads: a constant-address-space source)
+    const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const bool first = wave == 0 && lane == 0;
+    const int half = wave >> 2, w4 = wave & 3;
+    char* const lds = smem + half * ms::LDS_BYTES;
+    volatile __attribute__((address_space(3))) int* const tk =
+        (volatile __attribute__((address_space(3))) int*)(size_t)(__builtin_amdgcn_readfirstlane(smem_lds) + 2u * ms::LDS_BYTES);
+    size_t total = 0;
+    for (int k = 0; k < ow.nobj; k++) total += ms_pairs_of(ow, k);
+    const int last = 2 * (int)((total + 1) / 2 + nwg - 1);            // the value the LAST request of the launch returns
+    int t = 0;
+    // (a GLOBAL atomic: a flat one counts on lgkmcnt, and the first barrier of the item would wait for the request under way)
+    DURF_G(int)* const ticket = (DURF_G(int)*)ow.ticket;
+    if (first) { t = __hip_atomic_fetch_add(ticket, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); *tk = t; }
+    ms_barrier();
+    t = __builtin_amdgcn_readfirstlane(*tk);
+    while ((size_t)t < total) {
+        int tn = 0;
+        if (first) tn = __hip_atomic_fetch_add(ticket, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next request is under way while this item runs
+        size_t k, pair;
+        const bool live = ms_item(ow, (size_t)t + (size_t)half, k, pair);
+        ms_fwd_pair<TRAIN>(ow, lds, lane, w4, live, k, pair);
+        if (first) *tk = tn;
+        ms_barrier();
+        t = __builtin_amdgcn_readfirstlane(*tk);
+    }
+    if (first && t == last) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every other workgroup has made its last request
+}
+
+template <int W, bool TRAIN, int NWV = 8, bool ENC = false, bool MIX = false>
 __global__ void __launch_bounds__(512, 2)
 k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __restrict__ view,
           const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
           const char* __restrict__ wpack, float* __restrict__ raw, bf16x8* __restrict__ stash,
           uint4* __restrict__ relu_mask, FwdStrides bs, const int32_t* __restrict__ tail_idx,
-          const int32_t* __restrict__ tail_count, EncIn ei) {
+          const int32_t* __restrict__ tail_count, EncIn ei, MsFwd ow_arg) {
+    static_assert(!MIX || (W == 256 && NWV == 8 && ENC), "the mixed launch: background blocks of 8 waves + object items on 2 x 4");
+    (void)ow_arg;      // (read through the kernarg segment pointer behind the background loop, not held in SGPRs across it)
     using S = MlpSpec<W>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     if (gridDim.y > 1) {                             // batched object MLPs: this workgroup's object slab
@@ -260,12 +659,13 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         const size_t t = nrows_c + (size_t)(*tail_count);
         nrows = t < rows ? t : rows;
     }
-    if ((size_t)blockIdx.x * (32 * NWV) >= nrows) return;    // whole workgroup idle
+    const bool has_block = (size_t)blockIdx.x * (32 * NWV) < nrows;
+    if (!MIX && !has_block) return;                          // whole workgroup idle
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // Waves w and w+4 share a SIMD; static priority for the younger half staggers them so one
     // wave's epilogue can run under its partner's MFMAs.
-    if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+    if (wave >= 4 && has_block) __builtin_amdgcn_s_setprio(1);
     const size_t ntile32 = rows >> 5;
     const size_t nblk = (nrows + 32 * NWV - 1) / (32 * NWV);
 
@@ -277,7 +677,7 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     p.wave = wave; p.lane = lane; p.nw = NWV;
     // prologue: first tile group of stage 0 -> slot 0
     constexpr int G0 = group_tiles(S::WT, S::KE + 1, SLOT) * (S::KE + 1);
-    p.issue(0, G0);
+    if (!MIX || has_block) p.issue(0, G0);
 
   // Persistent workgroup: one CU holds one workgroup (136 KB of LDS), so looping over the
   // 256-sample blocks here instead of relaunching hides every block's start-up (first weight
@@ -480,304 +880,15 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
 #undef ST
 #undef MK
   }
-}
-
-// ---------------------------------------------------------------------------
-// M-split forward for the object MLPs (W = 128): latency per tile instead of work per wave.
-//
-// k_mlp_fwd gives every wave 32 samples and ALL output tiles of a layer: a block is a chain of 11 stages x 32 MFMAs per
-// wave behind a workgroup barrier and a weight DMA each, ~2.3 us per stage whatever the occupancy -- and the object launches
-// of a step are one round of a few dozen such blocks, i.e. pure latency (25-45 us per launch at the reference's 512-ray
-// batch and at K = 8).  Here a workgroup is 4 waves x 64 samples (two 32-sample MFMA tiles); wave w owns output tile w of
-// every layer, so a stage is 8-12 k-steps x 2 independent accumulators per wave.  Activations are exchanged through LDS
-// as the very fragments the next stage's MFMAs read (the C-layout of tile w IS k-steps 2w, 2w+1 of the next B operand:
-// mlp_spec.h), weights come straight from L2 (each wave reads only its own tile's 9-13 KB per stage: no LDS staging, no
-// DMA waits), one barrier per stage.  Same MFMA instruction, same operands, same k order per output as k_mlp_fwd<128>:
-// raw, encoding tile, stash, masks and view tile are BIT-identical (tests/test_gpu_fused_encode.py).
-// ---------------------------------------------------------------------------
-namespace ms {
-using S = MlpSpec<128>;
-constexpr int NT = 2;                                  // 32-sample tiles per workgroup
-constexpr int X_BYTES = NT * S::KW * 1024;             // one activation fragment buffer: [tile][k-step][lane][16 B]
-constexpr int OFF_X = 0;                               // two of them (written by stage s, read by stage s + 1)
-constexpr int OFF_E = 2 * X_BYTES;                     // encoding fragments [tile][KE][lane][16 B] (natural order)
-constexpr int OFF_V = OFF_E + NT * S::KE * 1024;       // view fragments     [tile][KV][lane][16 B]
-constexpr int OFF_M = OFF_V + NT * S::KV * 1024;       // ReLU-flag pieces   [2][tile][wave][lane] u32
-constexpr int LDS_BYTES = OFF_M + 2 * NT * 4 * 64 * 4;
-}  // namespace ms
-
-template <bool TRAIN>
-__global__ void __launch_bounds__(256)      // one wave per SIMD: the register file is this workgroup's (latency, not occupancy)
-k_mlp_fwd_ms(size_t rows, int N, const bf16x8* __restrict__ enc_g, const bf16x8* __restrict__ view,
-             const int32_t* __restrict__ ray_idx_g, const int32_t* __restrict__ count_g, const char* __restrict__ wpack_g,
-             float* __restrict__ raw_g, bf16x8* __restrict__ stash_g, uint4* __restrict__ relu_mask_g, FwdStrides bs, EncIn ei_g,
-             int nobj) {
-    using S = ms::S;
-    constexpr int NT = ms::NT;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int n = lane & 31, hi = lane >> 5;
-    const size_t ntile32 = rows >> 5;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    char* const X0 = smem + ms::OFF_X;
-    char* const E = smem + ms::OFF_E;
-    char* const V = smem + ms::OFF_V;
-    unsigned* const M = (unsigned*)(smem + ms::OFF_M);
-    // The work items are (object, pair of 32-sample tiles); the hit counts live on the device.  A 1-D grid deals them in
-    // order -- object 0's pairs, object 1's, ... -- so the workgroups that find work are exactly the first sum(pairs) of the
-    // grid.  (With a (object, pair) grid the first 256 workgroups dispatched covered only pairs < 256 / K of every object: at
-    // K = 8 an object with more than 32 pairs waited for a second round of CUs although fewer than 256 workgroups had work --
-    // 47 us a launch for 26 us of work.)
-    auto pairs_of = [&](int k) -> size_t {
-        const size_t c = (size_t)count_g[k] * (size_t)N;
-        return ((c < rows ? c : rows) + 32 * NT - 1) / (32 * NT);
-    };
-    size_t total = 0;
-    for (int k = 0; k < nobj; k++) total += pairs_of(k);
-
-    for (size_t item = blockIdx.x; item < total; item += gridDim.x) {
-        size_t k = 0, pair = item;
-        for (;; k++) {
-            const size_t np = pairs_of((int)k);
-            if (pair < np) break;
-            pair -= np;
-        }
-        k = (size_t)__builtin_amdgcn_readfirstlane((unsigned)k);
-        // this object's slabs (0 strides for a single MLP)
-        const bf16x8* __restrict__ enc = (const bf16x8*)((const char*)enc_g + k * bs.enc);
-        const int32_t* __restrict__ ray_idx = ray_idx_g + k * bs.idx;
-        const char* __restrict__ wpack = wpack_g + k * bs.wpack;
-        float* __restrict__ raw = (float*)((char*)raw_g + k * bs.raw);
-        EncIn ei = ei_g;
-        if (ei.view_tile) ei.view_tile = (char*)ei.view_tile + k * ei.view_stride;
-        bf16x8* __restrict__ stash = TRAIN ? (bf16x8*)((char*)stash_g + k * bs.stash) : nullptr;
-        uint4* __restrict__ relu_mask = TRAIN ? (uint4*)((char*)relu_mask_g + k * bs.mask) : nullptr;
-        const size_t c = (size_t)count_g[k] * (size_t)N;
-        const size_t nrows = c < rows ? c : rows;          // a multiple of 32 (N % 32 == 0)
-        const size_t t32[NT] = {pair * NT, pair * NT + 1};
-        const bool tv[NT] = {true, t32[1] * 32 < nrows};
-        ms_barrier();                               // the previous pair is done with the LDS
-        // ---- inputs: the tiles' encodings (computed here or read), view directions ----
-        if (ei.obj) {
-            if (wave == 0) {                           // lane = sample: 64 lanes = both tiles; the stand-alone encoder's body
-                const int t = lane >> 5;
-                const size_t row = t32[t] * 32 + n;
-                if (tv[t]) {
-                    const int j = (int)(row / (size_t)N), nn = (int)(row % (size_t)N);
-                    const int b = ray_idx[j];
-                    const float t0 = ei.t_vals[(size_t)b * (N + 1) + nn], t1 = ei.t_vals[(size_t)b * (N + 1) + nn + 1];
-                    float o[3] = {ei.origins_s[b * 3], ei.origins_s[b * 3 + 1], ei.origins_s[b * 3 + 2]};
-                    float d[3] = {ei.dirs_s[b * 3], ei.dirs_s[b * 3 + 1], ei.dirs_s[b * 3 + 2]};
-                    Gauss g = frustum_gaussian(t0, t1, o, d, ei.radii[b], (ei.flags & DURF_ENC_CYLINDER) != 0);
-                    if (ei.flags & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
-                    BarfW bw;
-#pragma unroll
-                    for (int i = 0; i < 10; i++) bw.w[i] = ei.w[i];
-                    char* const eg = (char*)enc + t32[t] * (S::KE * 1024);
-                    lane_features<true>(g, bw, [&](auto q_, const bf16x8& o8) {
-                        constexpr int q = decltype(q_)::value;             // features [8 q, 8 q + 8): k-step q / 2, half q % 2
-                        const int off = (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16;
-                        *(bf16x8*)(E + t * (S::KE * 1024) + off) = o8;
-                        *(bf16x8*)(eg + off) = o8;      // the encoding tile the weight-gradient GEMMs of Dense_0 / Dense_5 read
-                    });
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 8; q++) *(bf16x8*)(E + t * (S::KE * 1024) + (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16) = zero8;
-                }
-            }
-        } else {
-            for (int ch = wave; ch < NT * S::KE; ch += 4) {                // chunk = (tile, k-step)
-                const int t = ch / S::KE, k = ch % S::KE;
-                *(bf16x8*)(E + ch * 1024 + lane * 16) =
-                    tv[t] ? *(const bf16x8*)((const char*)enc + t32[t] * (S::KE * 1024) + k * 1024 + lane * 16) : zero8;
-            }
-        }
-        if (wave >= 2) {                               // waves 2, 3: the view-direction fragments of tile 0, 1
-            const int t = wave - 2;
-            const size_t row = t32[t] * 32 + n;
-            size_t ray = 0;
-            if (tv[t]) ray = (size_t)ray_idx[row / (size_t)N];
-#pragma unroll
-            for (int k = 0; k < S::KV; k++) {
-                const bf16x8 v = tv[t] ? view[ray * (DURF_VIEW_DIM / 8) + 2 * k + hi] : zero8;
-                *(bf16x8*)(V + (t * S::KV + k) * 1024 + lane * 16) = v;
-                if (TRAIN && ei.view_tile && tv[t]) *(bf16x8*)((char*)ei.view_tile + (t32[t] * S::KV + k) * 1024 + lane * 16) = v;
-            }
-        }
-
-        // ---- one stage: this wave's output tile `mo` of forward stage s for both sample tiles ----
-        // B operands: NX k-steps from the activation buffer Xin, then NE from the encoding, then NV from the view fragments
-        f32x16 acc[NT];
-        // Weights of (stage s, output tile mo): T A-fragments + the 16 bias values of this lane, straight from L2 into registers.
-        // They are requested ONE STAGE AHEAD (two register sets, alternating), so a stage never waits for its own loads.
-        struct WSet { bf16x8 A[S::KW + S::KE]; f32x4 b[4]; };
-        auto load_w = [&](auto s_, int mo, WSet& w) {
-            constexpr int s = decltype(s_)::value, T = S::n_ks(s);
-            const char* wt = wpack + (size_t)(S::stage_chunk_base(s) + mo * S::tile_chunks(s)) * 1024;     // wave-uniform
-            // (opaque: the stream is read-only, so hipcc would otherwise hoist EVERY later stage's loads above the barriers in
-            // between -- the inference instantiation needed all 512 registers and still spilled)
-            asm volatile("" : "+s"(wt));
-#pragma unroll
-            for (int k = 0; k < T; k++) w.A[k] = *(const bf16x8*)(wt + k * 1024 + lane * 16);
-            const f32x4* bp = (const f32x4*)(wt + T * 1024 + hi * 64);     // the bias rows: the initial accumulators
-#pragma unroll
-            for (int g = 0; g < 4; g++) w.b[g] = bp[g];
-        };
-        auto stage_mma = [&](auto s_, const WSet& w, auto nx_, auto ne_, auto nv_, const char* Xin) {
-            constexpr int s = decltype(s_)::value, NX = decltype(nx_)::value, NE = decltype(ne_)::value, NV = decltype(nv_)::value;
-            constexpr int T = NX + NE + NV;
-            static_assert(T == S::n_ks(s), "k-steps of the stage");
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-#pragma unroll
-                for (int t = 0; t < NT; t++) { acc[t][4 * g] = w.b[g][0]; acc[t][4 * g + 1] = w.b[g][1]; acc[t][4 * g + 2] = w.b[g][2]; acc[t][4 * g + 3] = w.b[g][3]; }
-            }
-#pragma unroll
-            for (int k = 0; k < T; k++) {
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const char* src = k < NX ? Xin + (t * S::KW + k) * 1024
-                                             : (k < NX + NE ? E + (t * S::KE + (k - NX)) * 1024 : V + (t * S::KV + (k - NX - NE)) * 1024);
-                    const bf16x8 b = *(const bf16x8*)(src + lane * 16);
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], b, acc[t], 0, 0, 0);
-                }
-            }
-        };
-        // epilogue of a stashed ReLU stage: fragments 2 mo, 2 mo + 1 of the next stage's input, the stash, the flag pieces
-        auto hand_over = [&](auto relu_, int mo, char* Xout, int jstash, unsigned* Mbuf) {
-            constexpr bool RELU = decltype(relu_)::value;
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                bf16x8 o0, o1;
-                const unsigned bits = pack_tile<RELU, TRAIN && RELU>(acc[t], o0, o1);
-                *(bf16x8*)(Xout + (t * S::KW + 2 * mo) * 1024 + lane * 16) = o0;
-                *(bf16x8*)(Xout + (t * S::KW + 2 * mo + 1) * 1024 + lane * 16) = o1;
-                if (TRAIN && RELU && tv[t]) {
-                    char* sd = (char*)stash + ((size_t)S::stash_ks_before(jstash) * ntile32 + t32[t] * S::stash_ks(jstash)) * 1024;
-                    STREAM_STORE(sd + (2 * mo) * 1024 + lane * 16, o0);
-                    STREAM_STORE(sd + (2 * mo + 1) * 1024 + lane * 16, o1);
-                    Mbuf[(t * 4 + mo) * 64 + lane] = bits << (8 * (mo & 1));
-                }
-            }
-        };
-        // waves 0 / 1 assemble the previous stage's flags of tile 0 / 1 into k_mlp_fwd's layout (one uint4 per lane: words
-        // 0, 1 = tile pairs (0,1), (2,3)) -- after the barrier that made every wave's piece visible
-        auto flush_mask = [&](int jmask, const unsigned* Mbuf) {
-            if (TRAIN && wave < NT && tv[wave]) {
-                const unsigned* m = Mbuf + (wave * 4) * 64 + lane;
-                const uint4 w4 = make_uint4(m[0] | m[64], m[128] | m[192], 0u, 0u);
-                *(uint4*)((char*)relu_mask + ((size_t)jmask * ntile32 + t32[wave]) * 1024 + lane * 16) = w4;
-            }
-        };
-        using I0 = std::integral_constant<int, 0>;
-        char* Xa = X0;
-        char* Xb = X0 + ms::X_BYTES;
-        unsigned* Ma = M;
-        unsigned* Mb = M + NT * 4 * 64;
-        WSet w0, w1, wd;                               // two alternating weight sets + wave 0's density-head tile
-        load_w(std::integral_constant<int, 0>{}, wave, w0);
-        ms_barrier();                               // encodings and view fragments are in place
-        using IE = std::integral_constant<int, S::KE>;
-        using IW = std::integral_constant<int, S::KW>;
-        auto swap = [&]() { char* tx = Xa; Xa = Xb; Xb = tx; unsigned* tm = Ma; Ma = Mb; Mb = tm; };
-        // stage 0: enc -> Xa
-        load_w(std::integral_constant<int, 1>{}, wave, w1);
-        stage_mma(std::integral_constant<int, 0>{}, w0, I0{}, IE{}, I0{}, Xa);
-        hand_over(std::true_type{}, wave, Xa, 0, Ma);
-        ms_barrier();
-        // stages 1-4 (the next stage's weights are requested before this stage's MFMAs)
-        flush_mask(0, Ma);
-        load_w(std::integral_constant<int, 2>{}, wave, w0);
-        stage_mma(std::integral_constant<int, 1>{}, w1, IW{}, I0{}, I0{}, Xa);
-        hand_over(std::true_type{}, wave, Xb, 1, Mb);
-        ms_barrier();
-        swap();
-        flush_mask(1, Ma);
-        load_w(std::integral_constant<int, 3>{}, wave, w1);
-        stage_mma(std::integral_constant<int, 2>{}, w0, IW{}, I0{}, I0{}, Xa);
-        hand_over(std::true_type{}, wave, Xb, 2, Mb);
-        ms_barrier();
-        swap();
-        flush_mask(2, Ma);
-        load_w(std::integral_constant<int, 4>{}, wave, w0);
-        stage_mma(std::integral_constant<int, 3>{}, w1, IW{}, I0{}, I0{}, Xa);
-        hand_over(std::true_type{}, wave, Xb, 3, Mb);
-        ms_barrier();
-        swap();
-        flush_mask(3, Ma);
-        load_w(std::integral_constant<int, 5>{}, wave, w1);
-        stage_mma(std::integral_constant<int, 4>{}, w0, IW{}, I0{}, I0{}, Xa);
-        hand_over(std::true_type{}, wave, Xb, 4, Mb);
-        ms_barrier();
-        swap();
-        // stage 5: [h4, enc] (obbpose_model.py:333-334)
-        flush_mask(4, Ma);
-        load_w(std::integral_constant<int, 6>{}, wave, w0);
-        stage_mma(std::integral_constant<int, 5>{}, w1, IW{}, IE{}, I0{}, Xa);
-        hand_over(std::true_type{}, wave, Xb, 5, Mb);
-        ms_barrier();
-        swap();
-        // stages 6, 7
-        flush_mask(5, Ma);
-        load_w(std::integral_constant<int, 7>{}, wave, w1);
-        if (wave == 0) load_w(std::integral_constant<int, 8>{}, S::WT, wd);       // the density head's tile, two stages ahead
-        stage_mma(std::integral_constant<int, 6>{}, w0, IW{}, I0{}, I0{}, Xa);
-        hand_over(std::true_type{}, wave, Xb, 6, Mb);
-        ms_barrier();
-        swap();
-        flush_mask(6, Ma);
-        load_w(std::integral_constant<int, 8>{}, wave, w0);
-        stage_mma(std::integral_constant<int, 7>{}, w1, IW{}, I0{}, I0{}, Xa);
-        hand_over(std::true_type{}, wave, Xb, 7, Mb);
-        ms_barrier();
-        swap();
-        // stage 8: h7 -> bottleneck (linear, tile `wave`) and, wave 0, the density head (tile WT)
-        flush_mask(7, Ma);
-        load_w(std::integral_constant<int, 9>{}, wave, w1);
-        float dens[NT] = {0.0f, 0.0f};
-        if (wave == 0) {
-            stage_mma(std::integral_constant<int, 8>{}, wd, IW{}, I0{}, I0{}, Xa);
-#pragma unroll
-            for (int t = 0; t < NT; t++) dens[t] = acc[t][0];
-        }
-        stage_mma(std::integral_constant<int, 8>{}, w0, IW{}, I0{}, I0{}, Xa);
-        hand_over(std::false_type{}, wave, Xb, 8, Mb);
-        ms_barrier();
-        { char* tx = Xa; Xa = Xb; Xb = tx; }
-        // stage 9: [bottleneck, view] -> hc (128, relu); its flags go to mask region 8
-        if (wave == 0) load_w(std::integral_constant<int, 10>{}, 0, w0);
-        stage_mma(std::integral_constant<int, 9>{}, w1, IW{}, I0{}, std::integral_constant<int, S::KV>{}, Xa);
-        hand_over(std::true_type{}, wave, Xb, 9, Mb);
-        ms_barrier();
-        flush_mask(8, Mb);
-        // stage 10: hc -> rgb (wave 0), raw = (rgb, density)
-        if (wave == 0) {
-            // jnp.maximum propagates NaN, v_max_f32 does not: a non-finite encoding poisons the sample's output (as k_mlp_fwd:
-            // the lane's 8 features of each k-step, then the sample's other half)
-            bool bad[NT] = {false, false};
-#pragma unroll
-            for (int t = 0; t < NT; t++)
-#pragma unroll
-                for (int k = 0; k < S::KE; k++) {
-                    const bf16x8 e8 = *(const bf16x8*)(E + (t * S::KE + k) * 1024 + lane * 16);
-#pragma unroll
-                    for (int e = 0; e < 8; e++) bad[t] |= !(fabsf((float)e8[e]) <= 3.0e38f);
-                }
-#pragma unroll
-            for (int t = 0; t < NT; t++) bad[t] |= (__shfl_xor((int)bad[t], 32, 64) != 0);
-            stage_mma(std::integral_constant<int, 10>{}, w0, std::integral_constant<int, S::KC>{}, I0{}, I0{}, Xb);
-            if (lane < 32) {
-                const float qn = __builtin_nanf("");
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    if (!tv[t]) continue;
-                    const f32x4 o = {bad[t] ? qn : acc[t][0], bad[t] ? qn : acc[t][1], bad[t] ? qn : acc[t][2], bad[t] ? qn : dens[t]};
-                    *(f32x4*)(raw + (t32[t] * 32 + n) * 4) = o;
-                }
-            }
-        }
-    }
+  if constexpr (MIX) {
+    // ---- the object items: two groups of four waves, (object, tile pair) items by ticket ----
+    // (every weight DMA of the background blocks has been consumed -- the last block prefetches nothing -- and the stores
+    // still in flight do not touch the LDS; the barrier makes sure every wave is past its last weight read)
+    if (has_block) __builtin_amdgcn_s_setprio(0);
+    ms_barrier();
+    const unsigned long long ka = (unsigned long long)(const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
+    mix_object_items<TRAIN>(lds_addr_of(smem), wave, (int)gridDim.x, (unsigned)ka, (unsigned)(ka >> 32));
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -836,6 +947,68 @@ int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, cons
     ei.view_tile = view_tile;
     return durf::launch_mlp_fwd(stream, 256, rows, N, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash,
                                 relu_mask, 1, FwdStrides{}, tail_idx, tail_count, &ei);
+}
+
+// durf_mlp_fwd_enc + durf_obj_fwd_batch as ONE launch where that pays (include/durf_hip.h), else as the two launches
+int durf_mlp_fwd_enc_obj(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
+                         const float* radii, const int32_t* hit, int K, int enc_flags, void* enc_tile, const void* view_bf16,
+                         const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
+                         void* relu_mask, const int32_t* tail_idx, const int32_t* tail_count, void* view_tile,
+                         int B, const int32_t* obj_idx, const int32_t* obj_count, const float* barf_w, int obj_flags,
+                         const void* obj_wpack_fwd, void* obj_enc, float* obj_raw, void* obj_stash, void* obj_relu_mask,
+                         void* obj_view_tile) {
+    DURF_REQUIRE(K > 0 && B > 0 && (size_t)B * N == rows, "K object MLPs over rows = B * N sample rows");
+    DURF_REQUIRE(obj_idx && obj_count && barf_w && obj_wpack_fwd && obj_enc && obj_raw, "the object launch's buffers");
+    DURF_REQUIRE((stash == nullptr) == (obj_stash == nullptr), "training or inference: both MLP classes alike");
+    const char* e = getenv("DURF_OBJ_MIX");
+    const bool mix = !(e && e[0] == '0') && stash != nullptr && obj_relu_mask != nullptr && durf::obj_msplit(rows) && N % 32 == 0 &&
+                     ray_idx != nullptr;
+    if (!mix) {
+        int rc = durf_mlp_fwd_enc(stream, rows, N, t_vals, origins_s, dirs_s, radii, hit, K, enc_flags, enc_tile, view_bf16, ray_idx,
+                                  count, wpack_fwd, raw, stash, relu_mask, tail_idx, tail_count, view_tile);
+        if (rc) return rc;
+        return durf_obj_fwd_batch(stream, K, B, N, obj_idx, obj_count, t_vals, origins_s, dirs_s, radii, barf_w, obj_flags, view_bf16,
+                                  obj_wpack_fwd, obj_enc, obj_raw, obj_stash, obj_relu_mask, obj_view_tile);
+    }
+    DURF_REQUIRE((tail_idx == nullptr) == (tail_count == nullptr), "tail_idx and tail_count go together");
+    DURF_REQUIRE(tail_idx == nullptr || count != nullptr, "tail rows follow a compacted ray list");
+    DURF_REQUIRE(t_vals && origins_s && dirs_s && radii && enc_tile && hit, "ray data, hit masks and the encoding tile buffer");
+    DURF_REQUIRE(K <= DURF_MAX_OBJ, "K <= DURF_MAX_OBJ");
+    DURF_REQUIRE(!(enc_flags & DURF_FWD_RAW_FULL) || rows < ((size_t)1 << 32), "DURF_FWD_RAW_FULL: 32-bit row numbers");
+    EncIn ei{};
+    ei.t_vals = t_vals; ei.origins_s = origins_s; ei.dirs_s = dirs_s; ei.radii = radii; ei.hit = hit; ei.K = K; ei.flags = enc_flags;
+    ei.view_tile = view_tile;
+    // the object items: durf_obj_fwd_batch's arguments as the M-split kernel takes them
+    MsFwd ow{};
+    ow.rows = rows; ow.N = N; ow.enc = (const bf16x8*)obj_enc; ow.view = (const bf16x8*)view_bf16; ow.ray_idx = obj_idx;
+    ow.count = obj_count; ow.wpack = (const char*)obj_wpack_fwd; ow.raw = obj_raw; ow.stash = (bf16x8*)obj_stash;
+    ow.relu_mask = (uint4*)obj_relu_mask; ow.nobj = K;
+    ow.bs.enc = durf_obj_enc_stride(B, N); ow.bs.idx = (size_t)B; ow.bs.wpack = durf_wpack_fwd_bytes(DURF_W_OBJ);
+    ow.bs.raw = rows * 4 * sizeof(float); ow.bs.stash = durf_mlp_stash_bytes(DURF_W_OBJ, rows); ow.bs.mask = durf_mlp_mask_bytes(rows);
+    ow.ei.t_vals = t_vals; ow.ei.origins_s = origins_s; ow.ei.dirs_s = dirs_s; ow.ei.radii = radii;
+    ow.ei.flags = obj_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER); ow.ei.obj = 1;
+    for (int i = 0; i < 10; i++) ow.ei.w[i] = barf_w[i];
+    ow.ei.view_tile = obj_view_tile; ow.ei.view_stride = durf_obj_view_stride(B, N);
+    ow.ticket = durf::next_ticket();
+    DURF_REQUIRE(ow.ticket != nullptr, "no item counter for the mixed launch (device allocation failed)");
+    hipStream_t s = (hipStream_t)stream;
+    // one workgroup per CU: the background blocks' (capacity: the counts live on the device), then room for the object items
+    const unsigned nblk = durf_cdiv(rows, 256), nobj = durf_cdiv((size_t)K * durf_cdiv(rows, 64), 2);
+    const unsigned g = nblk + nobj < 256u ? nblk + nobj : 256u;
+    constexpr int lds = 2 * 4 * (MlpSpec<256>::KW + 1) * 1024;
+    static_assert(2 * ms::LDS_BYTES + 16 <= lds, "two object groups fit the background block's LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)k_mlp_fwd<256, true, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((k_mlp_fwd<256, true, 8, true, true>), dim3(g), dim3(512), lds, s, rows, N, (const bf16x8*)enc_tile,
+                       (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask,
+                       FwdStrides{}, tail_idx, tail_count, ei, ow);
+    DURF_CHECK_LAUNCH("durf_mlp_fwd_enc_obj");
+    durf::note_dispatch(DURF_DISPATCH_FWD256_8W | DURF_DISPATCH_FWD_ENC | DURF_DISPATCH_FWD_MIX | (tail_idx ? DURF_DISPATCH_FWD_TAIL : 0u) |
+                        ((enc_flags & DURF_FWD_RAW_FULL) ? DURF_DISPATCH_FWD_RAW_FULL : 0u));
+    return 0;
 }
 
 int durf_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile,
@@ -911,12 +1084,12 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
     if (width == 128 && ray_idx && count && obj_msplit(rows)) {
         const size_t items = (size_t)K * durf_cdiv(rows, 64);           // capacity; the counts decide (see the kernel)
         dim3 g((unsigned)(items < 256 ? items : 256)), b(256);         // one workgroup per CU at most: one round
+        const MsFwd A{rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw,
+                      (bf16x8*)stash, (uint4*)relu_mask, st, ei, K, nullptr};
         if (stash)
-            hipLaunchKernelGGL((k_mlp_fwd_ms<true>), g, b, ms::LDS_BYTES, s, rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16,
-                               ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei, K);
+            hipLaunchKernelGGL((k_mlp_fwd_ms<true>), g, b, ms::LDS_BYTES, s, A);
         else
-            hipLaunchKernelGGL((k_mlp_fwd_ms<false>), g, b, ms::LDS_BYTES, s, rows, N, (const bf16x8*)enc_tile, (const bf16x8*)view_bf16,
-                               ray_idx, count, (const char*)wpack_fwd, raw, (bf16x8*)stash, (uint4*)relu_mask, st, ei, K);
+            hipLaunchKernelGGL((k_mlp_fwd_ms<false>), g, b, ms::LDS_BYTES, s, A);
         DURF_CHECK_LAUNCH("durf_mlp_fwd (M-split)");
         note_dispatch(DURF_DISPATCH_FWD128_MSPLIT | (ei.obj ? DURF_DISPATCH_FWD_ENC : 0u));
         return 0;
@@ -931,7 +1104,7 @@ int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_
         }                                                                                         \
         hipLaunchKernelGGL((k_mlp_fwd<WW, TR, NWV, EN>), grid, block, lds, s, rows, N, (const bf16x8*)enc_tile, \
                            (const bf16x8*)view_bf16, ray_idx, count, (const char*)wpack_fwd, raw,  \
-                           (bf16x8*)stash, (uint4*)relu_mask, st, tail_idx, tail_count, ei);       \
+                           (bf16x8*)stash, (uint4*)relu_mask, st, tail_idx, tail_count, ei, MsFwd{}); \
     }
     if (enc_in && width == 128) { if (stash) LAUNCH_F(128, true, 8, true) else LAUNCH_F(128, false, 8, true) }
     else if (enc_in) {

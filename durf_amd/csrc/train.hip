@@ -220,6 +220,9 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         for (int k = 0; k < K; k++) raw_obj[l][k] = w.obj_raw[l] + (size_t)k * rows * 4;
     const int obj_flags = f.enc_flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER);
     const durf::Overlap ov = durf::overlap_for(stream, rows, Kb);
+    // Small steps (one stream): the bf16 object MLPs' forward and backward are items of the background MLP's persistent launches
+    // (durf_mlp_fwd_enc_obj / durf_mlp_bwd_obj, round 6; those fall back to two launches each where the mix does not apply)
+    const bool mix = Kb > 0 && !ov.sd;
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = f.t_vals[lvl];
         if (ov.sd) {              // bf16 objects of a large step: issued first, on the side stream (joined before the composite)
@@ -231,6 +234,14 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         if (K > 0) {
             // (bf16 objects: the forward writes raw in the full layout itself, DURF_FWD_RAW_FULL; fp32 objects: the box-hit
             // rays' rows come from k_bkgd_hit_rays' fp32 evaluation instead, through durf_expand_raw)
+            if (mix)          // small step, bf16 objects: the object MLPs' items ride in the background launch (k_mlp_fwd<.., MIX>)
+                TIMED(DURF_TIMED_FWD + lvl,
+                      durf_mlp_fwd_enc_obj(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags | DURF_FWD_RAW_FULL,
+                                           w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, w.raw_b[lvl], w.stash[lvl], w.mask[lvl],
+                                           w.idx_cls + B, w.count_cls + 1, lvl == 0 ? w.view_tile : nullptr, B, w.idx_obj, w.count_obj,
+                                           f.barf_w, obj_flags, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
+                                           lvl == 0 ? w.obj_view_tile : nullptr));
+            else
             TIMED(DURF_TIMED_FWD + lvl,
                   durf_mlp_fwd_enc(stream, rows, N, t_vals, w.o_s, w.d_s, f.radii, w.hit, K, f.enc_flags | (f32o ? 0 : DURF_FWD_RAW_FULL),
                                    w.enc[lvl], w.view, w.idx_cls, w.count_cls, w.wf_bkgd, f32o ? w.raw_c[lvl] : w.raw_b[lvl], w.stash[lvl],
@@ -253,7 +264,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
                 STEP(durf_objf32_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, nullptr, w.view27, f.obj_params,
                                            f.obj_param_stride, w.obj_ws, w.obj_raw[lvl], w.act32[lvl], t_vals, w.o_s, w.d_s,
                                            f.radii, f.barf_w, obj_flags));
-            else if (!ov.sd)
+            else if (!ov.sd && !mix)
                 STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, f.radii, f.barf_w, obj_flags,
                                         w.view, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
                                         lvl == 0 ? w.obj_view_tile : nullptr));
@@ -296,8 +307,8 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     }
     STEP(ov.fork());          // (ONE fork for the whole backward: the object launches read d(raw), which the loss launch above wrote
                               // for every level, and what their own forward left on the side stream)
-    if (Kb > 0) {             // the object backward of EVERY level: one launch at small batches (in front of the background's), level
-                              // by level on the side stream, in the shadow of the background backward, at large ones
+    if (Kb > 0 && !mix) {     // the object backward of EVERY level: level by level on the side stream, in the shadow of the background
+                              // backward (large steps; a small step's rides in the background launches below)
         const float* dr[ML]; const void* mk[ML]; void* dzl[ML]; void* dzo[ML];
         for (int l = 0; l < L; l++) { dr[l] = w.draw[L - 1 - l]; mk[l] = w.obj_mask[L - 1 - l]; dzl[l] = w.obj_dz[L - 1 - l]; dzo[l] = w.obj_dz_out[L - 1 - l]; }
         STEP(durf_obj_bwd_batch_levels(ov.obj(), K, B, N, L, w.idx_obj, w.count_obj, dr, w.wb_obj, mk, dzl, dzo));
@@ -316,7 +327,13 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     }
     for (int lvl = L - 1; lvl >= 0; lvl--) {
         float* rs = K > 0 ? w.ray_sums + (size_t)lvl * B * 4 : nullptr;
-        if (K > 0) {
+        if (mix) {            // this level's background backward + the object MLPs' backward of the same level: one launch
+            const float* dr1[1] = {w.draw[lvl]}; const void* mk1[1] = {w.obj_mask[lvl]};
+            void* dz1[1] = {w.obj_dz[lvl]}; void* dzo1[1] = {w.obj_dz_out[lvl]};
+            TIMED(DURF_TIMED_BWD + lvl,
+                  durf_mlp_bwd_obj(stream, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
+                                   w.idx_cls + B, w.count_cls + 1, rs, K, B, 1, w.idx_obj, w.count_obj, dr1, w.wb_obj, mk1, dz1, dzo1));
+        } else if (K > 0) {
             TIMED(DURF_TIMED_BWD + lvl,
                   durf_mlp_bwd(stream, 256, rows, N, w.draw[lvl], w.idx_cls, w.count_cls, w.wb_bkgd, w.mask[lvl], w.dz[lvl], w.dz_out[lvl],
                                nullptr, w.idx_cls + B, w.count_cls + 1, rs));

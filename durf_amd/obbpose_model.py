@@ -370,7 +370,18 @@ class MipNerfModel:
                 vt = None
                 if train and lvl == 0 and ops.FUSED_ENCODE:   # ... and writes the view-direction tile of the weight-gradient launch
                     vt = ctx['view_tile'] = torch.empty(ops.tile_rows(rows), ops.VIEW_DIM, dtype=torch.bfloat16, device=dev)
-                if dd is not None and ops.FUSED_ENCODE:       # the forward encodes its own tiles (durf_mlp_fwd_enc)
+                # a small training step (one stream): the K object MLPs' forward rides in the background MLP's persistent
+                # launch as (object, tile pair) items (durf_mlp_fwd_enc_obj, round 6) -- bit-identical to the two launches
+                mixed = (train and bool(Kb) and dd is not None and ops.FUSED_ENCODE and ops.FWD_SCATTER_RAW and
+                         not side.enabled and ops.obj_mix(rows))
+                if mixed:
+                    scatter = True
+                    raw_c, enc_b = ops.mlp_fwd_enc_obj(rows, N, t_vals, o_s, d_s, radii, hit, view, packs['MLP_0'][0], slabs, idx,
+                                                       count, alpha, packs['obj'][0], dd['idx'][0], dd['count'][0:1], dd['idx'][1],
+                                                       dd['count'][1:2], stash_b, mask_b, view_tile=vt,
+                                                       obj_view_tile=view_tiles_obj if lvl == 0 else None, **enc_kw)
+                    obj_first = True                          # (the objects are done: nothing left to launch below)
+                elif dd is not None and ops.FUSED_ENCODE:       # the forward encodes its own tiles (durf_mlp_fwd_enc)
                     side.fork()
                     # (raw straight in the full layout unless the box-hit rays' rows come from the fp32 evaluation, raw_tail)
                     scatter = not obj_f32 and ops.FWD_SCATTER_RAW
@@ -536,6 +547,30 @@ class MipNerfModel:
             density_noise=dn, density_rand=noise.get('density') if dn else None)
         box_rot0 = pose[0, 3:] if K > 0 else ops.const_tensor(dev, (3,))
         return [tuple(o) + ([pose[:, :3], box_rot0], dyn, zo) for o in outs]
+
+    def render_image_one_call(self, variables, rays, init, ext, ts, white_bkgd, alpha, chunk=8192):
+        """render_image (obbpose_model.py:421-479) for one device as ONE library call (durf_render_image, csrc/forward.hip): the
+        chunk loop runs in C over the image's rays where they are -- no per-chunk slicing, output allocation or argument
+        marshalling in the interpreter.  rays: [H, W, .] fields -> (rgb [H,W,3], distance [H,W], acc [H,W]), bit-identical to
+        render_image over apply_one_call chunks.  Same scope as apply_one_call (supports_one_call)."""
+        self._check()
+        variables = self._kernel_variables(variables)
+        lay = variables.layout
+        K = lay.K
+        if not self.supports_one_call(variables):
+            raise NotImplementedError('durf_render_image covers the bf16 inference path (dynamics=True, bf16 object MLPs)')
+        height, width = rays[0].shape[:2]
+        flat = utils.namedtuple_map(lambda r: r.reshape(height * width, -1), rays)
+        pose = variables['params']['box_centers'][int(ts)].contiguous()
+        flags = ((ops.ENC_CONTRACT if self.contraction else 0) | (ops.ENC_NO_INTEGRATION if self.disable_integration else 0) |
+                 (ops.ENC_CYLINDER if self.ray_shape == 'cylinder' else 0))
+        o0 = lay.mlp_off['BoxMLP_0'] if K else 0
+        rgb, dist_, acc = ops.render_image_call(
+            flat, pose, ext.reshape(-1, 3).contiguous() if K else None, variables.mlp_flat('MLP_0'),
+            variables.flat[o0:o0 + K * lay.mlp_size[W_OBJ]] if K else None, lay.mlp_size[W_OBJ], self.num_samples, self.num_levels,
+            alpha, flags, chunk, lindisp=self.lindisp, bkgd_mode=ops.BKGD_WHITE if white_bkgd else ops.BKGD_GREY,
+            density_bias=self.density_bias, resample_padding=self.resample_padding)
+        return rgb.reshape(height, width, 3), dist_.reshape(height, width), acc.reshape(height, width)
 
     def apply(self, variables, rng, rays, init, ext, ts, randomized, rand_bkgd, white_bkgd, alpha,
               noise=None):

@@ -229,7 +229,7 @@ def tile_rows(rows):
 DISPATCH = dict(FWD256_8W=0x1, FWD256_4W=0x2, FWD128_SAMPLE=0x4, FWD128_MSPLIT=0x8, BWD256_8W=0x10, BWD256_4W=0x20,
                 BWD128_SAMPLE=0x40, BWD128_MSPLIT=0x80, DW256_256WG=0x100, DW256_512WG=0x200, DW128_128WG=0x400,
                 DW128_256WG=0x800, FWD_ENC=0x1000, FWD_RAW_FULL=0x2000, FWD_TAIL=0x4000, F32_DW_TILE=0x8000,
-                F32_DW_B2=0x10000, BWD_POSE=0x20000)
+                F32_DW_B2=0x10000, BWD_POSE=0x20000, FWD_MIX=0x40000, BWD_MIX=0x80000)
 
 
 def dispatch_reset():
@@ -886,6 +886,60 @@ def obj_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha, vi
             _p(wf), _p(slabs.enc), _p(slabs.raw), _p(slabs.stash), _p(slabs.mask), _p(view_tile)), 'durf_obj_fwd_batch')
 
 
+def obj_mix(rows):
+    """whether a training step of `rows` sample rows per level issues its bf16 object MLPs as items of the background MLP's
+    persistent launches (durf_mlp_fwd_enc_obj / durf_mlp_bwd_obj: one stream, the M-split regime; DURF_OBJ_MIX=0: A/B switch)"""
+    return (os.environ.get('DURF_OBJ_MIX', '1') != '0' and os.environ.get('DURF_OBJ_MSPLIT', '1') != '0' and
+            rows < OVERLAP_MIN_ROWS and overlap_mode(rows) == '0')
+
+
+def mlp_fwd_enc_obj(rows, N, t_vals, origins_s, dirs_s, radii, hit, view_bf16, wpack_fwd, slabs, obj_idx, obj_count, alpha, obj_wf,
+                    ray_idx, count, tail_idx, tail_count, stash, relu_mask, contraction=True, disable_integration=False,
+                    cylinder=False, view_tile=None, raw_full=True, obj_view_tile=None):
+    """mlp_fwd_enc (the background MLP on the de-duplicated ray classes) + obj_fwd_batch (the K object MLPs into `slabs`) as
+    ONE launch (durf_mlp_fwd_enc_obj: the heterogeneous persistent grid of a small training step) -> (raw, enc_tile);
+    every output bit-identical to the two calls"""
+    dev = t_vals.device
+    K = hit.shape[1]
+    raw = torch.empty(rows, 4, device=dev)
+    enc_tile = torch.empty(tile_rows(rows), ENC_DIM, dtype=torch.bfloat16, device=dev)
+    flags = ((ENC_CONTRACT if contraction else 0) | (ENC_NO_INTEGRATION if disable_integration else 0) |
+             (ENC_CYLINDER if cylinder else 0) | (FWD_RAW_FULL if raw_full else 0))
+    wa = (C.c_float * 10)(*[float(x) for x in barf_weights(alpha)])
+    with _Timed('mlp_fwd_256%s' % ('_train' if stash is not None else '')):
+        _lib.check(_lib.lib().durf_mlp_fwd_enc_obj(
+            _stream(), rows, N, _p(_f32(t_vals)), _p(_f32(origins_s)), _p(_f32(dirs_s)), _p(_f32(radii)), _p(hit), K, flags,
+            _p(enc_tile), _p(view_bf16), _p(ray_idx), _p(count), _p(wpack_fwd), _p(raw), _p(stash), _p(relu_mask), _p(tail_idx),
+            _p(tail_count), _p(view_tile), slabs.B, _p(obj_idx), _p(obj_count), wa,
+            (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0), _p(obj_wf), _p(slabs.enc),
+            _p(slabs.raw), _p(slabs.stash), _p(slabs.mask), _p(obj_view_tile)), 'durf_mlp_fwd_enc_obj')
+    return raw, enc_tile
+
+
+def mlp_bwd_obj(rows, N, draw, wpack_bwd, relu_mask, ray_idx, count, tail_idx, tail_count, draw_ray_sum, slabs_levels, obj_idx,
+                obj_count, obj_draws, obj_wb):
+    """mlp_bwd(256) of the background MLP + obj_bwd_batch_levels of the K object MLPs (slabs_levels / obj_draws: per level)
+    as ONE launch (durf_mlp_bwd_obj) -> (dz, dz_out) of the background MLP; the slabs receive dz / dz_out; bit-identical"""
+    L = _lib.lib()
+    dev = draw.device
+    dz = torch.empty(mlp_stash_bytes(256, rows), dtype=torch.uint8, device=dev)
+    dz_out = torch.empty(tile_rows(rows), 16, dtype=torch.bfloat16, device=dev)
+    s0 = slabs_levels[0]
+    K, B, nl = s0.K, s0.B, len(slabs_levels)
+    for sl in slabs_levels:
+        sl.dz = torch.empty(K * mlp_stash_bytes(W_OBJ_, B * N), dtype=torch.uint8, device=dev)
+        sl.dz_out = torch.empty(K * int(L.durf_obj_dzout_stride(B, N)), dtype=torch.uint8, device=dev)
+        sl.d_enc = None
+    arr = lambda ts: (C.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    with _Timed('mlp_bwd_256'):
+        _lib.check(L.durf_mlp_bwd_obj(_stream(), rows, N, _p(_f32(draw)), _p(ray_idx), _p(count), _p(wpack_bwd), _p(relu_mask),
+                                      _p(dz), _p(dz_out), _p(tail_idx), _p(tail_count), _p(draw_ray_sum), K, B, nl, _p(obj_idx),
+                                      _p(obj_count), arr([_f32(d) for d in obj_draws]), _p(obj_wb),
+                                      arr([s.mask for s in slabs_levels]), arr([s.dz for s in slabs_levels]),
+                                      arr([s.dz_out for s in slabs_levels])), 'durf_mlp_bwd_obj')
+    return dz, dz_out
+
+
 def obj_view_tiles(K, B, N, device):
     return torch.empty(K * int(_lib.lib().durf_obj_view_stride(B, N)), dtype=torch.uint8, device=device)
 
@@ -1281,8 +1335,9 @@ def _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_st
         assert len(dr) == num_levels and all(t.numel() == B * N for t in dr)
         keep.extend(dr)
         a.density_rand = _vp4(*([t.data_ptr() for t in dr] + [None] * (FORWARD_MAX_LEVELS - num_levels)))
-    for i, name in enumerate(('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')):
-        setattr(a, name, _vp4(*([o[i].data_ptr() for o in outs] + [None] * (FORWARD_MAX_LEVELS - num_levels))))
+    if outs is not None:          # (durf_render_image keeps the per-chunk outputs in its workspace)
+        for i, name in enumerate(('rgb', 'depth', 'acc', 'weights', 't_vals', 't_mids', 't_dists')):
+            setattr(a, name, _vp4(*([o[i].data_ptr() for o in outs] + [None] * (FORWARD_MAX_LEVELS - num_levels))))
     a.dyn_mask, a.zo = _p(dyn), _p(zo)
 
 
@@ -1306,6 +1361,27 @@ def forward_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, 
     with _Timed('forward_call'):
         _lib.check(L.durf_forward(_stream(), C.byref(a), _p(ws), ws.numel()), 'durf_forward')
     return outs, dyn, zo
+
+
+def render_image_call(rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, chunk,
+                      lindisp=False, bkgd_mode=BKGD_GREY, density_bias=-1.0, resample_padding=0.01):
+    """render_image on one device as ONE library call (durf_render_image: the chunk loop in C over the ray buffer resident on
+    the device) -> rgb [n,3], distance [n], acc [n] of the last level; rays: flattened [n, .] fields of the whole image"""
+    n, K = rays.origins.shape[0], pose.shape[0]
+    dev = rays.origins.device
+    L = _lib.lib()
+    rgb, dist_, acc = torch.empty(n, 3, device=dev), torch.empty(n, device=dev), torch.empty(n, device=dev)
+    a = ForwardArgs()
+    keep = []
+    rays = type(rays)(*[t.contiguous() for t in rays])
+    _fill_forward_args(a, rays, pose, ext, bkgd_params, obj_params, obj_param_stride, N, num_levels, alpha, enc_flags, lindisp,
+                       bkgd_mode, density_bias, resample_padding, None, None, None, None, None, keep)
+    a.B = min(chunk, n)
+    ws = _workspace(dev, int(L.durf_render_image_workspace_bytes(min(chunk, n), N, K, num_levels)))
+    with _Timed('render_image_call'):
+        _lib.check(L.durf_render_image(_stream(), C.byref(a), n, min(chunk, n), _p(rgb), _p(dist_), _p(acc), _p(ws), ws.numel()),
+                   'durf_render_image')
+    return rgb, dist_, acc
 
 
 _WORKSPACE = {}

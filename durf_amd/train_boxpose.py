@@ -306,7 +306,10 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
     # whenever all the levels' d(raw) exist already and no d(enc) is wanted (the pose gradient behind bf16 objects takes the
     # per-level kernel with the d(enc) epilogue)
     obj_bwd_done = bool(Kb) and not pose_opt and not f32 and all(d is not None for d in draws)
-    if obj_bwd_done:
+    # ... or, at a small step on one stream, level by level as items of the background backward's persistent launch
+    # (durf_mlp_bwd_obj, round 6: bit-identical to the launches of their own)
+    obj_bwd_mixed = obj_bwd_done and dd is not None and not obj_side.enabled and ops.obj_mix(rows)
+    if obj_bwd_done and not obj_bwd_mixed:
         obj_side.fork()
         with obj_side:
             if obj_side.enabled:
@@ -346,7 +349,11 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             continue
         if not obj_bwd_done:
             obj_side.fork()                  # the object backward runs in the shadow of the background backward
-        if dd is not None:
+        if obj_bwd_mixed:
+            dzs[lvl] = ops.mlp_bwd_obj(rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'], dd['idx'][0], dd['count'][0:1],
+                                       dd['idx'][1], dd['count'][1:2], ray_sums[lvl], [lv['slabs']], ctx['idx'], ctx['count'],
+                                       [draw], ctx['packs']['obj'][1])
+        elif dd is not None:
             dzs[lvl] = ops.mlp_bwd(om.W_BKGD, rows, N, draw, ctx['packs']['MLP_0'][1], lv['mask_b'], ray_idx=dd['idx'][0],
                                    count=dd['count'][0:1], tail_idx=dd['idx'][1], tail_count=dd['count'][1:2],
                                    draw_ray_sum=ray_sums[lvl])
@@ -751,8 +758,13 @@ def make_render_fn(model, config, variables, one_call=None):
 def evaluate(model, config, variables, test_case, alpha, chunk=8192, rng=0):
     """One test image (train_boxpose.py:535-563): render, PSNR, SSIM.  -> dict(psnr, ssim, rgb, distance, acc, rays)"""
     from . import metrics
-    rgb, dist_, acc = om.render_image(make_render_fn(model, config, variables), test_case['rays'], test_case['init'],
-                                      test_case['ext'], test_case['ts'], rng, alpha, chunk=chunk)
+    if _dist() is None and model.supports_one_call(variables):
+        # one device: the whole image as ONE C call (durf_render_image: the chunk loop over the resident ray buffer)
+        rgb, dist_, acc = model.render_image_one_call(variables, test_case['rays'], test_case['init'], test_case['ext'],
+                                                      test_case['ts'], config.white_bkgd, alpha, chunk=chunk)
+    else:
+        rgb, dist_, acc = om.render_image(make_render_fn(model, config, variables), test_case['rays'], test_case['init'],
+                                          test_case['ext'], test_case['ts'], rng, alpha, chunk=chunk)
     gt = test_case['pixels'][..., :3]
     psnr = dmath.mse_to_psnr(((rgb - gt) ** 2).mean())                                   # :562
     ssim = metrics.compute_ssim(rgb, gt, 1.0) if rgb.is_cuda else None                   # :563

@@ -80,6 +80,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_mlp_fwd_enc.restype = i32
     L.durf_mlp_fwd_enc.argtypes = [vp, u64, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     #   (stream, rows, N, t_vals, origins_s, dirs_s, radii, hit, K, enc_flags, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash, relu_mask, tail_idx, tail_count, view_tile)
+    L.durf_mlp_fwd_enc_obj.restype = i32
+    L.durf_mlp_fwd_enc_obj.argtypes = [vp, u64, i32, vp, vp, vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, C.POINTER(f32), i32, vp, vp, vp, vp, vp, vp]
+    #   (stream, rows, N, t_vals, origins_s, dirs_s, radii, hit, K, enc_flags, enc_tile, view_bf16, ray_idx, count, wpack_fwd, raw, stash, relu_mask, tail_idx, tail_count, view_tile, B, obj_idx, obj_count, barf_w, obj_flags, obj_wpack_fwd, obj_enc, obj_raw, obj_stash, obj_relu_mask, obj_view_tile)
     L.durf_composite_fwd.restype = i32
     L.durf_composite_fwd.argtypes = [vp, i32, i32, i32, vp, C.POINTER(vp), vp, vp, vp, f32, i32, vp, vp, vp, vp, vp, vp]
     #   (stream, B, N, K, raw_bkgd, raw_obj, slot, t_vals, dirs_s, density_bias, bkgd_mode, rgb, depth, acc, weights, t_mids, t_dists)
@@ -137,6 +140,12 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_forward.restype = i32
     L.durf_forward.argtypes = [vp, vp, vp, u64]
     #   (stream, args, workspace, workspace_bytes)
+    L.durf_render_image_workspace_bytes.restype = u64
+    L.durf_render_image_workspace_bytes.argtypes = [i32, i32, i32, i32]
+    #   (chunk, N, K, num_levels)
+    L.durf_render_image.restype = i32
+    L.durf_render_image.argtypes = [vp, vp, u64, i32, vp, vp, vp, vp, u64]
+    #   (stream, args, n_rays, chunk, rgb, distance, acc, workspace, workspace_bytes)
     L.durf_train_workspace_bytes.restype = u64
     L.durf_train_workspace_bytes.argtypes = [i32, i32, i32, i32, u64]
     #   (B, N, K, num_levels, n_params)
@@ -235,6 +244,9 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_obj_bwd_batch_levels.restype = i32
     L.durf_obj_bwd_batch_levels.argtypes = [vp, i32, i32, i32, i32, vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
     #   (stream, K, B, N, nlevels, idx, count, draw, wpack_bwd, relu_mask, dz, dz_out)
+    L.durf_mlp_bwd_obj.restype = i32
+    L.durf_mlp_bwd_obj.argtypes = [vp, u64, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, C.POINTER(vp), vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    #   (stream, rows, N, draw, ray_idx, count, wpack_bwd, relu_mask, dz, dz_out, tail_idx, tail_count, draw_ray_sum, K, B, nlevels, obj_idx, obj_count, obj_draw, obj_wpack_bwd, obj_relu_mask, obj_dz, obj_dz_out)
     L.durf_obj_dw_batch.restype = i32
     L.durf_obj_dw_batch.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), i32, vp, vp, vp, u64, vp]
     #   (stream, K, B, N, count, nlevels, enc, view_tile, stash, dz, dz_out, in_dim, part, bpart, grad_mlp, grad_stride, mlp_params)

@@ -64,6 +64,8 @@ int durf_version(void);
 #define DURF_DISPATCH_F32_DW_TILE 0x8000   /* k_mlp_dw_f32: one output tile per workgroup (the fp32 object branch) */
 #define DURF_DISPATCH_F32_DW_B2 0x10000    /* k_mlp_dw_f32_b2: 2 x 2 blocks (W = 256) */
 #define DURF_DISPATCH_BWD_POSE 0x20000     /* k_mlp_bwd<.., POSE>: d(enc) for the box-pose gradient */
+#define DURF_DISPATCH_FWD_MIX 0x40000      /* k_mlp_fwd<256, .., MIX>: background blocks + the object MLPs' items in ONE launch */
+#define DURF_DISPATCH_BWD_MIX 0x80000      /* k_mlp_bwd<256, .., MIX>: the same for the backward */
 int durf_dispatch_seen(void);
 int durf_dispatch_reset(void);
 
@@ -211,6 +213,24 @@ int durf_mlp_fwd_enc(void* stream, size_t rows, int N, const float* t_vals, cons
                      const void* wpack_fwd, float* raw, void* stash /* nullable */, void* relu_mask /* nullable */,
                      const int32_t* tail_idx /* nullable */, const int32_t* tail_count /* nullable */,
                      void* view_tile /* nullable */);
+/* One level's forward of BOTH MLP classes of a small training step as ONE launch (round 6): durf_mlp_fwd_enc (the background
+ * MLP on the de-duplicated ray classes: arguments as there, ray_idx / count / tail_* required) + durf_obj_fwd_batch (the K
+ * BoxMLPs on their compacted hit lists, obbpose_model.py:174-201: B rays, obj_idx [K,B] / obj_count [K] from
+ * durf_compact_hits, slabs as there).  A heterogeneous persistent grid: every workgroup walks its background blocks, then
+ * becomes two 4-wave groups that take (object, tile pair) items off an atomic ticket counter -- the ~10 % of the workgroups
+ * the de-duplication leaves without a block (512 rays) or with one block fewer (1024 rays, K = 8) absorb the object MLPs
+ * inside the background launch's own duration, where a second launch cost 22 us per level and a second stream delayed the
+ * persistent workgroups.  Every output (raw, encoding tiles, stashes, masks, view tiles of both classes) is bit-identical
+ * to the two separate calls'.  Applies in training below 2048 x 128 sample rows (the M-split regime of the object
+ * kernels); otherwise, with inference buffers (stash == NULL) or under DURF_OBJ_MIX=0, the call issues the two launches. */
+int durf_mlp_fwd_enc_obj(void* stream, size_t rows, int N, const float* t_vals, const float* origins_s, const float* dirs_s,
+                         const float* radii, const int32_t* hit, int K, int enc_flags, void* enc_tile, const void* view_bf16,
+                         const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw,
+                         void* stash /* nullable */, void* relu_mask /* nullable */, const int32_t* tail_idx /* nullable */,
+                         const int32_t* tail_count /* nullable */, void* view_tile /* nullable */, int B,
+                         const int32_t* obj_idx, const int32_t* obj_count, const float* barf_w /* host float[10] */,
+                         int obj_flags, const void* obj_wpack_fwd, void* obj_enc, float* obj_raw,
+                         void* obj_stash /* nullable */, void* obj_relu_mask /* nullable */, void* obj_view_tile /* nullable */);
 
 /* K8 merge + activations + volumetric_rendering (obbpose_model.py:232-254, mip.py:285-327).
  * raw_bkgd [B*N,4]; raw_obj[k] [count_k*N,4] compacted, slot from durf_compact_hits.
@@ -412,6 +432,16 @@ size_t durf_forward_workspace_bytes(int B, int N, int K);
  * a buffer smaller than durf_forward_workspace_bytes(B, N, K) instead of carving its intermediates out of memory the
  * caller does not own. */
 int durf_forward(void* stream, const durf_forward_args* args, void* workspace, size_t workspace_bytes);
+/* One C call per IMAGE: render_image (obbpose_model.py:421-479) on one device -- the chunk loop the reference runs from Python
+ * (one pmapped call + one host round trip per chunk, :446-475) over a ray buffer RESIDENT on the device.  `args` as for
+ * durf_forward with the ray fields (origins, directions, viewdirs [n_rays,3]; radii, near, far [n_rays]) pointing at the whole
+ * image and B, the per-level output pointers, dyn_mask and zo ignored (they live in the workspace, per chunk); test mode only
+ * (no draws).  Chunks of `chunk` rays (the last one the remainder) run durf_forward's launch sequence; the LAST level's rgb
+ * [n_rays,3], distance [n_rays] and acc [n_rays] are written in place -- bit-identical to render_image over durf_forward
+ * chunks.  workspace: durf_render_image_workspace_bytes(chunk, N, K, num_levels) bytes, 256-byte aligned, size checked. */
+size_t durf_render_image_workspace_bytes(int chunk, int N, int K, int num_levels);
+int durf_render_image(void* stream, const durf_forward_args* args, size_t n_rays, int chunk, float* rgb, float* distance,
+                      float* acc, void* workspace, size_t workspace_bytes);
 
 /* ---- one shard's training step as ONE call (csrc/train.hip) ------------------------------------------------
  * durf_loss_backward: value_and_grad(loss_fn) of train_step (train_boxpose.py:67-252) -- the forward with activations
@@ -610,6 +640,16 @@ int durf_obj_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, co
 int durf_obj_bwd_batch_levels(void* stream, int K, int B, int N, int nlevels, const int32_t* idx, const int32_t* count,
                               const float* const* draw, const void* wpack_bwd, const void* const* relu_mask, void* const* dz,
                               void* const* dz_out);
+/* The backward counterpart of durf_mlp_fwd_enc_obj (round 6): durf_mlp_bwd(width 256, no d(enc)) of the background MLP +
+ * durf_obj_bwd_batch_levels of the K object MLPs over `nlevels` levels (host arrays of per-level device buffers) as ONE
+ * heterogeneous persistent launch -- background blocks, then (level, object, tile pair) items off a ticket counter on two
+ * 4-wave groups per workgroup.  dz / dz_out of both classes bit-identical to the two calls, which it falls back to above
+ * 2048 x 128 sample rows or under DURF_OBJ_MIX=0. */
+int durf_mlp_bwd_obj(void* stream, size_t rows, int N, const float* draw, const int32_t* ray_idx, const int32_t* count,
+                     const void* wpack_bwd, const void* relu_mask, void* dz, void* dz_out, const int32_t* tail_idx /* nullable */,
+                     const int32_t* tail_count /* nullable */, const float* draw_ray_sum /* nullable */, int K, int B, int nlevels,
+                     const int32_t* obj_idx, const int32_t* obj_count, const float* const* obj_draw, const void* obj_wpack_bwd,
+                     const void* const* obj_relu_mask, void* const* obj_dz, void* const* obj_dz_out);
 int durf_obj_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels,
                       const void* const* enc, const void* const* view_tile, const void* const* stash,
                       const void* const* dz, const void* const* dz_out, int in_dim, float* part, float* bpart,

@@ -34,10 +34,15 @@ def _env(**kw):
 # (what must have run, the oracle-compared scenario that selects it)
 ROWS = [
     # 256 rays x 32 samples = 32 blocks: 128-sample blocks of 4 waves; objects on the M-split kernels; one-round dW plans
+    # 256 rays x 32 samples: the object MLPs' forward / backward ride as items in the background MLP's persistent launches
+    # (round 6: k_mlp_fwd / k_mlp_bwd <.., MIX>, 256-sample blocks of 8 waves); one-round dW plans
     ('small step vs the bf16-rounded oracle',
-     {'FWD256_4W', 'BWD256_4W', 'FWD128_MSPLIT', 'BWD128_MSPLIT', 'DW256_256WG', 'DW128_128WG', 'FWD_ENC', 'FWD_TAIL',
-      'FWD_RAW_FULL'},
+     {'FWD256_8W', 'BWD256_8W', 'FWD_MIX', 'BWD_MIX', 'DW256_256WG', 'DW128_128WG', 'FWD_ENC', 'FWD_TAIL', 'FWD_RAW_FULL'},
      lambda cuda: TR.test_train_step(cuda, 3, 32, 256)),
+    # the same with the mix switched off: 128-sample blocks of 4 waves (32 blocks), objects on the M-split kernels of their own
+    ('small step with launches of their own for the objects',
+     {'FWD256_4W', 'BWD256_4W', 'FWD128_MSPLIT', 'BWD128_MSPLIT'},
+     lambda cuda: _unmixed(cuda)),
     # the same oracle comparison with the LARGE batches' choices forced: sample-split object kernels (>= 2048 x 128 rows in
     # production) and the two-round / 256-per-object weight-gradient plans (>= 3072 x 256 rows)
     ('small step under the large-batch variants',
@@ -98,6 +103,11 @@ def _bf16_objects_with_pose_gradient(cuda):
 
 def _forced(cuda):
     with _env(DURF_OBJ_MSPLIT=0, DURF_DW_WGS=512, DURF_DW_WGS_OBJ=256):
+        TR.test_train_step(cuda, 3, 32, 256)
+
+
+def _unmixed(cuda):
+    with _env(DURF_OBJ_MIX=0):
         TR.test_train_step(cuda, 3, 32, 256)
 
 

@@ -147,3 +147,35 @@ def test_an_undersized_workspace_is_refused(cuda, monkeypatch):
     assert torch.equal(variables.flat, before), 'refused before the first launch'
     monkeypatch.setattr(ops, '_workspace', real)
     _same(model.apply_one_call(*args, **kw), good, 'the right size is accepted')
+
+
+@pytest.mark.parametrize('K,N,hw,chunk', [(3, 128, (96, 100), 8192), (2, 32, (37, 53), 512), (0, 64, (20, 31), 256)])
+def test_one_call_per_image_is_bit_identical_to_render_image_over_chunks(cuda, K, N, hw, chunk):
+    """durf_render_image (csrc/forward.hip): render_image (obbpose_model.py:421-479) for one device with the chunk loop in C
+    over the ray buffer resident on the device -- the last level's rgb / distance / acc of every pixel must be the bits
+    render_image produces over durf_forward chunks (ragged last chunk included), which in turn equals apply() chunk by chunk"""
+    from durf_amd import train_boxpose
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\n' % N)
+    config = utils.configured(utils.Config)
+    Hh, Ww = hw
+    b = synthetic.make_batch(Hh * Ww, K, seed=21 + K)
+    db = H.device_batch(b, cuda)
+    model, variables = obbpose_model.construct_mipnerf(1, db, device=cuda)
+    rays = utils.namedtuple_map(lambda r: r.reshape(Hh, Ww, -1), db['rays'])
+    fn = train_boxpose.make_render_fn(model, config, variables, one_call=True)
+    want = obbpose_model.render_image(fn, rays, db['init'], db['ext'], b['ts'], 0, 10.0, chunk=chunk)
+    got = model.render_image_one_call(variables, rays, db['init'], db['ext'], b['ts'], config.white_bkgd, 10.0, chunk=chunk)
+    torch.cuda.synchronize()
+    for name, g, w in zip(('rgb', 'distance', 'acc'), got, want):
+        assert g.shape == w.shape
+        assert torch.allclose(g, w, rtol=0, atol=0, equal_nan=True), name
+    # evaluate() takes that path on one device and reports the same PSNR as the chunked render
+    case = dict(rays=rays, pixels=db['pixels'].reshape(Hh, Ww, -1), init=db['init'], ext=db['ext'], ts=b['ts'])
+    ev = train_boxpose.evaluate(model, config, variables, case, 10.0, chunk=chunk)
+    assert torch.allclose(ev['rgb'], want[0], rtol=0, atol=0, equal_nan=True)
+    # a workspace sized for a smaller chunk is refused
+    import ctypes
+    L = ops._lib.lib()
+    small = int(L.durf_render_image_workspace_bytes(chunk // 2, N, K, 2))
+    assert small < int(L.durf_render_image_workspace_bytes(chunk, N, K, 2))
