@@ -209,6 +209,7 @@ int launch_encode_obj(void* stream, int K, int max_rays, int N, const int32_t* i
                       const float* t_vals, const float* origins_s, const float* dirs_s, const float* radii,
                       const float* barf_w, int flags, void* out_tile, size_t out_stride, float* out_f32);
 bool obj_msplit(size_t rows);
+bool obj_mix(size_t rows);
 int launch_mlp_fwd(void* stream, int width, size_t rows, int N, const void* enc_tile, const void* view_bf16,
                    const int32_t* ray_idx, const int32_t* count, const void* wpack_fwd, float* raw, void* stash,
                    void* relu_mask, int K, const FwdStrides& st, const int32_t* tail_idx = nullptr,

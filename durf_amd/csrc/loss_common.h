@@ -55,6 +55,42 @@ __device__ __forceinline__ void write_prep(float* __restrict__ prep, int B, int 
     prep[(size_t)PREP_DYN * B + b] = dynf;
 }
 
+// k_reduce_rows' row reduction (loss.hip: 1024 threads -- strided partial sums, xor-shuffle trees, the 16 waves' sums in
+// order) carried out by a 256-thread workgroup with the SAME order of additions, i.e. the same bits: thread t plays the
+// virtual threads t + 256 j (j = 0..3), whose wave is (t >> 6) + 4 j and whose lane is this thread's own.  s16: 16 floats of
+// shared memory.  Every thread of the workgroup must call it (two __syncthreads per row).
+__device__ __forceinline__ void reduce_rows_256(int rows, int n, int min_row, const float* __restrict__ in, float* __restrict__ out,
+                                                float* s16) {
+    const int t = threadIdx.x;
+    for (int r = 0; r < rows; r++) {
+        const bool is_min = (min_row >= 0 && r % PREP_ROWS == min_row);
+        const float* p = in + (size_t)r * n;
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v[j] = is_min ? __builtin_inff() : 0.0f;
+            for (int i = t + 256 * j; i < n; i += 1024) v[j] = is_min ? fminf(v[j], p[i]) : v[j] + p[i];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const float x = __shfl_xor(v[j], o, 64);
+                v[j] = is_min ? fminf(v[j], x) : v[j] + x;
+            }
+        if ((t & 63) == 0)
+#pragma unroll
+            for (int j = 0; j < 4; j++) s16[(t >> 6) + 4 * j] = v[j];
+        __syncthreads();
+        if (t == 0) {
+            float a = s16[0];
+            for (int w = 1; w < 16; w++) a = is_min ? fminf(a, s16[w]) : a + s16[w];
+            out[r] = a;
+        }
+        __syncthreads();
+    }
+}
+
 namespace durf {
 // out[r] = sum over in[r*n .. r*n+n), or the minimum for rows with r % PREP_ROWS == min_row (min_row < 0: none)
 void launch_reduce_rows(hipStream_t s, int rows, int n, int min_row, const float* in, float* out);

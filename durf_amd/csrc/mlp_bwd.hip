@@ -409,14 +409,12 @@ struct BwdKernArgs {
     const float* draw_ray_sum; MsBwd ow;
 };
 // The object phase of a mixed backward workgroup (k_mlp_bwd<.., MIX>): two groups of four waves take (level, object, tile
-// pair) items off the ticket counter.  Not inlined, arguments from the kernarg segment: see mix_object_items in mlp_fwd.hip.
-__device__ __attribute__((noinline)) void mix_object_items_bwd(unsigned smem_lds, int wave_v, int nwg_v, unsigned ka_lo, unsigned ka_hi) {
-    const int wave = __builtin_amdgcn_readfirstlane(wave_v), nwg = __builtin_amdgcn_readfirstlane(nwg_v);
-    char* const smem = (char*)(__attribute__((address_space(3))) char*)(size_t)__builtin_amdgcn_readfirstlane(smem_lds);
+// pair) items off the ticket counter.  Inlined, arguments from the kernarg segment: see mix_object_items in mlp_fwd.hip.
+__device__ __forceinline__ void mix_object_items_bwd(char* smem, int wave, int nwg) {
     typedef const __attribute__((address_space(4))) char* kptr_t;
-    // (the kernarg segment pointer comes from the KERNEL: in a callee __builtin_amdgcn_kernarg_segment_ptr() is lowered to null)
-    kptr_t ka = (kptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_hi) << 32) |
-                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_lo));
+    kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));          // (opaque: the loads below stay below the background loop)
+    const unsigned smem_lds = lds_addr_of(smem);
     MsBwd ow;
     load_kernarg(ow, ka + offsetof(BwdKernArgs, ow));
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -589,8 +587,7 @@ k_mlp_bwd(size_t rows, int N, const float* __restrict__ draw, const int32_t* __r
   if constexpr (MIX) {
     if (has_block) __builtin_amdgcn_s_setprio(0);
     ms_barrier();                  // every wave is past its last weight read; no DMA is in flight (the last block prefetches none)
-    const unsigned long long ka = (unsigned long long)(const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-    mix_object_items_bwd(lds_addr_of(smem), wave, (int)gridDim.x, (unsigned)ka, (unsigned)(ka >> 32));
+    mix_object_items_bwd(smem, wave, (int)gridDim.x);
   }
 }
 
@@ -1290,8 +1287,7 @@ int durf_mlp_bwd_obj(void* stream, size_t rows, int N, const float* draw, const 
     DURF_REQUIRE(K > 0 && B > 0 && (size_t)B * N == rows, "K object MLPs over rows = B * N sample rows");
     DURF_REQUIRE(nlevels >= 1 && nlevels <= DURF_MAX_LEVELS, "1 <= nlevels <= DURF_MAX_LEVELS");
     DURF_REQUIRE(obj_idx && obj_count && obj_draw && obj_wpack_bwd && obj_relu_mask && obj_dz && obj_dz_out, "the object launch's buffers");
-    const char* e = getenv("DURF_OBJ_MIX");
-    const bool mix = !(e && e[0] == '0') && durf::obj_msplit(rows) && N % 32 == 0 && ray_idx != nullptr && count != nullptr;
+    const bool mix = durf::obj_mix(rows) && N % 32 == 0 && ray_idx != nullptr && count != nullptr;
     if (!mix) {
         int rc = durf_mlp_bwd(stream, 256, rows, N, draw, ray_idx, count, wpack_bwd, relu_mask, dz, dz_out, nullptr, tail_idx, tail_count,
                               draw_ray_sum);

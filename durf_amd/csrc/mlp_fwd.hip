@@ -579,19 +579,20 @@ struct FwdKernArgs {
     float* raw; bf16x8* stash; uint4* relu_mask; FwdStrides bs; const int32_t* tail_idx; const int32_t* tail_count; EncIn ei;
     MsFwd ow;
 };
-// The object phase of a mixed workgroup.  NOT inlined: it is compiled with a register allocation of its own -- inlined behind
-// the background loop its scalar-register spills reserved a third vector register throughout the kernel, and the loop,
-// which sits at the 256-register cap, spilled three more of its own values (a scratch reload drains the weight prefetch).
-// Nothing of the caller is live across the call.  The object arguments are fetched from the kernarg segment here.
+// The object phase of a mixed workgroup, inlined behind the background loop.  Two things keep it from costing that loop --
+// which sits at the 256-register cap -- anything: (i) nothing of it lives in a vector register across the loop (the lane number
+// is re-derived, everything else is wave-uniform), (ii) its ~70 dwords of arguments are fetched from the kernarg segment
+// HERE, behind an opaque pointer, instead of at kernel entry (as ordinary arguments hipcc keeps them in scalar registers
+// across the loop: 85 more SGPR spills, two more vector registers reserved for them).  What remains is one more vector
+// register of SGPR spill lanes than the plain kernel has: 28 B of scratch instead of 12, six reloads per 256-sample block.
+// (As a real CALL -- own register allocation, the loop untouched -- the phase needs a 360-byte frame for the callee-saved
+// registers, and a launch with that much scratch per lane took ~23 us longer whatever it did: profiles/r06_mix.txt.)
 template <bool TRAIN>
-__device__ __attribute__((noinline)) void mix_object_items(unsigned smem_lds, int wave_v, int nwg_v, unsigned ka_lo, unsigned ka_hi) {
-    // (arguments of a real call arrive in vector registers: make the wave-uniform ones scalar again)
-    const int wave = __builtin_amdgcn_readfirstlane(wave_v), nwg = __builtin_amdgcn_readfirstlane(nwg_v);
-    char* const smem = (char*)(__attribute__((address_space(3))) char*)(size_t)__builtin_amdgcn_readfirstlane(smem_lds);
+__device__ __forceinline__ void mix_object_items(char* smem, int wave, int nwg) {
     typedef const __attribute__((address_space(4))) char* kptr_t;
-    // (the kernarg segment pointer comes from the KERNEL: in a callee __builtin_amdgcn_kernarg_segment_ptr() is lowered to null)
-    kptr_t ka = (kptr_t)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_hi) << 32) |
-                         (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)ka_lo));
+    kptr_t ka = (kptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));          // (opaque: the loads below stay below)
+    const unsigned smem_lds = lds_addr_of(smem);
     MsFwd ow;
     load_kernarg(ow, ka + offsetof(FwdKernArgs, ow));      // (scalar loads: a constant-address-space source)
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -659,7 +660,8 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
         const size_t t = nrows_c + (size_t)(*tail_count);
         nrows = t < rows ? t : rows;
     }
-    const bool has_block = (size_t)blockIdx.x * (32 * NWV) < nrows;
+    bool has_block = (size_t)blockIdx.x * (32 * NWV) < nrows;
+    if (MIX && (ei.flags & (1 << 30))) { has_block = false; nrows = 0; }      // (DURF_MIX_PROBE=2: timing probe, object items only)
     if (!MIX && !has_block) return;                          // whole workgroup idle
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -886,8 +888,7 @@ k_mlp_fwd(size_t rows, int N, const bf16x8* __restrict__ enc, const bf16x8* __re
     // still in flight do not touch the LDS; the barrier makes sure every wave is past its last weight read)
     if (has_block) __builtin_amdgcn_s_setprio(0);
     ms_barrier();
-    const unsigned long long ka = (unsigned long long)(const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr();
-    mix_object_items<TRAIN>(lds_addr_of(smem), wave, (int)gridDim.x, (unsigned)ka, (unsigned)(ka >> 32));
+    mix_object_items<TRAIN>(smem, wave, (int)gridDim.x);
   }
 }
 
@@ -960,9 +961,7 @@ int durf_mlp_fwd_enc_obj(void* stream, size_t rows, int N, const float* t_vals, 
     DURF_REQUIRE(K > 0 && B > 0 && (size_t)B * N == rows, "K object MLPs over rows = B * N sample rows");
     DURF_REQUIRE(obj_idx && obj_count && barf_w && obj_wpack_fwd && obj_enc && obj_raw, "the object launch's buffers");
     DURF_REQUIRE((stash == nullptr) == (obj_stash == nullptr), "training or inference: both MLP classes alike");
-    const char* e = getenv("DURF_OBJ_MIX");
-    const bool mix = !(e && e[0] == '0') && stash != nullptr && obj_relu_mask != nullptr && durf::obj_msplit(rows) && N % 32 == 0 &&
-                     ray_idx != nullptr;
+    const bool mix = durf::obj_mix(rows) && stash != nullptr && obj_relu_mask != nullptr && N % 32 == 0 && ray_idx != nullptr;
     if (!mix) {
         int rc = durf_mlp_fwd_enc(stream, rows, N, t_vals, origins_s, dirs_s, radii, hit, K, enc_flags, enc_tile, view_bf16, ray_idx,
                                   count, wpack_fwd, raw, stash, relu_mask, tail_idx, tail_count, view_tile);
@@ -991,6 +990,11 @@ int durf_mlp_fwd_enc_obj(void* stream, size_t rows, int N, const float* t_vals, 
     ow.ei.view_tile = obj_view_tile; ow.ei.view_stride = durf_obj_view_stride(B, N);
     ow.ticket = durf::next_ticket();
     DURF_REQUIRE(ow.ticket != nullptr, "no item counter for the mixed launch (device allocation failed)");
+    if (const char* pr = getenv("DURF_MIX_PROBE"))        // timing probe (the results are WRONG): the launch without its object items
+    {
+        if (pr[0] == '1') ow.nobj = 0;
+        if (pr[0] == '2') ei.flags |= 1 << 30;               // ... and without its background blocks
+    }
     hipStream_t s = (hipStream_t)stream;
     // one workgroup per CU: the background blocks' (capacity: the counts live on the device), then room for the object items
     const unsigned nblk = durf_cdiv(rows, 256), nobj = durf_cdiv((size_t)K * durf_cdiv(rows, 64), 2);
@@ -1031,6 +1035,12 @@ static bool msplit_enabled() {           // read per call: tests toggle it
 }
 // whether launch_mlp_fwd / launch_mlp_bwd take the M-split kernels for a W = 128 launch on compacted ray lists of `rows` rows
 bool obj_msplit(size_t rows) { return rows < (size_t)2048 * 128 && msplit_enabled(); }
+// whether a training step of `rows` sample rows per level issues its bf16 object MLPs as items of the background MLP's launches
+// (durf_mlp_fwd_enc_obj / durf_mlp_bwd_obj; DURF_OBJ_MIX=0: A/B switch, bit-identical results)
+bool obj_mix(size_t rows) {
+    const char* e = getenv("DURF_OBJ_MIX");
+    return !(e && e[0] == '0') && obj_msplit(rows);
+}
 
 int pack_bwd_launch(void* stream, int width, int in_dim, int K, const float* params, size_t param_stride, void* wpack_bwd);
 

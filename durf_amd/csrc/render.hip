@@ -133,6 +133,14 @@ __device__ __forceinline__ float resample_ray(bool active, int b, int lane, int 
                                               float* __restrict__ t_out, const float* gt_eps_dm, bool blur = true) {
     float pw[P];
     float tot = 0.0f;
+    // (this lane's draws, requested before the pdf / cdf arithmetic and the barrier below instead of inside the search loop)
+    constexpr int NU = (RS_MAXN + 1 + 63) / 64;
+    float uv[NU];
+#pragma unroll
+    for (int q = 0; q < NU; q++) {
+        const int j = lane + 64 * q;
+        uv[q] = (u_rand && active && j <= N) ? u_rand[(size_t)b * (N + 1) + j] : 0.0f;
+    }
 #pragma unroll
     for (int p = 0; p < P; p++) {
         const int n = lane * P + p;
@@ -170,11 +178,14 @@ __device__ __forceinline__ float resample_ray(bool active, int b, int lane, int 
     if (!active) return mind2;
     const float one_m_eps = 0.99999988079071045f;                        // 1 - finfo(float32).eps
     const int num = N + 1;
-    for (int j = lane; j < num; j += 64) {
+#pragma unroll
+    for (int q = 0; q < NU; q++) {
+        const int j = lane + 64 * q;
+        if (j >= num) break;
         float u;
         if (u_rand) {                                                    // math.py:254-262
             const float s = 1.0f / (float)num;
-            u = (float)j * s + u_rand[(size_t)b * num + j] * (s - 1.1920928955078125e-07f);
+            u = (float)j * s + uv[q] * (s - 1.1920928955078125e-07f);
             u = fminf(u, one_m_eps);
         } else {                                                         // linspace(0, 1-eps, num)
             u = (j == num - 1) ? one_m_eps : one_m_eps * ((float)j / (float)(num - 1));
@@ -227,6 +238,9 @@ struct PrepArgs {
     const float* lossmult; const float* gt_depth; const float* sky; const int32_t* dyn; const float* zo;
     float eps, box_loss_mult; int level, disable_multiscale;
     float* prep_this; float* prep_next;
+    // round 6: the batch reduction of the prep rows (the loss normalisers: k_reduce_rows, a launch of its own until then) is
+    // done by whichever workgroup finishes LAST -- counter: a zeroed int the launch leaves zeroed (durf::next_ticket)
+    float* norm_this; float* norm_next; int* counter;
 };
 
 template <int P>
@@ -248,6 +262,11 @@ k_composite_resample(int B, int N, int K, const float* __restrict__ raw_bkgd, Ob
     float gt_eps_dm[3] = {0.f, 0.f, 0.f};
     RayMasks rm_next = {};
     float dynf = 0.0f;
+    // (the per-ray scalars of the loss prep, requested HERE with the ray's other inputs: they used to be fetched behind the
+    // composite's stores -- one more dependent round trip in a kernel that is a chain of them)
+    float p_gt = 0.f, p_lm = 0.f, p_sky = 0.f, p_zo = 0.f;
+    int p_dyn = 0;
+    if (active && pa.lossmult) { p_gt = pa.gt_depth[b]; p_lm = pa.lossmult[b]; p_sky = pa.sky[b]; p_zo = pa.zo[b]; p_dyn = pa.dyn[b]; }
     if (active) {
         const float dx = dirs_s[b * 3], dy = dirs_s[b * 3 + 1], dz = dirs_s[b * 3 + 2];
         const float dnorm = sqrtf(dx * dx + dy * dy + dz * dz);
@@ -265,18 +284,18 @@ k_composite_resample(int B, int N, int K, const float* __restrict__ raw_bkgd, Ob
         if (pa.lossmult) {
             LossCfg c = {};
             c.eps = pa.eps; c.box_loss_mult = pa.box_loss_mult; c.disable_multiscale = pa.disable_multiscale;
-            const float gt = pa.gt_depth[b];
-            dynf = (float)pa.dyn[b];
+            const float gt = p_gt;
+            dynf = (float)p_dyn;
             if (pa.prep_this) {
                 c.level = pa.level;
-                const RayMasks r = ray_masks(c, pa.lossmult[b], gt, pa.sky[b], dynf, pa.zo[b]);
+                const RayMasks r = ray_masks(c, p_lm, gt, p_sky, dynf, p_zo);
                 float mind2 = __builtin_inff();
                 for (int n = lane; n < N; n += 64) mind2 = fminf(mind2, near_d2(tv[n], gt, c.eps, r.dm));
                 mind2 = wave_min(mind2);
                 if (lane == 0) write_prep(pa.prep_this, B, b, r, mind2, dynf);
             }
             c.level = pa.level + 1;
-            rm_next = ray_masks(c, pa.lossmult[b], gt, pa.sky[b], dynf, pa.zo[b]);
+            rm_next = ray_masks(c, p_lm, gt, p_sky, dynf, p_zo);
             gt_eps_dm[0] = gt; gt_eps_dm[1] = c.eps; gt_eps_dm[2] = rm_next.dm;
         }
     }
@@ -286,6 +305,28 @@ k_composite_resample(int B, int N, int K, const float* __restrict__ raw_bkgd, Ob
     if (active && pa.lossmult) {
         mind2 = wave_min(mind2);
         if (lane == 0) write_prep(pa.prep_next, B, b, rm_next, mind2, dynf);
+    }
+    if (pa.counter) {
+        // the LAST workgroup to get here reduces the prep rows over the batch (k_reduce_rows' sums, bit for bit): every
+        // workgroup publishes its rows (release), takes a number; the last one sees them all (acquire)
+        __shared__ int s_last;
+        __shared__ float s16[16];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            s_last = (__hip_atomic_fetch_add(pa.counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1);
+        }
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            if (pa.prep_this && pa.prep_next == pa.prep_this + (size_t)PREP_ROWS * B && pa.norm_next == pa.norm_this + PREP_ROWS) {
+                reduce_rows_256(2 * PREP_ROWS, B, (int)PREP_MIND2, pa.prep_this, pa.norm_this, s16);
+            } else {
+                if (pa.prep_this) reduce_rows_256(PREP_ROWS, B, (int)PREP_MIND2, pa.prep_this, pa.norm_this, s16);
+                reduce_rows_256(PREP_ROWS, B, (int)PREP_MIND2, pa.prep_next, pa.norm_next, s16);
+            }
+            if (threadIdx.x == 0) __hip_atomic_store(pa.counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -349,7 +390,15 @@ int durf_composite_resample(void* stream, int B, int N, int K, const float* raw_
     if (B <= 0) return 0;
     ObjPtrs op;
     for (int k = 0; k < DURF_MAX_OBJ; k++) op.p[k] = (k < K) ? raw_obj[k] : nullptr;
-    const PrepArgs pa = {lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level, disable_multiscale, prep_this, prep_next};
+    PrepArgs pa = {lossmult, gt_depth, sky, dyn, zo, eps, box_loss_mult, level, disable_multiscale, prep_this, prep_next,
+                   norm_this, norm_next, nullptr};
+    {   // DURF_PREP_REDUCE_INKERNEL=1: the batch reduction by the last workgroup of this launch instead of k_reduce_rows
+        // launches behind it (the same sums).  Measured and NOT the default (profiles/r06_mix.txt): the release / acquire
+        // fences every workgroup pays (L2 write-back + invalidate at device scope) and the one-workgroup reduction tail cost
+        // 26-30 us a launch against 8-12 + 5.5 for the two launches.
+        const char* e = getenv("DURF_PREP_REDUCE_INKERNEL");
+        if (lossmult && e && e[0] == '1') pa.counter = durf::next_ticket();
+    }
     dim3 grid(durf_cdiv(B, 4)), block(256);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_CR(P)                                                                                       \
@@ -358,7 +407,7 @@ int durf_composite_resample(void* stream, int B, int N, int K, const float* raw_
                        u_rand, t_vals_out, pa)
     if (N <= 64) LAUNCH_CR(1); else if (N <= 128) LAUNCH_CR(2); else LAUNCH_CR(4);
 #undef LAUNCH_CR
-    if (lossmult) {
+    if (lossmult && pa.counter == nullptr) {
         // prep_this and prep_next may be adjacent ([2, PREP_ROWS, B]) with adjacent norms: one reduction launch
         if (prep_this && prep_next == prep_this + (size_t)PREP_ROWS * B && norm_next == norm_this + PREP_ROWS) {
             durf::launch_reduce_rows(s, 2 * PREP_ROWS, B, (int)PREP_MIND2, prep_this, norm_this);

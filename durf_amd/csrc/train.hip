@@ -222,7 +222,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     const durf::Overlap ov = durf::overlap_for(stream, rows, Kb);
     // Small steps (one stream): the bf16 object MLPs' forward and backward are items of the background MLP's persistent launches
     // (durf_mlp_fwd_enc_obj / durf_mlp_bwd_obj, round 6; those fall back to two launches each where the mix does not apply)
-    const bool mix = Kb > 0 && !ov.sd;
+    const bool mix = Kb > 0 && !ov.sd && durf::obj_mix(rows) && N % 32 == 0;
     for (int lvl = 0; lvl < L; lvl++) {
         float* t_vals = f.t_vals[lvl];
         if (ov.sd) {              // bf16 objects of a large step: issued first, on the side stream (joined before the composite)

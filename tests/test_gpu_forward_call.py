@@ -156,7 +156,7 @@ def test_one_call_per_image_is_bit_identical_to_render_image_over_chunks(cuda, K
     render_image produces over durf_forward chunks (ragged last chunk included), which in turn equals apply() chunk by chunk"""
     from durf_amd import train_boxpose
     utils.clear_gin()
-    utils.parse_gin('MipNerfModel.num_samples = %d\n' % N)
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\n' % N)
     config = utils.configured(utils.Config)
     Hh, Ww = hw
     b = synthetic.make_batch(Hh * Ww, K, seed=21 + K)
