@@ -145,6 +145,12 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
     }
 }
 
+#ifndef MIX_ROLE_ROT
+#define MIX_ROLE_ROT 2
+#endif
+#ifndef MIX_TICKET_WAVE
+#define MIX_TICKET_WAVE 1        // the wave that requests the mixed launches' tickets (A/B: tools/experiments/r06_mix_ab.sh)
+#endif
 // A by-value kernel argument read from the kernarg segment where it is needed -- dword by dword through a constant-address-
 // space pointer, i.e. scalar loads -- instead of at kernel entry (the mixed launches: their object arguments must not live in
 // scalar registers across the background loop)

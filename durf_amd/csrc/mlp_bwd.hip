@@ -418,13 +418,21 @@ __device__ __forceinline__ void mix_object_items_bwd(char* smem, int wave, int n
     MsBwd ow;
     load_kernarg(ow, ka + offsetof(BwdKernArgs, ow));
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const bool first = wave == 0 && lane == 0;
-    const int half = wave >> 2, w4 = wave & 3;
+    // (the ticket requests are wave 1's: wave 0 starts every item with the ray loads of the encoding / the head gradients, and
+    // a returning atomic ahead of them in its queue would be waited for with them)
+    const bool first = wave == MIX_TICKET_WAVE && lane == 0;
+    // (waves w and w + 4 share a SIMD: the second group's roles are rotated by two, so that the two groups' role-0 waves --
+    // the serial head of an item: the encoding / the head gradients -- run on different SIMDs)
+    const int half = wave >> 2, w4 = (wave + MIX_ROLE_ROT * half) & 3;
     char* const lds = smem + half * msb::LDS_BYTES;
     volatile __attribute__((address_space(3))) int* const tk =
         (volatile __attribute__((address_space(3))) int*)(size_t)(__builtin_amdgcn_readfirstlane(smem_lds) + 2u * msb::LDS_BYTES);
+    volatile __attribute__((address_space(3))) int* const npl = tk + 4;         // the objects' pair counts, once per workgroup
+    if (wave == 0 && lane < ow.nobj) npl[lane] = (int)msb_pairs_of(ow, lane);
+    ms_barrier();
     size_t total = 0;
-    for (int k = 0; k < ow.nobj; k++) total += msb_pairs_of(ow, k);
+    for (int k = 0; k < ow.nobj; k++) total += (size_t)npl[k];
+    total = (size_t)__builtin_amdgcn_readfirstlane((unsigned)total);
     const size_t items = total * (size_t)ow.lv.n;
     const int last = 2 * (int)((items + 1) / 2 + nwg - 1);            // the value the LAST request of the launch returns
     int t = 0;
@@ -436,8 +444,16 @@ __device__ __forceinline__ void mix_object_items_bwd(char* smem, int wave, int n
     while ((size_t)t < items) {
         int tn = 0;
         if (first) tn = __hip_atomic_fetch_add(ticket, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next request is under way while this item runs
-        int level; size_t k, pair;
-        const bool live = msb_item(ow, total, (size_t)t + (size_t)half, level, k, pair);
+        const size_t item = (size_t)t + (size_t)half;
+        const bool live = item < items;
+        const int level = __builtin_amdgcn_readfirstlane(live ? (int)(item / total) : 0);
+        size_t k = 0, pair = live ? item - (size_t)level * total : 0;
+        for (; live && k + 1 < (size_t)ow.nobj; k++) {
+            const size_t np = (size_t)npl[k];
+            if (pair < np) break;
+            pair -= np;
+        }
+        k = (size_t)__builtin_amdgcn_readfirstlane((unsigned)(live ? k : 0));
         // (this level's operands straight from the kernarg segment: a dynamically indexed copy would live in scratch)
         const __attribute__((address_space(4))) MsBwd* kp = (const __attribute__((address_space(4))) MsBwd*)(ka + offsetof(BwdKernArgs, ow));
         const float* draw = kp->lv.draw[level];
@@ -1313,7 +1329,7 @@ int durf_mlp_bwd_obj(void* stream, size_t rows, int N, const float* draw, const 
     const unsigned nblk = durf_cdiv(rows, 256), nobj = durf_cdiv((size_t)nlevels * K * durf_cdiv(rows, 64), 2);
     const unsigned g = nblk + nobj < 256u ? nblk + nobj : 256u;
     constexpr int lds = 2 * 4 * (MlpSpec<256>::KW + 1) * 1024;
-    static_assert(2 * msb::LDS_BYTES + 16 <= lds, "two object groups fit the background block's LDS");
+    static_assert(2 * msb::LDS_BYTES + 96 <= lds, "two object groups fit the background block's LDS");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_mlp_bwd<256, false, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);

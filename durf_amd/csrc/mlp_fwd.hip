@@ -596,13 +596,23 @@ __device__ __forceinline__ void mix_object_items(char* smem, int wave, int nwg) 
     MsFwd ow;
     load_kernarg(ow, ka + offsetof(FwdKernArgs, ow));      // (scalar loads: a constant-address-space source)
     const int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const bool first = wave == 0 && lane == 0;
-    const int half = wave >> 2, w4 = wave & 3;
+    // (the ticket requests are wave 1's: wave 0 starts every item with the ray loads of the encoding / the head gradients, and
+    // a returning atomic ahead of them in its queue would be waited for with them)
+    const bool first = wave == MIX_TICKET_WAVE && lane == 0;
+    // (waves w and w + 4 share a SIMD: the second group's roles are rotated by two, so that the two groups' role-0 waves --
+    // the serial head of an item: the encoding / the head gradients -- run on different SIMDs)
+    const int half = wave >> 2, w4 = (wave + MIX_ROLE_ROT * half) & 3;
     char* const lds = smem + half * ms::LDS_BYTES;
     volatile __attribute__((address_space(3))) int* const tk =
         (volatile __attribute__((address_space(3))) int*)(size_t)(__builtin_amdgcn_readfirstlane(smem_lds) + 2u * ms::LDS_BYTES);
+    // (the objects' pair counts once per workgroup, in LDS: re-read from memory for every item they were a chain of K
+    // dependent loads in front of it)
+    volatile __attribute__((address_space(3))) int* const npl = tk + 4;
+    if (wave == 0 && lane < ow.nobj) npl[lane] = (int)ms_pairs_of(ow, lane);
+    ms_barrier();
     size_t total = 0;
-    for (int k = 0; k < ow.nobj; k++) total += ms_pairs_of(ow, k);
+    for (int k = 0; k < ow.nobj; k++) total += (size_t)npl[k];
+    total = (size_t)__builtin_amdgcn_readfirstlane((unsigned)total);
     const int last = 2 * (int)((total + 1) / 2 + nwg - 1);            // the value the LAST request of the launch returns
     int t = 0;
     // (a GLOBAL atomic: a flat one counts on lgkmcnt, and the first barrier of the item would wait for the request under way)
@@ -613,8 +623,15 @@ __device__ __forceinline__ void mix_object_items(char* smem, int wave, int nwg) 
     while ((size_t)t < total) {
         int tn = 0;
         if (first) tn = __hip_atomic_fetch_add(ticket, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next request is under way while this item runs
-        size_t k, pair;
-        const bool live = ms_item(ow, (size_t)t + (size_t)half, k, pair);
+        size_t k = 0, pair = (size_t)t + (size_t)half;
+        const bool live = pair < total;
+        for (; live && k + 1 < (size_t)ow.nobj; k++) {
+            const size_t np = (size_t)npl[k];
+            if (pair < np) break;
+            pair -= np;
+        }
+        k = (size_t)__builtin_amdgcn_readfirstlane((unsigned)(live ? k : 0));
+        pair = live ? pair : 0;
         ms_fwd_pair<TRAIN>(ow, lds, lane, w4, live, k, pair);
         if (first) *tk = tn;
         ms_barrier();
@@ -1000,7 +1017,7 @@ int durf_mlp_fwd_enc_obj(void* stream, size_t rows, int N, const float* t_vals, 
     const unsigned nblk = durf_cdiv(rows, 256), nobj = durf_cdiv((size_t)K * durf_cdiv(rows, 64), 2);
     const unsigned g = nblk + nobj < 256u ? nblk + nobj : 256u;
     constexpr int lds = 2 * 4 * (MlpSpec<256>::KW + 1) * 1024;
-    static_assert(2 * ms::LDS_BYTES + 16 <= lds, "two object groups fit the background block's LDS");
+    static_assert(2 * ms::LDS_BYTES + 96 <= lds, "two object groups fit the background block's LDS");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)k_mlp_fwd<256, true, 8, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
