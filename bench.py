@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument('--config', default='cfg3', choices=sorted(WORKLOADS))
     ap.add_argument('--rays', type=int, default=0, help='rays per GPU (default: the workload\'s)')
     ap.add_argument('--objects', type=int, default=-1, help='override the number of dynamic boxes K')
-    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32'],
+    ap.add_argument('--precision', default='bf16', choices=['bf16', 'f32', 'bf16x3'],
                     help="f32: the whole model in the reference's own arithmetic (MipNerfModel.mlp_precision = 'f32': every "
                          'Dense layer on v_mfma_f32_32x32x2_f32, accurate-libm encodings; obbpose_model.py:326-327, '
                          'internal/math.py:22-24) -- the roofline is then priced against the 157.3 TFLOP/s fp32-MFMA peak')
@@ -140,7 +140,9 @@ def setup_workload(name, dev, rank=0, world=1, rays=0, objects=-1, precision='bf
     """Config, model, train state and this rank's shard of the named workload (also used by tools/)."""
     from durf_amd import obbpose_model, synthetic, train_boxpose, utils
     gin, K_OBJ, far, wl_rays, extra, noise, alpha, label = WORKLOADS[name]
-    if precision != 'bf16':
+    if precision == 'bf16x3':       # the fp32 object branch's GEMMs on split bf16 operands (MipNerfModel.obj_precision, round 6)
+        extra = tuple(extra) + ('MipNerfModel.obj_precision = "bf16x3"',)
+    elif precision != 'bf16':
         extra = tuple(extra) + ('MipNerfModel.mlp_precision = "%s"' % precision,)
     if objects >= 0:
         K_OBJ = objects
@@ -635,6 +637,7 @@ EXTRA_WORKLOADS = [          # (the small steps get as many steps as the headlin
     ('cfg2', 'cfg2', 0, 'bf16', 40, 5),
     ('cfg3_512rays', 'cfg3', 512, 'bf16', 200, 20),
     ('cfg4', 'cfg4', 0, 'bf16', 100, 10),
+    ('cfg4_bf16x3', 'cfg4', 0, 'bf16x3', 100, 10),
     ('cfg5', 'cfg5', 0, 'bf16', 100, 10),
     ('cfg3_f32', 'cfg3', 0, 'f32', 5, 2),
 ]

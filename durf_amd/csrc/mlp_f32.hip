@@ -119,7 +119,21 @@ struct F32Sched {
 
 // packed streams of one MLP: [forward stream | backward stream]; element (chunk g, row rr, column c) of the forward
 // stream = kernel_l[c_g KC + rr][c], of the backward stream = kernel_l[c][c_g KC + rr] (transposed), zero outside
-template <int W, int IN>
+// operand packing of the "bf16x3" variants (see chunk_mma_x3 below)
+__device__ __forceinline__ float x3_pack(float x) {
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    const unsigned w = ((unsigned)__builtin_bit_cast(unsigned short, h) << 16) | (unsigned)__builtin_bit_cast(unsigned short, l);
+    return __builtin_bit_cast(float, w);
+}
+__device__ __forceinline__ float x3_unpack(float p) {
+    const unsigned w = __builtin_bit_cast(unsigned, p);
+    return __builtin_bit_cast(float, w & 0xffff0000u) + __builtin_bit_cast(float, w << 16);
+}
+template <bool X3> __device__ __forceinline__ float opk(float x) { if constexpr (X3) return x3_pack(x); else return x; }
+template <bool X3> __device__ __forceinline__ float oup(float p) { if constexpr (X3) return x3_unpack(p); else return p; }
+
+template <int W, int IN, bool X3 = false>
 __global__ void __launch_bounds__(256)
 k_f32_pack(const float* __restrict__ P, float* __restrict__ ws, size_t p_stride, size_t ws_stride) {
     constexpr F32Spec S = f32_spec(W, IN);
@@ -150,7 +164,7 @@ k_f32_pack(const float* __restrict__ P, float* __restrict__ ws, size_t p_stride,
             if (r < fo && c < cv) v = P[S.L[l].w_off + (size_t)c * fo + r];
         }
     });
-    ws[e] = v;
+    ws[e] = opk<X3>(v);          // (bf16x3: the stream holds (hi, lo) bf16 pairs in the words of the fp32 values)
 }
 
 // ---- weight chunks: stream -> registers (issue) -> LDS (commit), 16 bytes per lane ------------------------------
@@ -241,6 +255,111 @@ __device__ __forceinline__ void chunk_mma(const float* wb, const float* xr, int 
     }
 }
 
+// ---- "bf16x3" (round 6): the same data flow on the bf16 matrix pipe ------------------------------------------------
+// Every MFMA operand is kept as a PAIR of bf16 -- x = hi + lo, hi = bf16(x), lo = bf16(x - hi): 16-17 significant bits --
+// packed in the 32-bit word the fp32 value would occupy (hi in the upper half), so streams, LDS layouts and the chunk
+// schedule are unchanged; a product is three v_mfma_f32_32x32x16_bf16 (hi.hi + hi.lo + lo.hi; lo.lo is below 2^-17 of
+// it) in place of eight v_mfma_f32_32x32x2_f32: 96 instead of 512 matrix-pipe cycles per 16 k values.  The packing is
+// done where an operand is WRITTEN (the weight stream by k_f32_pack, the activations by the layer epilogues), so the
+// inner loop only reads words and sorts halves (v_perm_b32).  fp32 accumulation, bias, ReLU, records and heads as before.
+typedef unsigned u32x8_ __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+template <int OFF>
+__device__ __forceinline__ unsigned lds_read_u32(unsigned addr) {
+    unsigned r;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// eight packed words (k = k0 .. k0 + 7 of one row / column) -> the hi and the lo MFMA fragment (8 bf16 each)
+__device__ __forceinline__ void x3_frags(const unsigned (&w)[8], bf16x8& fh, bf16x8& fl) {
+    u32x4_ h, l;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        h[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x07060302u);
+        l[j] = __builtin_amdgcn_perm(w[2 * j + 1], w[2 * j], 0x05040100u);
+    }
+    fh = __builtin_bit_cast(bf16x8, h);
+    fl = __builtin_bit_cast(bf16x8, l);
+}
+// the eight words of a fragment are valid once at most N younger LDS reads are outstanding.  Every one of them is tied to the
+// wait as a SCALAR register -- the asm reads must land in the very registers the v_perm below reads: gathered into a vector
+// first, hipcc copies them (a v_mov right behind the ds_read, i.e. BEFORE the data has arrived: seen as run-to-run different
+// losses in the first build of this routine)
+template <int N>
+__device__ __forceinline__ void x3_wait(unsigned (&w)[8]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]) : "n"(N));
+}
+#define X3_MMA(a, b, c) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+// chunk_mma on packed operands: lane (m, kk) holds k = 16 s + 8 kk .. + 7 of A row / B column m.  The reads go out in GROUPS of
+// eight (one fragment's words), one group ahead of the one being consumed: never more than eight in flight -- lgkmcnt is a
+// 4-bit counter, and a first build that issued a whole chunk's 32-48 reads at once was not bit-reproducible in the backward --
+// and every group is waited for (lgkmcnt(0)) right before its words are sorted into fragments, which the next group's reads
+// and this group's perms / MFMAs overlap.
+template <int C, int KC, int NW, int TPW>
+__device__ __forceinline__ void chunk_mma_x3(const float* wb, const float* xr, int wave, int lane, f32x16 (&acc)[TPW]) {
+    static_assert(KC % 16 == 0, "whole 16-k MFMA steps per chunk");
+    const int m = lane & 31, kk = lane >> 5;
+    if (wave >= C / 32) return;
+    constexpr int NS = KC / 16;
+    const unsigned xb_ = lds_addr_of((const char*)(xr + 8 * kk * F32_XS + m));
+    const unsigned a0_ = lds_addr_of((const char*)(wb + 8 * kk * C + 32 * wave + m));
+    const bool two = TPW > 1 && wave + NW < C / 32;
+    // group q of a step: 0 = B (activations), 1 = A (this wave's tile), 2 = the second tile's A
+    auto issue = [&](auto s_, auto q_, unsigned (&w)[8]) {
+        constexpr int s = decltype(s_)::value, q = decltype(q_)::value;
+        static_for<0, 8>([&](auto j_) {
+            constexpr int j = decltype(j_)::value;
+            if constexpr (q == 0) w[j] = lds_read_u32<(16 * s + j) * F32_XS * 4>(xb_);
+            else if constexpr (q == 1) w[j] = lds_read_u32<(16 * s + j) * C * 4>(a0_);
+            else w[j] = lds_read_u32<((16 * s + j) * C + 32 * NW) * 4>(a0_);
+        });
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    unsigned g0[8], g1[8];                 // two word buffers; their roles swap every step (never copied: a copy of a register
+                                           // whose read is still in flight reads the old value)
+    if (two) {
+        issue(I0{}, I0{}, g0);
+        auto step = [&](auto s_, unsigned (&X)[8], unsigned (&Y)[8]) {        // on entry: B_s under way into X
+            constexpr int s = decltype(s_)::value;
+            bf16x8 bh, bl, ah, al;
+            x3_wait<0>(X); issue(s_, I1{}, Y); x3_frags(X, bh, bl);                        // B_s ready; A_s under way
+            x3_wait<0>(Y); issue(s_, I2{}, X); x3_frags(Y, ah, al);                        // A_s ready; the second tile's A_s under way
+            X3_MMA(ah, bh, acc[0]);
+            X3_MMA(ah, bl, acc[0]);
+            X3_MMA(al, bh, acc[0]);
+            x3_wait<0>(X);
+            if constexpr (s + 1 < NS) issue(std::integral_constant<int, s + 1>{}, I0{}, Y);    // B_{s+1} under way into Y
+            x3_frags(X, ah, al);
+            X3_MMA(ah, bh, acc[TPW - 1]);
+            X3_MMA(ah, bl, acc[TPW - 1]);
+            X3_MMA(al, bh, acc[TPW - 1]);
+        };
+        static_for<0, NS>([&](auto s_) {
+            if constexpr (decltype(s_)::value % 2 == 0) step(s_, g0, g1); else step(s_, g1, g0);
+        });
+    } else {
+        issue(I0{}, I0{}, g0);
+        static_for<0, NS>([&](auto s_) {            // B_s is always under way into g0 on entry
+            constexpr int s = decltype(s_)::value;
+            bf16x8 bh, bl, ah, al;
+            x3_wait<0>(g0); issue(s_, I1{}, g1); x3_frags(g0, bh, bl);
+            x3_wait<0>(g1);
+            if constexpr (s + 1 < NS) issue(std::integral_constant<int, s + 1>{}, I0{}, g0);
+            x3_frags(g1, ah, al);
+            X3_MMA(ah, bh, acc[0]);
+            X3_MMA(ah, bl, acc[0]);
+            X3_MMA(al, bh, acc[0]);
+        });
+    }
+}
+template <bool X3, int C, int KC, int NW, int TPW>
+__device__ __forceinline__ void chunk_mma_sel(const float* wb, const float* xr, int wave, int lane, f32x16 (&acc)[TPW]) {
+    if constexpr (X3) chunk_mma_x3<C, KC, NW, TPW>(wb, xr, wave, lane, acc);
+    else chunk_mma<C, KC, NW, TPW>(wb, xr, wave, lane, acc);
+}
+
 // Record accesses (tile-transposed act / dz blocks) through a buffer descriptor rebuilt per tile: element (float index f,
 // sample n) sits at byte (f * 32 + n) * 4, so the 16 accesses of an epilogue are `descriptor + one lane offset + an
 // immediate` with the record's offset in an SGPR -- as plain pointers they are 16 64-bit addresses per layer that hipcc
@@ -274,7 +393,7 @@ struct F32BwdBatch { size_t idx, params, ws, act, dz, d_enc; };
 //   enc == nullptr: every row is evaluated on the constant encoding of a zero-masked Gaussian ([0 x 30, 1 x 30]): the
 //   background MLP's single evaluation of a box-hit ray (obbpose_model.py:205-210; include/durf_hip.h durf_expand_raw)
 // ---------------------------------------------------------------------------------------------
-template <int W, int IN, bool TRAIN, bool ENC>
+template <int W, int IN, bool TRAIN, bool ENC, bool X3 = false>
 __global__ void __launch_bounds__(W * 2)
 k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __restrict__ view,
               const int32_t* __restrict__ ray_idx, const int32_t* __restrict__ count,
@@ -335,7 +454,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                 if (ray_idx) ray = (size_t)ray_idx[ray];
                 v = view[ray * 27 + f];
             }
-            vws[f * F32_XS + nn] = v;
+            vws[f * F32_XS + nn] = opk<X3>(v);
         }
         if constexpr (ENC) {
             // thread = (sample tid >> 3, 8-feature vector tid & 7): the tile's 32 x 64 encoding in one pass of 256 threads
@@ -353,20 +472,20 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                 obj_features8(g, ei.w, q, v);
             }
 #pragma unroll
-            for (int e = 0; e < 8; e++) { encs[(8 * q + e) * F32_XS + nn] = v[e]; xa[(8 * q + e) * F32_XS + nn] = v[e]; }
+            for (int e = 0; e < 8; e++) { encs[(8 * q + e) * F32_XS + nn] = opk<X3>(v[e]); xa[(8 * q + e) * F32_XS + nn] = opk<X3>(v[e]); }
         } else {
             for (int idx = tid; idx < 64 * 32; idx += NT) {
                 const int f = idx & 63, nn = idx >> 6;
                 float v = 0.0f;
                 if (f < in_dim && row0 + nn < nrows) v = enc ? enc[(row0 + nn) * (size_t)in_dim + f] : ((f >= 30 && f < 60) ? 1.0f : 0.0f);
-                encs[f * F32_XS + nn] = v;
-                xa[f * F32_XS + nn] = v;
+                encs[f * F32_XS + nn] = opk<X3>(v);
+                xa[f * F32_XS + nn] = opk<X3>(v);
             }
         }
         chunk_commit<Sc::cols(0), KC, NT, PFV>(pf[0], wbuf, tid);
         __syncthreads();
         if (TRAIN)
-            for (int idx = tid; idx < in_dim * 32; idx += NT) rec_store(ra, S.L[0].x_off + (idx >> 5), idx & 31, encs[(idx >> 5) * F32_XS + (idx & 31)]);
+            for (int idx = tid; idx < in_dim * 32; idx += NT) rec_store(ra, S.L[0].x_off + (idx >> 5), idx & 31, oup<X3>(encs[(idx >> 5) * F32_XS + (idx & 31)]));
 
         f32x16 acc[1];
         float dens3[3] = {0.f, 0.f, 0.f}, rgb[3] = {0.f, 0.f, 0.f};
@@ -376,7 +495,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
             if (part < 8) {
                 float sm[3] = {0.0f, 0.0f, 0.0f};
                 for (int k = part; k < fi; k += 8) {
-                    const float xv = x[k * F32_XS + nn];
+                    const float xv = oup<X3>(x[k * F32_XS + nn]);
                     for (int c = 0; c < fo; c++) sm[c] = fmaf(Wl[k * fo + c], xv, sm[c]);
                 }
                 for (int c = 0; c < fo; c++) red[(part * 4 + c) * 32 + nn] = sm[c];
@@ -402,7 +521,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
     #pragma unroll
                     for (int r = 0; r < 16; r++) acc[0][r] = cst[i * W + ((32 * wave + c_row(r, hi)) & (W - 1))];
                 }
-                chunk_mma<C, KC, Cf::NW, 1>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
+                chunk_mma_sel<X3, C, KC, Cf::NW, 1>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
                 if constexpr (c == Sc::nchunk(i) - 1) {
                     // this wave's output tile -> the next Dense's input (LDS) and its record (global)
                     constexpr int lrec = l == 7 ? 8 : (l == 9 ? 10 : l + 1);    // h7 is x8 (density head and bottleneck); bottleneck -> x10
@@ -412,7 +531,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                             const int o = 32 * wave + c_row(r, hi);
                             float v = acc[0][r];
                             if (l != 9) v = (v != v) ? v : fmaxf(v, 0.0f);     // jnp.maximum(x, 0) propagates NaN; fmaxf would drop it
-                            xout[o * F32_XS + n] = v;
+                            xout[o * F32_XS + n] = opk<X3>(v);
                             if (TRAIN) rec_store_t<S.L[lrec].x_off>(ra, lane_off, r, v);
                         }
                     }
@@ -421,7 +540,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                             const int f = idx >> 5, nn = idx & 31;
                             const float v = encs[f * F32_XS + nn];
                             xout[(W + f) * F32_XS + nn] = v;
-                            if (TRAIN && f < in_dim) rec_store(ra, S.L[5].x_off + W + f, nn, v);
+                            if (TRAIN && f < in_dim) rec_store(ra, S.L[5].x_off + W + f, nn, oup<X3>(v));
                         }
                     }
                     if constexpr (l == 9) {                                 // x10 = [bottleneck, view]   (:339, :346-347)
@@ -429,7 +548,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                             const int f = idx >> 5, nn = idx & 31;
                             const float v = vws[f * F32_XS + nn];
                             xout[(W + f) * F32_XS + nn] = v;
-                            if (TRAIN && f < 27) rec_store(ra, S.L[10].x_off + W + f, nn, v);
+                            if (TRAIN && f < 27) rec_store(ra, S.L[10].x_off + W + f, nn, oup<X3>(v));
                         }
                     }
                 }
@@ -460,7 +579,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                     constexpr int PAR = decltype(par_)::value;
                     chunk_commit<C, KC, NT, PFV>(pf[PAR ^ 1], wbuf + (PAR ^ 1) * CB, tid);
                     chunk_issue<C, KC, NT, PFV>(pf[PAR], rs, OFF0 + (unsigned)((c + 2) * KC * C * 4), tid);
-                    chunk_mma<C, KC, Cf::NW, 1>(wbuf + PAR * CB, xin + c * KC * F32_XS, wave, lane, acc);
+                    chunk_mma_sel<X3, C, KC, Cf::NW, 1>(wbuf + PAR * CB, xin + c * KC * F32_XS, wave, lane, acc);
                     __syncthreads();
                 };
 #pragma unroll 1
@@ -471,14 +590,14 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                 // chunk NCH - 2: commit NCH - 1, issue the next layer's chunk 0
                 chunk_commit<C, KC, NT, PFV>(pf[1], wbuf + CB, tid);
                 if constexpr (has_next) chunk_issue<CN, KC, NT, PFV>(pf[0], rs, OFFN, tid);
-                chunk_mma<C, KC, Cf::NW, 1>(wbuf, xin + (NCH - 2) * KC * F32_XS, wave, lane, acc);
+                chunk_mma_sel<X3, C, KC, Cf::NW, 1>(wbuf, xin + (NCH - 2) * KC * F32_XS, wave, lane, acc);
                 __syncthreads();
                 // chunk NCH - 1: commit the next layer's chunk 0, issue its chunk 1, multiply, hand the tile over
                 if constexpr (has_next) {
                     chunk_commit<CN, KC, NT, PFV>(pf[0], wbuf, tid);
                     chunk_issue<CN, KC, NT, PFV>(pf[1], rs, OFFN + (unsigned)(KC * CN * 4), tid);
                 }
-                chunk_mma<C, KC, Cf::NW, 1>(wbuf + CB, xin + (NCH - 1) * KC * F32_XS, wave, lane, acc);
+                chunk_mma_sel<X3, C, KC, Cf::NW, 1>(wbuf + CB, xin + (NCH - 1) * KC * F32_XS, wave, lane, acc);
                 {
                     // this wave's output tile -> the next Dense's input (LDS) and its record (global)
                     constexpr int lrec = l == 7 ? 8 : (l == 9 ? 10 : l + 1);    // h7 is x8 (density head and bottleneck); bottleneck -> x10
@@ -488,7 +607,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                             const int o = 32 * wave + c_row(r, hi);
                             float v = acc[0][r];
                             if (l != 9) v = (v != v) ? v : fmaxf(v, 0.0f);     // jnp.maximum(x, 0) propagates NaN; fmaxf would drop it
-                            xout[o * F32_XS + n] = v;
+                            xout[o * F32_XS + n] = opk<X3>(v);
                             if (TRAIN) rec_store_t<S.L[lrec].x_off>(ra, lane_off, r, v);
                         }
                     }
@@ -497,7 +616,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                             const int f = idx >> 5, nn = idx & 31;
                             const float v = encs[f * F32_XS + nn];
                             xout[(W + f) * F32_XS + nn] = v;
-                            if (TRAIN && f < in_dim) rec_store(ra, S.L[5].x_off + W + f, nn, v);
+                            if (TRAIN && f < in_dim) rec_store(ra, S.L[5].x_off + W + f, nn, oup<X3>(v));
                         }
                     }
                     if constexpr (l == 9) {                                 // x10 = [bottleneck, view]   (:339, :346-347)
@@ -505,7 +624,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
                             const int f = idx >> 5, nn = idx & 31;
                             const float v = vws[f * F32_XS + nn];
                             xout[(W + f) * F32_XS + nn] = v;
-                            if (TRAIN && f < 27) rec_store(ra, S.L[10].x_off + W + f, nn, v);
+                            if (TRAIN && f < 27) rec_store(ra, S.L[10].x_off + W + f, nn, oup<X3>(v));
                         }
                     }
             
@@ -525,7 +644,7 @@ k_mlp_fwd_f32(size_t rows, int N, const float* __restrict__ enc, const float* __
 // ---------------------------------------------------------------------------------------------
 // backward (data path): d(loss)/d(pre-activation) of every Dense, d(loss)/d(enc) (stored when d_enc != nullptr)
 // ---------------------------------------------------------------------------------------------
-template <int W, int IN>
+template <int W, int IN, bool X3 = false>
 __global__ void __launch_bounds__(W * 2)
 k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t* __restrict__ ray_idx,
               const int32_t* __restrict__ count, const float* __restrict__ P, const float* __restrict__ ws,
@@ -589,7 +708,7 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
             for (int c = 0; c < 3; c++) v = fmaf(w11s[k * 3 + c], gsm[c * 32 + nn], v);
             const float h = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (unsigned)(((S.L[11].x_off + k) * 32 + nn) * 4), 0, 0));
             v = h > 0.0f ? v : 0.0f;
-            xa[k * F32_XS + nn] = v;
+            xa[k * F32_XS + nn] = opk<X3>(v);
             rec_store(rz, S.L[10].dz_off + k, nn, v);
         }
         chunk_commit<Sc::cols(0), KC, NT, PFV>(pf[0], wbuf, tid);
@@ -614,7 +733,7 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
                         for (int r = 0; r < 16; r++) hm[r] = rec_load_t<h_off>(ra, lane_off, r);
                     }
                 }
-                chunk_mma<C, KC, Cf::NW, 2>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
+                chunk_mma_sel<X3, C, KC, Cf::NW, 2>(wbuf + (g & 1) * CB, xin + c * KC * F32_XS, wave, lane, acc);
                 if constexpr (c == Sc::nchunk(i) - 1) {
                     if constexpr (l != 0) {
                         // d x_l (its first W features) -> dz of the Dense that produced them, masked by that Dense's ReLU output
@@ -627,7 +746,7 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
                             float v = acc[0][r];
                             if (l == 9) v += w8s[k] * gsm[3 * 32 + n];
                             if (relu) v = hm[r] > 0.0f ? v : 0.0f;
-                            xout[k * F32_XS + n] = v;
+                            xout[k * F32_XS + n] = opk<X3>(v);
                             rec_store_t<S.L[lp].dz_off>(rz, lane_off, r, v);
                         }
                         if constexpr (l == 5) {            // skip connection: output tiles W/32 and W/32 + 1 are d enc
@@ -670,7 +789,7 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
                     constexpr int PAR = decltype(par_)::value;
                     chunk_commit<C, KC, NT, PFV>(pf[PAR ^ 1], wbuf + (PAR ^ 1) * CB, tid);
                     chunk_issue<C, KC, NT, PFV>(pf[PAR], rs, OFF0 + (unsigned)((c + 2) * KC * C * 4), tid);
-                    chunk_mma<C, KC, Cf::NW, 2>(wbuf + PAR * CB, xin + c * KC * F32_XS, wave, lane, acc);
+                    chunk_mma_sel<X3, C, KC, Cf::NW, 2>(wbuf + PAR * CB, xin + c * KC * F32_XS, wave, lane, acc);
                     __syncthreads();
                 };
 #pragma unroll 1
@@ -680,13 +799,13 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
                 }
                 chunk_commit<C, KC, NT, PFV>(pf[1], wbuf + CB, tid);
                 if constexpr (has_next) chunk_issue<CN, KC, NT, PFV>(pf[0], rs, OFFN, tid);
-                chunk_mma<C, KC, Cf::NW, 2>(wbuf, xin + (NCH - 2) * KC * F32_XS, wave, lane, acc);
+                chunk_mma_sel<X3, C, KC, Cf::NW, 2>(wbuf, xin + (NCH - 2) * KC * F32_XS, wave, lane, acc);
                 __syncthreads();
                 if constexpr (has_next) {
                     chunk_commit<CN, KC, NT, PFV>(pf[0], wbuf, tid);
                     chunk_issue<CN, KC, NT, PFV>(pf[1], rs, OFFN + (unsigned)(KC * CN * 4), tid);
                 }
-                chunk_mma<C, KC, Cf::NW, 2>(wbuf + CB, xin + (NCH - 1) * KC * F32_XS, wave, lane, acc);
+                chunk_mma_sel<X3, C, KC, Cf::NW, 2>(wbuf + CB, xin + (NCH - 1) * KC * F32_XS, wave, lane, acc);
                 {
                     if constexpr (l != 0) {
                         // d x_l (its first W features) -> dz of the Dense that produced them, masked by that Dense's ReLU output
@@ -699,7 +818,7 @@ k_mlp_bwd_f32(size_t rows, int N, const float* __restrict__ draw, const int32_t*
                             float v = acc[0][r];
                             if (l == 9) v += w8s[k] * gsm[3 * 32 + n];
                             if (relu) v = hm[r] > 0.0f ? v : 0.0f;
-                            xout[k * F32_XS + n] = v;
+                            xout[k * F32_XS + n] = opk<X3>(v);
                             rec_store_t<S.L[lp].dz_off>(rz, lane_off, r, v);
                         }
                         if constexpr (l == 5) {            // skip connection: output tiles W/32 and W/32 + 1 are d enc
@@ -1113,23 +1232,28 @@ void launch_dw_f32(hipStream_t s, const F32Spec& S, const F32DwArgs& a, int nspl
     }
 }
 
-template <int W, int IN, bool TRAIN, bool ENC>
+template <int W, int IN, bool TRAIN, bool ENC, bool X3 = false>
 void launch_fwd_k(hipStream_t s, dim3 grid, size_t rows, int N, const float* enc, const float* view27, const int32_t* ray_idx,
                   const int32_t* count, const float* P, const float* ws, float* raw, float* act, const F32FwdBatch& bs,
                   const F32Enc& ei) {
     constexpr int lds = F32Cfg<W>::LDS_FLOATS * (int)sizeof(float);
-    (void)hipFuncSetAttribute((const void*)k_mlp_fwd_f32<W, IN, TRAIN, ENC>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL((k_mlp_fwd_f32<W, IN, TRAIN, ENC>), grid, dim3(W * 2), lds, s, rows, N, enc, view27, ray_idx, count, P, ws,
+    (void)hipFuncSetAttribute((const void*)k_mlp_fwd_f32<W, IN, TRAIN, ENC, X3>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL((k_mlp_fwd_f32<W, IN, TRAIN, ENC, X3>), grid, dim3(W * 2), lds, s, rows, N, enc, view27, ray_idx, count, P, ws,
                        raw, act, bs, ei);
 }
 // ei != nullptr (W = 128 only): the kernel encodes its own tiles from the ray data instead of reading `enc`
 template <int W, int IN>
 int launch_fwd(hipStream_t s, size_t rows, int N, const float* enc, const float* view27, const int32_t* ray_idx,
                const int32_t* count, const float* P, const float* ws, float* raw, float* act, int K, const F32FwdBatch& bs,
-               const F32Enc* ei = nullptr) {
+               const F32Enc* ei = nullptr, bool x3 = false) {
     const unsigned nt_ = durf_cdiv(rows, 32), cap = K > 1 ? 128u : 512u;          // workgroups per MLP (see k_mlp_fwd_f32)
     const dim3 grid(nt_ < cap ? nt_ : cap, K);
     if constexpr (W == 128) {
+        if (ei && x3) {          // the object MLPs on the bf16 matrix pipe with split operands (wstream: durf_mlp_f32_pack_x3)
+            if (act) launch_fwd_k<W, IN, true, true, true>(s, grid, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs, *ei);
+            else launch_fwd_k<W, IN, false, true, true>(s, grid, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs, *ei);
+            return 0;
+        }
         if (ei) {
             if (act) launch_fwd_k<W, IN, true, true>(s, grid, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs, *ei);
             else launch_fwd_k<W, IN, false, true>(s, grid, rows, N, enc, view27, ray_idx, count, P, ws, raw, act, bs, *ei);
@@ -1142,10 +1266,18 @@ int launch_fwd(hipStream_t s, size_t rows, int N, const float* enc, const float*
 }
 template <int W, int IN>
 int launch_bwd(hipStream_t s, size_t rows, int N, const float* draw, const int32_t* ray_idx, const int32_t* count,
-               const float* P, const float* ws, const float* act, float* dz, float* d_enc, int K, const F32BwdBatch& bs) {
+               const float* P, const float* ws, const float* act, float* dz, float* d_enc, int K, const F32BwdBatch& bs,
+               bool x3 = false) {
     constexpr int lds = F32Cfg<W>::LDS_FLOATS * (int)sizeof(float);
     const unsigned nt_ = durf_cdiv(rows, 32), cap = K > 1 ? 128u : 512u;
     const dim3 grid(nt_ < cap ? nt_ : cap, K), block(W * 2);
+    if constexpr (W == 128) {
+        if (x3) {
+            (void)hipFuncSetAttribute((const void*)k_mlp_bwd_f32<W, IN, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            hipLaunchKernelGGL((k_mlp_bwd_f32<W, IN, true>), grid, block, lds, s, rows, N, draw, ray_idx, count, P, ws, act, dz, d_enc, bs);
+            return 0;
+        }
+    }
     (void)hipFuncSetAttribute((const void*)k_mlp_bwd_f32<W, IN>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     hipLaunchKernelGGL((k_mlp_bwd_f32<W, IN>), grid, block, lds, s, rows, N, draw, ray_idx, count, P, ws, act, dz, d_enc, bs);
     return 0;
@@ -1179,6 +1311,16 @@ int durf_mlp_f32_pack(void* stream, int width, int in_dim, int K, const float* m
     else
         hipLaunchKernelGGL((k_f32_pack<128, 63>), dim3(durf_cdiv(n, 256), K), dim3(256), 0, (hipStream_t)stream, mlp_params, wstream, param_stride, n);
     DURF_CHECK_LAUNCH("durf_mlp_f32_pack");
+    return 0;
+}
+
+// the W = 128 stream with every weight as a (hi, lo) bf16 pair: what the DURF_F32_X3 object kernels consume
+int durf_mlp_f32_pack_x3(void* stream, int K, const float* obj_params, size_t param_stride, float* wstream) {
+    if (K <= 0) return 0;
+    const size_t n = durf_mlp_f32_wstream_floats(DURF_W_OBJ);
+    hipLaunchKernelGGL((k_f32_pack<128, 63, true>), dim3(durf_cdiv(n, 256), K), dim3(256), 0, (hipStream_t)stream, obj_params, wstream,
+                       param_stride, n);
+    DURF_CHECK_LAUNCH("durf_mlp_f32_pack_x3");
     return 0;
 }
 
@@ -1255,8 +1397,9 @@ int durf_objf32_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx,
     F32FwdBatch bs{rows * 63, (size_t)B, param_stride, durf_mlp_f32_wstream_floats(DURF_W_OBJ), rows * 4, durf_objf32_act_stride(B, N)};
     F32Enc ei{t_vals, origins_s, dirs_s, radii, BarfW{}, flags & (DURF_ENC_NO_INTEGRATION | DURF_ENC_CYLINDER)};
     if (!enc) for (int i = 0; i < 10; i++) ei.w.w[i] = barf_w[i];
+    DURF_REQUIRE(!(flags & DURF_F32_X3) || enc == nullptr, "DURF_F32_X3: the self-encoding forward");
     launch_fwd<DURF_W_OBJ, 63>((hipStream_t)stream, rows, N, enc, view27, idx, count, obj_params, wstream, raw, act, K, bs,
-                               enc ? nullptr : &ei);
+                               enc ? nullptr : &ei, (flags & DURF_F32_X3) != 0);
     DURF_CHECK_LAUNCH("durf_objf32_fwd_batch");
     return 0;
 }
@@ -1271,6 +1414,19 @@ int durf_objf32_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx,
                    durf_objf32_dz_stride(B, N), rows * DURF_ENC_DIM};
     launch_bwd<DURF_W_OBJ, 63>((hipStream_t)stream, rows, N, draw, idx, count, obj_params, wstream, act, dz, d_enc, K, bs);
     DURF_CHECK_LAUNCH("durf_objf32_bwd_batch");
+    return 0;
+}
+
+int durf_objf32_bwd_batch_x3(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* draw,
+                             const float* obj_params, size_t param_stride, const float* wstream, const float* act,
+                             float* dz, float* d_enc) {
+    DURF_REQUIRE(K >= 1 && K <= DURF_MAX_OBJ, "1 <= K <= DURF_MAX_OBJ");
+    if (B <= 0) return 0;
+    const size_t rows = (size_t)B * N;
+    F32BwdBatch bs{(size_t)B, param_stride, durf_mlp_f32_wstream_floats(DURF_W_OBJ), durf_objf32_act_stride(B, N),
+                   durf_objf32_dz_stride(B, N), rows * DURF_ENC_DIM};
+    launch_bwd<DURF_W_OBJ, 63>((hipStream_t)stream, rows, N, draw, idx, count, obj_params, wstream, act, dz, d_enc, K, bs, true);
+    DURF_CHECK_LAUNCH("durf_objf32_bwd_batch_x3");
     return 0;
 }
 

@@ -155,7 +155,8 @@ int check_args(const durf_train_args* a, void* workspace) {
     for (int l = 0; l < f.num_levels && f.density_noise != 0.0f; l++)
         DURF_REQUIRE(f.density_rand[l] != nullptr || f.draw_noise, "density_noise: density_rand[level] or draw_noise");
     DURF_REQUIRE(!f.draw_noise || (f.t_rand == nullptr && f.u_rand == nullptr), "draw_noise: the library makes the draws");
-    DURF_REQUIRE((a->flags & ~(DURF_TRAIN_OBJ_FP32 | DURF_TRAIN_POSE_OPT)) == 0, "unknown flags");
+    DURF_REQUIRE((a->flags & ~(DURF_TRAIN_OBJ_FP32 | DURF_TRAIN_POSE_OPT | DURF_TRAIN_OBJ_X3)) == 0, "unknown flags");
+    DURF_REQUIRE(!(a->flags & DURF_TRAIN_OBJ_X3) || (a->flags & DURF_TRAIN_OBJ_FP32), "DURF_TRAIN_OBJ_X3 is a variant of the fp32 object branch");
     if (a->flags & DURF_TRAIN_POSE_OPT) {
         DURF_REQUIRE(f.K > 0 && (a->flags & DURF_TRAIN_OBJ_FP32), "box-pose optimisation runs behind the fp32 object branch");
         DURF_REQUIRE(a->want_pos || a->want_rot, "pose optimisation without a pose gradient to compute");
@@ -195,6 +196,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
     int rc;
     // ---- forward (obbpose_model.py:68-261), activations stashed ----
     const bool f32o = K > 0 && (a->flags & DURF_TRAIN_OBJ_FP32), pose_opt = f32o && (a->flags & DURF_TRAIN_POSE_OPT);
+    const bool x3 = f32o && (a->flags & DURF_TRAIN_OBJ_X3);      // ... their forward / backward GEMMs on split bf16 operands
     const int Kb = f32o ? 0 : K;                          // objects on the bf16 kernels
     // (ray setup, view encoding, level-0 samples, the step's draws, the gradient's zero fill AND every bf16 weight stream: one launch)
     STEP(durf_ray_prologue_pack(stream, B, K, N, f.origins, f.directions, f.pose, f.ext, w.o_s, w.d_s, w.hit, f.zo, f.viewdirs, w.view,
@@ -212,7 +214,8 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
         // weight streams, and the background MLP's ONE evaluation of every box-hit ray redone in fp32 -- the constant
         // trunk once, the view layer + rgb head per ray (the Python path runs these beside the prologue on a side stream)
         STEP(durf_view_enc(stream, B, f.viewdirs, nullptr, w.view27));
-        STEP(durf_mlp_f32_pack(stream, 128, 63, K, f.obj_params, f.obj_param_stride, w.obj_ws));
+        if (x3) STEP(durf_mlp_f32_pack_x3(stream, K, f.obj_params, f.obj_param_stride, w.obj_ws));
+        else STEP(durf_mlp_f32_pack(stream, 128, 63, K, f.obj_params, f.obj_param_stride, w.obj_ws));
         // (the constant trunk + the box-hit rays' view layer and rgb head: behind the level-0 forward, below)
     }
     const float* raw_obj[ML][DURF_MAX_OBJ];
@@ -263,7 +266,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
             if (f32o)
                 STEP(durf_objf32_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, nullptr, w.view27, f.obj_params,
                                            f.obj_param_stride, w.obj_ws, w.obj_raw[lvl], w.act32[lvl], t_vals, w.o_s, w.d_s,
-                                           f.radii, f.barf_w, obj_flags));
+                                           f.radii, f.barf_w, obj_flags | (x3 ? DURF_F32_X3 : 0)));
             else if (!ov.sd && !mix)
                 STEP(durf_obj_fwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, t_vals, w.o_s, w.d_s, f.radii, f.barf_w, obj_flags,
                                         w.view, w.wf_obj, w.obj_enc[lvl], w.obj_raw[lvl], w.obj_stash[lvl], w.obj_mask[lvl],
@@ -317,8 +320,9 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
                           // object for EVERY level as one launch pair (levels added last level first, as one pair per level would)
         const float *de[ML], *tv[ML];
         for (int lvl = L - 1; lvl >= 0; lvl--) {
-            STEP(durf_objf32_bwd_batch(stream, K, B, N, w.idx_obj, w.count_obj, w.draw[lvl], f.obj_params, f.obj_param_stride, w.obj_ws,
-                                       w.act32[lvl], w.dz32[lvl], pose_opt ? w.d_enc32[lvl] : nullptr));
+            STEP((x3 ? durf_objf32_bwd_batch_x3 : durf_objf32_bwd_batch)(stream, K, B, N, w.idx_obj, w.count_obj, w.draw[lvl], f.obj_params,
+                                                                         f.obj_param_stride, w.obj_ws, w.act32[lvl], w.dz32[lvl],
+                                                                         pose_opt ? w.d_enc32[lvl] : nullptr));
             de[L - 1 - lvl] = w.d_enc32[lvl]; tv[L - 1 - lvl] = f.t_vals[lvl];
         }
         if (pose_opt)

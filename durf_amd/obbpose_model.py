@@ -170,16 +170,24 @@ class MipNerfModel:
     obj_precision: str = 'auto'
 
     def object_precision(self):
+        """'bf16' or 'f32': which kernels the object branch runs on ('bf16x3' is the fp32 branch's data flow on split bf16
+        operands: object_x3())"""
         if self.mlp_precision == 'f32':
             return 'f32'
         if self.obj_precision == 'auto':
             return 'bf16' if (self.no_pose_opt and self.no_yaw_opt) else 'f32'
-        return self.obj_precision
+        return 'f32' if self.obj_precision == 'bf16x3' else self.obj_precision
+
+    def object_x3(self):
+        """obj_precision = 'bf16x3' (round 6): the fp32 object branch -- records, weight gradients, pose gradient as under 'f32'
+        -- with its forward / backward GEMMs on the bf16 matrix pipe as three products of (hi, lo) split operands
+        (csrc/mlp_f32.hip chunk_mma_x3: ~2^-16 relative error per product instead of exact fp32)"""
+        return self.mlp_precision != 'f32' and self.obj_precision == 'bf16x3'
 
     def _check(self):
         bad = []
         if self.mlp_precision not in ('bf16', 'f32'): bad.append('mlp_precision')
-        if self.obj_precision not in ('auto', 'bf16', 'f32'): bad.append('obj_precision')
+        if self.obj_precision not in ('auto', 'bf16', 'f32', 'bf16x3'): bad.append('obj_precision')
         if self.ray_shape not in ('cone', 'cylinder'): bad.append('ray_shape')
         if (self.min_deg_point, self.max_deg_point, self.deg_view) != (0, 10, 4): bad.append('degrees')
         if not self.dynamics and not (self.no_pose_opt and self.no_yaw_opt):
@@ -292,12 +300,12 @@ class MipNerfModel:
         view_tiles_obj = ops.obj_view_tiles(Kb, B, N, dev) if (train and Kb and not f32) else None
         ctx = dict(o_s=o_s, d_s=d_s, hit=hit, zo=zo, idx=idx, count=count, slot=slot, view=view,
                    packs=packs, levels=[], B=B, N=N, K=Kd, ts=ts, bkgd_mode=bk, view_tiles_obj=view_tiles_obj,
-                   obj_f32=obj_f32 or (f32 and bool(Kd)))
+                   obj_f32=obj_f32 or (f32 and bool(Kd)), obj_x3=obj_f32 and self.object_x3())
         obj_flat = None
         if ctx['obj_f32']:                           # BoxMLP_0 .. BoxMLP_{K-1} sit back to back in the flat buffer
             o0 = lay.mlp_off['BoxMLP_0']
             obj_flat = variables.flat[o0:o0 + Kd * lay.mlp_size[W_OBJ]]
-            ctx['obj_ws'] = ops.mlp_f32_pack(W_OBJ, IN_OBJ, obj_flat, K=Kd, param_stride=lay.mlp_size[W_OBJ])
+            ctx['obj_ws'] = ops.mlp_f32_pack(W_OBJ, IN_OBJ, obj_flat, K=Kd, param_stride=lay.mlp_size[W_OBJ], x3=ctx['obj_x3'])
         if f32:
             ctx['bkgd_ws'] = ops.mlp_f32_pack(W_BKGD, IN_BKGD, variables.mlp_flat('MLP_0'))
         raw_tail = None
@@ -478,7 +486,7 @@ class MipNerfModel:
         encodings + the fp32 MFMA forward of all K objects, one launch each (csrc/mlp_f32.hip, durf_objf32_*)"""
         slabs = ops.ObjSlabsF32(Kd, B, N, t_vals.device, train)
         ops.objf32_fwd_batch(slabs, idx, count, t_vals, o_s, d_s, radii, alpha, view27, obj_flat, stride, ws,
-                             disable_integration=self.disable_integration, cylinder=cyl)
+                             disable_integration=self.disable_integration, cylinder=cyl, x3=self.object_x3())
         return dict(raws=slabs.raws(), slabs32=slabs)
 
     def prefetch_const_trunk(self, variables):

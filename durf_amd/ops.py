@@ -1106,11 +1106,16 @@ def pose_finish(pose, sums, want_pos, want_rot, grad6):
 # exact-fp32 MLP (csrc/mlp_f32.hip): the object branch of a step with box-pose optimisation (MipNerfModel.object_precision)
 # and the parity instrument behind MipNerfModel(mlp_precision='f32')
 # ---------------------------------------------------------------------------
-def mlp_f32_pack(width, in_dim, mlp_params, K=1, param_stride=0):
+def mlp_f32_pack(width, in_dim, mlp_params, K=1, param_stride=0, x3=False):
     """fp32 weight streams of K MLPs (durf_mlp_f32_pack): the wide Dense kernels as the chunks the fp32 forward / the
-    backward (transposed) consume, in order; re-packed whenever the parameters change"""
+    backward (transposed) consume, in order; re-packed whenever the parameters change.  x3 (W = 128): every weight as a
+    (hi, lo) bf16 pair, for the 'bf16x3' object kernels (durf_mlp_f32_pack_x3)"""
     L = _lib.lib()
     out = torch.empty(int(K) * int(L.durf_mlp_f32_wstream_floats(width)), device=mlp_params.device)
+    if x3:
+        assert width == W_OBJ_ and in_dim == IN_OBJ_
+        _lib.check(L.durf_mlp_f32_pack_x3(_stream(), int(K), _p(_f32(mlp_params)), int(param_stride), _p(out)), 'durf_mlp_f32_pack_x3')
+        return out
     _lib.check(L.durf_mlp_f32_pack(_stream(), width, in_dim, int(K), _p(_f32(mlp_params)), int(param_stride), _p(out)),
                'durf_mlp_f32_pack')
     return out
@@ -1196,20 +1201,24 @@ class ObjSlabsF32:
         return [self.raw[k] for k in range(self.K)]
 
 
+F32_X3 = 16               # durf_objf32_fwd_batch flag (include/durf_hip.h DURF_F32_X3)
+
+
 def objf32_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha, view27, obj_params, param_stride, wstream,
-                     disable_integration=False, cylinder=False, fused_encode=True):
+                     disable_integration=False, cylinder=False, fused_encode=True, x3=False):
     """accurate fp32 encodings + fp32 forward of all K object MLPs of one level: ONE launch (the forward encodes its own
     tiles); fused_encode=False: durf_encode_obj_f32_batch into slabs.enc first, then the forward reads it (bit-identical)"""
     w = barf_weights(alpha)
     wa = (C.c_float * 10)(*[float(x) for x in w])
     L = _lib.lib()
-    flags = (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0)
+    flags = (ENC_NO_INTEGRATION if disable_integration else 0) | (ENC_CYLINDER if cylinder else 0) | (F32_X3 if x3 else 0)
+    assert fused_encode or not x3
     with _Timed('objf32_fwd_batch'):
         if not fused_encode:
             slabs.enc = torch.empty(slabs.K, slabs.B * slabs.N, IN_OBJ_, device=t_vals.device)
             _lib.check(L.durf_encode_obj_f32_batch(
                 _stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count), _p(_f32(t_vals)), _p(_f32(origins_s)),
-                _p(_f32(dirs_s)), _p(_f32(radii)), wa, flags, _p(slabs.enc)), 'durf_encode_obj_f32_batch')
+                _p(_f32(dirs_s)), _p(_f32(radii)), wa, flags & ~F32_X3, _p(slabs.enc)), 'durf_encode_obj_f32_batch')
         _lib.check(L.durf_objf32_fwd_batch(_stream(), slabs.K, slabs.B, slabs.N, _p(idx), _p(count),
                                            _p(None if fused_encode else slabs.enc), _p(_f32(view27)), _p(_f32(obj_params)),
                                            int(param_stride), _p(wstream), _p(slabs.raw), _p(slabs.act), _p(_f32(t_vals)),
@@ -1217,16 +1226,16 @@ def objf32_fwd_batch(slabs, idx, count, t_vals, origins_s, dirs_s, radii, alpha,
                    'durf_objf32_fwd_batch')
 
 
-def objf32_bwd_batch(slabs, idx, count, draw, obj_params, param_stride, wstream, want_d_enc=False):
+def objf32_bwd_batch(slabs, idx, count, draw, obj_params, param_stride, wstream, want_d_enc=False, x3=False):
     L = _lib.lib()
     dev = draw.device
     K, B, N = slabs.K, slabs.B, slabs.N
     slabs.dz = torch.empty(K * int(L.durf_objf32_dz_stride(B, N)), device=dev)
     slabs.d_enc = torch.empty(K, B * N, ENC_DIM, device=dev) if want_d_enc else None     # every valid row is written
     with _Timed('objf32_bwd_batch'):
-        _lib.check(L.durf_objf32_bwd_batch(_stream(), K, B, N, _p(idx), _p(count), _p(_f32(draw)), _p(_f32(obj_params)),
-                                           int(param_stride), _p(wstream), _p(slabs.act), _p(slabs.dz),
-                                           _p(slabs.d_enc)), 'durf_objf32_bwd_batch')
+        fn = L.durf_objf32_bwd_batch_x3 if x3 else L.durf_objf32_bwd_batch
+        _lib.check(fn(_stream(), K, B, N, _p(idx), _p(count), _p(_f32(draw)), _p(_f32(obj_params)), int(param_stride), _p(wstream),
+                      _p(slabs.act), _p(slabs.dz), _p(slabs.d_enc)), 'durf_objf32_bwd_batch')
 
 
 def objf32_dw_batch(slabs_levels, count, grad_obj, grad_stride, nsplit=8):
@@ -1277,7 +1286,7 @@ class TrainArgs(C.Structure):
                  ('const_trunk', C.c_void_p), ('const_trunk_valid', C.c_int), ('prefetch_const_trunk', C.c_int)])
 
 
-TRAIN_OBJ_FP32, TRAIN_POSE_OPT = 1, 2          # durf_train_args.flags
+TRAIN_OBJ_FP32, TRAIN_POSE_OPT, TRAIN_OBJ_X3 = 1, 2, 4          # durf_train_args.flags
 TIMED_FWD, TIMED_BWD, TIMED_COMPOSITE, TIMED_DW, TIMED_STAGES = 0, 4, 8, 12, 13      # durf_step_timing slots
 
 
@@ -1410,7 +1419,7 @@ def release_workspace():
 def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_floats, N, num_levels, alpha, enc_flags,
                lossmult, pixels, gt_depth, sky, target6, prev6, eps, box_loss_mult, bg, disable_multiscale, level_mults,
                stat_mults, lr, max_val, max_norm, step, lindisp=False, bkgd_mode=BKGD_GREY, density_bias=-1.0,
-               resample_padding=0.01, t_rand=None, u_rand=None, update=True, obj_fp32=False, want_pos=False, want_rot=False,
+               resample_padding=0.01, t_rand=None, u_rand=None, update=True, obj_fp32=False, obj_x3=False, want_pos=False, want_rot=False,
                tv_loss_mult=0.0, seed=None, comm=None, world=1, reduce_stats=False, density_noise=0.0, density_rand=None,
                weight_decay_mult=0.0, const_trunk=None, const_trunk_valid=False):
     """One shard's training step as ONE library call (durf_train_step; update=False: durf_loss_backward, parameters
@@ -1453,7 +1462,8 @@ def train_call(rays, pose, ext, params_flat, m, v, box_floats, mlp0_floats, obj_
     pose_opt = bool(K) and (want_pos or want_rot)
     if pose_opt and not obj_fp32:
         raise NotImplementedError('durf_train_step: DURF_TRAIN_POSE_OPT needs DURF_TRAIN_OBJ_FP32 (csrc/train.hip)')
-    a.flags = (TRAIN_OBJ_FP32 if (K and obj_fp32) else 0) | (TRAIN_POSE_OPT if pose_opt else 0)
+    a.flags = ((TRAIN_OBJ_FP32 if (K and obj_fp32) else 0) | (TRAIN_POSE_OPT if pose_opt else 0) |
+               (TRAIN_OBJ_X3 if (K and obj_fp32 and obj_x3) else 0))
     a.want_pos, a.want_rot, a.tv_loss_mult = int(bool(want_pos)), int(bool(want_rot)), float(tv_loss_mult)
     a.comm, a.world, a.reduce_stats = (comm.handle if comm is not None else None), int(world), int(bool(reduce_stats))
     pose_used = torch.empty_like(pose) if K else None

@@ -340,7 +340,7 @@ def loss_and_grad(model, config, rng, variables, batch, eps, alpha, prev, noise=
             sl = lv['f32']['slabs32']
             o0, sz = lay.mlp_off['BoxMLP_0'], lay.mlp_size[om.W_OBJ]
             ops.objf32_bwd_batch(sl, ctx['idx'], ctx['count'], draw, variables.flat[o0:o0 + K * sz], sz, ctx['obj_ws'],
-                                 want_d_enc=pose_opt)
+                                 want_d_enc=pose_opt, x3=ctx.get('obj_x3', False))
             if pose_opt:
                 ops.encode_obj_bwd_batch(K, ctx['idx'], ctx['count'], sl.d_enc, lv['t_vals'], ctx['o_s'], ctx['d_s'], radii,
                                          rays.origins, rays.directions, pose_ts, alpha, pose_sums, precise=True,
@@ -644,7 +644,7 @@ def train_step_one_call(model, config, rng, state, batch, lr, eps, alpha, prev, 
         bkgd_mode=ops.BKGD_RAND if config.rand_bkgd else (ops.BKGD_WHITE if config.white_bkgd else ops.BKGD_GREY),
         density_bias=model.density_bias, resample_padding=model.resample_padding,
         t_rand=noise['t_rand'] if config.randomized else None, u_rand=noise['u_rand'] if config.randomized else None,
-        update=update, obj_fp32=obj_fp32, want_pos=pose_opt and not model.no_pose_opt, want_rot=pose_opt and not model.no_yaw_opt,
+        update=update, obj_fp32=obj_fp32, obj_x3=model.object_x3(), want_pos=pose_opt and not model.no_pose_opt, want_rot=pose_opt and not model.no_yaw_opt,
         tv_loss_mult=config.tv_loss_mult if pose_opt else 0.0, seed=seed, comm=comm,
         world=dist.get_world_size() if dist is not None else 1, reduce_stats=dist is not None and reduce_stats,
         density_noise=dn, density_rand=noise.get('density') if dn else None, weight_decay_mult=config.weight_decay_mult,

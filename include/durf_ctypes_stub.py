@@ -220,6 +220,12 @@ def bind(path='durf_amd/libdurf_hip.so'):
     L.durf_objf32_bwd_batch.restype = i32
     L.durf_objf32_bwd_batch.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, u64, vp, vp, vp, vp]
     #   (stream, K, B, N, idx, count, draw, obj_params, param_stride, wstream, act, dz, d_enc)
+    L.durf_mlp_f32_pack_x3.restype = i32
+    L.durf_mlp_f32_pack_x3.argtypes = [vp, i32, vp, u64, vp]
+    #   (stream, K, obj_params, param_stride, wstream)
+    L.durf_objf32_bwd_batch_x3.restype = i32
+    L.durf_objf32_bwd_batch_x3.argtypes = [vp, i32, i32, i32, vp, vp, vp, vp, u64, vp, vp, vp, vp]
+    #   (stream, K, B, N, idx, count, draw, obj_params, param_stride, wstream, act, dz, d_enc)
     L.durf_objf32_dw_batch.restype = i32
     L.durf_objf32_dw_batch.argtypes = [vp, i32, i32, i32, vp, i32, C.POINTER(vp), C.POINTER(vp), i32, vp, vp, u64]
     #   (stream, K, B, N, count, nlevels, act, dz, nsplit, scratch, grad_obj, grad_stride)

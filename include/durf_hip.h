@@ -475,6 +475,7 @@ int durf_render_image(void* stream, const durf_forward_args* args, size_t n_rays
  * the entry points themselves keep no other state between calls (durf_last_error is thread-local). */
 #define DURF_TRAIN_OBJ_FP32 1
 #define DURF_TRAIN_POSE_OPT 2
+#define DURF_TRAIN_OBJ_X3 4        /* with DURF_TRAIN_OBJ_FP32: that branch's forward / backward on split bf16 operands (durf_objf32_*_x3) */
 /* Live timing of the step's dominant launches for a roofline line (bench.py): hipEvent_t handles (created with timing
  * enabled, any may be NULL) that the call records on `stream` right before / after the background MLP's forward and backward
  * launch of level l (DURF_TIMED_FWD + l, DURF_TIMED_BWD + l), the fused per-ray launch behind level l's forward
@@ -610,6 +611,17 @@ int durf_objf32_fwd_batch(void* stream, int K, int B, int N, const int32_t* idx,
 int durf_objf32_bwd_batch(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* draw,
                           const float* obj_params, size_t param_stride, const float* wstream, const float* act,
                           float* dz, float* d_enc /* nullable */);
+/* "bf16x3" (round 6): the same object forward / backward on the bf16 matrix pipe -- every MFMA operand a (hi, lo) pair of
+ * bf16 (x = hi + lo: 16-17 significant bits), a product three v_mfma_f32_32x32x16_bf16 (hi.hi + hi.lo + lo.hi) in place of eight
+ * v_mfma_f32_32x32x2_f32, fp32 accumulation, bias, ReLU, heads; records, streams' sizes and every other argument as the exact
+ * kernels'.  ~2^-16 relative error per product instead of exact fp32 (the reference's HIGHEST-precision matmul,
+ * internal/math.py:22-24): MipNerfModel.obj_precision = 'bf16x3'.  durf_mlp_f32_pack_x3 writes the W = 128 weight streams for
+ * them; the forward is durf_objf32_fwd_batch with DURF_F32_X3 in `flags` (enc must be NULL: the self-encoding form). */
+#define DURF_F32_X3 16
+int durf_mlp_f32_pack_x3(void* stream, int K, const float* obj_params, size_t param_stride, float* wstream);
+int durf_objf32_bwd_batch_x3(void* stream, int K, int B, int N, const int32_t* idx, const int32_t* count, const float* draw,
+                             const float* obj_params, size_t param_stride, const float* wstream, const float* act,
+                             float* dz, float* d_enc /* nullable */);
 int durf_objf32_dw_batch(void* stream, int K, int B, int N, const int32_t* count, int nlevels, const float* const* act,
                          const float* const* dz, int nsplit, float* scratch, float* grad_obj, size_t grad_stride);
 

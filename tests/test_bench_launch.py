@@ -72,9 +72,9 @@ def test_extra_workloads_cover_every_baseline_config():
     sys.path.insert(0, ROOT)
     import bench
     names = [w[0] for w in bench.EXTRA_WORKLOADS]
-    assert names == ['cfg1', 'cfg2', 'cfg3_512rays', 'cfg4', 'cfg5', 'cfg3_f32']
+    assert names == ['cfg1', 'cfg2', 'cfg3_512rays', 'cfg4', 'cfg4_bf16x3', 'cfg5', 'cfg3_f32']
     for name, cfg, rays, prec, steps, warm in bench.EXTRA_WORKLOADS:
-        assert cfg in bench.WORKLOADS and prec in ('bf16', 'f32') and steps >= 5 and warm >= 2
+        assert cfg in bench.WORKLOADS and prec in ('bf16', 'f32', 'bf16x3') and steps >= 5 and warm >= 2
     o = dict(value=1.0, ms_per_step=2.0, steps=3, dtype='bf16', loss=0.5,
              config=dict(rays_per_gpu=512, num_samples=64, objects=0, pose_opt=False),
              roofline=dict(kernel='mlp_dw_256', bound='hbm', frac=0.3, mfma_frac=0.3, hbm_dataflow_frac=0.7, launch_us=9.0,
