@@ -48,7 +48,7 @@ FwdWs carve(void* workspace, int B, int N, int K) {
     w.raw_b = (float*)c.take(rows * 4 * 4);
     w.obj_enc = c.take(K > 0 ? (size_t)K * durf_obj_enc_stride(B, N) : 0);
     w.obj_raw = (float*)c.take(K > 0 ? (size_t)K * rows * 4 * 4 : 0);
-    w.u_rand = (float*)c.take((size_t)B * (N + 1) * 4);              // draw_noise: the resampling draws of the prologue
+    w.u_rand = (float*)c.take((size_t)3 * B * (N + 1) * 4);              // draw_noise: the resampling draws of the prologue
     w.total = (c.off + 255) & ~(size_t)255;
     return w;
 }
@@ -115,7 +115,7 @@ static int forward_launches(void* stream, const durf_forward_args* a, const FwdW
         STEP(durf_composite_fwd(stream, B, N, K, w.raw_b, raw_obj, w.slot_obj, t_vals, w.d_s, a->density_bias, a->bkgd_mode,
                                 a->rgb[lvl], a->depth[lvl], a->acc[lvl], a->weights[lvl], a->t_mids[lvl], a->t_dists[lvl]));
         if (lvl + 1 < L)
-            STEP(durf_resample(stream, B, N, t_vals, a->weights[lvl], a->resample_padding, a->draw_noise ? w.u_rand : a->u_rand, a->t_vals[lvl + 1]));
+            STEP(durf_resample(stream, B, N, t_vals, a->weights[lvl], a->resample_padding, a->draw_noise ? w.u_rand + (size_t)lvl * B * (N + 1) : a->u_rand, a->t_vals[lvl + 1]));
     }
 #undef STEP
     return 0;

@@ -190,9 +190,9 @@ k_compact_all(int B, int K, int N, const int32_t* __restrict__ hit, int32_t* __r
 // Philox4x32-10 (Salmon et al., SC'11: "Parallel random numbers: as easy as 1, 2, 3"), counter (c0, 0, 0, 0), key (k0, k1):
 // the stratified-sampling draws of a step made INSIDE its first launch, as the reference makes them inside its program
 // (mip.py:364, math.py:257-260: jax.random.uniform on a key) instead of by a generator kernel in front of it.  Word 0 of
-// block i jitters level-0 sample position i, word 1 is the resampling draw i of the following levels.  Restated on the
+// block i jitters level-0 sample position i, words 1 / 2 / 3 are the resampling draw i behind levels 0 / 1 / 2.  Restated on the
 // CPU (with the generator's known-answer vectors) in oracle/philox_ref.py; tests/test_gpu_sampling_noise.py.
-__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned k0, unsigned k1, unsigned& x0, unsigned& x1, unsigned c1 = 0u) {
+__device__ __forceinline__ void philox4x32_10_4(unsigned c0, unsigned k0, unsigned k1, unsigned (&x)[4], unsigned c1 = 0u) {
     unsigned c2 = 0u, c3 = 0u;
 #pragma unroll
     for (int r = 0; r < 10; r++) {
@@ -202,7 +202,12 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned k0, unsigned
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
-    x0 = c0; x1 = c1;
+    x[0] = c0; x[1] = c1; x[2] = c2; x[3] = c3;
+}
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned k0, unsigned k1, unsigned& x0, unsigned& x1, unsigned c1 = 0u) {
+    unsigned x[4];
+    philox4x32_10_4(c0, k0, k1, x, c1);
+    x0 = x[0]; x1 = x[1];
 }
 // 24 random bits -> [0, 1) (what jax.random.uniform's fp32 draw resolves, 2^-24 apart here)
 __device__ __forceinline__ float u01_24(unsigned x) { return (float)(x >> 8) * 5.9604644775390625e-08f; }
@@ -216,10 +221,14 @@ __device__ __forceinline__ void sample_t_block(size_t blk, int B, int N, const f
     if (i >= tot) return;
     float jitter = 0.0f;
     if (draw) {
-        unsigned x0, x1;
-        philox4x32_10((unsigned)i, seed_lo, seed_hi, x0, x1);
-        jitter = u01_24(x0);
-        u_rand_out[i] = u01_24(x1);
+        // words 1, 2, 3 of the block: the resampling draws of the resamples behind levels 0, 1, 2 -- one plane [B, N+1] each
+        // (round 6: one plane for every level correlated the draws of num_levels > 2; at most DURF_FORWARD_MAX_LEVELS - 1 = 3)
+        unsigned x[4];
+        philox4x32_10_4((unsigned)i, seed_lo, seed_hi, x);
+        jitter = u01_24(x[0]);
+        u_rand_out[i] = u01_24(x[1]);
+        u_rand_out[tot + i] = u01_24(x[2]);
+        u_rand_out[2 * tot + i] = u01_24(x[3]);
     }
     const int b = (int)(i / (N + 1)), n = (int)(i % (N + 1));
     const float nr = near[b], fr = far[b];

@@ -86,7 +86,7 @@ TrainWs carve(void* workspace, int B, int N, int K, int L, size_t n_params, int 
     w.opart = (float*)c.take(K > 0 ? (size_t)K * durf_dw_part_floats(128) * 4 : 0);
     w.obpart = (float*)c.take(K > 0 ? (size_t)K * durf_dw_bpart_floats(128) * 4 : 0);
     w.scratch = (float*)c.take(durf_optim_scratch_floats(n_params) * 4);
-    w.u_rand = (float*)c.take((size_t)B * (N + 1) * 4);              // f.draw_noise: the resampling draws of the prologue
+    w.u_rand = (float*)c.take((size_t)3 * B * (N + 1) * 4);              // f.draw_noise: the resampling draws of the prologue
     w.weight_l2 = (float*)c.take(4);                                 // weight_decay_mult * mean(theta^2) (durf_weight_decay)
     for (int l = 0; l < L; l++) {
         w.terms[l] = (float*)c.take((size_t)7 * B * 4);
@@ -284,7 +284,7 @@ int loss_backward(void* stream, const durf_train_args* a, const TrainWs& w, bool
             TIMED(DURF_TIMED_COMPOSITE + lvl,
                  durf_composite_resample(stream, B, N, K, w.raw_b[lvl], raw_obj[lvl], w.slot_obj, t_vals, w.d_s, f.density_bias,
                                          f.bkgd_mode, f.rgb[lvl], f.depth[lvl], f.acc[lvl], f.weights[lvl], f.t_mids[lvl],
-                                         f.t_dists[lvl], f.resample_padding, f.draw_noise ? w.u_rand : f.u_rand, f.t_vals[lvl + 1], a->lossmult, a->gt_depth,
+                                         f.t_dists[lvl], f.resample_padding, f.draw_noise ? w.u_rand + (size_t)lvl * B * (N + 1) : f.u_rand, f.t_vals[lvl + 1], a->lossmult, a->gt_depth,
                                          a->sky, f.dyn_mask, f.zo, a->eps, a->box_loss_mult, lvl, a->disable_multiscale,
                                          lvl == 0 ? w.prep : nullptr, lvl == 0 ? w.norms : nullptr, w.prep + (size_t)5 * B,
                                          w.norms + (size_t)(lvl + 1) * 5));

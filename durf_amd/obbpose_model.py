@@ -345,7 +345,7 @@ class MipNerfModel:
                 t_vals = t_next
             else:
                 t_vals = ops.resample(t_vals, weights, self.resample_padding,
-                                      noise['u_rand'] if randomized else None)
+                                      _u_plane(noise, lvl - 1) if randomized else None)
             if f32:
                 lvd = self._level_f32(variables, obj_flat, ctx, train, t_vals, o_s, d_s, radii, hit, Kd, cyl, view27, idx, count,
                                       alpha, B, N)
@@ -448,7 +448,7 @@ class MipNerfModel:
             if fused and not last:
                 rgb, depth, acc, weights, t_mids, t_dists, t_next = ops.composite_resample(
                     raw_b, raws, slot, t_vals, d_s, self.density_bias, bk, self.resample_padding,
-                    noise['u_rand'] if randomized else None, prep=dict(loss_prep, level=lvl))
+                    _u_plane(noise, lvl) if randomized else None, prep=dict(loss_prep, level=lvl))
             elif fused:
                 t_next = None
                 rgb, depth, acc = torch.empty(B, 3, device=dev), torch.empty(B, device=dev), torch.empty(B, device=dev)
@@ -589,6 +589,13 @@ class MipNerfModel:
                              alpha, train=False, noise=noise)[0]
 
     __call__ = apply
+
+
+def _u_plane(noise, level):
+    """the resampling draws of the resample behind `level`: plane `level` of the library's own draws ([3,B,N+1]: Philox words
+    1, 2, 3), or the one [B,N+1] array of injected draws (tests: the same array at every level)"""
+    u = noise['u_rand']
+    return u[level] if (u is not None and u.dim() == 3) else u
 
 
 def glorot_uniform_(t, fan_in, fan_out, gen):

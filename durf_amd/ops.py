@@ -99,7 +99,7 @@ def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, 
     -> origins_s[B,3], dirs_s[B,3], hit[B,K] int32, zo[B], view[B,32] bf16, t_vals[B,N+1]
     pose_copy [K,6]: receives a snapshot of `pose`; zero: a contiguous fp32 tensor the launch zero fills (the gradient)
     seed (int, instead of t_rand): the launch draws the step's stratified-sampling noise itself (Philox under this key) and
-    also returns u_rand[B,N+1], the resampling draws of the following levels -> (..., t_vals, u_rand)
+    also returns u_rand [3,B,N+1], the resampling draws behind levels 0, 1, 2 (Philox words 1, 2, 3) -> (..., t_vals, u_rand)
     pack = (bkgd_params, K, obj_params, obj_param_stride, want_bwd): pack_weights_all's work rides in the same launch
     (durf_ray_prologue_pack); its result ((bkgd_fwd, bkgd_bwd), (obj_fwd, obj_bwd) or None) is appended to the tuple"""
     B, K = origins.shape[0], pose.shape[0]
@@ -115,7 +115,7 @@ def ray_prologue(origins, dirs, pose, ext, viewdirs, near, far, N, t_rand=None, 
     u_out = None
     if seed is not None:
         assert t_rand is None
-        u_out = torch.empty(B, N + 1, device=dev)
+        u_out = torch.empty(3, B, N + 1, device=dev)
     lo, hi = (0, 0) if seed is None else split_seed(seed)
     common = (_stream(), B, K, N, _p(_f32(origins)), _p(_f32(dirs)), _p(_f32(pose)),
               _p(_f32(ext)), _p(o_s), _p(d_s), _p(hit), _p(zo), _p(_f32(viewdirs)), _p(view),

@@ -181,6 +181,8 @@ def pin_host_thread(local, n_local):
         return None
     try:
         cpus = _cpus_near_gpu(local, n_local, os.sched_getaffinity(0))
+        if len(cpus) < 4:           # (the runtime's own threads -- RCCL's proxy, HIP's signal handler -- inherit the mask: a rank
+            return None             # squeezed onto fewer than four cores is worse off than an unpinned one)
         os.sched_setaffinity(0, cpus)
         COLLECTIVE_INFO['host_cpus'] = '%d-%d (%d)' % (cpus[0], cpus[-1], len(cpus))
         return cpus

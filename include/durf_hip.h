@@ -118,11 +118,13 @@ int durf_compact_all(void* stream, int B, int K, int N, const int32_t* hit, int3
  * its own otherwise): pose_copy [K,6] receives a snapshot of `pose` (train_step returns the poses it rendered with,
  * train_boxpose.py:315, while the optimizer updates the parameters in place), and zero_buf[0..zero_count) -- the flat
  * gradient buffer, 16-byte aligned -- is zero filled.
- * u_rand_out (nullable [B,N+1]; t_rand must then be NULL): the launch DRAWS the step's stratified-sampling noise itself, as
+ * u_rand_out (nullable [3, B, N+1]; t_rand must then be NULL): the launch DRAWS the step's stratified-sampling noise itself, as
  * the reference draws inside its program (mip.py:364, math.py:257-260): Philox4x32-10 with counter (i, 0, 0, 0) and key
  * (seed_lo, seed_hi) for i in [0, B (N+1)); its output word 0, as (x >> 8) 2^-24 in [0, 1), jitters level-0 sample
- * position i exactly as t_rand[i] would, word 1 is written to u_rand_out[i] -- the u_rand of durf_composite_resample /
- * durf_resample for the following levels.  No generator launch in front of the step; oracle/philox_ref.py restates it. */
+ * position i exactly as t_rand[i] would; words 1, 2, 3 are written to planes 0, 1, 2 of u_rand_out -- plane l is the u_rand of
+ * the durf_composite_resample / durf_resample that turns level l into level l + 1 (round 6: until then ONE plane served every
+ * level, which correlated the draws of num_levels > 2).  No generator launch in front of the step; oracle/philox_ref.py
+ * restates it. */
 int durf_ray_prologue(void* stream, int B, int K, int N, const float* origins, const float* dirs, const float* pose,
                       const float* ext, float* origins_s, float* dirs_s, int32_t* hit, float* zo,
                       const float* viewdirs, void* view_bf16, const float* near, const float* far,

@@ -54,6 +54,19 @@ def step_draws(seed, B, N):
     return u(x[:, 0]), u(x[:, 1])
 
 
+def step_draws_planes(seed, B, N):
+    """(t_rand [B,N+1], u_rand [3,B,N+1]): step_draws with every resampling plane -- words 1, 2, 3 of block i are the draws of
+    the resamples behind levels 0, 1, 2 (durf_ray_prologue's u_rand_out)"""
+    n = B * (N + 1)
+    ctr = np.zeros((n, 4), dtype=np.uint32)
+    ctr[:, 0] = np.arange(n, dtype=np.uint32)
+    s = int(seed) & 0xFFFFFFFFFFFFFFFF
+    key = np.tile(np.array([s & 0xFFFFFFFF, s >> 32], dtype=np.uint32), (n, 1))
+    x = philox4x32_10(ctr, key)
+    u = lambda w: ((w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)).reshape(B, N + 1)
+    return u(x[:, 0]), np.stack([u(x[:, 1]), u(x[:, 2]), u(x[:, 3])])
+
+
 def density_draws(seed, rows, level):
     """Standard-normal draws [rows] float32 as durf_density_noise(normal = NULL) makes them (MipNerfModel.density_noise,
     /root/reference/internal/obbpose_model.py:236-240 draws them with jax.random.normal on the step's key): Philox block

@@ -22,9 +22,12 @@ def test_in_kernel_draws_are_the_oracles_philox_stream(cuda, B, N, seed):
     pose, ext = db['init'][b['ts']].contiguous(), db['ext'].reshape(-1, 3).contiguous()
     near, far = r.near.reshape(-1).contiguous(), r.far.reshape(-1).contiguous()
     t_ref, u_ref = philox_ref.step_draws(seed, B, N)
+    _, u_all = philox_ref.step_draws_planes(seed, B, N)
     own = ops.ray_prologue(r.origins, r.directions, pose, ext, r.viewdirs, near, far, N, seed=seed)
     fed = ops.ray_prologue(r.origins, r.directions, pose, ext, r.viewdirs, near, far, N, t_rand=torch.from_numpy(t_ref).to(cuda))
-    assert torch.equal(own[6].cpu(), torch.from_numpy(u_ref)), 'resampling draws: word 1 of every Philox block'
+    assert torch.equal(own[6].cpu(), torch.from_numpy(u_all)), 'resampling draws: words 1, 2, 3 of every Philox block, a plane per level'
+    assert np.array_equal(u_all[0], u_ref) and not np.array_equal(u_all[0], u_all[1]) and not np.array_equal(u_all[1], u_all[2])
+    own = own[:6] + (own[6][0],)
     assert torch.equal(own[5], fed[5]), 'level-0 sample positions: jittered by word 0 exactly as t_rand would'
     for a, c in zip(own[:5], fed[:5]):
         assert torch.equal(a, c)
@@ -35,7 +38,7 @@ def test_in_kernel_draws_are_the_oracles_philox_stream(cuda, B, N, seed):
     assert abs(float(u.mean()) - 0.5) < 4.0 / (12 * n) ** 0.5 and abs(float(u.var()) - 1.0 / 12) < 0.01
     assert abs(float(np.corrcoef(t_ref.ravel(), u_ref.ravel())[0, 1])) < 4.0 / n ** 0.5
     other = ops.ray_prologue(r.origins, r.directions, pose, ext, r.viewdirs, near, far, N, seed=seed + 1)
-    assert not torch.equal(other[6], own[6]) and not torch.equal(other[5], own[5])
+    assert not torch.equal(other[6][0], own[6]) and not torch.equal(other[5], own[5])
 
 
 @pytest.mark.parametrize('K,one_call', [(3, False), (3, True), (0, False)])
@@ -106,3 +109,33 @@ def test_a_model_that_draws_its_density_noise_equals_the_model_handed_the_oracle
     model.density_noise = 0.0
     quiet = model.apply(variables, rng, db['rays'], db['init'], db['ext'], b['ts'], **kw)
     assert (quiet[1][3][single] - own[1][3][single]).abs().max() > 1e-2, 'the noise must matter in this test'
+
+
+def test_three_levels_draw_a_plane_of_their_own_each(cuda):
+    """num_levels = 3: the resample behind level 0 uses Philox word 1, the one behind level 1 word 2 (until round 6 both used
+    word 1: correlated draws).  A step that draws for itself == the step handed the oracle's planes; and handing it plane 0 for
+    both resamples (the old behaviour) gives a DIFFERENT level-2 sample set."""
+    B, N, K, rng = 200, 32, 2, 77
+    utils.clear_gin()
+    utils.parse_gin('MipNerfModel.num_samples = %d\nMipNerfModel.num_levels = 3\nMipNerfModel.density_noise = 0.0\n'
+                    'MipNerfModel.no_pose_opt = True\nMipNerfModel.no_yaw_opt = True\nConfig.randomized = True\n' % N)
+    config = utils.configured(utils.Config)
+    db = H.device_batch(synthetic.make_batch(B, K, seed=12), cuda)
+    t_ref, u_all = philox_ref.step_draws_planes(rng, B, N)
+    tt, uu = torch.from_numpy(t_ref).to(cuda), torch.from_numpy(u_all).to(cuda)
+    out = []
+    for nz in (None, dict(t_rand=tt, u_rand=uu), dict(t_rand=tt, u_rand=uu[0].contiguous())):
+        model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
+        ret = model.apply(variables, rng, db['rays'], db['init'], db['ext'], 0, randomized=True, rand_bkgd=False, white_bkgd=False,
+                          alpha=10.0, noise=nz)
+        torch.cuda.synchronize()
+        out.append([r[4].clone() for r in ret])                 # t_vals of every level
+    for a, c in zip(out[0], out[1]):
+        assert torch.equal(a, c)
+    assert torch.equal(out[0][1], out[2][1]) and not torch.equal(out[0][2], out[2][2])
+    # ... and the one C call draws the same planes
+    model, variables = obbpose_model.construct_mipnerf(5, db, device=cuda)
+    one = model.apply_one_call(variables, rng, db['rays'], db['init'], db['ext'], 0, randomized=True, rand_bkgd=False,
+                               white_bkgd=False, alpha=10.0)
+    for lvl in range(3):
+        assert torch.equal(one[lvl][4], out[0][lvl])
