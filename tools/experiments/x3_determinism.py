@@ -3,7 +3,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from durf_amd import obbpose_model, synthetic, train_boxpose, utils
-from tests import helpers as H
 
 dev = torch.device('cuda', 0)
 for prec in ('f32', 'bf16x3'):
@@ -16,7 +15,7 @@ for prec in ('f32', 'bf16x3'):
                             'MipNerfModel.obj_precision = "%s"\n' % (N, prec))
             config = utils.configured(utils.Config)
             b = synthetic.make_batch(B, 3, seed=31, noise_boxes=0.5, redraw_noisy_multi_hit=True)
-            db = H.device_batch(b, dev)
+            db = synthetic.device_batch(b, dev)
             model, variables = obbpose_model.construct_mipnerf(5, db, device=dev)
             grad, raw, pose = train_boxpose.loss_and_grad(model, config, 0, variables, db, 3.0, 3.3, db['init'][0:1] + 0.01)
             torch.cuda.synchronize()
