@@ -21,21 +21,27 @@ void durf::note_dispatch(unsigned bits) { g_dispatch.fetch_or(bits, std::memory_
 // two launches in flight on different streams never share a counter (the ring is 16 384 launches long).
 int* durf::next_ticket() {
     constexpr int RING = 16384;
-    static int* tab[64] = {};
+    static std::atomic<int*> tab[64];
     static std::atomic<unsigned> next[64];
     static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    if (tab[dev] == nullptr) {
+    int* base = tab[dev].load(std::memory_order_acquire);
+    if (base == nullptr) {
         std::lock_guard<std::mutex> lock(mu);
-        if (tab[dev] == nullptr) {
+        base = tab[dev].load(std::memory_order_relaxed);
+        if (base == nullptr) {
             int* p = nullptr;
             if (hipMalloc((void**)&p, RING * sizeof(int)) != hipSuccess) return nullptr;
-            if (hipMemset(p, 0, RING * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return nullptr;
-            tab[dev] = p;
+            if (hipMemset(p, 0, RING * sizeof(int)) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+                (void)hipFree(p);
+                return nullptr;
+            }
+            tab[dev].store(p, std::memory_order_release);
+            base = p;
         }
     }
-    return tab[dev] + (next[dev].fetch_add(1u, std::memory_order_relaxed) % RING);
+    return base + (next[dev].fetch_add(1u, std::memory_order_relaxed) % RING);
 }
 
 extern "C" {
