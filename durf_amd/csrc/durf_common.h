@@ -148,6 +148,12 @@ __device__ __forceinline__ void wait_vmcnt_le(int n) {
 #ifndef MIX_ROLE_ROT
 #define MIX_ROLE_ROT 2
 #endif
+#ifndef MS_ENC_SPLIT
+#define MS_ENC_SPLIT 1          // the M-split object forward's encoding: two feature vectors per wave (0: all eight on wave 0, round 5)
+#endif
+#ifndef MS_RING
+#define MS_RING 4               // B-fragment reads in flight per wave in a stage of the M-split object forward (0: hipcc's schedule)
+#endif
 #ifndef MIX_TICKET_WAVE
 #define MIX_TICKET_WAVE 1        // the wave that requests the mixed launches' tickets (A/B: tools/experiments/r06_mix_ab.sh)
 #endif

@@ -72,7 +72,10 @@ __device__ __forceinline__ Gauss bkgd_sample_gaussian(int b, int n, int N, const
 
 // The 64 feature slots of one sample (OBJ: 3 coordinates + 60 weighted IPE features + pad; else 60 IPE features + pad),
 // handed to `sink(integral_constant<q>, bf16x8)` as the eight 16-byte vectors [8 q, 8 q + 8) in the order they complete.
-template <bool OBJ, class Sink>
+// QMASK: the vectors q this call produces (bit q).  Every feature is a function of the sample alone, so a caller may deal the
+// eight vectors to several waves (the M-split object forward: four waves x two vectors); what a call does not hand out is
+// dead code, the values it does hand out are the full call's, bit for bit.
+template <bool OBJ, unsigned QMASK = 0xFFu, class Sink>
 __device__ __forceinline__ void lane_features(const Gauss& g, const BarfW& barf_w, Sink&& sink) {
     float feat[64];
 #pragma unroll
@@ -93,7 +96,7 @@ __device__ __forceinline__ void lane_features(const Gauss& g, const BarfW& barf_
                 const int f = q * 8 + e - OFF;
                 if (f >= 0 && f < 60) { const int d = (f % 30) / 3; last = d > last ? d : last; }
             }
-            if (last == deg) {
+            if (last == deg && ((QMASK >> q) & 1u)) {
                 bf16x8 o8;
 #pragma unroll
                 for (int e = 0; e < 8; e++) o8[e] = (__bf16)feat[q * 8 + e];

@@ -271,6 +271,28 @@ __device__ __forceinline__ bool ms_item(const MsFwd& A, size_t item, size_t& k_o
     return ok;
 }
 
+// Timing probe of one item (variant builds only: tools/build_variant.sh stamps "-DDURF_MS_STAMPS"): role-0's lane 0 writes the
+// 100 MHz s_memrealtime at the marks below into g_ms_stamps[item slot][32]; tools/experiments/ms_stamps.py reads them back.
+#ifndef MS_PROBE_NOSTORE
+#define MS_PROBE_NOSTORE 0       // timing probe only: the item without its stash / mask stores (wrong results)
+#endif
+#if defined(DURF_MS_STAMPS)
+__device__ unsigned long long g_ms_stamps[4096 * 32];
+__device__ unsigned g_ms_n;
+#define MS_STAMP(i) do { if (ms_probe) g_ms_stamps[ms_slot * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define MS_STAMP_WAIT(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MS_STAMP(i); } while (0)
+extern "C" int durf_debug_ms_stamps(void* dst, int reset) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ms_n), sizeof(n)) != hipSuccess) return -1;
+    if (dst && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_ms_stamps), sizeof(unsigned long long) * 4096 * 32) != hipSuccess) return -1;
+    if (reset) { const unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ms_n), &z, sizeof(z)) != hipSuccess) return -1; }
+    return (int)n;
+}
+#else
+#define MS_STAMP(i) do { } while (0)
+#define MS_STAMP_WAIT(i) do { } while (0)
+#endif
+
 template <bool TRAIN>
 __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane, int wave, bool live, size_t k, size_t pair) {
     using S = ms::S;
@@ -301,33 +323,62 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
     // (a group without an item -- live == false: the other half of a mixed workgroup still has one -- runs the same stages
     // on zeros with every global load / store predicated off by these flags, so that both halves meet at every barrier)
     const bool tv[NT] = {live, live && t32[1] * 32 < nrows};
+#if defined(DURF_MS_STAMPS)
+    const bool ms_probe = live && wave == 0 && lane == 0;
+    unsigned ms_slot = 0;
+    if (ms_probe) {
+        ms_slot = atomicAdd(&g_ms_n, 1u) & 4095u;
+        g_ms_stamps[ms_slot * 32 + 30] = ((unsigned long long)blockIdx.x << 32) | (unsigned long long)(k * 100000 + pair);
+        g_ms_stamps[ms_slot * 32 + 31] = (unsigned long long)lds_addr_of(smem);
+    }
+#endif
+    MS_STAMP(0);
     ms_barrier();                               // the previous pair is done with the LDS
+    MS_STAMP(1);
     // ---- inputs: the tiles' encodings (computed here or read), view directions ----
     if (ei.obj) {
-        if (wave == 0) {                           // lane = sample: 64 lanes = both tiles; the stand-alone encoder's body
+        // lane = sample: 64 lanes = both tiles; the stand-alone encoder's body.  Every wave derives the sample's Gaussian (a few
+        // loads that hit in L2 + ~0.5 us of arithmetic) and then produces TWO of the eight feature vectors, q = wave and
+        // wave + 4 (MS_ENC_SPLIT, round 6: with all eight on wave 0 the features were 4.9 of an item's 21 us, three waves
+        // waiting: tools/experiments/ms_stamps.py).  A feature is a function of the sample alone: the same bits whoever computes it.
+        if (MS_ENC_SPLIT || wave == 0) {
             const int t = lane >> 5;
             const size_t row = t32[t] * 32 + n;
             if (tv[t]) {
                 const int j = (int)(row / (size_t)N), nn = (int)(row % (size_t)N);
                 const int b = ray_idx[j];
+                MS_STAMP_WAIT(26);
                 const float t0 = ei.t_vals[(size_t)b * (N + 1) + nn], t1 = ei.t_vals[(size_t)b * (N + 1) + nn + 1];
                 float o[3] = {ei.origins_s[b * 3], ei.origins_s[b * 3 + 1], ei.origins_s[b * 3 + 2]};
                 float d[3] = {ei.dirs_s[b * 3], ei.dirs_s[b * 3 + 1], ei.dirs_s[b * 3 + 2]};
-                Gauss g = frustum_gaussian(t0, t1, o, d, ei.radii[b], (ei.flags & DURF_ENC_CYLINDER) != 0);
+                const float rad = ei.radii[b];
+                MS_STAMP_WAIT(27);
+                Gauss g = frustum_gaussian(t0, t1, o, d, rad, (ei.flags & DURF_ENC_CYLINDER) != 0);
                 if (ei.flags & DURF_ENC_NO_INTEGRATION) g.var[0] = g.var[1] = g.var[2] = 0.0f;      // obbpose_model.py:164-165
+#if defined(DURF_MS_STAMPS)
+                asm volatile("" : "+v"(g.x[0]), "+v"(g.x[1]), "+v"(g.x[2]), "+v"(g.var[0]), "+v"(g.var[1]), "+v"(g.var[2]));
+#endif
+                MS_STAMP(28);
                 BarfW bw;
 #pragma unroll
                 for (int i = 0; i < 10; i++) bw.w[i] = ei.w[i];
                 char* const eg = (char*)enc + t32[t] * (S::KE * 1024);
-                lane_features<true>(g, bw, [&](auto q_, const bf16x8& o8) {
+                auto put = [&](auto q_, const bf16x8& o8) {
                     constexpr int q = decltype(q_)::value;             // features [8 q, 8 q + 8): k-step q / 2, half q % 2
                     const int off = (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16;
                     *(bf16x8*)(E + t * (S::KE * 1024) + off) = o8;
                     *(DURF_G(bf16x8)*)(eg + off) = o8;      // the encoding tile the weight-gradient GEMMs of Dense_0 / Dense_5 read
-                });
+                };
+                if (!MS_ENC_SPLIT) lane_features<true>(g, bw, put);
+                else if (wave == 0) lane_features<true, 0x11u>(g, bw, put);
+                else if (wave == 1) lane_features<true, 0x22u>(g, bw, put);
+                else if (wave == 2) lane_features<true, 0x44u>(g, bw, put);
+                else lane_features<true, 0x88u>(g, bw, put);
+                MS_STAMP(29);
             } else {
 #pragma unroll
-                for (int q = 0; q < 8; q++) *(bf16x8*)(E + t * (S::KE * 1024) + (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16) = zero8;
+                for (int q = 0; q < 8; q++)
+                    if (!MS_ENC_SPLIT || (q & 3) == wave) *(bf16x8*)(E + t * (S::KE * 1024) + (q >> 1) * 1024 + ((q & 1) * 32 + n) * 16) = zero8;
             }
         }
     } else {
@@ -381,6 +432,29 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
 #pragma unroll
             for (int t = 0; t < NT; t++) { acc[t][4 * g] = w.b[g][0]; acc[t][4 * g + 1] = w.b[g][1]; acc[t][4 * g + 2] = w.b[g][2]; acc[t][4 * g + 3] = w.b[g][3]; }
         }
+#if MS_RING > 0
+        // The B fragments through a ring of MS_RING explicit LDS reads with counted waits (round 6: left to hipcc, the object
+        // half of a mixed workgroup -- at the 256-register cap -- got ONE fragment register: read, wait, MFMA, sixteen times a
+        // stage, ~1.3 us of LDS latency per stage: tools/experiments/ms_stamps.py).  Same fragments, same order.
+        static_assert(NT == 2, "the ring alternates the two sample tiles");
+        constexpr int NR = 2 * T, D = MS_RING < NR ? MS_RING : NR;
+        const unsigned ax = lds_addr_of(Xin) + lane * 16, ae = lds_addr_of(E) + lane * 16, av = lds_addr_of(V) + lane * 16;
+        auto rd = [&](auto m_) -> v4i_ {
+            constexpr int m = decltype(m_)::value, k = m >> 1, t = m & 1;
+            if constexpr (k < NX) return lds_read16<(t * S::KW + k) * 1024>(ax);
+            else if constexpr (k < NX + NE) return lds_read16<(t * S::KE + (k - NX)) * 1024>(ae);
+            else return lds_read16<(t * S::KV + (k - NX - NE)) * 1024>(av);
+        };
+        v4i_ ring[D];
+        static_for<0, D>([&](auto i_) { ring[decltype(i_)::value] = rd(i_); });
+        static_for<0, NR>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, k = i >> 1, t = i & 1;
+            constexpr int later = (NR - 1 - i) < (D - 1) ? (NR - 1 - i) : (D - 1);
+            lds_wait<later>(ring[i % D]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], __builtin_bit_cast(bf16x8, ring[i % D]), acc[t], 0, 0, 0);
+            if constexpr (i + D < NR) ring[i % D] = rd(std::integral_constant<int, i + D>{});
+        });
+#else
 #pragma unroll
         for (int k = 0; k < T; k++) {
 #pragma unroll
@@ -391,6 +465,7 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], b, acc[t], 0, 0, 0);
             }
         }
+#endif
     };
     // epilogue of a stashed ReLU stage: fragments 2 mo, 2 mo + 1 of the next stage's input, the stash, the flag pieces
     auto hand_over = [&](auto relu_, int mo, char* Xout, int jstash, unsigned* Mbuf) {
@@ -401,7 +476,7 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
             const unsigned bits = pack_tile<RELU, TRAIN && RELU>(acc[t], o0, o1);
             *(bf16x8*)(Xout + (t * S::KW + 2 * mo) * 1024 + lane * 16) = o0;
             *(bf16x8*)(Xout + (t * S::KW + 2 * mo + 1) * 1024 + lane * 16) = o1;
-            if (TRAIN && RELU && tv[t]) {
+            if (TRAIN && RELU && tv[t] && !MS_PROBE_NOSTORE) {
                 char* sd = (char*)stash + ((size_t)S::stash_ks_before(jstash) * ntile32 + t32[t] * S::stash_ks(jstash)) * 1024;
                 STREAM_STORE(sd + (2 * mo) * 1024 + lane * 16, o0);
                 STREAM_STORE(sd + (2 * mo + 1) * 1024 + lane * 16, o1);
@@ -412,7 +487,7 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
     // waves 0 / 1 assemble the previous stage's flags of tile 0 / 1 into k_mlp_fwd's layout (one uint4 per lane: words
     // 0, 1 = tile pairs (0,1), (2,3)) -- after the barrier that made every wave's piece visible
     auto flush_mask = [&](int jmask, const unsigned* Mbuf) {
-        if (TRAIN && wave < NT && tv[wave]) {
+        if (TRAIN && wave < NT && tv[wave] && !MS_PROBE_NOSTORE) {
             const unsigned* m = Mbuf + (wave * 4) * 64 + lane;
             const uint4 w4 = make_uint4(m[0] | m[64], m[128] | m[192], 0u, 0u);
             typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
@@ -428,7 +503,9 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
     WSet8 w0;                                      // two alternating weight sets
     WSet w1;
     load_w(std::integral_constant<int, 0>{}, wave, w0);
+    MS_STAMP(2);
     ms_barrier();                               // encodings and view fragments are in place
+    MS_STAMP(3);
     using IE = std::integral_constant<int, S::KE>;
     using IW = std::integral_constant<int, S::KW>;
     auto swap = [&]() { char* tx = Xa; Xa = Xb; Xb = tx; unsigned* tm = Ma; Ma = Mb; Mb = tm; };
@@ -436,51 +513,67 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
     load_w(std::integral_constant<int, 1>{}, wave, w1);
     stage_mma(std::integral_constant<int, 0>{}, w0, I0{}, IE{}, I0{}, Xa);
     hand_over(std::true_type{}, wave, Xa, 0, Ma);
+    MS_STAMP(16);
     ms_barrier();
+    MS_STAMP(4);
     // stages 1-4 (the next stage's weights are requested before this stage's MFMAs)
     flush_mask(0, Ma);
     load_w(std::integral_constant<int, 2>{}, wave, w0);
     stage_mma(std::integral_constant<int, 1>{}, w1, IW{}, I0{}, I0{}, Xa);
     hand_over(std::true_type{}, wave, Xb, 1, Mb);
+    MS_STAMP(17);
     ms_barrier();
+    MS_STAMP(5);
     swap();
     flush_mask(1, Ma);
     load_w(std::integral_constant<int, 3>{}, wave, w1);
     stage_mma(std::integral_constant<int, 2>{}, w0, IW{}, I0{}, I0{}, Xa);
     hand_over(std::true_type{}, wave, Xb, 2, Mb);
+    MS_STAMP(18);
     ms_barrier();
+    MS_STAMP(6);
     swap();
     flush_mask(2, Ma);
     load_w(std::integral_constant<int, 4>{}, wave, w0);
     stage_mma(std::integral_constant<int, 3>{}, w1, IW{}, I0{}, I0{}, Xa);
     hand_over(std::true_type{}, wave, Xb, 3, Mb);
+    MS_STAMP(19);
     ms_barrier();
+    MS_STAMP(7);
     swap();
     flush_mask(3, Ma);
     load_w(std::integral_constant<int, 5>{}, wave, w1);
     stage_mma(std::integral_constant<int, 4>{}, w0, IW{}, I0{}, I0{}, Xa);
     hand_over(std::true_type{}, wave, Xb, 4, Mb);
+    MS_STAMP(20);
     ms_barrier();
+    MS_STAMP(8);
     swap();
     // stage 5: [h4, enc] (obbpose_model.py:333-334)
     flush_mask(4, Ma);
     load_w(std::integral_constant<int, 6>{}, wave, w0);
     stage_mma(std::integral_constant<int, 5>{}, w1, IW{}, IE{}, I0{}, Xa);
     hand_over(std::true_type{}, wave, Xb, 5, Mb);
+    MS_STAMP(21);
     ms_barrier();
+    MS_STAMP(9);
     swap();
     // stages 6, 7
     flush_mask(5, Ma);
     load_w(std::integral_constant<int, 7>{}, wave, w1);
     stage_mma(std::integral_constant<int, 6>{}, w0, IW{}, I0{}, I0{}, Xa);
     hand_over(std::true_type{}, wave, Xb, 6, Mb);
+    MS_STAMP(22);
     ms_barrier();
+    MS_STAMP(10);
     swap();
     flush_mask(6, Ma);
     load_w(std::integral_constant<int, 8>{}, wave, w0);
     stage_mma(std::integral_constant<int, 7>{}, w1, IW{}, I0{}, I0{}, Xa);
     hand_over(std::true_type{}, wave, Xb, 7, Mb);
+    MS_STAMP(23);
     ms_barrier();
+    MS_STAMP(11);
     swap();
     // stage 8: h7 -> bottleneck (linear, tile `wave`) and, wave 0, the density head (tile WT)
     flush_mask(7, Ma);
@@ -502,13 +595,17 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
         stage_mma(std::integral_constant<int, 8>{}, w0, IW{}, I0{}, I0{}, Xa);
         hand_over(std::false_type{}, wave, Xb, 8, Mb);
     }
+    MS_STAMP(24);
     ms_barrier();
+    MS_STAMP(12);
     { char* tx = Xa; Xa = Xb; Xb = tx; }
     // stage 9: [bottleneck, view] -> hc (128, relu); its flags go to mask region 8
     if (wave == 0) load_w(std::integral_constant<int, 10>{}, 0, w0);
     stage_mma(std::integral_constant<int, 9>{}, w1, IW{}, I0{}, std::integral_constant<int, S::KV>{}, Xa);
     hand_over(std::true_type{}, wave, Xb, 9, Mb);
+    MS_STAMP(25);
     ms_barrier();
+    MS_STAMP(13);
     flush_mask(8, Mb);
     // stage 10: hc -> rgb (wave 0), raw = (rgb, density)
     if (wave == 0) {
@@ -536,6 +633,7 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
             }
         }
     }
+    MS_STAMP(14);
 }
 
 template <bool TRAIN>
