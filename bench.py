@@ -462,7 +462,8 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     # GPU timestamps (diagnostic: `step_ms`) after every `group`-th step -- a record between two steps costs the stream
     # 5-11 us like any other (0.3 % of a 4096-ray step, 1.5 % of a 512-ray one), so the outlier check works on groups of steps
     group = 1 if (args.max_ahead > 0 or steps < 16) else 4
-    marks = {0: torch.cuda.Event(enable_timing=True)}
+    # (the marks are events that exist already -- the pre-warmed pool: none is created inside the timed region)
+    marks = {0: ops._timing_event()}
     t0 = time.perf_counter()
     marks[0].record()
     sampled = 0
@@ -471,7 +472,7 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
         sampled += int(ops.TIMERS_ACTIVE)
         state, stats, rng, _ = step(state, rng, i + 1)
         if (i + 1) % group == 0 or i + 1 == steps:
-            marks[i + 1] = torch.cuda.Event(enable_timing=True)
+            marks[i + 1] = ops._timing_event()
             marks[i + 1].record()
         if args.max_ahead > 0 and i + 1 > args.max_ahead:
             marks[i + 1 - args.max_ahead].synchronize()      # the host never runs more than max_ahead steps ahead
@@ -479,6 +480,7 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     dt = time.perf_counter() - t0
     at = sorted(marks)
     step_raw = [marks[a].elapsed_time(marks[b]) / (b - a) for a, b in zip(at[:-1], at[1:])]     # ms per step, by group
+    ops.EVENT_POOL.extend(marks.values())
     step_times = sorted(step_raw)
     tt = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:

@@ -296,6 +296,26 @@ __device__ __forceinline__ void msb_bwd_pair(const MsBwd& A, const float* __rest
         for (int t = 0; t < NT; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = 0.0f;
+#if MS_RING > 0
+        // (the B fragments through a ring of explicit LDS reads with counted waits, as k_mlp_fwd_ms: same fragments, same order)
+        static_assert(NT == 2, "the ring alternates the two sample tiles");
+        constexpr int NR = 2 * T, D = MS_RING < NR ? MS_RING : NR;
+        const unsigned ax = lds_addr_of(Xin) + lane * 16, ag = lds_addr_of(G) + g * 1024 + lane * 16;
+        auto rd = [&](auto m_) -> v4i_ {
+            constexpr int m = decltype(m_)::value, k = m >> 1, t = m & 1;
+            if constexpr (k < NX) return lds_read16<(t * S::KW + k) * 1024>(ax);
+            else return lds_read16<t * 2048>(ag);
+        };
+        v4i_ ring[D];
+        static_for<0, D>([&](auto i_) { ring[decltype(i_)::value] = rd(i_); });
+        static_for<0, NR>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, k = i >> 1, t = i & 1;
+            constexpr int later = (NR - 1 - i) < (D - 1) ? (NR - 1 - i) : (D - 1);
+            lds_wait<later>(ring[i % D]);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], __builtin_bit_cast(bf16x8, ring[i % D]), acc[t], 0, 0, 0);
+            if constexpr (i + D < NR) ring[i % D] = rd(std::integral_constant<int, i + D>{});
+        });
+#else
 #pragma unroll
         for (int k = 0; k < T; k++) {
 #pragma unroll
@@ -305,6 +325,7 @@ __device__ __forceinline__ void msb_bwd_pair(const MsBwd& A, const float* __rest
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], bv, acc[t], 0, 0, 0);
             }
         }
+#endif
     };
     // mask with the forward's ReLU flags of stash region jm (this wave's tile: word wave / 2, parity wave % 2), hand the
     // fragments over, store dz region jd (jd < 0: not stored -- the linear bottleneck's gradient)
