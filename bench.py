@@ -20,6 +20,7 @@ cfg2 (CARLA, K=1, far=200), cfg4 (Waymo + box-pose optimisation, 1024 rays/GPU) 
 1024 rays/GPU).  Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import subprocess
@@ -464,6 +465,10 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     group = 1 if (args.max_ahead > 0 or steps < 16) else 4
     # (the marks are events that exist already -- the pre-warmed pool: none is created inside the timed region)
     marks = {0: ops._timing_event()}
+    # (no cyclic-GC pass inside the timed region: at 512 rays the host is only a few steps ahead of the GPU, and a 10-30 ms
+    # generation-2 collection showed up as one slow group of steps in ~1 run of 15: profiles/r06_mix.txt section 8)
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     marks[0].record()
     sampled = 0
@@ -478,6 +483,7 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
             marks[i + 1 - args.max_ahead].synchronize()      # the host never runs more than max_ahead steps ahead
     sync()
     dt = time.perf_counter() - t0
+    gc.enable()
     at = sorted(marks)
     step_raw = [marks[a].elapsed_time(marks[b]) / (b - a) for a, b in zip(at[:-1], at[1:])]     # ms per step, by group
     ops.EVENT_POOL.extend(marks.values())

@@ -273,6 +273,9 @@ __device__ __forceinline__ bool ms_item(const MsFwd& A, size_t item, size_t& k_o
 
 // Timing probe of one item (variant builds only: tools/build_variant.sh stamps "-DDURF_MS_STAMPS"): role-0's lane 0 writes the
 // 100 MHz s_memrealtime at the marks below into g_ms_stamps[item slot][32]; tools/experiments/ms_stamps.py reads them back.
+#ifndef MS_PROBE_ONEW
+#define MS_PROBE_ONEW 0          // timing probe only: ONE weight fragment per stage and wave instead of 9-13 (wrong results)
+#endif
 #ifndef MS_PROBE_NOSTORE
 #define MS_PROBE_NOSTORE 0       // timing probe only: the item without its stash / mask stores (wrong results)
 #endif
@@ -281,6 +284,19 @@ __device__ unsigned long long g_ms_stamps[4096 * 32];
 __device__ unsigned g_ms_n;
 #define MS_STAMP(i) do { if (ms_probe) g_ms_stamps[ms_slot * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define MS_STAMP_WAIT(i) do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MS_STAMP(i); } while (0)
+#if defined(MS_STAMP_STAGE)      // the inside of ONE stage instead of the inside of the input phase (same slots 26-29)
+#undef MS_STAMP_WAIT
+#define MS_STAMP_WAIT(i) do { } while (0)
+#define MS_STAMP_IN(s, i) do { if constexpr ((s) == MS_STAMP_STAGE) MS_STAMP(i); } while (0)
+#define MS_STAMP_IN_WAITW(s, i) do { if constexpr ((s) == MS_STAMP_STAGE) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MS_STAMP(i); } } while (0)
+#define MS_STAMP_IN_ACC(s, i) do { if constexpr ((s) == MS_STAMP_STAGE) { float t0_, t1_; asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(t0_), "=v"(t1_) : "v"(acc[0][15]), "v"(acc[1][15])); MS_STAMP(i); } } while (0)
+#define MS_STAMP_HO(j, i) do { if ((j) == MS_STAMP_STAGE) MS_STAMP(i); } while (0)
+#else
+#define MS_STAMP_IN(s, i) do { } while (0)
+#define MS_STAMP_IN_WAITW(s, i) do { } while (0)
+#define MS_STAMP_IN_ACC(s, i) do { } while (0)
+#define MS_STAMP_HO(j, i) do { } while (0)
+#endif
 extern "C" int durf_debug_ms_stamps(void* dst, int reset) {
     unsigned n = 0;
     if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ms_n), sizeof(n)) != hipSuccess) return -1;
@@ -291,6 +307,10 @@ extern "C" int durf_debug_ms_stamps(void* dst, int reset) {
 #else
 #define MS_STAMP(i) do { } while (0)
 #define MS_STAMP_WAIT(i) do { } while (0)
+#define MS_STAMP_IN(s, i) do { } while (0)
+#define MS_STAMP_IN_WAITW(s, i) do { } while (0)
+#define MS_STAMP_IN_ACC(s, i) do { } while (0)
+#define MS_STAMP_HO(j, i) do { } while (0)
 #endif
 
 template <bool TRAIN>
@@ -418,7 +438,7 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
         // between -- the inference instantiation needed all 512 registers and still spilled)
         asm volatile("" : "+s"(wt));
 #pragma unroll
-        for (int k = 0; k < T; k++) w.A[k] = *(const __attribute__((address_space(1))) bf16x8*)(wt + k * 1024 + lane * 16);
+        for (int k = 0; k < T; k++) w.A[k] = *(const __attribute__((address_space(1))) bf16x8*)(wt + (MS_PROBE_ONEW ? 0 : k) * 1024 + lane * 16);
         const __attribute__((address_space(1))) f32x4* bp = (const __attribute__((address_space(1))) f32x4*)(wt + T * 1024 + hi * 64);     // the bias rows: the initial accumulators
 #pragma unroll
         for (int g = 0; g < 4; g++) w.b[g] = bp[g];
@@ -447,13 +467,16 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
         };
         v4i_ ring[D];
         static_for<0, D>([&](auto i_) { ring[decltype(i_)::value] = rd(i_); });
+        MS_STAMP_IN(s, 26);
         static_for<0, NR>([&](auto i_) {
             constexpr int i = decltype(i_)::value, k = i >> 1, t = i & 1;
+            if constexpr (i == 0) MS_STAMP_IN_WAITW(s, 27);
             constexpr int later = (NR - 1 - i) < (D - 1) ? (NR - 1 - i) : (D - 1);
             lds_wait<later>(ring[i % D]);
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.A[k], __builtin_bit_cast(bf16x8, ring[i % D]), acc[t], 0, 0, 0);
             if constexpr (i + D < NR) ring[i % D] = rd(std::integral_constant<int, i + D>{});
         });
+        MS_STAMP_IN_ACC(s, 28);
 #else
 #pragma unroll
         for (int k = 0; k < T; k++) {
@@ -483,6 +506,7 @@ __device__ __forceinline__ void ms_fwd_pair(const MsFwd& A, char* smem, int lane
                 Mbuf[(t * 4 + mo) * 64 + lane] = bits << (8 * (mo & 1));
             }
         }
+        MS_STAMP_HO(jstash, 29);
     };
     // waves 0 / 1 assemble the previous stage's flags of tile 0 / 1 into k_mlp_fwd's layout (one uint4 per lane: words
     // 0, 1 = tile pairs (0,1), (2,3)) -- after the barrier that made every wave's piece visible

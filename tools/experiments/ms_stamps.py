@@ -55,6 +55,12 @@ for i in range(10):
 lab += ['stage 10 + raw']
 for l, m, mx in zip(lab, rows.mean(0), rows.max(0)):
     print('  %-18s mean %6.2f us   max %6.2f' % (l, m, mx))
+if os.environ.get('MS_STAMP_STAGE'):       # variant built with -DMS_STAMP_STAGE=2: slots 26-29 are the inside of stage 2
+    st = np.stack([s[:, 26] - s[:, 5], s[:, 27] - s[:, 26], s[:, 28] - s[:, 27], s[:, 29] - s[:, 28], s[:, 18] - s[:, 29], s[:, 6] - s[:, 18]], 1) * 0.01
+    for l, m in zip(['mask flush, weight requests, ring reads issued', 'this stage\'s weights have arrived', '16 MFMAs, results readable',
+                     'pack + LDS writes + stash stores issued', 'lgkmcnt(0) before the barrier', 'barrier'], st.mean(0)):
+        print('    stage 2: %-48s mean %6.2f us' % (l, m))
+    sys.exit(0)
 enc = np.stack([s[:, 26] - s[:, 1], s[:, 27] - s[:, 26], s[:, 28] - s[:, 27], s[:, 29] - s[:, 28], s[:, 2] - s[:, 29]], 1) * 0.01
 for l, m in zip(['ray_idx load', 'ray data loads', 'frustum gaussian', 'features + stores', 'view / load_w issue'], enc.mean(0)):
     print('    inputs: %-20s mean %6.2f us' % (l, m))
