@@ -451,6 +451,13 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     # seven timed launches, 1.5 % of a 4096-ray step and 9 % of a 512-ray step (profiles/r04_event_overhead.txt).  The
     # averages are over the sampled launches, all inside the timed region.
     every = 1 if profile_ops else (args.time_every if args.time_every > 0 else max(1, min(8, steps // 5)))
+    # The cyclic collector, once, BEFORE the warm-up, and everything alive then frozen out of its view.  At 512 rays the host is
+    # only a few steps ahead of the GPU, and ~3 % of the runs had ONE 10-50 ms stall inside the timed region (step_ms.max): a
+    # collector pass over the set-up's garbage.  Collected here instead, the warm-up and the timed steps see the same allocator
+    # state (a gc.collect() between them changes what the caching allocator hands the timed steps: every kernel of a 512-ray
+    # step then ran 1.5 % slower, 14 % under rocprofv3 -- profiles/r06_mix.txt section 8).
+    gc.collect()
+    gc.freeze()
     for i in range(warmup):
         ops.TIMERS_ACTIVE = i % every == 0
         state, stats, rng, _ = step(state, rng, i)
@@ -465,10 +472,6 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     group = 1 if (args.max_ahead > 0 or steps < 16) else 4
     # (the marks are events that exist already -- the pre-warmed pool: none is created inside the timed region)
     marks = {0: ops._timing_event()}
-    # (no cyclic-GC pass inside the timed region: at 512 rays the host is only a few steps ahead of the GPU, and a 10-30 ms
-    # generation-2 collection showed up as one slow group of steps in ~1 run of 15: profiles/r06_mix.txt section 8)
-    gc.collect()
-    gc.disable()
     t0 = time.perf_counter()
     marks[0].record()
     sampled = 0
@@ -483,7 +486,7 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
             marks[i + 1 - args.max_ahead].synchronize()      # the host never runs more than max_ahead steps ahead
     sync()
     dt = time.perf_counter() - t0
-    gc.enable()
+    gc.unfreeze()
     at = sorted(marks)
     step_raw = [marks[a].elapsed_time(marks[b]) / (b - a) for a, b in zip(at[:-1], at[1:])]     # ms per step, by group
     ops.EVENT_POOL.extend(marks.values())
