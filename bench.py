@@ -453,9 +453,9 @@ def run_train(args, cfg_name, dev, rank, world, steps, warmup, rays=0, objects=-
     every = 1 if profile_ops else (args.time_every if args.time_every > 0 else max(1, min(8, steps // 5)))
     # The cyclic collector, once, BEFORE the warm-up, and everything alive then frozen out of its view.  At 512 rays the host is
     # only a few steps ahead of the GPU, and ~3 % of the runs had ONE 10-50 ms stall inside the timed region (step_ms.max): a
-    # collector pass over the set-up's garbage.  Collected here instead, the warm-up and the timed steps see the same allocator
-    # state (a gc.collect() between them changes what the caching allocator hands the timed steps: every kernel of a 512-ray
-    # step then ran 1.5 % slower, 14 % under rocprofv3 -- profiles/r06_mix.txt section 8).
+    # collector pass over the set-up's garbage.  Collected HERE, not between the warm-up and the timed region: the pass takes
+    # 30-50 ms of host time, the GPU idles through it and starts the timed region at a lower clock -- every kernel of a 512-ray
+    # step then ran 1.5 % slower over the 200 steps, 14 % in rocprofv3's 20-step trace (profiles/r06_mix.txt section 8).
     gc.collect()
     gc.freeze()
     for i in range(warmup):
