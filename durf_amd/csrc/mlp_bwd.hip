@@ -226,6 +226,21 @@ __device__ __forceinline__ bool msb_item(const MsBwd& A, size_t total, size_t it
     return ok;
 }
 
+// Timing probe of one backward item (variant builds only, -DDURF_MS_STAMPS: see the forward's in mlp_fwd.hip; tools/experiments/ms_stamps.py --bwd)
+#if defined(DURF_MS_STAMPS)
+__device__ unsigned long long g_msb_stamps[4096 * 32];
+__device__ unsigned g_msb_n;
+#define MSB_STAMP(i) do { if (msb_probe) g_msb_stamps[msb_slot * 32 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+extern "C" int durf_debug_msb_stamps(void* dst, int reset) {
+    unsigned n = 0;
+    if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_msb_n), sizeof(n)) != hipSuccess) return -1;
+    if (dst && hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_msb_stamps), sizeof(unsigned long long) * 4096 * 32) != hipSuccess) return -1;
+    if (reset) { const unsigned z = 0; if (hipMemcpyToSymbol(HIP_SYMBOL(g_msb_n), &z, sizeof(z)) != hipSuccess) return -1; }
+    return (int)n;
+}
+#else
+#define MSB_STAMP(i) do { } while (0)
+#endif
 // One (level, object, tile pair) item on FOUR waves and msb::LDS_BYTES of LDS at `smem` (every barrier inside is the workgroup's)
 // (the level's operands are resolved by the caller: draw [B*N,4], relu_mask / dz / dz_out [K, ...] slabs of that level)
 __device__ __forceinline__ void msb_bwd_pair(const MsBwd& A, const float* __restrict__ draw, const uint4* relu_mask_g, bf16x8* dz_g,
@@ -251,7 +266,17 @@ __device__ __forceinline__ void msb_bwd_pair(const MsBwd& A, const float* __rest
     const size_t t32[NT] = {pair * NT, pair * NT + 1};
     // (live == false: the other group of a mixed workgroup still has an item -- same stages on zeros, every global access off)
     const bool tv[NT] = {live, live && t32[1] * 32 < nrows};
+#if defined(DURF_MS_STAMPS)
+    const bool msb_probe = live && wave == 0 && lane == 0;
+    unsigned msb_slot = 0;
+    if (msb_probe) {
+        msb_slot = atomicAdd(&g_msb_n, 1u) & 4095u;
+        g_msb_stamps[msb_slot * 32 + 30] = ((unsigned long long)blockIdx.x << 32) | (unsigned long long)(k * 100000 + pair);
+    }
+#endif
+    MSB_STAMP(0);
     ms_barrier();
+    MSB_STAMP(1);
     // head gradients (fp32 [*,4]: d raw_rgb[3], d raw_density), gathered by ray: waves 0 / 1 build tile 0 / 1's fragments
     if (wave < NT) {
         const int t = wave;
@@ -283,7 +308,8 @@ __device__ __forceinline__ void msb_bwd_pair(const MsBwd& A, const float* __rest
         for (int k = 0; k < T; k++) w.A[k] = *(const __attribute__((address_space(1))) bf16x8*)(wt + k * 1024 + lane * 16);
     };
     // this wave's tile of backward stage b: NX k-steps from Xin, then NG head-gradient fragments (g: 0 rgb, 1 density)
-    unsigned mword[NT] = {0u, 0u};                 // this stage's ReLU flags (requested before its MFMAs, used in its epilogue)
+    unsigned mword[NT] = {0u, 0u};                 // this stage's ReLU flags: requested before its MFMAs AND before the next stage's
+                                                   // weights (loads return in order: behind the 9 KB of weights the epilogue waited for those too)
     auto load_mask = [&](int jm) {
 #pragma unroll
         for (int t = 0; t < NT; t++)
@@ -353,59 +379,80 @@ __device__ __forceinline__ void msb_bwd_pair(const MsBwd& A, const float* __rest
     char* Xb = X0 + msb::X_BYTES;
     WSet w0, w1;
     load_w(std::integral_constant<int, 0>{}, w0);
+    MSB_STAMP(2);
     ms_barrier();                               // head-gradient fragments in place
+    MSB_STAMP(3);
     // bwd of stage 10 (rgb head): d rgb -> d A9, masked by A9 (mask region 8) -> dz region 9
-    load_w(std::integral_constant<int, 1>{}, w1);
     load_mask(8);
+    load_w(std::integral_constant<int, 1>{}, w1);
     stage_mma(std::integral_constant<int, 0>{}, w0, I0{}, I1{}, 0, Xa);
     hand_over(std::true_type{}, 8, 9, Xa);
+    MSB_STAMP(16);
     ms_barrier();
+    MSB_STAMP(4);
     // bwd of stage 9 (view layer): d Z9 -> d bottleneck (linear; not stored)
     load_w(std::integral_constant<int, 2>{}, w0);
     stage_mma(std::integral_constant<int, 1>{}, w1, std::integral_constant<int, S::KC>{}, I0{}, 0, Xa);
     hand_over(std::false_type{}, 0, -1, Xb);
+    MSB_STAMP(17);
     ms_barrier();
+    MSB_STAMP(5);
     // bwd of stage 8 (bottleneck + density head): -> d A7 (mask region 7, dz region 7)
-    load_w(std::integral_constant<int, 3>{}, w1);
     load_mask(7);
+    load_w(std::integral_constant<int, 3>{}, w1);
     stage_mma(std::integral_constant<int, 2>{}, w0, IW{}, I1{}, 1, Xb);
     hand_over(std::true_type{}, 7, 7, Xa);
+    MSB_STAMP(18);
     ms_barrier();
+    MSB_STAMP(6);
     // bwd of stages 7, 6, 5 (trunk rows) -> d Z6, d Z5, d Z4
-    load_w(std::integral_constant<int, 4>{}, w0);
     load_mask(6);
+    load_w(std::integral_constant<int, 4>{}, w0);
     stage_mma(std::integral_constant<int, 3>{}, w1, IW{}, I0{}, 0, Xa);
     hand_over(std::true_type{}, 6, 6, Xb);
+    MSB_STAMP(19);
     ms_barrier();
-    load_w(std::integral_constant<int, 5>{}, w1);
+    MSB_STAMP(7);
     load_mask(5);
+    load_w(std::integral_constant<int, 5>{}, w1);
     stage_mma(std::integral_constant<int, 4>{}, w0, IW{}, I0{}, 0, Xb);
     hand_over(std::true_type{}, 5, 5, Xa);
+    MSB_STAMP(20);
     ms_barrier();
-    load_w(std::integral_constant<int, 7>{}, w0);
+    MSB_STAMP(8);
     load_mask(4);
+    load_w(std::integral_constant<int, 7>{}, w0);
     stage_mma(std::integral_constant<int, 5>{}, w1, IW{}, I0{}, 0, Xa);
     hand_over(std::true_type{}, 4, 4, Xb);
+    MSB_STAMP(21);
     ms_barrier();
+    MSB_STAMP(9);
     // bwd of stages 4..1 -> d Z3 .. d Z0
-    load_w(std::integral_constant<int, 8>{}, w1);
     load_mask(3);
+    load_w(std::integral_constant<int, 8>{}, w1);
     stage_mma(std::integral_constant<int, 7>{}, w0, IW{}, I0{}, 0, Xb);
     hand_over(std::true_type{}, 3, 3, Xa);
+    MSB_STAMP(22);
     ms_barrier();
-    load_w(std::integral_constant<int, 9>{}, w0);
+    MSB_STAMP(10);
     load_mask(2);
+    load_w(std::integral_constant<int, 9>{}, w0);
     stage_mma(std::integral_constant<int, 8>{}, w1, IW{}, I0{}, 0, Xa);
     hand_over(std::true_type{}, 2, 2, Xb);
+    MSB_STAMP(23);
     ms_barrier();
-    load_w(std::integral_constant<int, 10>{}, w1);
+    MSB_STAMP(11);
     load_mask(1);
+    load_w(std::integral_constant<int, 10>{}, w1);
     stage_mma(std::integral_constant<int, 9>{}, w0, IW{}, I0{}, 0, Xb);
     hand_over(std::true_type{}, 1, 1, Xa);
+    MSB_STAMP(24);
     ms_barrier();
+    MSB_STAMP(12);
     load_mask(0);
     stage_mma(std::integral_constant<int, 10>{}, w1, IW{}, I0{}, 0, Xa);
     hand_over(std::true_type{}, 0, 0, Xb);
+    MSB_STAMP(15);
 }
 
 __global__ void __launch_bounds__(256)

@@ -17,24 +17,48 @@ from durf_amd import _lib, train_boxpose
 ap = argparse.ArgumentParser()
 ap.add_argument('--config', default='cfg3')
 ap.add_argument('--rays', type=int, default=512)
+ap.add_argument('--bwd', action='store_true', help='the backward item (msb_bwd_pair) instead of the forward one')
 a = ap.parse_args()
 dev = torch.device('cuda', 0)
 lib = ctypes.CDLL(_lib.LIB_PATH)
 lib.durf_debug_ms_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+lib.durf_debug_msb_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
+read_stamps = lib.durf_debug_msb_stamps if a.bwd else lib.durf_debug_ms_stamps
 w = bench.setup_workload(a.config, dev, rays=a.rays)
 model, config, state, batch, prev = (w[k] for k in ('model', 'config', 'state', 'batch', 'prev'))
 rng = 0
 for i in range(4):
     state, stats, rng, _ = train_boxpose.train_step_one_call(model, config, rng, state, batch, 5e-4, 3.0, w['alpha'], prev, reduce_stats=False)
 torch.cuda.synchronize()
-lib.durf_debug_ms_stamps(None, 1)
+read_stamps(None, 1)
 state, stats, rng, _ = train_boxpose.train_step_one_call(model, config, rng, state, batch, 5e-4, 3.0, w['alpha'], prev, reduce_stats=False)
 torch.cuda.synchronize()
 buf = np.zeros((4096, 32), dtype=np.uint64)
-n = lib.durf_debug_ms_stamps(buf.ctypes.data, 1)
+n = read_stamps(buf.ctypes.data, 1)
 print('items recorded in one step: %d (both levels)' % n)
 s = buf[:min(n, 4096)].astype(np.int64)
 t0 = s[:, 0].min()
+if a.bwd:
+    rows = []
+    for r in s:
+        ent = [r[1] - r[0], r[2] - r[1], r[3] - r[2]]
+        post = r[3]
+        for i in range(10):
+            ent += [r[16 + i] - post, r[4 + i] - r[16 + i]]
+            post = r[4 + i]
+        ent.append(r[15] - post)
+        rows.append(ent)
+    rows = np.array(rows, dtype=np.float64) * 0.01
+    tot = (s[:, 15] - s[:, 0]) * 0.01
+    print('backward item: mean %.2f us  min %.2f  max %.2f' % (tot.mean(), tot.min(), tot.max()))
+    lab = ['wait prev', 'head gradients', 'barrier'] + sum((['stage %d work' % i, 'stage %d barrier' % i] for i in range(10)), []) + ['last stage']
+    for l, m, mx in zip(lab, rows.mean(0), rows.max(0)):
+        print('  %-18s mean %6.2f us   max %6.2f' % (l, m, mx))
+    start = (s[:, 0] - t0) * 0.01; end = (s[:, 15] - t0) * 0.01
+    print('first item starts 0.0, last item ends %.1f us after it; %d distinct workgroups' % (end.max(), len(set((s[:, 30] >> 32).tolist()))))
+    hist, edges = np.histogram(start, bins=12)
+    print('  start histogram:', ' '.join('%d@%.0f' % (h, e) for h, e in zip(hist, edges[:-1])))
+    sys.exit(0)
 NAMES = ['wait prev', 'inputs', 'wait inputs'] + ['st%d work' % i for i in range(10)] + ['st10']
 rows = []
 for r in s:
