@@ -271,7 +271,7 @@ __device__ __forceinline__ bool ms_item(const MsFwd& A, size_t item, size_t& k_o
     return ok;
 }
 
-// Timing probe of one item (variant builds only: tools/build_variant.sh stamps "-DDURF_MS_STAMPS"): role-0's lane 0 writes the
+// Timing probe of one item (variant builds only: tools/build_variant.sh stamps -DDURF_MS_STAMPS, one -D per argument): role 0's lane 0 writes the
 // 100 MHz s_memrealtime at the marks below into g_ms_stamps[item slot][32]; tools/experiments/ms_stamps.py reads them back.
 #ifndef MS_PROBE_ONEW
 #define MS_PROBE_ONEW 0          // timing probe only: ONE weight fragment per stage and wave instead of 9-13 (wrong results)
@@ -722,7 +722,8 @@ __device__ __forceinline__ void mix_object_items(char* smem, int wave, int nwg) 
     // a returning atomic ahead of them in its queue would be waited for with them)
     const bool first = wave == MIX_TICKET_WAVE && lane == 0;
     // (waves w and w + 4 share a SIMD: the second group's roles are rotated by two, so that the two groups' role-0 waves --
-    // the serial head of an item: the encoding / the head gradients -- run on different SIMDs)
+    // which carry an item's extra work: the density and rgb heads (and, until the encoding was dealt to all four waves, the
+    // whole input phase) -- run on different SIMDs)
     const int half = wave >> 2, w4 = (wave + MIX_ROLE_ROT * half) & 3;
     char* const lds = smem + half * ms::LDS_BYTES;
     volatile __attribute__((address_space(3))) int* const tk =
