@@ -48,5 +48,5 @@ extern "C" {
 int durf_dispatch_seen(void) { return (int)g_dispatch.load(std::memory_order_relaxed); }
 int durf_dispatch_reset(void) { g_dispatch.store(0u, std::memory_order_relaxed); return 0; }
 const char* durf_last_error(void) { return g_err; }
-int durf_version(void) { return 39; }      // bump with every kernel change: bench.py quotes PMC traffic per version
+int durf_version(void) { return 40; }      // bump with every kernel change: bench.py quotes PMC traffic per version
 }

@@ -1175,22 +1175,35 @@ k_bottleneck_grads(FinArgs A) {
     const int wt = W / 32, nA = wt * wt, nC = wt * 4;
     const int t = blockIdx.x, tid = threadIdx.x;
     const int tx = tid & 31, ty = tid >> 5;          // output (row = ty + 8 q, col = tx), q = 0..3
+    // this thread's float4 of a fragment: lane = tid / 4 = (hi, jn), r = 4 (tid % 4) + e  ->  P row / column (frag_index inverted)
+    const int f_hi = tid >> 7, f_jn = (tid >> 2) & 31, f_r0 = (tid & 3) * 4;
+    auto frag_col = [&](int mo, int e) { const int r = f_r0 + e; return cperm_feat(32 * mo + (r & 3) + 8 * (r >> 2) + 4 * f_hi); };
     if (t < nA) {
         const int i0 = (t / wt) * 32, o0 = (t % wt) * 32;
         // (operand gathers: ALL of a thread's 16 + 16 loads in flight at once -- P was summed a moment ago on other XCDs, every
         // round of loads is a trip past this XCD's L2; one at a time the tile was a chain of them, 8 + 8 at a time two)
         {
-            float va[16], vb[16];
+            // P rows i0..i0+31 x all 128 columns = the four WHOLE fragments (mo = 0..3, ni = i0 / 32) of job 10's [mo][ni][lane][16]
+            // space: one float4 per thread and fragment, coalesced, scattered into the LDS rows (frag_index inverted) -- as 16
+            // gathered dwords per thread every load instruction touched up to 64 lines (round 6: the launch 17 -> 1x us)
+            f32x4 pa[4];
+            float vb[16];
+            const int ni = i0 >> 5;
+#pragma unroll
+            for (int mo = 0; mo < 4; mo++) pa[mo] = *(const f32x4*)(part10 + ((size_t)(mo * NI + ni)) * 1024 + tid * 4);
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 256 * u, r = e >> 7, j = e & 127;
-                va[u] = part10[frag_index(W, i0 + r, j, NI)];
                 vb[u] = K10[(size_t)(o0 + r) * 128 + j];
             }
+            const int rr = cperm_feat(32 * ni + f_jn) - i0;
+#pragma unroll
+            for (int mo = 0; mo < 4; mo++)
+#pragma unroll
+                for (int e = 0; e < 4; e++) sa[rr][frag_col(mo, e)] = pa[mo][e];
 #pragma unroll
             for (int u = 0; u < 16; u++) {
                 const int e = tid + 256 * u, r = e >> 7, j = e & 127;
-                sa[r][j] = va[u];
                 sb[r][j] = bf16r(vb[u]);
             }
         }
@@ -1225,22 +1238,28 @@ k_bottleneck_grads(FinArgs A) {
         }
     } else if (t < nA + nC) {
         const int u = t - nA, o0 = (u / 4) * 32, j0 = (u % 4) * 32;
-        const int wsh = W == 256 ? 8 : 7;                           // W is 128 or 256
+        // P^T rows j0..j0+31 x all W columns = the W / 32 whole fragments (mo = j0 / 32, ni): coalesced float4s as above; K9's
+        // columns o0..o0+31 by rows (a lane per column: 128 contiguous bytes per row instead of one line per lane)
 #pragma unroll 1
-        for (int e0 = tid; e0 < 32 * W; e0 += 16 * 256) {          // 32 W = 4096 or 8192: one or two rounds of 16 + 16 loads
-            float va[16], vb[16];
+        for (int n0 = 0; n0 < wt; n0 += 4) {                       // W / 32 = 4 or 8 fragments, four at a time
+            f32x4 pb[4];
+            float va[16];
+            const int mo = j0 >> 5;
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int e = e0 + 256 * u, r = e >> wsh, i = e & (W - 1);
-                va[u] = K9[(size_t)i * W + o0 + r];                    // K9^T rows: output feature o0 + r
-                vb[u] = part10[frag_index(W, i, j0 + r, NI)];          // P^T rows: dz10 feature j0 + r
+            for (int f = 0; f < 4; f++) pb[f] = *(const f32x4*)(part10 + ((size_t)(mo * NI + n0 + f)) * 1024 + tid * 4);
+#pragma unroll
+            for (int u = 0; u < 16; u++) {                          // rows i = 32 n0 + (tid >> 5) + 8 u, column o0 + (tid & 31)
+                const int i = 32 * n0 + (tid >> 5) + 8 * u;
+                va[u] = K9[(size_t)i * W + o0 + (tid & 31)];
             }
 #pragma unroll
-            for (int u = 0; u < 16; u++) {
-                const int e = e0 + 256 * u, r = e >> wsh, i = e & (W - 1);
-                sa[r][i] = bf16r(va[u]);
-                sb[r][i] = vb[u];
+            for (int f = 0; f < 4; f++) {
+                const int i = cperm_feat(32 * (n0 + f) + f_jn);
+#pragma unroll
+                for (int e = 0; e < 4; e++) sb[frag_col(mo, e) - j0][i] = pb[f][e];
             }
+#pragma unroll
+            for (int u = 0; u < 16; u++) sa[tid & 31][32 * n0 + (tid >> 5) + 8 * u] = bf16r(va[u]);
         }
         __syncthreads();
         float s4[4];

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: the ONE evidence set of the round (library version 39): default bench line + per-op table + rocprofv3 stats + the three
+# round 6: the ONE evidence set of the round (library version 40): default bench line + per-op table + rocprofv3 stats + the three
 # PMC passes (tools/collect_profiles.sh), step timelines of the small workloads, eval, the GPU suite.   -> gpurun_out/r06/
 out=gpurun_out/r06; mkdir -p $out
 timeout 1500 bash tools/collect_profiles.sh r06 cfg3
